@@ -1,0 +1,389 @@
+"""TEST INFRASTRUCTURE ONLY — generate tests/golden/*.json by running the upstream Python
+reference (imported from /root/reference in the BUILD CONTAINER; see oracle/ref_import.py).
+
+The fixtures are data only: inputs (coordinates, strategies, rolls) and the outputs the
+reference produced for them, plus constants transcribed from the reference's own test
+goldens (EXPECTED_ROWS, EXPECTED_H2H_BLOCKS, the deterministic-counts KAT).  Nothing here
+travels to the GPU box except the generated JSON.
+
+    python oracle/gen_golden.py            # regenerate everything (about a minute)
+"""
+from __future__ import annotations
+
+import csv
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+
+class _Enc(json.JSONEncoder):
+    def default(self, o):
+        if isinstance(o, np.integer):
+            return int(o)
+        if isinstance(o, np.bool_):
+            return bool(o)
+        return super().default(o)
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+import ref_import  # noqa: E402
+
+ref_import.import_reference()
+
+from farkle.game.scoring import SCORE_TABLE, default_score  # noqa: E402
+from farkle.simulation import run_tournament as rt  # noqa: E402
+from farkle.simulation.game_profile import (  # noqa: E402
+    GameProfile,
+    H2HMaxRoundsOverride,
+    TournamentMaxRoundsOverride,
+)
+from farkle.simulation.simulation import (  # noqa: E402
+    PlayerRngCoordinates,
+    _play_game,
+    generate_strategy_grid,
+    simulate_many_games,
+)
+from farkle.simulation.strategies import (  # noqa: E402
+    FavorDiceOrScore,
+    ThresholdStrategy,
+    build_strategy_manifest,
+)
+from farkle.simulation.time_farkle import make_random_strategies  # noqa: E402
+from farkle.utils import random as ur  # noqa: E402
+from farkle.utils.random import RandomPurpose  # noqa: E402
+
+OUT = HERE.parent / "tests" / "golden"
+OUT.mkdir(parents=True, exist_ok=True)
+
+
+def _dump(obj, fh):
+    json.dump(obj, fh, cls=_Enc, separators=(",", ":"))
+    fh.close()
+
+
+def strat_tuple(s: ThresholdStrategy) -> list[int]:
+    return [
+        int(s.score_threshold), int(s.dice_threshold), int(s.smart_five), int(s.smart_one),
+        int(s.consider_score), int(s.consider_dice), int(s.require_both), int(s.auto_hot_dice),
+        int(s.run_up_score), int(s.favor_dice_or_score is FavorDiceOrScore.SCORE),
+        -1 if s.strategy_id is None else int(s.strategy_id),
+    ]
+
+
+def row_to_compact(row: dict, k: int) -> dict:
+    """Reduce a reference row dict to the integer fields the engine owns."""
+    seats = []
+    for i in range(1, k + 1):
+        p = f"P{i}_"
+        seats.append(
+            [row[p + "score"], row[p + "strategy"], row[p + "farkles"], row[p + "rolls"], row[p + "n_turns"],
+             row[p + "highest_turn"], row[p + "smart_five_uses"], row[p + "n_smart_five_dice"],
+             row[p + "smart_one_uses"], row[p + "n_smart_one_dice"], row[p + "hot_dice"],
+             0 if row[p + "rank"] is None else int(row[p + "rank"]), int(bool(row[p + "hit_max_rounds"]))]
+        )
+    return {
+        "n_rounds": int(row["n_rounds"]),
+        "status": 0 if row["termination_status"] == "completed" else 1,
+        "winner_seat": -1 if row["winner_seat"] is None else int(row["winner_seat"][1:]) - 1,
+        "winner_strategy": row["winner_strategy"],
+        "winning_score": row["winning_score"],
+        "victory_margin": row["victory_margin"],
+        "seat_ranks": row["seat_ranks"],
+        "game_seed": int(row["game_seed"]),
+        "seats": [[int(v) for v in s] for s in seats],
+    }
+
+
+def grid(**kw) -> list[ThresholdStrategy]:
+    strategies, _ = generate_strategy_grid(**kw)
+    return strategies
+
+
+def grid64():
+    return grid(score_thresholds=[250, 300, 350, 400], dice_thresholds=[0, 1, 2, 3], smart_five_opts=[True],
+                smart_one_opts=[True], consider_score_opts=[True], consider_dice_opts=[True],
+                auto_hot_dice_opts=[True], run_up_score_opts=[True], include_stop_at=False,
+                include_stop_at_heuristic=False)
+
+
+def grid_oracle4():
+    # tests/helpers/raw_simulation_oracle.py:108-118
+    return grid(score_thresholds=[500], dice_thresholds=[2], smart_five_opts=[False], smart_one_opts=[False],
+                consider_score_opts=[True], consider_dice_opts=[True], auto_hot_dice_opts=[False, True],
+                run_up_score_opts=[False], include_stop_at=False, include_stop_at_heuristic=False)
+
+
+def grid_default():
+    return grid()
+
+
+# ---------------------------------------------------------------------------
+def gen_rng():
+    rs = np.random.default_rng(20261004)
+    cases = []
+    for _ in range(24):
+        purpose = int(rs.choice([1, 10, 11, 101, 102, 103, 202, 203]))
+        kw = dict(root_seed=int(rs.integers(0, 2**62)) * 4 + int(rs.integers(0, 4)), k=int(rs.integers(0, 13)),
+                  shuffle_index=int(rs.integers(0, 2**40)), pair_id=int(rs.integers(0, 5000)),
+                  order=int(rs.integers(0, 2)), game_index=int(rs.integers(0, 2**33)), seat_index=int(rs.integers(0, 12)))
+        g = ur.coordinate_rng(purpose, **kw)
+        raw = [int(x) for x in g.bit_generator.random_raw(8)]
+        sizes = [int(x) for x in rs.integers(1, 7, size=40)]
+        g = ur.coordinate_rng(purpose, **kw)
+        dice = [int(v) for n in sizes for v in g.integers(1, 7, size=n)]
+        perms = {}
+        for S in (4, 64, 80):
+            g = ur.coordinate_rng(purpose, **kw)
+            perms[str(S)] = [int(v) for v in g.permutation(S)]
+        cases.append({"purpose": purpose, **kw, "raw64": raw, "sizes": sizes, "dice": dice, "perms": perms,
+                      "seed32": ur.coordinate_seed(purpose, dtype=np.uint32, **kw),
+                      "seed64": ur.coordinate_seed(purpose, dtype=np.uint64, **kw)})
+    # one full-grid permutation and the spawn_seeds path
+    g = ur.coordinate_rng(RandomPurpose.SHUFFLE_PERMUTATION, root_seed=0, k=4, shuffle_index=7)
+    big = [int(v) for v in g.permutation(5160)]
+    spawn = [int(v) for v in ur.spawn_seeds(16, seed=42)]
+    _dump({"cases": cases, "perm5160": {"root_seed": 0, "k": 4, "shuffle_index": 7, "perm": big},
+               "spawn_seeds_42": spawn}, open(OUT / "rng_vectors.json", "w"))
+
+
+def gen_scoring():
+    table = [[int(x) for x in (*key, v[0], v[1], v[3], v[4])] for key, v in SCORE_TABLE.items()]
+    assert len(table) == 923
+    # the reference's own 152-roll CSV (tests/data/test_farkle_scores_data.csv): data fixture
+    rows = list(csv.DictReader(open("/root/reference/tests/data/test_farkle_scores_data.csv")))
+    rs = np.random.default_rng(7)
+    grids = grid_default()
+    cases = []
+    for _ in range(2500):
+        n = int(rs.integers(1, 7))
+        roll = [int(v) for v in rs.integers(1, 7, size=n)]
+        if rs.random() < 0.35:  # bias toward ones/fives so discards trigger
+            roll = [int(rs.choice([1, 5, 5, 1, 2, 3, 4, 6])) for _ in range(n)]
+        s = grids[int(rs.integers(0, len(grids)))]
+        pre = int(rs.integers(0, 30)) * 50
+        res = default_score(roll, turn_score_pre=pre, smart_five=s.smart_five, smart_one=s.smart_one,
+                            consider_score=s.consider_score, consider_dice=s.consider_dice,
+                            require_both=s.require_both, score_threshold=s.score_threshold,
+                            dice_threshold=s.dice_threshold, favor_dice_or_score=s.favor_dice_or_score,
+                            return_discards=True)
+        cases.append({"roll": roll, "pre": pre, "strategy": strat_tuple(s), "out": [int(v) for v in res]})
+    dec = []
+    for _ in range(1500):
+        s = grids[int(rs.integers(0, len(grids)))]
+        a = dict(turn_score=int(rs.integers(0, 40)) * 50, dice_left=int(rs.integers(1, 7)),
+                 has_scored=bool(rs.integers(0, 2)), final_round=bool(rs.integers(0, 2)),
+                 score_to_beat=int(rs.integers(90, 110)) * 100, running_total=int(rs.integers(90, 110)) * 100)
+        dec.append({"strategy": strat_tuple(s), **{k: int(v) for k, v in a.items()},
+                    "out": int(s.decide(score_needed=0, **a))})
+    _dump({"table": table, "csv_rows": rows, "default_score": cases, "decide": dec},
+              open(OUT / "scoring_vectors.json", "w"))
+
+
+def play(strats, purpose, root, k, shuffle=0, pair=0, order=0, game=0, target=10_000, max_rounds=200):
+    coords = PlayerRngCoordinates(purpose=purpose, root_seed=root, k=k, shuffle_index=shuffle, pair_id=pair,
+                                  order=order, game_index=game)
+    return _play_game(0, strats, target_score=target, max_rounds=max_rounds, player_rng_coordinates=coords)
+
+
+def gen_games():
+    rs = np.random.default_rng(99)
+    out = {"grids": {}, "games": []}
+    grids = {"g64": grid64(), "default": grid_default()}
+    out["grids"]["g64"] = [strat_tuple(s) for s in grids["g64"]]
+    # the default grid is regenerated by the build's own grid builder; store only its size and a digest sample
+    out["grids"]["default_size"] = len(grids["default"])
+    out["grids"]["default_sample"] = {str(i): strat_tuple(grids["default"][i]) for i in range(0, 5160, 129)}
+    plan = [("g64", 2, 60, {}), ("g64", 4, 25, {}), ("g64", 8, 10, {}), ("default", 2, 60, {}), ("default", 3, 20, {}),
+            ("default", 4, 30, {}), ("default", 5, 12, {}), ("default", 6, 12, {}), ("default", 8, 10, {}),
+            ("default", 12, 6, {}), ("g64", 2, 20, {"target": 1500}), ("default", 4, 10, {"max_rounds": 3}),
+            ("g64", 2, 6, {"max_rounds": 0}), ("default", 2, 10, {"target": 100, "max_rounds": 1})]
+    for gname, k, n, extra in plan:
+        g = grids[gname]
+        for _ in range(n):
+            idx = [int(v) for v in rs.choice(len(g), size=k, replace=False)]
+            purpose = int(rs.choice([103, 203, 10])) if k == 2 else int(rs.choice([103, 10]))
+            root = int(rs.integers(0, 2**63))
+            kw = dict(shuffle=int(rs.integers(0, 10**6)), game=int(rs.integers(0, 3000)))
+            if purpose == 203:
+                kw = dict(pair=int(rs.integers(0, 1000)), order=int(rs.integers(0, 2)), game=int(rs.integers(0, 10**6)))
+            if purpose == 10:
+                kw = dict(game=int(rs.integers(0, 10**6)))
+            row = play([g[i] for i in idx], purpose, root, k, target=extra.get("target", 10_000),
+                       max_rounds=extra.get("max_rounds", 200), **kw)
+            out["games"].append({"grid": gname, "strategies": idx, "k": k, "purpose": purpose, "root_seed": root,
+                                 **{"shuffle": 0, "pair": 0, "order": 0, "game": 0, **kw},
+                                 "target": extra.get("target", 10_000), "max_rounds": extra.get("max_rounds", 200),
+                                 "row": row_to_compact(row, k)})
+    # force some never-bank pairings (safety-limit games) on the 64-grid
+    g = grids["g64"]
+    never = [i for i, s in enumerate(g) if s.dice_threshold == 0 and s.require_both is False]
+    for j in range(6):
+        idx = [never[j], never[j + 1]]
+        root = 1000 + j
+        row = play([g[i] for i in idx], 103, root, 2, shuffle=j, game=j)
+        out["games"].append({"grid": "g64", "strategies": idx, "k": 2, "purpose": 103, "root_seed": root,
+                             "shuffle": j, "pair": 0, "order": 0, "game": j, "target": 10_000, "max_rounds": 200,
+                             "row": row_to_compact(row, 2)})
+    _dump(out, open(OUT / "game_vectors.json", "w"))
+
+
+def counter_payload(wins, sums, sqs):
+    return {"wins": {str(k): int(v) for k, v in wins.items()},
+            "attempted": {str(k): int(v) for k, v in wins.attempted_exposures.items()},
+            "completed": {str(k): int(v) for k, v in wins.completed_exposures.items()},
+            "safety": {str(k): int(v) for k, v in wins.safety_limit_exposures.items()},
+            "games": [wins.games_attempted, wins.games_completed, wins.games_safety_limit],
+            "sums": {m: {str(k): int(v) for k, v in d.items()} for m, d in sums.items()},
+            "sq_sums": {m: {str(k): int(v) for k, v in d.items()} for m, d in sqs.items()}}
+
+
+def gen_tournament():
+    out = {"cases": []}
+    for name, strategies, k, root, shuffles, profile in [
+        ("g64_k2", grid64(), 2, 42, [0, 1, 2, 312499], None),
+        ("g64_k4", grid64(), 4, 42, [0, 5], None),
+        ("g64_k8", grid64(), 8, 7, [3], None),
+        ("oracle4_k2_r11", grid_oracle4(), 2, 11, [0, 1], "oracle"),
+        ("oracle4_k4_r11", grid_oracle4(), 4, 11, [0, 1], "oracle"),
+        ("oracle4_k2_r22", grid_oracle4(), 2, 22, [0, 1], "oracle"),
+        ("oracle4_k4_r22", grid_oracle4(), 4, 22, [0, 1], "oracle"),
+    ]:
+        gp = None
+        if profile == "oracle":  # tests/helpers/raw_simulation_oracle.py:57-78
+            gp = GameProfile(default_target_score=100, default_max_rounds=200,
+                             tournament_max_rounds_overrides=(TournamentMaxRoundsOverride(11, 2, 0, 0, 0),))
+        cfg = rt.TournamentConfig(n_players=k, n_strategies=len(strategies))
+        rt._init_worker(strategies, cfg, gp)
+        for sh in shuffles:
+            task = rt.ShuffleTask(root_seed=root, k=k, shuffle_index=sh, shuffle_seed=0, deterministic_batch_id=0)
+            wins, sums, sqs, rows = rt._play_one_shuffle(task, collect_rows=True)
+            perm = ur.coordinate_rng(RandomPurpose.SHUFFLE_PERMUTATION, root_seed=root, k=k, shuffle_index=sh).permutation(len(strategies))
+            out["cases"].append({"name": name, "k": k, "root_seed": root, "shuffle": sh,
+                                 "target": 100 if gp else 10_000, "profile": profile,
+                                 "strategies": [strat_tuple(s) for s in strategies], "perm": [int(v) for v in perm],
+                                 "tally": counter_payload(wins, sums, sqs),
+                                 "rows": [row_to_compact(r, k) for r in rows]})
+    # the reference's own EXPECTED_ROWS (tests/integration/test_raw_simulation_oracle.py:45-58):
+    # (root, k, shuffle, game) -> (seat strategies, status, winner_strategy, n_rounds, sum n_turns, scores)
+    out["EXPECTED_ROWS"] = [
+        [[11, 2, 0, 0], [[0, 2], "safety_limit", None, 0, 0, [0, 0]]],
+        [[11, 2, 0, 1], [[1, 3], "completed", 1, 2, 5, [1950, 1100]]],
+        [[11, 2, 1, 0], [[2, 1], "completed", 2, 2, 4, [500, 0]]],
+        [[11, 2, 1, 1], [[0, 3], "completed", 0, 1, 2, [600, 0]]],
+        [[11, 4, 0, 0], [[0, 1, 2, 3], "completed", 2, 1, 4, [700, 0, 800, 0]]],
+        [[11, 4, 1, 0], [[3, 2, 1, 0], "completed", 3, 1, 5, [3050, 2900, 0, 0]]],
+        [[22, 2, 0, 0], [[3, 0], "completed", 3, 1, 2, [600, 0]]],
+        [[22, 2, 0, 1], [[1, 2], "completed", 2, 1, 2, [500, 1100]]],
+        [[22, 2, 1, 0], [[2, 0], "completed", 2, 1, 2, [950, 0]]],
+        [[22, 2, 1, 1], [[3, 1], "completed", 3, 1, 3, [750, 550]]],
+        [[22, 4, 0, 0], [[1, 2, 0, 3], "completed", 2, 1, 5, [0, 700, 0, 0]]],
+        [[22, 4, 1, 0], [[0, 2, 1, 3], "completed", 1, 1, 4, [700, 0, 1100, 0]]],
+    ]
+    _dump(out, open(OUT / "tournament_vectors.json", "w"))
+
+
+def gen_h2h():
+    from farkle.analysis import h2h_schedule as h2h
+
+    strategies = grid_oracle4()
+    manifest = build_strategy_manifest(strategies)
+    profile = GameProfile(default_target_score=100, default_max_rounds=200,
+                          h2h_max_rounds_overrides=(H2HMaxRoundsOverride(11, 0, 0, 0, 0), H2HMaxRoundsOverride(11, 1, 0, 0, 0),
+                                                    H2HMaxRoundsOverride(11, 1, 0, 1, 0)))
+    pairs = {0: (0, 1), 1: (0, 3), 2: (1, 3)}
+    blocks = []
+    for pair_id, (a, b) in pairs.items():
+        for root in (11, 22):
+            for order in (0, 1):
+                s1, s2 = (a, b) if order == 0 else (b, a)
+                block = {"pair_id": pair_id, "root_seed": root, "order": order, "seat1_strategy": s1, "seat2_strategy": s2,
+                         "n_completed_required": 1, "max_attempts": 2,
+                         "rng_scheme_version": 2, "rng_purpose_namespace": 203}
+                res = h2h._simulate_block_from_manifest(dict(block), manifest, 5000, profile)
+                blocks.append({**block, "out": [res["games_attempted"], res["games_completed"], res["games_safety_limit"],
+                                                res["wins_seat1"], res["wins_seat2"], res["wins_a"], res["wins_b"],
+                                                res["replacement_attempt_count"], res["completion_status"]]})
+    # bigger blocks on the 64-grid, default limits, incl. a chunked (resumed) block
+    g = grid64()
+    m64 = build_strategy_manifest(g)
+    big = []
+    for pair_id, (a, b), root, order, target, max_att, chunk in [(5, (3, 40), 42, 0, 40, 60, 5000), (5, (3, 40), 42, 1, 40, 60, 5000),
+                                                                  (9, (0, 8), 7, 0, 30, 33, 5000), (2, (17, 63), 1, 1, 25, 50, 7)]:
+        s1, s2 = (a, b) if order == 0 else (b, a)
+        block = {"pair_id": pair_id, "root_seed": root, "order": order, "seat1_strategy": s1, "seat2_strategy": s2,
+                 "n_completed_required": target, "max_attempts": max_att,
+                 "rng_scheme_version": 2, "rng_purpose_namespace": 203}
+        trace = []
+        cur = dict(block)
+        for _ in range(50):
+            cur = h2h._simulate_block_from_manifest(dict(cur), m64, chunk, None)
+            trace.append([cur["games_attempted"], cur["games_completed"], cur["games_safety_limit"], cur["wins_seat1"], cur["wins_seat2"]])
+            if cur["completion_status"] != "partial_resumable":
+                break
+        big.append({**block, "chunk": chunk, "trace": trace, "status": cur["completion_status"]})
+    # EXPECTED_H2H_BLOCKS from tests/helpers/tournament_analysis_oracle.py:65-78
+    expected = [[[0, 11, 0], [2, 1, 1, 1, 0, 1, "complete"]], [[0, 11, 1], [1, 1, 0, 0, 1, 0, "complete"]],
+                [[0, 22, 0], [1, 1, 0, 1, 0, 0, "complete"]], [[0, 22, 1], [1, 1, 0, 0, 1, 0, "complete"]],
+                [[1, 11, 0], [2, 0, 2, 0, 0, 1, "unresolved_nonviable"]], [[1, 11, 1], [1, 1, 0, 0, 1, 0, "complete"]],
+                [[1, 22, 0], [1, 1, 0, 0, 1, 0, "complete"]], [[1, 22, 1], [1, 1, 0, 0, 1, 0, "complete"]],
+                [[2, 11, 0], [1, 1, 0, 1, 0, 0, "complete"]], [[2, 11, 1], [1, 1, 0, 0, 1, 0, "complete"]],
+                [[2, 22, 0], [1, 1, 0, 0, 1, 0, "complete"]], [[2, 22, 1], [1, 1, 0, 0, 1, 0, "complete"]]]
+    _dump({"oracle4": [strat_tuple(s) for s in strategies], "blocks": blocks, "g64_blocks": big,
+               "EXPECTED_H2H_BLOCKS": expected}, open(OUT / "h2h_vectors.json", "w"))
+
+
+def gen_time_path():
+    out = {"random_strategies": [], "many_games": []}
+    for players, seed in [(2, 42), (5, 42), (3, 7), (8, 123456789)]:
+        out["random_strategies"].append({"players": players, "seed": seed,
+                                         "strategies": [strat_tuple(s) for s in make_random_strategies(players, seed)]})
+    # tests/unit/simulation/test_simulation.py:184-199 deterministic-counts KAT
+    strategies = [ThresholdStrategy(score_threshold=0, dice_threshold=6), ThresholdStrategy(score_threshold=500, dice_threshold=3),
+                  ThresholdStrategy(score_threshold=1000, dice_threshold=2)]
+    df = simulate_many_games(n_games=10, strategies=strategies, target_score=5000, seed=123, n_jobs=1)
+    out["kat_counts"] = {"strategies": [strat_tuple(s) for s in strategies], "target": 5000, "seed": 123, "n_games": 10,
+                         "expected": {"P2": 6, "P1": 2, "P3": 2},
+                         "winner_seat_counts": {str(k): int(v) for k, v in df["winner_seat"].value_counts().items()},
+                         "rows": [row_to_compact(r, 3) for r in df.to_dict(orient="records")]}
+    for players, seed, n in [(2, 42, 40), (5, 42, 12)]:
+        strategies = make_random_strategies(players, seed)
+        df = simulate_many_games(n_games=n, strategies=strategies, seed=seed, n_jobs=1)
+        out["many_games"].append({"players": players, "seed": seed, "n_games": n,
+                                  "strategies": [strat_tuple(s) for s in strategies],
+                                  "game_seeds": [int(v) for v in df["game_seed"]],
+                                  "rows": [row_to_compact(r, players) for r in df.to_dict(orient="records")]})
+    _dump(out, open(OUT / "time_path_vectors.json", "w"))
+
+
+def gen_grids():
+    """Grid enumeration order (strategy_id = position): sizes + full tuples for the small grids."""
+    import yaml
+
+    fast = yaml.safe_load(open("/root/reference/configs/fast_config.yaml"))["sim"]
+    keys = ["score_thresholds", "dice_thresholds", "smart_five_opts", "smart_one_opts", "consider_score_opts",
+            "consider_dice_opts", "auto_hot_dice_opts", "run_up_score_opts"]
+    fast_kw = {k: fast[k] for k in keys if k in fast}
+    fast_grid = grid(**fast_kw, include_stop_at=bool(fast.get("include_stop_at", False)),
+                     include_stop_at_heuristic=bool(fast.get("include_stop_at_heuristic", False)))
+    d = grid_default()
+    import hashlib
+
+    digest = hashlib.sha256(json.dumps([strat_tuple(s) for s in d]).encode()).hexdigest()
+    _dump({"fast_kwargs": fast_kw, "fast": [strat_tuple(s) for s in fast_grid], "g64": [strat_tuple(s) for s in grid64()],
+               "oracle4": [strat_tuple(s) for s in grid_oracle4()], "default_size": len(d), "default_sha256": digest,
+               "default_head": [strat_tuple(s) for s in d[:40]], "default_tail": [strat_tuple(s) for s in d[-40:]]},
+              open(OUT / "grid_vectors.json", "w"))
+
+
+if __name__ == "__main__":
+    gen_rng()
+    gen_scoring()
+    gen_games()
+    gen_tournament()
+    gen_h2h()
+    gen_time_path()
+    gen_grids()
+    for p in sorted(OUT.glob("*.json")):
+        print(p.name, p.stat().st_size)

@@ -1,0 +1,255 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import this.
+The product package (``farkle_ii_amd``) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+LIB_PATH = HERE / "liboracle.so"
+
+STRATEGY_DTYPE = np.dtype(
+    [
+        ("score_threshold", "<i4"),
+        ("dice_threshold", "<i4"),
+        ("smart_five", "u1"),
+        ("smart_one", "u1"),
+        ("consider_score", "u1"),
+        ("consider_dice", "u1"),
+        ("require_both", "u1"),
+        ("auto_hot_dice", "u1"),
+        ("run_up_score", "u1"),
+        ("favor_score", "u1"),
+        ("strategy_id", "<i4"),
+    ]
+)
+COORD_DTYPE = np.dtype(
+    [
+        ("purpose", "<u4"),
+        ("pad", "<u4"),
+        ("root_seed", "<u8"),
+        ("k", "<u8"),
+        ("shuffle_index", "<u8"),
+        ("pair_id", "<u8"),
+        ("order", "<u8"),
+        ("game_index", "<u8"),
+        ("seat_index", "<u8"),
+        ("replicate_index", "<u8"),
+    ]
+)
+OVERRIDE_DTYPE = np.dtype(
+    [("root_seed", "<u8"), ("a", "<u8"), ("b", "<u8"), ("k_or_order", "<u4"), ("max_rounds", "<u4")]
+)
+SEAT_FIELDS = [
+    ("score", "<i4"),
+    ("strategy", "<i4"),
+    ("farkles", "<u2"),
+    ("rolls", "<u2"),
+    ("n_turns", "<u2"),
+    ("highest_turn", "<u2"),
+    ("smart_five_uses", "<u2"),
+    ("n_smart_five_dice", "<u2"),
+    ("smart_one_uses", "<u2"),
+    ("n_smart_one_dice", "<u2"),
+    ("hot_dice", "<u2"),
+    ("rank", "u1"),
+    ("hit_max_rounds", "u1"),
+]
+SEAT_DTYPE = np.dtype(SEAT_FIELDS)
+TALLY_COLS = 26
+
+
+def row_dtype(k: int) -> np.dtype:
+    return np.dtype(
+        [("n_rounds", "<u2"), ("status", "u1"), ("winner_seat", "i1"), ("seats", SEAT_DTYPE, (k,))]
+    )
+
+
+assert STRATEGY_DTYPE.itemsize == 20 and COORD_DTYPE.itemsize == 72 and SEAT_DTYPE.itemsize == 28
+assert OVERRIDE_DTYPE.itemsize == 32 and row_dtype(2).itemsize == 60
+
+_lib = None
+
+
+def build() -> None:
+    subprocess.run(["make", "-C", str(HERE), "liboracle.so"], check=True, capture_output=True)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        _lib = C.CDLL(str(LIB_PATH))
+        _lib.fko_coordinate_seed32.restype = C.c_uint32
+        _lib.fko_coordinate_seed64.restype = C.c_uint64
+        _lib.fko_integers.restype = C.c_int64
+        _lib.fko_decide.restype = C.c_int32
+    return _lib
+
+
+def _p(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_strategies(items) -> np.ndarray:
+    """items: iterable of dicts/tuples (score_thr, dice_thr, sf, so, cs, cd, rb, hot, run_up, favor_score[, id])."""
+    items = list(items)
+    out = np.zeros(len(items), dtype=STRATEGY_DTYPE)
+    for i, it in enumerate(items):
+        if isinstance(it, dict):
+            for key, val in it.items():
+                out[i][key] = val
+            if "strategy_id" not in it:
+                out[i]["strategy_id"] = i
+        else:
+            vals = list(it)
+            if len(vals) == 10:
+                vals.append(i)
+            out[i] = tuple(int(v) for v in vals)
+    return out
+
+
+def coord(purpose, root_seed, k=0, shuffle_index=0, pair_id=0, order=0, game_index=0, seat_index=0, replicate_index=0):
+    c = np.zeros(1, dtype=COORD_DTYPE)
+    c[0] = (purpose, 0, root_seed, k, shuffle_index, pair_id, order, game_index, seat_index, replicate_index)
+    return c
+
+
+def coordinate_seed32(c: np.ndarray) -> int:
+    return int(lib().fko_coordinate_seed32(_p(c)))
+
+
+def coordinate_seed64(c: np.ndarray) -> int:
+    return int(lib().fko_coordinate_seed64(_p(c)))
+
+
+def stream64(c: np.ndarray, n: int) -> np.ndarray:
+    out = np.zeros(n, dtype=np.uint64)
+    lib().fko_stream64(_p(c), C.c_int(n), _p(out))
+    return out
+
+
+def dice_stream(c: np.ndarray, sizes) -> np.ndarray:
+    sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+    out = np.zeros(int(sizes.sum()), dtype=np.uint8)
+    lib().fko_dice_stream(_p(c), C.c_int(len(sizes)), _p(sizes), _p(out))
+    return out
+
+
+def permutation(c: np.ndarray, n: int) -> np.ndarray:
+    rng = np.zeros(6, dtype=np.uint64)  # fko_rng is 40 bytes; over-allocate
+    lib().fko_rng_init(_p(rng), _p(c))
+    out = np.zeros(n, dtype=np.int32)
+    lib().fko_permutation(_p(rng), C.c_int32(n), _p(out))
+    return out
+
+
+def evaluate(counts) -> tuple[int, int, int, int]:
+    cts = np.ascontiguousarray(counts, dtype=np.int32)
+    r = [C.c_int32() for _ in range(4)]
+    lib().fko_evaluate(_p(cts), *[C.byref(x) for x in r])
+    return tuple(int(x.value) for x in r)  # type: ignore[return-value]
+
+
+def default_score(faces, turn_score_pre: int, strategy: np.ndarray) -> tuple[int, ...]:
+    f = np.ascontiguousarray(faces, dtype=np.uint8)
+    out = np.zeros(5, dtype=np.int32)
+    lib().fko_default_score(_p(f), C.c_int32(len(f)), C.c_int32(turn_score_pre), _p(strategy), _p(out))
+    return tuple(int(x) for x in out)
+
+
+def decide(strategy: np.ndarray, turn_score, dice_left, has_scored, final_round=False, score_to_beat=0, running_total=0) -> bool:
+    return bool(
+        lib().fko_decide(
+            _p(strategy), C.c_int32(turn_score), C.c_int32(dice_left), C.c_int32(bool(has_scored)),
+            C.c_int32(bool(final_round)), C.c_int32(score_to_beat), C.c_int32(running_total),
+        )
+    )
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        names = {-1: "turn exceeded 1000 rolls", -2: "invalid argument", -3: "counter overflow"}
+        raise OracleError(f"oracle error {rc}: {names.get(rc, '?')}")
+
+
+def play_game(game_coord, table, seat_strategy, target_score=10_000, max_rounds=200) -> np.ndarray:
+    ss = np.ascontiguousarray(seat_strategy, dtype=np.int32)
+    k = len(ss)
+    row = np.zeros(1, dtype=row_dtype(k))
+    _check(lib().fko_play_game(_p(game_coord), _p(table), _p(ss), C.c_int32(k), C.c_int32(target_score), C.c_int32(max_rounds), _p(row)))
+    return row
+
+
+def play_game_scripted(faces, table, seat_strategy, target_score=10_000, max_rounds=200) -> np.ndarray:
+    f = np.ascontiguousarray(faces, dtype=np.uint8)
+    ss = np.ascontiguousarray(seat_strategy, dtype=np.int32)
+    k = len(ss)
+    row = np.zeros(1, dtype=row_dtype(k))
+    _check(lib().fko_play_game_scripted(_p(f), C.c_int32(len(f)), _p(table), _p(ss), C.c_int32(k), C.c_int32(target_score), C.c_int32(max_rounds), _p(row)))
+    return row
+
+
+def play_games(coords, table, seat_strategy, k, target_score=10_000, max_rounds=200, n_threads=1) -> np.ndarray:
+    coords = np.ascontiguousarray(coords, dtype=COORD_DTYPE)
+    ss = np.ascontiguousarray(seat_strategy, dtype=np.int32).reshape(-1)
+    n = len(coords)
+    assert ss.size == n * k
+    rows = np.zeros(n, dtype=row_dtype(k))
+    _check(lib().fko_play_games(_p(coords), C.c_int64(n), _p(table), _p(ss), C.c_int32(k), C.c_int32(target_score), C.c_int32(max_rounds), _p(rows), C.c_int32(n_threads)))
+    return rows
+
+
+def make_overrides(items) -> np.ndarray:
+    items = list(items)
+    out = np.zeros(len(items), dtype=OVERRIDE_DTYPE)
+    for i, it in enumerate(items):
+        out[i] = tuple(it)  # (root_seed, a, b, k_or_order, max_rounds)
+    return out
+
+
+def tournament(table, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=None, target_score=10_000,
+               max_rounds=200, overrides=None, want_rows=False, want_perms=False, want_game_seeds=False, n_threads=1):
+    S = len(table)
+    n_sh = shuffle_end - shuffle_begin
+    spb = n_sh if not shuffles_per_batch else shuffles_per_batch
+    spb = max(spb, 1)
+    n_batches = max((n_sh + spb - 1) // spb, 0)
+    gps = S // k
+    tally = np.zeros((max(n_batches, 1), S, TALLY_COLS), dtype=np.int64)
+    rows = np.zeros(n_sh * gps, dtype=row_dtype(k)) if want_rows else None
+    perms = np.zeros((n_sh, S), dtype=np.int32) if want_perms else None
+    gseeds = np.zeros(n_sh * gps, dtype=np.uint32) if want_game_seeds else None
+    ov = overrides if overrides is not None else np.zeros(0, dtype=OVERRIDE_DTYPE)
+    _check(lib().fko_tournament(_p(table), C.c_int32(S), C.c_int32(k), C.c_uint64(root_seed), C.c_uint64(shuffle_begin),
+                                C.c_uint64(shuffle_end), C.c_uint32(spb), C.c_int32(target_score), C.c_int32(max_rounds),
+                                _p(ov), C.c_int32(len(ov)), _p(tally), _p(rows), _p(perms), _p(gseeds), C.c_int32(n_threads)))
+    return {"tally": tally[:n_batches], "rows": rows, "perms": perms, "game_seeds": gseeds}
+
+
+def h2h_block(seats, root_seed, pair_id, order, target, max_attempts, chunk_games, target_score=10_000, max_rounds=200,
+              overrides=None, state=None) -> np.ndarray:
+    st = np.zeros(5, dtype=np.uint64) if state is None else np.ascontiguousarray(state, dtype=np.uint64).copy()
+    ov = overrides if overrides is not None else np.zeros(0, dtype=OVERRIDE_DTYPE)
+    _check(lib().fko_h2h_block(_p(seats), C.c_uint64(root_seed), C.c_uint64(pair_id), C.c_uint32(order), C.c_uint64(target),
+                               C.c_uint64(max_attempts), C.c_uint64(chunk_games), C.c_int32(target_score), C.c_int32(max_rounds),
+                               _p(ov), C.c_int32(len(ov)), _p(st)))
+    return st
+
+
+def random_strategy(seed: int, k: int, seat_index: int) -> np.ndarray:
+    out = np.zeros(1, dtype=STRATEGY_DTYPE)
+    lib().fko_random_strategy(C.c_uint64(seed), C.c_uint64(k), C.c_uint64(seat_index), _p(out))
+    return out
