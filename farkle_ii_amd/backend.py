@@ -1,0 +1,269 @@
+"""ctypes binding of the C-ABI library (``include/farkle_hip.h`` -> ``farkle_ii_amd/libfarkle_hip.so``).
+
+This is the only door from Python into the simulation: there is no CPU fallback.  If the shared
+library has not been built, or no HIP device is usable, constructing an :class:`Engine` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from .strategies import STRATEGY_DTYPE
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libfarkle_hip.so"
+SRC_DIR = PKG_DIR / "csrc"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+COORD_DTYPE = np.dtype(
+    [("purpose", "<u4"), ("pad", "<u4"), ("root_seed", "<u8"), ("k", "<u8"), ("shuffle_index", "<u8"),
+     ("pair_id", "<u8"), ("order", "<u8"), ("game_index", "<u8"), ("seat_index", "<u8"), ("replicate_index", "<u8")]
+)
+OVERRIDE_DTYPE = np.dtype(
+    [("root_seed", "<u8"), ("a", "<u8"), ("b", "<u8"), ("k_or_order", "<u4"), ("max_rounds", "<u4")]
+)
+SEAT_DTYPE = np.dtype(
+    [("score", "<i4"), ("strategy", "<i4"), ("farkles", "<u2"), ("rolls", "<u2"), ("n_turns", "<u2"),
+     ("highest_turn", "<u2"), ("smart_five_uses", "<u2"), ("n_smart_five_dice", "<u2"), ("smart_one_uses", "<u2"),
+     ("n_smart_one_dice", "<u2"), ("hot_dice", "<u2"), ("rank", "u1"), ("hit_max_rounds", "u1")]
+)
+TALLY_COLS = 26
+# tally columns (run_tournament.py:109-121, 165-195)
+COL_WINS, COL_ATTEMPTED, COL_COMPLETED, COL_SAFETY, COL_SUMS, COL_SQ_SUMS = 0, 1, 2, 3, 4, 15
+
+FK_ERR_ROLL_LIMIT, FK_ERR_ARG, FK_ERR_COUNTER_OVERFLOW, FK_ERR_HIP, FK_ERR_NO_DEVICE = -1, -2, -3, -4, -5
+
+
+def row_dtype(k: int) -> np.dtype:
+    """Structured dtype of one game row: 4-byte header + k 28-byte seat records."""
+    return np.dtype([("n_rounds", "<u2"), ("status", "u1"), ("winner_seat", "i1"), ("seats", SEAT_DTYPE, (k,))])
+
+
+class _DeviceInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("arch", C.c_char * 32), ("compute_units", C.c_int32), ("clock_mhz", C.c_int32),
+                ("wavefront_size", C.c_int32), ("lds_bytes_per_cu", C.c_int32), ("hbm_bytes", C.c_uint64)]
+
+
+class _Timing(C.Structure):
+    _fields_ = [("perm_ms", C.c_float), ("seed_ms", C.c_float), ("play_ms", C.c_float), ("total_ms", C.c_float),
+                ("play_launches", C.c_int32), ("play_block", C.c_int32), ("play_grid", C.c_int32),
+                ("play_lds_bytes", C.c_int32), ("games", C.c_int64)]
+
+
+class FarkleHipError(RuntimeError):
+    """Raised for every non-zero return of the C-ABI; ``code`` is the FK_ERR_* value."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+def hip_sources() -> list[Path]:
+    return [SRC_DIR / "farkle_hip.hip"]
+
+
+def build_library(force: bool = False, verbose: bool = False) -> Path:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    deps = hip_sources() + [SRC_DIR / "fk_device.h", PKG_DIR.parent / "include" / "farkle_hip.h"]
+    if LIB_PATH.exists() and not force and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return LIB_PATH
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(LIB_PATH),
+           *[str(s) for s in hip_sources()]]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(" ".join(cmd))
+        print(res.stdout, res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({res.returncode}): {res.stderr[-2000:]}")
+    return LIB_PATH
+
+
+_EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
+            "fk_tournament_run", "fk_play_games", "fk_h2h_run", "fk_debug_score", "fk_debug_should_continue",
+            "fk_debug_dice", "fk_debug_dice_state"]
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree library; loud failure when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the simulation path)")
+        lib = C.CDLL(str(LIB_PATH))
+        for name in _EXPORTS:
+            getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        lib.fk_last_error.restype = C.c_char_p
+        lib.fk_last_error.argtypes = [C.c_void_p]
+        lib.fk_destroy.restype = None
+        lib.fk_destroy.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def make_overrides(items) -> np.ndarray:
+    """items: (root_seed, a, b, k_or_order, max_rounds) tuples -> fk_override[]."""
+    items = list(items)
+    out = np.zeros(len(items), dtype=OVERRIDE_DTYPE)
+    for i, it in enumerate(items):
+        out[i] = tuple(int(v) for v in it)
+    return out
+
+
+def make_coords(purpose, root_seed, k, shuffle_index=0, pair_id=0, order=0, game_index=0, n: int | None = None) -> np.ndarray:
+    """Broadcast scalars/arrays into an fk_coord[] (seat_index = replicate_index = 0)."""
+    arrs = [np.atleast_1d(np.asarray(v)) for v in (purpose, root_seed, k, shuffle_index, pair_id, order, game_index)]
+    n = max(len(a) for a in arrs) if n is None else n
+    out = np.zeros(n, dtype=COORD_DTYPE)
+    for name, a in zip(("purpose", "root_seed", "k", "shuffle_index", "pair_id", "order", "game_index"), arrs):
+        out[name] = a
+    return out
+
+
+class Engine:
+    """One context (HIP stream + device workspace) on one GPU."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        rc = self._lib.fk_init(C.c_int(device), C.byref(self._ctx))
+        if rc != 0:
+            self._ctx = C.c_void_p()
+            names = {FK_ERR_NO_DEVICE: "no usable HIP device (this engine has no CPU fallback)", FK_ERR_ARG: "bad device ordinal",
+                     FK_ERR_HIP: "HIP runtime failure during fk_init"}
+            raise FarkleHipError(rc, f"fk_init({device}) failed: {names.get(rc, rc)}")
+        self.device = device
+
+    # -- plumbing -------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.fk_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            msg = self._lib.fk_last_error(self._ctx)
+            raise FarkleHipError(rc, (msg or b"").decode() or f"error {rc}")
+
+    def set_option(self, name: str, value: int) -> None:
+        self._check(self._lib.fk_set_option(self._ctx, name.encode(), C.c_int64(int(value))))
+
+    def device_info(self) -> dict:
+        info = _DeviceInfo()
+        self._check(self._lib.fk_get_device_info(self._ctx, C.byref(info)))
+        return {"name": info.name.decode(), "arch": info.arch.decode(), "compute_units": info.compute_units,
+                "clock_mhz": info.clock_mhz, "wavefront_size": info.wavefront_size,
+                "lds_bytes_per_cu": info.lds_bytes_per_cu, "hbm_bytes": int(info.hbm_bytes)}
+
+    def timing(self) -> dict:
+        t = _Timing()
+        self._check(self._lib.fk_get_timing(self._ctx, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in _Timing._fields_}
+
+    # -- hot path ------------------------------------------------------------------------
+    def tournament(self, table: np.ndarray, k: int, root_seed: int, shuffle_begin: int, shuffle_end: int,
+                   shuffles_per_batch: int | None = None, target_score: int = 10_000, max_rounds: int = 200,
+                   overrides: np.ndarray | None = None, want_rows: bool = False, want_perms: bool = False) -> dict:
+        """All games of shuffles ``[shuffle_begin, shuffle_end)``: per-batch tallies (+ rows / permutations)."""
+        table = np.ascontiguousarray(table, dtype=STRATEGY_DTYPE)
+        S = len(table)
+        n_sh = int(shuffle_end) - int(shuffle_begin)
+        spb = n_sh if not shuffles_per_batch else int(shuffles_per_batch)
+        spb = max(spb, 1)
+        n_batches = max((n_sh + spb - 1) // spb, 0)
+        gps = S // k if k > 0 else 0
+        tally = np.zeros((max(n_batches, 1), S, TALLY_COLS), dtype=np.int64)
+        rows = np.zeros(max(n_sh, 0) * gps, dtype=row_dtype(k)) if want_rows else None
+        perms = np.zeros((max(n_sh, 0), S), dtype=np.int32) if want_perms else None
+        ov = overrides if overrides is not None else np.zeros(0, dtype=OVERRIDE_DTYPE)
+        ov = np.ascontiguousarray(ov, dtype=OVERRIDE_DTYPE)
+        self._check(self._lib.fk_tournament_run(
+            self._ctx, _p(table), C.c_int32(S), C.c_int32(k), C.c_uint64(root_seed), C.c_uint64(shuffle_begin),
+            C.c_uint64(shuffle_end), C.c_uint32(spb), C.c_int32(target_score), C.c_int32(max_rounds), _p(ov),
+            C.c_int32(len(ov)), _p(tally), _p(rows), _p(perms)))
+        return {"tally": tally[:n_batches], "rows": rows, "perms": perms}
+
+    def play_games(self, coords: np.ndarray, table: np.ndarray, seat_strategy, k: int, target_score: int = 10_000,
+                   max_rounds: int = 200) -> np.ndarray:
+        coords = np.ascontiguousarray(coords, dtype=COORD_DTYPE)
+        table = np.ascontiguousarray(table, dtype=STRATEGY_DTYPE)
+        ss = np.ascontiguousarray(seat_strategy, dtype=np.int32).reshape(-1)
+        n = len(coords)
+        if ss.size != n * k:
+            raise ValueError("seat_strategy must hold n_games * k entries")
+        rows = np.zeros(n, dtype=row_dtype(k))
+        self._check(self._lib.fk_play_games(self._ctx, _p(coords), C.c_int64(n), _p(table), C.c_int32(len(table)), _p(ss),
+                                            C.c_int32(k), C.c_int32(target_score), C.c_int32(max_rounds), _p(rows)))
+        return rows
+
+    def h2h(self, seats: np.ndarray, root_seed: int, pair_id: int, order: int, target: int, max_attempts: int,
+            chunk_games: int, target_score: int = 10_000, max_rounds: int = 200, overrides: np.ndarray | None = None,
+            state=None) -> np.ndarray:
+        seats = np.ascontiguousarray(seats, dtype=STRATEGY_DTYPE)
+        if len(seats) != 2:
+            raise ValueError("H2H blocks seat exactly two strategies")
+        st = np.zeros(5, dtype=np.uint64) if state is None else np.ascontiguousarray(state, dtype=np.uint64).copy()
+        ov = overrides if overrides is not None else np.zeros(0, dtype=OVERRIDE_DTYPE)
+        ov = np.ascontiguousarray(ov, dtype=OVERRIDE_DTYPE)
+        self._check(self._lib.fk_h2h_run(self._ctx, _p(seats), C.c_uint64(root_seed), C.c_uint64(pair_id), C.c_uint32(order),
+                                         C.c_uint64(target), C.c_uint64(max_attempts), C.c_uint64(chunk_games),
+                                         C.c_int32(target_score), C.c_int32(max_rounds), _p(ov), C.c_int32(len(ov)), _p(st)))
+        return st
+
+    # -- single-op probes ------------------------------------------------------------------
+    def debug_score(self, faces: np.ndarray, lens, pre, strategies: np.ndarray) -> np.ndarray:
+        faces = np.ascontiguousarray(faces, dtype=np.uint8).reshape(-1, 6)
+        n = len(faces)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        pre = np.ascontiguousarray(pre, dtype=np.int32)
+        strategies = np.ascontiguousarray(strategies, dtype=STRATEGY_DTYPE)
+        out = np.zeros((n, 5), dtype=np.int32)
+        self._check(self._lib.fk_debug_score(self._ctx, C.c_int64(n), _p(faces), _p(lens), _p(pre), _p(strategies), _p(out)))
+        return out
+
+    def debug_should_continue(self, args: np.ndarray, strategies: np.ndarray) -> np.ndarray:
+        args = np.ascontiguousarray(args, dtype=np.int32).reshape(-1, 6)
+        strategies = np.ascontiguousarray(strategies, dtype=STRATEGY_DTYPE)
+        out = np.zeros(len(args), dtype=np.int32)
+        self._check(self._lib.fk_debug_should_continue(self._ctx, C.c_int64(len(args)), _p(args), _p(strategies), _p(out)))
+        return out
+
+    def debug_dice(self, coords: np.ndarray, sizes, want_raw: bool = True):
+        coords = np.ascontiguousarray(coords, dtype=COORD_DTYPE)
+        sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+        n = len(coords)
+        faces = np.zeros((n, int(sizes.sum())), dtype=np.uint8)
+        raw = np.zeros((n, 4), dtype=np.uint64) if want_raw else None
+        self._check(self._lib.fk_debug_dice(self._ctx, C.c_int64(n), _p(coords), C.c_int32(len(sizes)), _p(sizes), _p(faces), _p(raw)))
+        return faces, raw
+
+    def debug_dice_state(self, state: np.ndarray, sizes):
+        state = np.ascontiguousarray(state, dtype=np.uint64).reshape(-1, 6)
+        sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+        n = len(state)
+        faces = np.zeros((n, int(sizes.sum())), dtype=np.uint8)
+        out = np.zeros((n, 6), dtype=np.uint64)
+        self._check(self._lib.fk_debug_dice_state(self._ctx, C.c_int64(n), _p(state), C.c_int32(len(sizes)), _p(sizes), _p(faces), _p(out)))
+        return faces, out

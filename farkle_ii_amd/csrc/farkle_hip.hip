@@ -1,0 +1,1286 @@
+// farkle_hip.hip — gfx950 kernels + C-ABI (include/farkle_hip.h) of the Farkle simulation engine.
+//
+// Three kernels per chunk of work, all on the context's stream:
+//   fk_perm_kernel  one lane per shuffle: SeedSequence(ns=101) -> PCG64DXSM -> Fisher-Yates
+//                   (Generator.permutation, run_tournament.py:312-318), written shuffle-minor.
+//   fk_seed_kernel  one lane per game: coordinate -> SeedSequence -> PCG64DXSM (state, inc) of every
+//                   seat (random.py:80-188); fully converged, 32 B per seat to HBM.
+//   fk_play_kernel  persistent lanes, one lane = one game at a time, one roll per loop trip; seat
+//                   contexts in LDS (field-major, conflict free), finished lanes are handed new games
+//                   in wave-level batches; per-strategy tallies privatised in LDS when they fit.
+//
+// No MFMA (integer/table work), no CPU fallback.
+#include "../../include/farkle_hip.h"
+#include "fk_device.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace fk;
+
+// ========================================================================================
+// device side
+// ========================================================================================
+namespace {
+
+constexpr uint32_t HC_AFTER_6_WORDS = ss_hc(24); // 4 + 12 (all pairs) + 2*4 hashmix calls
+
+enum : uint32_t { MODE_PERM = 0, MODE_LIST = 1, MODE_FIXED = 2 };
+
+// LDS seat-context fields (dwords), layout lds[(field * K + seat) * BLOCK + tid]
+enum : uint32_t {
+    F_LO0 = 0, F_LO1, F_HI0, F_HI1, F_INC_LO0, F_INC_LO1, F_INC_HI0, F_INC_HI1,
+    F_BUF, F_SCORE, F_CA, F_CB, F_CC, F_CD, F_CE, F_SPX, F_SPY, NF
+};
+// packed u16 counter pairs
+//   cA = rolls | farkles << 16        cB = highest_turn | n_turns << 16
+//   cC = sf_uses | sf_dice << 16      cD = so_uses | so_dice << 16
+//   cE = hot_dice | flags << 16       flags: bit0 has_scored, bit1 has_buf
+constexpr uint32_t CE_HAS_SCORED = 1u << 16, CE_HAS_BUF = 1u << 17;
+
+constexpr uint32_t LT_COLS = 24; // LDS tally columns: wins, completed, safety, 10 sums, 10 square sums, pad
+constexpr uint32_t TICKET_CHUNK = 64;
+
+struct DevOverride {
+    uint32_t game; // chunk-local game id
+    uint32_t max_rounds;
+};
+
+struct SeedArgs {
+    SeedPool prefix;         // pool after entropy words 0..5 (version, namespace, root, k)
+    const fk_coord *coords;  // LIST mode: explicit coordinates (full SeedSequence per game)
+    uint64_t shuffle0, pair, order, game0;
+    uint32_t gps;            // games per shuffle (affine id -> (shuffle, game)); 0 = no split
+    uint32_t k;
+    uint32_t n_games;
+    uint4 *seeds;            // [n_games][k][2] = {state lo, state hi}, {inc lo, inc hi}
+};
+
+struct PlayArgs {
+    const uint2 *strat;          // [S] packed strategies
+    const uint16_t *perm_T;      // [S][n_sh] shuffle-minor permutations (MODE_PERM)
+    const int32_t *seat_strategy; // [n_games][k] (MODE_LIST)
+    const uint4 *seeds;
+    unsigned long long *tally;   // [n_batches][S][26]
+    uint8_t *rows;               // nullable, [n_games] * (4 + 28k)
+    uint32_t *ticket;
+    int32_t *err;                // [0] code, [1] game id
+    const DevOverride *ov;
+    uint32_t n_ov;
+    uint32_t mode;
+    uint32_t n_games, gps, n_sh, k, S;
+    uint32_t sh_offset, spb;     // batch = (sh_offset + sh_local) / spb
+    int32_t target;
+    uint32_t max_rounds;
+    uint32_t batch_threshold;
+    uint32_t use_lds_tally;
+};
+
+__device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ inline uint32_t mbcnt(uint64_t mask) { // lanes of `mask` below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ inline Strat unpack_strat(uint2 v) { return Strat{(int32_t)v.x, v.y}; }
+
+// ---------------------------------------------------------------------------------------
+__global__ void fk_perm_kernel(SeedPool prefix, uint64_t shuffle0, uint32_t n_sh, uint32_t S, uint16_t *perm_T) {
+    const uint32_t sh = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sh >= n_sh) return;
+    SeedPool p = prefix;
+    p.hc = HC_AFTER_6_WORDS;
+    ss_absorb64(p, shuffle0 + sh); // shuffle_index
+#pragma unroll
+    for (int i = 0; i < 5; ++i) ss_absorb64(p, 0); // pair_id, order, game_index, seat_index, replicate_index
+    uint32_t g8[8];
+    ss_generate<8>(p, g8);
+    Rng r;
+    pcg_seed(r, g8);
+    uint16_t *a = perm_T + sh;
+    for (uint32_t i = 0; i < S; ++i) a[(size_t)i * n_sh] = (uint16_t)i;
+    // Fisher-Yates: for i = S-1 .. 1: j = random_interval(i); swap(a[i], a[j])
+    for (uint32_t i = S - 1u; i >= 1u; --i) {
+        const uint32_t mask = 0xffffffffu >> __clz((int)i);
+        uint32_t j;
+        do {
+            j = pcg_next32(r) & mask;
+        } while (j > i);
+        const uint16_t ai = a[(size_t)i * n_sh], aj = a[(size_t)j * n_sh];
+        a[(size_t)i * n_sh] = aj;
+        a[(size_t)j * n_sh] = ai;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ void fk_seed_kernel(SeedArgs a) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= a.n_games) return;
+    SeedPool gp;
+    uint64_t seat0 = 0, replicate = 0;
+    if (a.coords) {
+        const fk_coord c = a.coords[id];
+        seat0 = c.seat_index;
+        replicate = c.replicate_index;
+        ss_begin(gp, 2u, c.purpose, (uint32_t)c.root_seed, (uint32_t)(c.root_seed >> 32));
+        ss_absorb64(gp, c.k);
+        ss_absorb64(gp, c.shuffle_index);
+        ss_absorb64(gp, c.pair_id);
+        ss_absorb64(gp, c.order);
+        ss_absorb64(gp, c.game_index);
+    } else {
+        gp = a.prefix;
+        gp.hc = HC_AFTER_6_WORDS;
+        uint64_t sh = a.shuffle0, g = a.game0 + id;
+        if (a.gps) {
+            const uint32_t q = id / a.gps;
+            sh = a.shuffle0 + q;
+            g = a.game0 + (id - q * a.gps);
+        }
+        ss_absorb64(gp, sh);
+        ss_absorb64(gp, a.pair);
+        ss_absorb64(gp, a.order);
+        ss_absorb64(gp, g);
+    }
+    for (uint32_t s = 0; s < a.k; ++s) {
+        SeedPool sp = gp;
+        ss_absorb64(sp, seat0 + s); // seat_index
+        ss_absorb64(sp, replicate); // replicate_index
+        uint32_t g8[8];
+        ss_generate<8>(sp, g8);
+        Rng r;
+        pcg_seed(r, g8);
+        uint4 *dst = a.seeds + ((size_t)id * a.k + s) * 2;
+        dst[0] = make_uint4((uint32_t)r.lo, (uint32_t)(r.lo >> 32), (uint32_t)r.hi, (uint32_t)(r.hi >> 32));
+        dst[1] = make_uint4((uint32_t)r.inc_lo, (uint32_t)(r.inc_lo >> 32), (uint32_t)r.inc_hi, (uint32_t)(r.inc_hi >> 32));
+    }
+}
+
+// attempted = completed + safety for every (batch, strategy) row
+__global__ void fk_finalize_tally(unsigned long long *tally, uint32_t n_rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    unsigned long long *t = tally + (size_t)i * FK_TALLY_COLS;
+    t[1] = t[2] + t[3];
+}
+
+// ---------------------------------------------------------------------------------------
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t K = a.k;
+    const uint32_t fstride = K * BLOCK; // dwords between fields
+    unsigned long long *tl = reinterpret_cast<unsigned long long *>(lds + NF * fstride);
+
+    if (a.use_lds_tally) {
+        for (uint32_t i = tid; i < a.S * LT_COLS; i += BLOCK) tl[i] = 0ull;
+        __syncthreads();
+    }
+
+    enum : uint32_t { ST_FRESH = 0, ST_ACTIVE = 1, ST_ENDED = 2, ST_DONE = 3 };
+    uint32_t st = ST_FRESH;
+    uint32_t pool_next = 0, pool_end = 0, exhausted = 0; // wave-uniform ticket pool
+
+    // game registers
+    uint32_t game_id = 0, seat = 0, rounds = 0, max_rounds = 0, trigger = 0;
+    uint32_t final_round = 0, safety = 0;
+    int32_t score_to_beat = 0;
+    // turn registers
+    uint32_t dice = 6, rolls_this_turn = 0;
+    int32_t turn_score = 0;
+    // seat context
+    Rng rng{};
+    int32_t score = 0;
+    uint32_t cA = 0, cB = 0, cC = 0, cD = 0, cE = 0;
+    Strat sp{0, 0};
+
+    auto L = [&](uint32_t field, uint32_t s) -> uint32_t & { return lds[field * fstride + s * BLOCK + tid]; };
+
+    auto strategy_index = [&](uint32_t id, uint32_t s) -> uint32_t {
+        if (a.mode == MODE_PERM) {
+            const uint32_t sh = id / a.gps, g = id - sh * a.gps;
+            return a.perm_T[(size_t)(g * K + s) * a.n_sh + sh];
+        }
+        if (a.mode == MODE_LIST) return (uint32_t)a.seat_strategy[(size_t)id * K + s];
+        return s;
+    };
+
+    auto begin_turn = [&](uint32_t s) {
+        rng.lo = (uint64_t)L(F_LO0, s) | ((uint64_t)L(F_LO1, s) << 32);
+        rng.hi = (uint64_t)L(F_HI0, s) | ((uint64_t)L(F_HI1, s) << 32);
+        rng.inc_lo = (uint64_t)L(F_INC_LO0, s) | ((uint64_t)L(F_INC_LO1, s) << 32);
+        rng.inc_hi = (uint64_t)L(F_INC_HI0, s) | ((uint64_t)L(F_INC_HI1, s) << 32);
+        rng.buf = L(F_BUF, s);
+        score = (int32_t)L(F_SCORE, s);
+        cA = L(F_CA, s);
+        cB = L(F_CB, s) + 0x10000u; // n_turns += 1 (engine.py:236)
+        cC = L(F_CC, s);
+        cD = L(F_CD, s);
+        cE = L(F_CE, s);
+        rng.has_buf = (cE & CE_HAS_BUF) ? 1u : 0u;
+        sp.score_thr = (int32_t)L(F_SPX, s);
+        sp.bits = L(F_SPY, s);
+        dice = 6;
+        turn_score = 0;
+        rolls_this_turn = 0;
+    };
+
+    auto store_turn = [&](uint32_t s) {
+        L(F_LO0, s) = (uint32_t)rng.lo;
+        L(F_LO1, s) = (uint32_t)(rng.lo >> 32);
+        L(F_HI0, s) = (uint32_t)rng.hi;
+        L(F_HI1, s) = (uint32_t)(rng.hi >> 32);
+        L(F_BUF, s) = rng.buf;
+        L(F_SCORE, s) = (uint32_t)score;
+        L(F_CA, s) = cA;
+        L(F_CB, s) = cB;
+        L(F_CC, s) = cC;
+        L(F_CD, s) = cD;
+        L(F_CE, s) = (cE & ~CE_HAS_BUF) | (rng.has_buf ? CE_HAS_BUF : 0u);
+    };
+
+    auto raise = [&](int32_t code) {
+        if (atomicCAS(&a.err[0], 0, code) == 0) a.err[1] = (int32_t)game_id;
+        st = ST_DONE;
+    };
+
+    // ---- finished game -> tallies / row (run_tournament.py:375-391, simulation.py:628-655) ----
+    auto finish_game = [&]() {
+        const bool completed = (safety == 0u);
+        uint32_t w = 0;
+        int32_t best = (int32_t)L(F_SCORE, 0);
+        for (uint32_t s = 1; s < K; ++s) { // stable sort on score desc: first maximum wins (engine.py:477)
+            const int32_t sc = (int32_t)L(F_SCORE, s);
+            if (sc > best) {
+                best = sc;
+                w = s;
+            }
+        }
+        uint32_t batch = 0;
+        if (a.mode == MODE_PERM) batch = (a.sh_offset + game_id / a.gps) / a.spb;
+        uint32_t widx = 0;
+        for (uint32_t s = 0; s < K; ++s) {
+            const uint32_t idx = strategy_index(game_id, s);
+            if (s == w) widx = idx;
+            if (a.use_lds_tally) atomicAdd(&tl[idx * LT_COLS + (completed ? 1u : 2u)], 1ull);
+            else atomicAdd(&a.tally[((size_t)batch * a.S + idx) * FK_TALLY_COLS + (completed ? 2u : 3u)], 1ull);
+        }
+        if (completed) {
+            const uint32_t wa = L(F_CA, w), wb = L(F_CB, w), wc = L(F_CC, w), wd = L(F_CD, w), we = L(F_CE, w);
+            const unsigned long long m[10] = {(unsigned long long)(uint32_t)best, rounds, wa >> 16, wa & 0xffffu,
+                                              wb & 0xffffu, wc & 0xffffu, wc >> 16, wd & 0xffffu, wd >> 16, we & 0xffffu};
+            if (a.use_lds_tally) {
+                unsigned long long *t = tl + widx * LT_COLS;
+                atomicAdd(&t[0], 1ull);
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    atomicAdd(&t[3 + j], m[j]);
+                    atomicAdd(&t[13 + j], m[j] * m[j]);
+                }
+            } else {
+                unsigned long long *t = a.tally + ((size_t)batch * a.S + widx) * FK_TALLY_COLS;
+                atomicAdd(&t[0], 1ull);
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    atomicAdd(&t[4 + j], m[j]);
+                    atomicAdd(&t[15 + j], m[j] * m[j]);
+                }
+            }
+        }
+        if (a.rows) {
+            const size_t row_bytes = sizeof(fk_row_hdr) + sizeof(fk_seat) * (size_t)K;
+            uint8_t *row = a.rows + (size_t)game_id * row_bytes;
+            fk_row_hdr hdr;
+            hdr.n_rounds = (uint16_t)rounds;
+            hdr.status = completed ? FK_COMPLETED : FK_SAFETY_LIMIT;
+            hdr.winner_seat = completed ? (int8_t)w : (int8_t)-1;
+            *reinterpret_cast<fk_row_hdr *>(row) = hdr;
+            for (uint32_t s = 0; s < K; ++s) {
+                const int32_t sc = (int32_t)L(F_SCORE, s);
+                uint32_t rank = 0;
+                if (completed) {
+                    rank = 1;
+                    for (uint32_t j = 0; j < K; ++j) {
+                        const int32_t o = (int32_t)L(F_SCORE, j);
+                        rank += (o > sc || (o == sc && j < s)) ? 1u : 0u;
+                    }
+                }
+                const uint32_t xa = L(F_CA, s), xb = L(F_CB, s), xc = L(F_CC, s), xd = L(F_CD, s), xe = L(F_CE, s);
+                uint32_t *d = reinterpret_cast<uint32_t *>(row + sizeof(fk_row_hdr) + sizeof(fk_seat) * s);
+                d[0] = (uint32_t)sc;
+                d[1] = strategy_index(game_id, s);
+                d[2] = (xa >> 16) | (xa << 16);                    // farkles, rolls
+                d[3] = (xb >> 16) | (xb << 16);                    // n_turns, highest_turn
+                d[4] = xc;                                         // sf_uses, sf_dice
+                d[5] = xd;                                         // so_uses, so_dice
+                d[6] = (xe & 0xffffu) | (rank << 16) | ((completed ? 0u : 1u) << 24); // hot_dice, rank, hit_max_rounds
+            }
+        }
+    };
+
+    // ---- fresh game for this lane ----
+    auto init_game = [&](uint32_t id) {
+        game_id = id;
+        max_rounds = a.max_rounds;
+        for (uint32_t i = 0; i < a.n_ov; ++i)
+            if (a.ov[i].game == id) max_rounds = a.ov[i].max_rounds;
+        for (uint32_t s = 0; s < K; ++s) {
+            const uint2 pk = a.strat[strategy_index(id, s)];
+            const uint4 *src = a.seeds + ((size_t)id * K + s) * 2;
+            const uint4 stv = src[0], inc = src[1];
+            L(F_LO0, s) = stv.x;
+            L(F_LO1, s) = stv.y;
+            L(F_HI0, s) = stv.z;
+            L(F_HI1, s) = stv.w;
+            L(F_INC_LO0, s) = inc.x;
+            L(F_INC_LO1, s) = inc.y;
+            L(F_INC_HI0, s) = inc.z;
+            L(F_INC_HI1, s) = inc.w;
+            L(F_BUF, s) = 0u;
+            L(F_SCORE, s) = 0u;
+            L(F_CA, s) = 0u;
+            L(F_CB, s) = 0u;
+            L(F_CC, s) = 0u;
+            L(F_CD, s) = 0u;
+            L(F_CE, s) = 0u;
+            L(F_SPX, s) = pk.x;
+            L(F_SPY, s) = pk.y;
+        }
+        seat = 0;
+        trigger = 0;
+        final_round = 0;
+        safety = 0;
+        score_to_beat = a.target; // engine.py:451
+        if (max_rounds == 0u) {   // `while rounds < max_rounds` never entered (engine.py:453)
+            rounds = 0;
+            safety = 1;
+            st = ST_ENDED;
+        } else {
+            rounds = 1;
+            begin_turn(0);
+            st = ST_ACTIVE;
+        }
+    };
+
+    // ---- end of a turn: bank, write back, advance the table (engine.py:265-273, 453-472, 523-550) ----
+    auto end_turn = [&]() {
+        if (!(cE & CE_HAS_SCORED) && turn_score >= 500) cE |= CE_HAS_SCORED;
+        if (cE & CE_HAS_SCORED) {
+            score += turn_score;
+            if ((uint32_t)turn_score > (cB & 0xffffu)) cB = (cB & 0xffff0000u) | (uint32_t)turn_score;
+        }
+        // u16 guard bands (a turn adds <= 1000 rolls / <= 2000 discarded dice)
+        if ((cA & 0xffffu) > 64000u || (cC >> 16) > 63000u || (cD >> 16) > 63000u) {
+            raise(FK_ERR_COUNTER_OVERFLOW);
+            return;
+        }
+        store_turn(seat);
+        uint32_t next;
+        bool ended = false;
+        if (!final_round) {
+            if (score >= a.target) { // first trigger starts the final round (engine.py:462-468)
+                final_round = 1;
+                score_to_beat = score;
+                trigger = seat;
+                next = (seat == 0u) ? 1u : 0u;
+            } else {
+                next = seat + 1u;
+                if (next == K) {
+                    if (rounds >= max_rounds) { // engine.py:453, 472
+                        safety = 1;
+                        ended = true;
+                    } else {
+                        rounds += 1u;
+                        next = 0u;
+                    }
+                }
+            }
+        } else {
+            if (score > score_to_beat) score_to_beat = score; // engine.py:547
+            next = seat + 1u;
+            if (next == trigger) next += 1u;
+        }
+        if (final_round && next >= K) ended = true;
+        if (ended) {
+            st = ST_ENDED;
+        } else {
+            seat = next;
+            begin_turn(seat);
+        }
+    };
+
+    // ---- one roll of the current turn (engine.py:241-263) ----
+    auto roll_step = [&]() {
+        if (rolls_this_turn >= 1000u) { // ROLL_LIMIT, engine.py:36,242
+            raise(FK_ERR_ROLL_LIMIT);
+            return;
+        }
+        const uint32_t n = dice;
+        const uint32_t counts = roll_counts(rng, n);
+        cA += 1u; // n_rolls (engine.py:98)
+        rolls_this_turn += 1u;
+        const RollResult rr = default_score(counts, (int32_t)n, turn_score, sp);
+        bool turn_over;
+        if (rr.score == 0) { // farkle (engine.py:135-137, 247-249)
+            cA += 0x10000u;
+            turn_score = 0;
+            turn_over = true;
+        } else {
+            if (rr.d5 > 0) cC += 1u + ((uint32_t)rr.d5 << 16); // engine.py:139-144
+            if (rr.d1 > 0) cD += 1u + ((uint32_t)rr.d1 << 16);
+            dice = (rr.used == (int32_t)n) ? 6u : (n - (uint32_t)rr.used); // engine.py:146
+            turn_score += rr.score;
+            if (turn_score > 0xffff) {
+                raise(FK_ERR_COUNTER_OVERFLOW);
+                return;
+            }
+            if (sp.has(SF_AUTO_HOT) && dice == 6u) { // _apply_hot_dice, engine.py:149-154, 253
+                cE += 1u;
+                turn_over = false;
+            } else {
+                turn_over = !should_continue(sp, turn_score, (int32_t)dice, (cE & CE_HAS_SCORED) != 0u,
+                                             final_round != 0u, score_to_beat, score);
+            }
+        }
+        if (turn_over) end_turn();
+    };
+
+    // ---- wave-level hand-over: finish ended games, deal new tickets ----
+    auto handover = [&](uint64_t waiting) {
+        const bool mine = (st == ST_FRESH || st == ST_ENDED);
+        if (st == ST_ENDED) finish_game();
+        const uint32_t n = (uint32_t)__popcll(waiting);
+        const uint32_t avail = pool_end - pool_next;
+        uint32_t new_base = 0, new_avail = 0;
+        if (avail < n && !exhausted) {
+            uint32_t base = 0;
+            if (mine && lane_id() == (uint32_t)(__ffsll((long long)waiting) - 1)) base = atomicAdd(a.ticket, TICKET_CHUNK);
+            base = (uint32_t)__shfl((int)base, __ffsll((long long)waiting) - 1);
+            if (base >= a.n_games) {
+                exhausted = 1;
+            } else {
+                new_base = base;
+                new_avail = min(TICKET_CHUNK, a.n_games - base);
+                if (new_avail < TICKET_CHUNK) exhausted = 1;
+            }
+        }
+        if (mine) {
+            const uint32_t rank = mbcnt(waiting);
+            if (rank < avail) init_game(pool_next + rank);
+            else if (rank - avail < new_avail) init_game(new_base + (rank - avail));
+            else st = ST_DONE;
+        }
+        if (n <= avail) {
+            pool_next += n;
+        } else {
+            const uint32_t used_new = min(n - avail, new_avail);
+            pool_next = new_base + used_new;
+            pool_end = new_base + new_avail;
+        }
+    };
+
+    while (true) {
+        const uint64_t waiting = __ballot(st == ST_FRESH || st == ST_ENDED);
+        const uint64_t active = __ballot(st == ST_ACTIVE);
+        if (!waiting && !active) break;
+        if (waiting && ((uint32_t)__popcll(waiting) >= a.batch_threshold || !active || exhausted)) {
+            handover(waiting);
+            continue;
+        }
+        if (st == ST_ACTIVE) roll_step();
+    }
+
+    if (a.use_lds_tally) {
+        __syncthreads();
+        for (uint32_t i = tid; i < a.S * LT_COLS; i += BLOCK) {
+            const unsigned long long v = tl[i];
+            if (v == 0ull) continue;
+            const uint32_t idx = i / LT_COLS, c = i - idx * LT_COLS;
+            if (c == LT_COLS - 1u) continue;
+            const uint32_t col = (c == 0u) ? 0u : (c == 1u) ? 2u : (c == 2u) ? 3u : (c < 13u) ? (c + 1u) : (c + 2u);
+            atomicAdd(&a.tally[(size_t)idx * FK_TALLY_COLS + col], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// single-op probes (parity tests of the device functions above)
+// ---------------------------------------------------------------------------------------
+__device__ inline uint32_t pack_faces(const uint8_t *f, int32_t n) {
+    uint32_t c = 0;
+    for (int32_t i = 0; i < n; ++i) c += 1u << (4u * (uint32_t)(f[i] - 1));
+    return c;
+}
+
+__global__ void fk_dbg_score_kernel(int64_t n, const uint8_t *faces, const int32_t *len, const int32_t *pre,
+                                    const uint2 *strat, int32_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Strat s = unpack_strat(strat[i]);
+    const RollResult r = default_score(pack_faces(faces + i * 6, len[i]), len[i], pre[i], s);
+    out[i * 5 + 0] = r.score;
+    out[i * 5 + 1] = r.used;
+    out[i * 5 + 2] = len[i] - r.used;
+    out[i * 5 + 3] = r.d5;
+    out[i * 5 + 4] = r.d1;
+}
+
+__global__ void fk_dbg_continue_kernel(int64_t n, const int32_t *args, const uint2 *strat, int32_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t *g = args + i * 6;
+    out[i] = should_continue(unpack_strat(strat[i]), g[0], g[1], g[2] != 0, g[3] != 0, g[4], g[5]) ? 1 : 0;
+}
+
+__global__ void fk_dbg_dice_kernel(int64_t n, const uint4 *seeds, const uint64_t *state_in, int32_t n_calls,
+                                   const int32_t *sizes, int32_t total, uint8_t *faces, uint64_t *raw64,
+                                   uint64_t *state_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng r;
+    if (seeds) {
+        const uint4 s = seeds[i * 2], c = seeds[i * 2 + 1];
+        r.lo = (uint64_t)s.x | ((uint64_t)s.y << 32);
+        r.hi = (uint64_t)s.z | ((uint64_t)s.w << 32);
+        r.inc_lo = (uint64_t)c.x | ((uint64_t)c.y << 32);
+        r.inc_hi = (uint64_t)c.z | ((uint64_t)c.w << 32);
+        r.buf = 0;
+        r.has_buf = 0;
+    } else {
+        const uint64_t *s = state_in + i * 6;
+        r.hi = s[0];
+        r.lo = s[1];
+        r.inc_hi = s[2];
+        r.inc_lo = s[3];
+        r.has_buf = (uint32_t)s[4];
+        r.buf = (uint32_t)s[5];
+    }
+    if (raw64) {
+        Rng t = r;
+        for (int j = 0; j < 4; ++j) raw64[i * 4 + j] = pcg_next64(t);
+    }
+    uint8_t *f = faces + i * total;
+    for (int32_t c = 0; c < n_calls; ++c) {
+        uint32_t packed = 0;
+        roll_counts(r, (uint32_t)sizes[c], &packed);
+        for (int32_t j = 0; j < sizes[c]; ++j) *f++ = (uint8_t)((packed >> (4 * j)) & 0xfu);
+    }
+    if (state_out) {
+        uint64_t *s = state_out + i * 6;
+        s[0] = r.hi;
+        s[1] = r.lo;
+        s[2] = r.inc_hi;
+        s[3] = r.inc_lo;
+        s[4] = r.has_buf;
+        s[5] = r.buf;
+    }
+}
+
+} // namespace
+
+// ========================================================================================
+// host side
+// ========================================================================================
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct fk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+    std::string err;
+    fk_timing timing{};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, dbg[6];
+    int64_t chunk_bytes = (int64_t)24 << 30;
+    int32_t batch_threshold = 6;
+    int32_t use_lds_tally = -1;
+    int32_t block = 0;
+};
+
+namespace {
+
+int fail(fk_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) return fail((c), FK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure(fk_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return FK_OK;
+    if (b.p) HIPCHK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = std::max<size_t>(bytes, 256);
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return FK_OK;
+}
+
+void release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+uint2 pack_strategy(const fk_strategy &s) {
+    uint32_t bits = (uint32_t)(uint8_t)(int8_t)s.dice_threshold;
+    if (s.smart_five) bits |= SF_SMART_FIVE;
+    if (s.smart_one) bits |= SF_SMART_ONE;
+    if (s.consider_score) bits |= SF_CONSIDER_SCORE;
+    if (s.consider_dice) bits |= SF_CONSIDER_DICE;
+    if (s.require_both) bits |= SF_REQUIRE_BOTH;
+    if (s.auto_hot_dice) bits |= SF_AUTO_HOT;
+    if (s.run_up_score) bits |= SF_RUN_UP;
+    if (s.favor_score) bits |= SF_FAVOR_SCORE;
+    return make_uint2((uint32_t)s.score_threshold, bits);
+}
+
+int validate_strategies(fk_ctx *c, const fk_strategy *s, int32_t S) {
+    for (int32_t i = 0; i < S; ++i) {
+        if (s[i].dice_threshold < -128 || s[i].dice_threshold > 127)
+            return fail(c, FK_ERR_ARG, "strategy %d: dice_threshold %d outside [-128, 127]", i, s[i].dice_threshold);
+        if (s[i].smart_one && !s[i].smart_five) // strategies.py:198
+            return fail(c, FK_ERR_ARG, "strategy %d: smart_one requires smart_five", i);
+        if (s[i].require_both && !(s[i].consider_score && s[i].consider_dice)) // strategies.py:202
+            return fail(c, FK_ERR_ARG, "strategy %d: require_both requires consider_score and consider_dice", i);
+    }
+    return FK_OK;
+}
+
+int upload_strategies(fk_ctx *c, const fk_strategy *s, int32_t S) {
+    int rc = validate_strategies(c, s, S);
+    if (rc) return rc;
+    std::vector<uint2> packed((size_t)S);
+    for (int32_t i = 0; i < S; ++i) packed[(size_t)i] = pack_strategy(s[i]);
+    rc = ensure(c, c->strat, sizeof(uint2) * (size_t)S);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->strat.p, packed.data(), sizeof(uint2) * (size_t)S, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // `packed` goes out of scope
+    return FK_OK;
+}
+
+SeedPool seed_prefix(uint32_t purpose, uint64_t root_seed, uint64_t k) {
+    SeedPool p;
+    ss_begin(p, 2u /* RNG_SCHEME_VERSION */, purpose, (uint32_t)root_seed, (uint32_t)(root_seed >> 32));
+    ss_absorb64(p, k);
+    return p;
+}
+
+struct LaunchPlan {
+    int block = 0, grid = 0;
+    size_t lds = 0;
+    bool lds_tally = false;
+};
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+LaunchPlan plan_play(const fk_ctx *c, int32_t k, int32_t S, bool single_batch) {
+    LaunchPlan p;
+    const size_t per_lane = (size_t)NF * 4 * (size_t)k;
+    const size_t tally_bytes = (size_t)S * LT_COLS * 8;
+    int block = c->block;
+    if (block == 0) {
+        for (int b : {1024, 512, 256, 128, 64}) {
+            if (per_lane * (size_t)b <= LDS_LIMIT) {
+                block = b;
+                break;
+            }
+        }
+        if (block == 0) block = 64;
+        // prefer a block that leaves room for the privatised tally
+        if (single_batch && c->use_lds_tally != 0 && per_lane * (size_t)block + tally_bytes > LDS_LIMIT && block > 256 &&
+            per_lane * (size_t)(block / 2) + tally_bytes <= LDS_LIMIT)
+            block /= 2;
+    }
+    p.block = block;
+    size_t seat_bytes = per_lane * (size_t)block;
+    bool want = single_batch && (c->use_lds_tally != 0);
+    p.lds_tally = want && (seat_bytes + tally_bytes <= LDS_LIMIT);
+    p.lds = seat_bytes + (p.lds_tally ? tally_bytes : 0);
+    int per_cu = (int)std::max<size_t>(1, LDS_LIMIT / std::max<size_t>(p.lds, 1));
+    per_cu = std::min(per_cu, 2048 / block);
+    per_cu = std::max(per_cu, 1);
+    p.grid = c->prop.multiProcessorCount * per_cu;
+    return p;
+}
+
+template <int BLOCK>
+hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fk_play_kernel<BLOCK>, dim3((unsigned)p.grid), dim3(BLOCK), p.lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
+    switch (p.block) {
+    case 1024: return launch_play_t<1024>(p, a, s);
+    case 512: return launch_play_t<512>(p, a, s);
+    case 256: return launch_play_t<256>(p, a, s);
+    case 128: return launch_play_t<128>(p, a, s);
+    default: return launch_play_t<64>(p, a, s);
+    }
+}
+
+struct Timer {
+    fk_ctx *c;
+    float *acc;
+    hipEvent_t a, b;
+    Timer(fk_ctx *ctx, float *dst, int slot) : c(ctx), acc(dst), a(ctx->ev[slot]), b(ctx->ev[slot + 1]) {
+        (void)hipEventRecord(a, c->stream);
+    }
+    void stop() { (void)hipEventRecord(b, c->stream); }
+    hipError_t collect() {
+        hipError_t e = hipEventSynchronize(b);
+        if (e != hipSuccess) return e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, a, b);
+        if (e == hipSuccess) *acc += ms;
+        return e;
+    }
+};
+
+int check_device_error(fk_ctx *c, const int32_t *d_err, int64_t game_base, const char *what) {
+    int32_t h[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(h, d_err, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h[0] == FK_ERR_ROLL_LIMIT)
+        return fail(c, FK_ERR_ROLL_LIMIT, "Turn exceeded 1000 rolls - aborting. (%s game %lld)", what,
+                    (long long)(game_base + h[1]));
+    if (h[0] == FK_ERR_COUNTER_OVERFLOW)
+        return fail(c, FK_ERR_COUNTER_OVERFLOW, "per-seat u16 counter left its guarded range (%s game %lld)", what,
+                    (long long)(game_base + h[1]));
+    if (h[0] != 0) return fail(c, h[0], "device error %d (%s game %lld)", h[0], what, (long long)(game_base + h[1]));
+    return FK_OK;
+}
+
+// Run seeds + games for `n_games` games whose seeds/strategy sources are already described by the args.
+int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &plan, int64_t game_base, const char *what) {
+    SeedArgs sa = sa_in;
+    int rc = ensure(c, c->seeds, (size_t)sa.n_games * sa.k * 32);
+    if (rc) return rc;
+    rc = ensure(c, c->misc, 64);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 64, c->stream));
+    sa.seeds = static_cast<uint4 *>(c->seeds.p);
+    {
+        Timer t(c, &c->timing.seed_ms, 0);
+        hipLaunchKernelGGL(fk_seed_kernel, dim3((sa.n_games + 255u) / 256u), dim3(256), 0, c->stream, sa);
+        t.stop();
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, t.collect());
+    }
+    pa.seeds = sa.seeds;
+    pa.ticket = static_cast<uint32_t *>(c->misc.p);
+    pa.err = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(c->misc.p) + 16);
+    pa.batch_threshold = (uint32_t)std::max(1, std::min(64, c->batch_threshold));
+    pa.use_lds_tally = plan.lds_tally ? 1u : 0u;
+    {
+        Timer t(c, &c->timing.play_ms, 2);
+        hipError_t e = launch_play(plan, pa, c->stream);
+        t.stop();
+        HIPCHK(c, e);
+        HIPCHK(c, t.collect());
+    }
+    c->timing.play_launches += 1;
+    c->timing.play_block = plan.block;
+    c->timing.play_grid = plan.grid;
+    c->timing.play_lds_bytes = (int32_t)plan.lds;
+    c->timing.games += sa.n_games;
+    return check_device_error(c, pa.err, game_base, what);
+}
+
+} // namespace
+
+extern "C" {
+
+int fk_init(int device_ordinal, fk_ctx **out) {
+    if (!out) return FK_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FK_ERR_NO_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= n) return FK_ERR_ARG;
+    fk_ctx *c = new fk_ctx();
+    c->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&c->prop, device_ordinal) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return FK_ERR_HIP;
+    }
+    for (auto &e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete c;
+            return FK_ERR_HIP;
+        }
+    *out = c;
+    return FK_OK;
+}
+
+void fk_destroy(fk_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->strat, &c->perm, &c->seeds, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist, &c->coords})
+        release(*b);
+    for (auto &b : c->dbg) release(b);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *fk_last_error(fk_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int fk_get_device_info(fk_ctx *c, fk_device_info *out) {
+    if (!c || !out) return FK_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", c->prop.name);
+    snprintf(out->arch, sizeof(out->arch), "%s", c->prop.gcnArchName);
+    out->compute_units = c->prop.multiProcessorCount;
+    out->clock_mhz = c->prop.clockRate / 1000;
+    out->wavefront_size = c->prop.warpSize;
+    out->lds_bytes_per_cu = (int32_t)c->prop.maxSharedMemoryPerMultiProcessor;
+    out->hbm_bytes = c->prop.totalGlobalMem;
+    return FK_OK;
+}
+
+int fk_get_timing(fk_ctx *c, fk_timing *out) {
+    if (!c || !out) return FK_ERR_ARG;
+    *out = c->timing;
+    return FK_OK;
+}
+
+int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return FK_ERR_ARG;
+    std::string n(name);
+    if (n == "chunk_bytes") c->chunk_bytes = std::max<int64_t>(value, 1 << 20);
+    else if (n == "batch_threshold") c->batch_threshold = (int32_t)value;
+    else if (n == "use_lds_tally") c->use_lds_tally = (int32_t)value;
+    else if (n == "block") {
+        if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
+            return fail(c, FK_ERR_ARG, "block must be 0, 64, 128, 256, 512 or 1024");
+        c->block = (int32_t)value;
+    } else return fail(c, FK_ERR_ARG, "unknown option %s", name);
+    return FK_OK;
+}
+
+int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                      uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
+                      int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms) {
+    if (!c) return FK_ERR_ARG;
+    if (!strategies || !tally) return fail(c, FK_ERR_ARG, "strategies and tally are required");
+    if (k < 1 || S < k || S % k != 0) return fail(c, FK_ERR_ARG, "n_players must divide %d", S); // run_tournament.py:274
+    if (S > 65535) return fail(c, FK_ERR_ARG, "S=%d exceeds 65535 strategies", S);
+    if (max_rounds < 0 || max_rounds > 65535) return fail(c, FK_ERR_ARG, "max_rounds must be in [0, 65535]");
+    if (shuffle_end < shuffle_begin || shuffles_per_batch == 0) return fail(c, FK_ERR_ARG, "bad shuffle range / batch size");
+    if (n_ov < 0 || (n_ov > 0 && !ov)) return fail(c, FK_ERR_ARG, "bad override list");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->timing = fk_timing{};
+
+    const uint64_t n_sh_total = shuffle_end - shuffle_begin;
+    const uint32_t gps = (uint32_t)(S / k);
+    const uint64_t n_batches = (n_sh_total + shuffles_per_batch - 1) / shuffles_per_batch;
+    const size_t tally_bytes = sizeof(int64_t) * (size_t)n_batches * (size_t)S * FK_TALLY_COLS;
+    if (n_sh_total == 0) return FK_OK;
+    const size_t row_bytes = sizeof(fk_row_hdr) + sizeof(fk_seat) * (size_t)k;
+
+    int rc = upload_strategies(c, strategies, S);
+    if (rc) return rc;
+    rc = ensure(c, c->tally, tally_bytes);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->tally.p, 0, tally_bytes, c->stream));
+
+    // chunk planning: whole shuffles per chunk inside the workspace budget
+    const size_t bytes_per_shuffle = (size_t)S * 2 + (size_t)gps * k * 32 + (rows ? (size_t)gps * row_bytes : 0);
+    uint64_t chunk_sh = std::max<uint64_t>(1, (uint64_t)c->chunk_bytes / bytes_per_shuffle);
+    chunk_sh = std::min<uint64_t>(chunk_sh, (uint64_t)0x7fffffff / gps);
+    chunk_sh = std::min<uint64_t>(chunk_sh, n_sh_total);
+
+    const LaunchPlan plan = plan_play(c, k, S, n_batches == 1);
+    const SeedPool perm_prefix = seed_prefix(101u /* SHUFFLE_PERMUTATION */, root_seed, (uint64_t)k);
+    const SeedPool seat_prefix = seed_prefix(103u /* TOURNAMENT_PLAYER */, root_seed, (uint64_t)k);
+
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    HIPCHK(c, hipEventCreate(&t0));
+    HIPCHK(c, hipEventCreate(&t1));
+    HIPCHK(c, hipEventRecord(t0, c->stream));
+
+    std::vector<uint16_t> perm_host;
+    for (uint64_t done = 0; done < n_sh_total; done += chunk_sh) {
+        const uint32_t n_sh = (uint32_t)std::min<uint64_t>(chunk_sh, n_sh_total - done);
+        const uint64_t sh0 = shuffle_begin + done;
+        const uint32_t n_games = n_sh * gps;
+
+        rc = ensure(c, c->perm, (size_t)S * n_sh * 2);
+        if (rc) return rc;
+        {
+            Timer t(c, &c->timing.perm_ms, 0);
+            hipLaunchKernelGGL(fk_perm_kernel, dim3((n_sh + 63u) / 64u), dim3(64), 0, c->stream, perm_prefix, sh0, n_sh,
+                               (uint32_t)S, static_cast<uint16_t *>(c->perm.p));
+            t.stop();
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, t.collect());
+        }
+        if (perms) {
+            perm_host.resize((size_t)S * n_sh);
+            HIPCHK(c, hipMemcpyAsync(perm_host.data(), c->perm.p, perm_host.size() * 2, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (uint32_t s = 0; s < n_sh; ++s)
+                for (int32_t i = 0; i < S; ++i)
+                    perms[(size_t)(done + s) * S + i] = perm_host[(size_t)i * n_sh + s];
+        }
+
+        // overrides that fall into this chunk -> chunk-local game ids
+        std::vector<DevOverride> dov;
+        for (int32_t i = 0; i < n_ov; ++i) {
+            if (ov[i].root_seed != root_seed || ov[i].k_or_order != (uint32_t)k) continue;
+            if (ov[i].a < sh0 || ov[i].a >= sh0 + n_sh || ov[i].b >= gps) continue;
+            if (ov[i].max_rounds > 65535u) return fail(c, FK_ERR_ARG, "override max_rounds must be <= 65535");
+            dov.push_back(DevOverride{(uint32_t)((ov[i].a - sh0) * gps + ov[i].b), ov[i].max_rounds});
+        }
+        if (!dov.empty()) {
+            rc = ensure(c, c->ov, dov.size() * sizeof(DevOverride));
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->ov.p, dov.data(), dov.size() * sizeof(DevOverride), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        if (rows) {
+            rc = ensure(c, c->rows, (size_t)n_games * row_bytes);
+            if (rc) return rc;
+        }
+
+        SeedArgs sa{};
+        sa.prefix = seat_prefix;
+        sa.coords = nullptr;
+        sa.shuffle0 = sh0;
+        sa.pair = 0;
+        sa.order = 0;
+        sa.game0 = 0;
+        sa.gps = gps;
+        sa.k = (uint32_t)k;
+        sa.n_games = n_games;
+
+        PlayArgs pa{};
+        pa.strat = static_cast<const uint2 *>(c->strat.p);
+        pa.perm_T = static_cast<const uint16_t *>(c->perm.p);
+        pa.seat_strategy = nullptr;
+        pa.tally = static_cast<unsigned long long *>(c->tally.p);
+        pa.rows = rows ? static_cast<uint8_t *>(c->rows.p) : nullptr;
+        pa.ov = static_cast<const DevOverride *>(c->ov.p);
+        pa.n_ov = (uint32_t)dov.size();
+        pa.mode = MODE_PERM;
+        pa.n_games = n_games;
+        pa.gps = gps;
+        pa.n_sh = n_sh;
+        pa.k = (uint32_t)k;
+        pa.S = (uint32_t)S;
+        pa.sh_offset = (uint32_t)done;
+        pa.spb = shuffles_per_batch;
+        pa.target = target_score;
+        pa.max_rounds = (uint32_t)max_rounds;
+
+        rc = run_chunk(c, sa, pa, plan, (int64_t)done * gps, "tournament");
+        if (rc) return rc;
+        if (rows) {
+            HIPCHK(c, hipMemcpyAsync(static_cast<uint8_t *>(rows) + (size_t)done * gps * row_bytes, c->rows.p,
+                                     (size_t)n_games * row_bytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+    }
+    const uint32_t n_rows = (uint32_t)(n_batches * (uint64_t)S);
+    hipLaunchKernelGGL(fk_finalize_tally, dim3((n_rows + 255u) / 256u), dim3(256), 0, c->stream,
+                       static_cast<unsigned long long *>(c->tally.p), n_rows);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(t1, c->stream));
+    HIPCHK(c, hipMemcpyAsync(tally, c->tally.p, tally_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventElapsedTime(&c->timing.total_ms, t0, t1));
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    return FK_OK;
+}
+
+int fk_play_games(fk_ctx *c, const fk_coord *coords, int64_t n_games, const fk_strategy *table, int32_t S,
+                  const int32_t *seat_strategy, int32_t k, int32_t target_score, int32_t max_rounds, void *rows) {
+    if (!c) return FK_ERR_ARG;
+    if (!coords || !table || !seat_strategy || !rows) return fail(c, FK_ERR_ARG, "coords, table, seat_strategy, rows are required");
+    if (k < 1 || S < 1 || n_games < 0 || n_games > 0x7fffffff / std::max(k, 1)) return fail(c, FK_ERR_ARG, "bad k / S / n_games");
+    if (max_rounds < 0 || max_rounds > 65535) return fail(c, FK_ERR_ARG, "max_rounds must be in [0, 65535]");
+    for (int64_t i = 0; i < n_games * k; ++i)
+        if (seat_strategy[i] < 0 || seat_strategy[i] >= S) return fail(c, FK_ERR_ARG, "seat_strategy[%lld] out of range", (long long)i);
+    for (int64_t i = 0; i < n_games; ++i) {
+        if (coords[i].k != (uint64_t)k) // simulation.py:438
+            return fail(c, FK_ERR_ARG, "Player RNG coordinate k does not match the number of seated strategies");
+        if (coords[i].seat_index != 0) return fail(c, FK_ERR_ARG, "game coordinates carry seat_index 0 (seats are implied)");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    c->timing = fk_timing{};
+    if (n_games == 0) return FK_OK;
+    int rc = upload_strategies(c, table, S);
+    if (rc) return rc;
+    const size_t row_bytes = sizeof(fk_row_hdr) + sizeof(fk_seat) * (size_t)k;
+    rc = ensure(c, c->coords, sizeof(fk_coord) * (size_t)n_games);
+    if (rc) return rc;
+    rc = ensure(c, c->seatlist, sizeof(int32_t) * (size_t)n_games * k);
+    if (rc) return rc;
+    rc = ensure(c, c->rows, (size_t)n_games * row_bytes);
+    if (rc) return rc;
+    rc = ensure(c, c->tally, sizeof(int64_t) * (size_t)S * FK_TALLY_COLS);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->coords.p, coords, sizeof(fk_coord) * (size_t)n_games, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->seatlist.p, seat_strategy, sizeof(int32_t) * (size_t)n_games * k, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->tally.p, 0, sizeof(int64_t) * (size_t)S * FK_TALLY_COLS, c->stream));
+
+    LaunchPlan plan = plan_play(c, k, S, false);
+
+    SeedArgs sa{};
+    sa.coords = static_cast<const fk_coord *>(c->coords.p);
+    sa.k = (uint32_t)k;
+    sa.n_games = (uint32_t)n_games;
+
+    PlayArgs pa{};
+    pa.strat = static_cast<const uint2 *>(c->strat.p);
+    pa.seat_strategy = static_cast<const int32_t *>(c->seatlist.p);
+    pa.tally = static_cast<unsigned long long *>(c->tally.p);
+    pa.rows = static_cast<uint8_t *>(c->rows.p);
+    pa.mode = MODE_LIST;
+    pa.n_games = (uint32_t)n_games;
+    pa.gps = 1;
+    pa.n_sh = 1;
+    pa.k = (uint32_t)k;
+    pa.S = (uint32_t)S;
+    pa.spb = 1;
+    pa.target = target_score;
+    pa.max_rounds = (uint32_t)max_rounds;
+    rc = run_chunk(c, sa, pa, plan, 0, "list");
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(rows, c->rows.p, (size_t)n_games * row_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->timing.total_ms = c->timing.seed_ms + c->timing.play_ms;
+    return FK_OK;
+}
+
+int fk_h2h_run(fk_ctx *c, const fk_strategy seats[2], uint64_t root_seed, uint64_t pair_id, uint32_t order, uint64_t target,
+               uint64_t max_attempts, uint64_t chunk_games, int32_t target_score, int32_t max_rounds, const fk_override *ov,
+               int32_t n_ov, uint64_t state[5]) {
+    if (!c) return FK_ERR_ARG;
+    if (!seats || !state) return fail(c, FK_ERR_ARG, "seats and state are required");
+    if (order > 1u) return fail(c, FK_ERR_ARG, "order must be 0 or 1");
+    if (max_rounds < 0 || max_rounds > 65535) return fail(c, FK_ERR_ARG, "max_rounds must be in [0, 65535]");
+    if (n_ov < 0 || (n_ov > 0 && !ov)) return fail(c, FK_ERR_ARG, "bad override list");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->timing = fk_timing{};
+    uint64_t attempted = state[0], completed = state[1], safety = state[2], w1 = state[3], w2 = state[4];
+    if (!(completed <= target) || !(attempted <= max_attempts) || completed + safety != attempted || w1 + w2 != completed)
+        return fail(c, FK_ERR_ARG, "inconsistent block state"); // h2h_schedule.py:1366, 1422-1468
+    uint64_t stop = attempted + chunk_games; // :1172
+    if (stop > max_attempts || stop < attempted) stop = max_attempts;
+    int rc = upload_strategies(c, seats, 2);
+    if (rc) return rc;
+    rc = ensure(c, c->tally, sizeof(int64_t) * 2 * FK_TALLY_COLS);
+    if (rc) return rc;
+    const SeedPool seat_prefix = seed_prefix(203u /* H2H_PLAYER */, root_seed, 2u);
+    const LaunchPlan plan = plan_play(c, 2, 2, true);
+    const uint64_t max_launch = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->chunk_bytes / 64, 1u << 30));
+
+    // The stop rule is a prefix rule (first attempt index at which `target` games have completed).
+    // Launching exactly (target - completed) attempts per pass can never overshoot it: the pass reaches
+    // the target only if every attempt in it completes, i.e. at its last attempt.
+    while (attempted < stop && completed < target) {
+        const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(stop - attempted, target - completed), max_launch);
+        std::vector<DevOverride> dov;
+        for (int32_t i = 0; i < n_ov; ++i) {
+            if (ov[i].root_seed != root_seed || ov[i].k_or_order != order || ov[i].a != pair_id) continue;
+            if (ov[i].b < attempted || ov[i].b >= attempted + n) continue;
+            if (ov[i].max_rounds > 65535u) return fail(c, FK_ERR_ARG, "override max_rounds must be <= 65535");
+            dov.push_back(DevOverride{(uint32_t)(ov[i].b - attempted), ov[i].max_rounds});
+        }
+        if (!dov.empty()) {
+            rc = ensure(c, c->ov, dov.size() * sizeof(DevOverride));
+            if (rc) return rc;
+            HIPCHK(c, hipMemcpyAsync(c->ov.p, dov.data(), dov.size() * sizeof(DevOverride), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        HIPCHK(c, hipMemsetAsync(c->tally.p, 0, sizeof(int64_t) * 2 * FK_TALLY_COLS, c->stream));
+        SeedArgs sa{};
+        sa.prefix = seat_prefix;
+        sa.shuffle0 = 0;
+        sa.pair = pair_id;
+        sa.order = order;
+        sa.game0 = attempted;
+        sa.gps = 0;
+        sa.k = 2;
+        sa.n_games = (uint32_t)n;
+        PlayArgs pa{};
+        pa.strat = static_cast<const uint2 *>(c->strat.p);
+        pa.tally = static_cast<unsigned long long *>(c->tally.p);
+        pa.ov = static_cast<const DevOverride *>(c->ov.p);
+        pa.n_ov = (uint32_t)dov.size();
+        pa.mode = MODE_FIXED;
+        pa.n_games = (uint32_t)n;
+        pa.gps = 1;
+        pa.n_sh = 1;
+        pa.k = 2;
+        pa.S = 2;
+        pa.spb = 1;
+        pa.target = target_score;
+        pa.max_rounds = (uint32_t)max_rounds;
+        rc = run_chunk(c, sa, pa, plan, (int64_t)attempted, "h2h attempt");
+        if (rc) return rc;
+        int64_t t[2 * FK_TALLY_COLS];
+        HIPCHK(c, hipMemcpyAsync(t, c->tally.p, sizeof(t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const uint64_t comp = (uint64_t)t[2], saf = (uint64_t)t[3]; // seat-1 strategy row: one exposure per game
+        if (comp + saf != n) return fail(c, FK_ERR_HIP, "h2h tally conservation failed (%llu + %llu != %llu)",
+                                         (unsigned long long)comp, (unsigned long long)saf, (unsigned long long)n);
+        attempted += n;
+        completed += comp;
+        safety += saf;
+        w1 += (uint64_t)t[0];
+        w2 += (uint64_t)t[FK_TALLY_COLS + 0];
+    }
+    state[0] = attempted;
+    state[1] = completed;
+    state[2] = safety;
+    state[3] = w1;
+    state[4] = w2;
+    c->timing.total_ms = c->timing.seed_ms + c->timing.play_ms;
+    return FK_OK;
+}
+
+// ---- probes ----
+int fk_debug_score(fk_ctx *c, int64_t n, const uint8_t *faces, const int32_t *len, const int32_t *pre,
+                   const fk_strategy *strategy, int32_t *out) {
+    if (!c || n < 0 || !faces || !len || !pre || !strategy || !out) return c ? fail(c, FK_ERR_ARG, "bad arguments") : FK_ERR_ARG;
+    if (n == 0) return FK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    for (int64_t i = 0; i < n; ++i) {
+        if (len[i] < 0 || len[i] > 6) return fail(c, FK_ERR_ARG, "roll cannot contain more than six dice");
+        for (int32_t j = 0; j < len[i]; ++j)
+            if (faces[i * 6 + j] < 1 || faces[i * 6 + j] > 6) return fail(c, FK_ERR_ARG, "dice faces must be between 1 and 6");
+    }
+    int rc = validate_strategies(c, strategy, (int32_t)std::min<int64_t>(n, 0x7fffffff));
+    if (rc) return rc;
+    std::vector<uint2> packed((size_t)n);
+    for (int64_t i = 0; i < n; ++i) packed[(size_t)i] = pack_strategy(strategy[i]);
+    const size_t sz[5] = {(size_t)n * 6, (size_t)n * 4, (size_t)n * 4, (size_t)n * 8, (size_t)n * 20};
+    for (int i = 0; i < 5; ++i)
+        if ((rc = ensure(c, c->dbg[i], sz[i]))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->dbg[0].p, faces, sz[0], hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dbg[1].p, len, sz[1], hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dbg[2].p, pre, sz[2], hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dbg[3].p, packed.data(), sz[3], hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(fk_dbg_score_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n,
+                       static_cast<const uint8_t *>(c->dbg[0].p), static_cast<const int32_t *>(c->dbg[1].p),
+                       static_cast<const int32_t *>(c->dbg[2].p), static_cast<const uint2 *>(c->dbg[3].p),
+                       static_cast<int32_t *>(c->dbg[4].p));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->dbg[4].p, sz[4], hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FK_OK;
+}
+
+int fk_debug_should_continue(fk_ctx *c, int64_t n, const int32_t *args, const fk_strategy *strategy, int32_t *out) {
+    if (!c || n < 0 || !args || !strategy || !out) return c ? fail(c, FK_ERR_ARG, "bad arguments") : FK_ERR_ARG;
+    if (n == 0) return FK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = validate_strategies(c, strategy, (int32_t)std::min<int64_t>(n, 0x7fffffff));
+    if (rc) return rc;
+    std::vector<uint2> packed((size_t)n);
+    for (int64_t i = 0; i < n; ++i) packed[(size_t)i] = pack_strategy(strategy[i]);
+    const size_t sz[3] = {(size_t)n * 24, (size_t)n * 8, (size_t)n * 4};
+    for (int i = 0; i < 3; ++i)
+        if ((rc = ensure(c, c->dbg[i], sz[i]))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->dbg[0].p, args, sz[0], hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dbg[1].p, packed.data(), sz[1], hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(fk_dbg_continue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n,
+                       static_cast<const int32_t *>(c->dbg[0].p), static_cast<const uint2 *>(c->dbg[1].p),
+                       static_cast<int32_t *>(c->dbg[2].p));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->dbg[2].p, sz[2], hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FK_OK;
+}
+
+static int debug_dice_common(fk_ctx *c, int64_t n, const fk_coord *coords, const uint64_t *state, int32_t n_calls,
+                             const int32_t *sizes, uint8_t *faces, uint64_t *raw64, uint64_t *state_out) {
+    if (!c || n < 0 || n_calls < 0 || !sizes || !faces) return c ? fail(c, FK_ERR_ARG, "bad arguments") : FK_ERR_ARG;
+    if (n == 0) return FK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int32_t total = 0;
+    for (int32_t i = 0; i < n_calls; ++i) {
+        if (sizes[i] < 1 || sizes[i] > 6) return fail(c, FK_ERR_ARG, "roll sizes must be in [1, 6]");
+        total += sizes[i];
+    }
+    int rc;
+    const uint4 *d_seeds = nullptr;
+    const uint64_t *d_state = nullptr;
+    if (coords) {
+        if ((rc = ensure(c, c->coords, sizeof(fk_coord) * (size_t)n))) return rc;
+        if ((rc = ensure(c, c->seeds, (size_t)n * 32))) return rc;
+        // one 1-seat "game" per coordinate; the seed kernel offsets the seat stream by coords[i].seat_index
+        HIPCHK(c, hipMemcpyAsync(c->coords.p, coords, sizeof(fk_coord) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        SeedArgs sa{};
+        sa.coords = static_cast<const fk_coord *>(c->coords.p);
+        sa.k = 1;
+        sa.n_games = (uint32_t)n;
+        sa.seeds = static_cast<uint4 *>(c->seeds.p);
+        hipLaunchKernelGGL(fk_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, sa);
+        HIPCHK(c, hipGetLastError());
+        d_seeds = sa.seeds;
+    } else {
+        if (!state) return fail(c, FK_ERR_ARG, "state is required");
+        if ((rc = ensure(c, c->dbg[0], (size_t)n * 48))) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->dbg[0].p, state, (size_t)n * 48, hipMemcpyHostToDevice, c->stream));
+        d_state = static_cast<const uint64_t *>(c->dbg[0].p);
+    }
+    if ((rc = ensure(c, c->dbg[1], (size_t)n_calls * 4 + 4))) return rc;
+    if ((rc = ensure(c, c->dbg[2], (size_t)n * std::max(total, 1)))) return rc;
+    if ((rc = ensure(c, c->dbg[3], (size_t)n * 32))) return rc;
+    if ((rc = ensure(c, c->dbg[4], (size_t)n * 48))) return rc;
+    if (n_calls) HIPCHK(c, hipMemcpyAsync(c->dbg[1].p, sizes, (size_t)n_calls * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(fk_dbg_dice_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, n, d_seeds, d_state, n_calls,
+                       static_cast<const int32_t *>(c->dbg[1].p), total, static_cast<uint8_t *>(c->dbg[2].p),
+                       raw64 ? static_cast<uint64_t *>(c->dbg[3].p) : nullptr,
+                       state_out ? static_cast<uint64_t *>(c->dbg[4].p) : nullptr);
+    HIPCHK(c, hipGetLastError());
+    if (total) HIPCHK(c, hipMemcpyAsync(faces, c->dbg[2].p, (size_t)n * total, hipMemcpyDeviceToHost, c->stream));
+    if (raw64) HIPCHK(c, hipMemcpyAsync(raw64, c->dbg[3].p, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+    if (state_out) HIPCHK(c, hipMemcpyAsync(state_out, c->dbg[4].p, (size_t)n * 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FK_OK;
+}
+
+int fk_debug_dice(fk_ctx *c, int64_t n, const fk_coord *coords, int32_t n_calls, const int32_t *sizes, uint8_t *faces,
+                  uint64_t *raw64) {
+    if (!coords) return c ? fail(c, FK_ERR_ARG, "coords is required") : FK_ERR_ARG;
+    return debug_dice_common(c, n, coords, nullptr, n_calls, sizes, faces, raw64, nullptr);
+}
+
+int fk_debug_dice_state(fk_ctx *c, int64_t n, const uint64_t *state, int32_t n_calls, const int32_t *sizes, uint8_t *faces,
+                        uint64_t *state_out) {
+    return debug_dice_common(c, n, nullptr, state, n_calls, sizes, faces, nullptr, state_out);
+}
+
+} // extern "C"

@@ -1,0 +1,393 @@
+// fk_device.h — device-side building blocks of the gfx950 Farkle engine.
+//
+// Everything here is integer VALU work written for 64-wide wavefronts: one lane = one game,
+// branch-light (predicated) code so that the lanes of a wave stay converged on the roll loop.
+// Reference semantics are cited as path:line under the reference's root; NumPy's generators
+// (third party, numpy>=1.26) are restated from their published algorithms.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fk {
+
+// ----------------------------------------------------------------------------------------
+// NumPy SeedSequence (seed_seq_fe128) — called by src/farkle/utils/random.py:156
+// ----------------------------------------------------------------------------------------
+constexpr uint32_t SS_INIT_A = 0x43b0d7e5u, SS_MULT_A = 0x931e8875u;
+constexpr uint32_t SS_INIT_B = 0x8b51f9ddu, SS_MULT_B = 0x58f38dedu;
+constexpr uint32_t SS_MIX_L = 0xca01f9ddu, SS_MIX_R = 0x4973f715u;
+
+// hash constant in front of the c-th hashmix call (0-based): INIT_A * MULT_A^c
+__host__ __device__ constexpr uint32_t ss_hc(int c) {
+    uint32_t h = SS_INIT_A;
+    for (int i = 0; i < c; ++i) h *= SS_MULT_A;
+    return h;
+}
+
+__host__ __device__ inline uint32_t ss_hashmix(uint32_t v, uint32_t &hc) {
+    v ^= hc;
+    hc *= SS_MULT_A;
+    v *= hc;
+    v ^= v >> 16;
+    return v;
+}
+
+__host__ __device__ inline uint32_t ss_mix(uint32_t x, uint32_t y) {
+    uint32_t r = SS_MIX_L * x - SS_MIX_R * y;
+    r ^= r >> 16;
+    return r;
+}
+
+// Pool state while entropy words are being absorbed.  `hc` is the running hash constant.
+struct SeedPool {
+    uint32_t p[4];
+    uint32_t hc;
+};
+
+// Absorb the first four entropy words and run the all-pairs mixing round.
+__host__ __device__ inline void ss_begin(SeedPool &s, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    s.hc = SS_INIT_A;
+    s.p[0] = ss_hashmix(w0, s.hc);
+    s.p[1] = ss_hashmix(w1, s.hc);
+    s.p[2] = ss_hashmix(w2, s.hc);
+    s.p[3] = ss_hashmix(w3, s.hc);
+#pragma unroll
+    for (int src = 0; src < 4; ++src) {
+#pragma unroll
+        for (int dst = 0; dst < 4; ++dst) {
+            if (src != dst) s.p[dst] = ss_mix(s.p[dst], ss_hashmix(s.p[src], s.hc));
+        }
+    }
+}
+
+// Absorb one further entropy word (index >= 4) into all four pool slots.
+__host__ __device__ inline void ss_absorb(SeedPool &s, uint32_t w) {
+#pragma unroll
+    for (int dst = 0; dst < 4; ++dst) s.p[dst] = ss_mix(s.p[dst], ss_hashmix(w, s.hc));
+}
+
+__host__ __device__ inline void ss_absorb64(SeedPool &s, uint64_t v) {
+    ss_absorb(s, (uint32_t)v);         // low word first (random.py:62)
+    ss_absorb(s, (uint32_t)(v >> 32));
+}
+
+// generate_state: n 32-bit words cycling over the pool
+template <int N>
+__host__ __device__ inline void ss_generate(const SeedPool &s, uint32_t (&out)[N]) {
+    uint32_t hc = SS_INIT_B;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        uint32_t v = s.p[i & 3];
+        v ^= hc;
+        hc *= SS_MULT_B;
+        v *= hc;
+        v ^= v >> 16;
+        out[i] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// NumPy PCG64DXSM — constructed at src/farkle/utils/random.py:188
+// ----------------------------------------------------------------------------------------
+constexpr uint64_t PCG_CHEAP_MULT = 0xda942042e4dd58b5ULL;
+constexpr uint64_t PCG_DEF_MULT_HI = 2549297995355413924ULL, PCG_DEF_MULT_LO = 4865540595714422341ULL;
+
+struct Rng {
+    uint64_t hi, lo;         // 128-bit LCG state
+    uint64_t inc_hi, inc_lo; // odd increment
+    uint32_t buf;            // buffered high half of the last 64-bit output
+    uint32_t has_buf;        // 0/1
+};
+
+__host__ __device__ inline uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// state = state * M(128 bit) + inc   (seeding uses the DEFAULT multiplier twice)
+__host__ __device__ inline void pcg_step_default(uint64_t &hi, uint64_t &lo, uint64_t inc_hi, uint64_t inc_lo) {
+    uint64_t nlo = lo * PCG_DEF_MULT_LO;
+    uint64_t nhi = mulhi64(lo, PCG_DEF_MULT_LO) + lo * PCG_DEF_MULT_HI + hi * PCG_DEF_MULT_LO;
+    nlo += inc_lo;
+    nhi += inc_hi + (nlo < inc_lo ? 1u : 0u);
+    hi = nhi;
+    lo = nlo;
+}
+
+__host__ __device__ inline void pcg_seed(Rng &r, const uint32_t (&g)[8]) {
+    uint64_t s0 = (uint64_t)g[0] | ((uint64_t)g[1] << 32), s1 = (uint64_t)g[2] | ((uint64_t)g[3] << 32);
+    uint64_t s2 = (uint64_t)g[4] | ((uint64_t)g[5] << 32), s3 = (uint64_t)g[6] | ((uint64_t)g[7] << 32);
+    // initstate = (s0 << 64) | s1 ; initseq = (s2 << 64) | s3 ; inc = (initseq << 1) | 1
+    r.inc_hi = (s2 << 1) | (s3 >> 63);
+    r.inc_lo = (s3 << 1) | 1u;
+    r.hi = 0;
+    r.lo = 0;
+    pcg_step_default(r.hi, r.lo, r.inc_hi, r.inc_lo);
+    uint64_t nlo = r.lo + s1;
+    r.hi = r.hi + s0 + (nlo < s1 ? 1u : 0u);
+    r.lo = nlo;
+    pcg_step_default(r.hi, r.lo, r.inc_hi, r.inc_lo);
+    r.buf = 0;
+    r.has_buf = 0;
+}
+
+// DXSM output of the current state, then the cheap-multiplier step.
+__host__ __device__ inline uint64_t pcg_next64(Rng &r) {
+    uint64_t h = r.hi, l = r.lo | 1u;
+    h ^= h >> 32;
+    h *= PCG_CHEAP_MULT;
+    h ^= h >> 48;
+    h *= l;
+    uint64_t nlo = r.lo * PCG_CHEAP_MULT;
+    uint64_t nhi = mulhi64(r.lo, PCG_CHEAP_MULT) + r.hi * PCG_CHEAP_MULT;
+    nlo += r.inc_lo;
+    nhi += r.inc_hi + (nlo < r.inc_lo ? 1u : 0u);
+    r.hi = nhi;
+    r.lo = nlo;
+    return h;
+}
+
+// buffered 32-bit draw: low half first, high half on the next call (persists across rolls)
+__host__ __device__ inline uint32_t pcg_next32(Rng &r) {
+    if (r.has_buf) {
+        r.has_buf = 0;
+        return r.buf;
+    }
+    uint64_t o = pcg_next64(r);
+    r.has_buf = 1;
+    r.buf = (uint32_t)(o >> 32);
+    return (uint32_t)o;
+}
+
+// ----------------------------------------------------------------------------------------
+// Dice: FarklePlayer._roll (src/farkle/game/engine.py:85-101) -> Generator.integers(1, 7, size=n)
+// = per die Lemire's bounded draw on the buffered 32-bit stream; rejection iff low32(r*6) < 4.
+// Returns the roll as nibble-packed face counts: count(face f) at bits [4(f-1), 4(f-1)+3).
+// ----------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t roll_counts_sequential(Rng &r, uint32_t n, uint32_t *faces_out) {
+    uint32_t counts = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t m = (uint64_t)pcg_next32(r) * 6u;
+        uint32_t left = (uint32_t)m;
+        if (left < 6u) {
+            while (left < 4u) { // threshold = (2^32 - 6) % 6 = 4
+                m = (uint64_t)pcg_next32(r) * 6u;
+                left = (uint32_t)m;
+            }
+        }
+        uint32_t f = (uint32_t)(m >> 32); // face - 1
+        counts += 1u << (4u * f);
+        if (faces_out) *faces_out |= (f + 1u) << (4u * i);
+    }
+    return counts;
+}
+
+// Converged fast path: all 64-bit outputs a roll can need (<= 3) are generated under per-lane
+// predicates, the six candidate words are selected with v_cndmask, and the (once in ~2^30 dice)
+// Lemire rejection falls back to the sequential form from the saved generator state.
+__device__ inline uint32_t roll_counts(Rng &r, uint32_t n, uint32_t *faces_out = nullptr) {
+    const Rng saved = r;
+    const uint32_t hb = r.has_buf;
+    const uint32_t need = (n - hb + 1u) >> 1; // new 64-bit outputs: ceil((n - has_buf) / 2), 0..3
+    uint32_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0, last_hi = r.buf;
+    if (need > 0u) {
+        uint64_t o = pcg_next64(r);
+        lo0 = (uint32_t)o;
+        hi0 = (uint32_t)(o >> 32);
+        last_hi = hi0;
+    }
+    if (need > 1u) {
+        uint64_t o = pcg_next64(r);
+        lo1 = (uint32_t)o;
+        hi1 = (uint32_t)(o >> 32);
+        last_hi = hi1;
+    }
+    if (need > 2u) {
+        uint64_t o = pcg_next64(r);
+        lo2 = (uint32_t)o;
+        hi2 = (uint32_t)(o >> 32);
+        last_hi = hi2;
+    }
+    uint32_t w[6];
+    w[0] = hb ? saved.buf : lo0;
+    w[1] = hb ? lo0 : hi0;
+    w[2] = hb ? hi0 : lo1;
+    w[3] = hb ? lo1 : hi1;
+    w[4] = hb ? hi1 : lo2;
+    w[5] = hb ? lo2 : hi2;
+    uint32_t counts = 0, reject = 0, faces = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 6; ++i) {
+        uint32_t f = __umulhi(w[i], 6u);
+        uint32_t left = w[i] * 6u;
+        bool on = i < n;
+        reject |= (on && left < 4u) ? 1u : 0u;
+        counts += on ? (1u << (4u * f)) : 0u;
+        faces |= on ? ((f + 1u) << (4u * i)) : 0u;
+    }
+    r.has_buf = (n + hb) & 1u;
+    r.buf = last_hi;
+    if (reject) { // rare: redo this roll exactly as NumPy would
+        r = saved;
+        faces = 0;
+        counts = roll_counts_sequential(r, n, &faces);
+    }
+    if (faces_out) *faces_out = faces;
+    return counts;
+}
+
+// ----------------------------------------------------------------------------------------
+// Scoring: _evaluate_nb (src/farkle/game/scoring_lookup.py:123-172) on nibble-packed counts.
+// With <= 6 dice at most ONE face can form a set outside the four 6-dice patterns, so the
+// set is found with one SWAR compare + ffs instead of a per-face loop.
+// ----------------------------------------------------------------------------------------
+struct RawScore {
+    int32_t score, used, sf, so; // points, dice used, lone fives, lone ones
+};
+
+__host__ __device__ inline uint32_t nibble_eq(uint32_t c, uint32_t v) {
+    uint32_t x = c ^ (v * 0x111111u);
+    return ~(x | (x >> 1) | (x >> 2)) & 0x111111u; // exact per-nibble flags (counts < 8)
+}
+
+__host__ __device__ inline int popc32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popc(x);
+#else
+    return __builtin_popcount(x);
+#endif
+}
+
+__host__ __device__ inline int ctz32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffs((int)x) - 1;
+#else
+    return __builtin_ctz(x);
+#endif
+}
+
+__host__ __device__ inline RawScore score_counts(uint32_t c) {
+    RawScore r;
+    const uint32_t e2 = nibble_eq(c, 2u), e3 = nibble_eq(c, 3u), e4 = nibble_eq(c, 4u);
+    const bool straight = (c == 0x111111u);                 // _straight :28-38
+    const bool three_pairs = popc32(e2) == 3;               // _three_pairs :42-53
+    const bool two_triplets = popc32(e3) == 2;              // _two_triplets :57-68
+    const bool four_two = (e4 != 0u) && (e2 != 0u);         // _four_kind_plus_pair :72-82
+    if (straight || three_pairs || two_triplets || four_two) {
+        r.score = two_triplets && !(straight || three_pairs) ? 2500 : 1500;
+        r.used = 6;
+        r.sf = 0;
+        r.so = 0;
+        return r;
+    }
+    // n-of-a-kind (_apply_sets :86-115): nibble >= 3  <=>  bit 3 of (nibble + 5)
+    const uint32_t ge3 = (c + 0x555555u) & 0x888888u;
+    int32_t set_pts = 0, set_n = 0;
+    uint32_t rest = c;
+    if (ge3) {
+        const int sh = ctz32(ge3) - 3; // 4 * face_index
+        const int32_t n = (int32_t)((c >> sh) & 7u);
+        const int32_t face = (sh >> 2) + 1;
+        set_pts = (n == 3) ? (face == 1 ? 300 : face * 100) : (n - 3) * 1000;
+        set_n = n;
+        rest = c & ~(0xFu << sh);
+    }
+    const int32_t ones = (int32_t)(rest & 7u), fives = (int32_t)((rest >> 16) & 7u);
+    r.score = set_pts + 100 * ones + 50 * fives; // :168-172
+    r.used = set_n + ones + fives;
+    r.sf = fives;
+    r.so = ones;
+    return r;
+}
+
+// ----------------------------------------------------------------------------------------
+// Strategy record as the kernels see it: two dwords.
+//   x = score_threshold (i32)
+//   y = bits 0..7 dice_threshold (i8) | flag bits from 8
+// ----------------------------------------------------------------------------------------
+enum : uint32_t {
+    SF_SMART_FIVE = 1u << 8,
+    SF_SMART_ONE = 1u << 9,
+    SF_CONSIDER_SCORE = 1u << 10,
+    SF_CONSIDER_DICE = 1u << 11,
+    SF_REQUIRE_BOTH = 1u << 12,
+    SF_AUTO_HOT = 1u << 13,
+    SF_RUN_UP = 1u << 14,
+    SF_FAVOR_SCORE = 1u << 15
+};
+
+struct Strat {
+    int32_t score_thr;
+    uint32_t bits;
+    __host__ __device__ int32_t dice_thr() const { return (int32_t)(int8_t)(bits & 0xffu); }
+    __host__ __device__ bool has(uint32_t f) const { return (bits & f) != 0u; }
+};
+
+// _must_bank, src/farkle/game/scoring.py:283-300
+__host__ __device__ inline bool must_bank(const Strat &s, int32_t score_after, int32_t dice_left_after) {
+    const bool cs = s.has(SF_CONSIDER_SCORE), cd = s.has(SF_CONSIDER_DICE);
+    const bool hit_score = cs && (score_after >= s.score_thr);
+    const bool hit_dice = cd && (dice_left_after <= s.dice_thr());
+    return (cs && cd && s.has(SF_REQUIRE_BOTH)) ? (hit_score && hit_dice) : (hit_score || hit_dice);
+}
+
+struct RollResult {
+    int32_t score, used, d5, d1;
+};
+
+// default_score (src/farkle/game/scoring.py:618-693) = raw score + Smart-5/Smart-1 discard choice.
+// The reference enumerates re-scored sub-rolls (generate_sequences/score_lister/_select_candidate,
+// :197-366); every candidate that survives its `drop > singles` filter (:326-329) only removes lone
+// 1s/5s, so its score is raw - 50*d5 - 100*d1 and its used dice raw_used - d5 - d1 (closed form).
+__host__ __device__ inline RollResult default_score(uint32_t counts, int32_t n, int32_t turn_pre, const Strat &s) {
+    const RawScore raw = score_counts(counts);
+    RollResult out{raw.score, raw.used, 0, 0};
+    if (!s.has(SF_SMART_FIVE) || raw.used == n || (raw.sf == 0 && raw.so == 0)) return out; // :433
+    const int32_t max1 = s.has(SF_SMART_ONE) ? raw.so : 0;
+    const bool favor_score = s.has(SF_FAVOR_SCORE);
+    int32_t best_key = -1, b5 = 0, b1 = 0;
+    for (int32_t d5 = 0; d5 <= raw.sf; ++d5) {       // outer loop over fives (:224)
+        for (int32_t d1 = 0; d1 <= max1; ++d1) {     // inner loop over ones (:225)
+            const int32_t cs = raw.score - 50 * d5 - 100 * d1;
+            if (cs == 0) continue;                                   // score_lister :262
+            const int32_t score_after = turn_pre + cs;               // :331
+            const int32_t dice_left_after = n - (raw.used - d5 - d1); // :334
+            if (must_bank(s, score_after, dice_left_after)) continue; // :337
+            // lexicographic key (:346-353) folded into one int: dice_left < 8, score_after < 2^20
+            const int32_t key = favor_score ? (score_after * 8 + dice_left_after)
+                                            : (dice_left_after * (1 << 20) + score_after);
+            if (key > best_key) { // strict '>' keeps the first of equal keys (:354)
+                best_key = key;
+                b5 = d5;
+                b1 = d1;
+            }
+        }
+    }
+    out.d5 = b5; // == single_fives - best_sf (:467)
+    out.d1 = b1;
+    out.score = raw.score - 50 * b5 - 100 * b1; // apply_discards :575-578
+    out.used = raw.used - b5 - b1;
+    return out;
+}
+
+// FarklePlayer._should_continue (src/farkle/game/engine.py:156-205) with ThresholdStrategy.decide
+// (src/farkle/simulation/strategies.py:212-275) and _decide_continue (:125-162) inlined.
+__host__ __device__ inline bool should_continue(const Strat &s, int32_t turn_score, int32_t dice_left, bool has_scored,
+                                                bool final_round, int32_t score_to_beat, int32_t player_score) {
+    const int32_t running_total = player_score + turn_score;
+    if (final_round && running_total > score_to_beat && !s.has(SF_RUN_UP)) return false; // engine.py:189
+    if (final_round && running_total <= score_to_beat) return true;                       // engine.py:202 (overrides decide)
+    if (!has_scored && turn_score < 500) return true;                                     // strategies.py:249
+    // final_round here implies running_total > score_to_beat and run_up_score: fall through (:253-262)
+    const bool cs = s.has(SF_CONSIDER_SCORE), cd = s.has(SF_CONSIDER_DICE);
+    const bool want_s = cs && turn_score < s.score_thr;
+    const bool want_d = cd && dice_left > s.dice_thr();
+    if (cs && cd) return s.has(SF_REQUIRE_BOTH) ? (want_s || want_d) : (want_s && want_d);
+    return cs ? want_s : (cd ? want_d : false);
+}
+
+} // namespace fk

@@ -1,0 +1,164 @@
+/*
+ * farkle_hip.h — C-ABI of the MI355X (gfx950) Farkle simulation engine.
+ *
+ * The reference (Isaac-McPadden/Farkle_II) is pure Python and has no FFI; its seams for
+ * the simulation hot path are in-process callables.  Each entry point below replaces one
+ * of those seams (citations are path:line under the reference's root):
+ *
+ *   fk_tournament_run  <-  _play_one_shuffle / _run_chunk / _run_chunk_metrics
+ *                          src/farkle/simulation/run_tournament.py:301-393, 403-457, 473-585
+ *   fk_play_games      <-  _play_game over an explicit coordinate list
+ *                          src/farkle/simulation/simulation.py:576-655 (callers: simulate_many_games
+ *                          :658-722, _measure_throughput run_tournament.py:593-619)
+ *   fk_h2h_run         <-  _simulate_block_from_manifest attempt loop (the BlockRunner contract)
+ *                          src/farkle/analysis/h2h_schedule.py:1149-1243, 1521
+ *   fk_debug_*         <-  FarklePlayer._roll (src/farkle/game/engine.py:85-101) and
+ *                          default_score / decide (src/farkle/game/scoring.py:618-693,
+ *                          src/farkle/simulation/strategies.py:212-275): single-op probes of the
+ *                          SAME device functions the game kernel uses, for parity tests.
+ *
+ * Conventions: plain C types, caller-allocated caller-owned HOST buffers, no callbacks.
+ * Every function returns FK_OK (0) or a negative error code; fk_last_error() gives the
+ * message (for FK_ERR_ROLL_LIMIT it names the offending game, mirroring the RuntimeError of
+ * engine.py:242-243).  One context per process/GPU; calls on a context are serialised by the
+ * caller.  There is NO CPU fallback: fk_init fails if no HIP device is usable.
+ */
+#ifndef FARKLE_HIP_H
+#define FARKLE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    FK_OK = 0,
+    FK_ERR_ROLL_LIMIT = -1,       /* a turn exceeded 1000 rolls (engine.py:36,242) */
+    FK_ERR_ARG = -2,              /* invalid argument */
+    FK_ERR_COUNTER_OVERFLOW = -3, /* a per-seat u16 counter left its guarded range */
+    FK_ERR_HIP = -4,              /* HIP runtime failure */
+    FK_ERR_NO_DEVICE = -5
+};
+
+enum { FK_COMPLETED = 0, FK_SAFETY_LIMIT = 1 };
+
+/* ThresholdStrategy (src/farkle/simulation/strategies.py:165-194), 20 bytes */
+typedef struct {
+    int32_t score_threshold;
+    int32_t dice_threshold;
+    uint8_t smart_five, smart_one, consider_score, consider_dice;
+    uint8_t require_both, auto_hot_dice, run_up_score, favor_score; /* favor_score=1: FavorDiceOrScore.SCORE */
+    int32_t strategy_id; /* carried, not interpreted */
+} fk_strategy;
+
+/* Per-seat part of a game row (PlayerStats, src/farkle/game/engine.py:360-406), 28 bytes */
+typedef struct {
+    int32_t score;
+    int32_t strategy; /* INDEX into the strategy table of the call */
+    uint16_t farkles, rolls, n_turns, highest_turn;
+    uint16_t smart_five_uses, n_smart_five_dice, smart_one_uses, n_smart_one_dice, hot_dice;
+    uint8_t rank;           /* 1-based; 0 = null (safety limit) */
+    uint8_t hit_max_rounds; /* 0/1 */
+} fk_seat;
+
+/* Row = fk_row_hdr followed by k fk_seat records: 4 + 28*k bytes (simulation.py:628-655) */
+typedef struct {
+    uint16_t n_rounds;
+    uint8_t status;     /* FK_COMPLETED / FK_SAFETY_LIMIT */
+    int8_t winner_seat; /* 0-based; -1 = none */
+} fk_row_hdr;
+
+/* max_rounds override (src/farkle/simulation/game_profile.py:24-69).
+ * Tournament: a=shuffle_index, b=game_index, k_or_order=k.  H2H: a=pair_id, b=attempt_index, k_or_order=order. */
+typedef struct {
+    uint64_t root_seed;
+    uint64_t a, b;
+    uint32_t k_or_order;
+    uint32_t max_rounds;
+} fk_override;
+
+/* Seat-stream coordinate of one game (src/farkle/utils/random.py:80-124); seat_index is implied */
+typedef struct {
+    uint32_t purpose;
+    uint32_t pad;
+    uint64_t root_seed, k, shuffle_index, pair_id, order, game_index, seat_index, replicate_index;
+} fk_coord;
+
+#define FK_TALLY_COLS 26 /* wins, attempted, completed, safety, 11 metric sums, 11 square sums (run_tournament.py:109-121) */
+
+typedef struct {
+    char name[64];
+    char arch[32];
+    int32_t compute_units;
+    int32_t clock_mhz;
+    int32_t wavefront_size;
+    int32_t lds_bytes_per_cu;
+    uint64_t hbm_bytes;
+} fk_device_info;
+
+/* Timing of the last fk_tournament_run / fk_play_games / fk_h2h_run on this context, from HIP events
+ * recorded on the context's stream. */
+typedef struct {
+    float perm_ms;    /* shuffle-permutation kernel(s) */
+    float seed_ms;    /* SeedSequence -> PCG64DXSM seeding kernel(s) */
+    float play_ms;    /* game kernel(s) */
+    float total_ms;   /* first launch -> last kernel done (device time incl. memsets) */
+    int32_t play_launches;
+    int32_t play_block, play_grid, play_lds_bytes;
+    int64_t games;
+} fk_timing;
+
+typedef struct fk_ctx fk_ctx;
+
+int fk_init(int device_ordinal, fk_ctx **out);
+void fk_destroy(fk_ctx *ctx);
+const char *fk_last_error(fk_ctx *ctx);
+int fk_get_device_info(fk_ctx *ctx, fk_device_info *out);
+int fk_get_timing(fk_ctx *ctx, fk_timing *out);
+/* Tunables: "chunk_bytes" (device workspace budget per chunk), "batch_threshold" (lanes that must be waiting
+ * before a wave runs its game hand-over), "use_lds_tally" (0/1/-1 auto), "block" (0 auto). */
+int fk_set_option(fk_ctx *ctx, const char *name, int64_t value);
+
+/* Tournament shuffles [shuffle_begin, shuffle_end) of the S-strategy table at k players.
+ *   tally       int64 [n_batches][S][26], n_batches = ceil(n_shuffles / shuffles_per_batch); overwritten.
+ *   rows        nullable; n_shuffles * (S/k) rows of 4+28k bytes, game-major in (shuffle, game) order.
+ *   perms       nullable; int32 [n_shuffles][S] (the permutation of each shuffle; tests/diagnostics).
+ * Requires S % k == 0 (run_tournament.py:274), S <= 65535, max_rounds <= 65535. */
+int fk_tournament_run(fk_ctx *ctx, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                      uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch,
+                      int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov,
+                      int64_t *tally, void *rows, int32_t *perms);
+
+/* Explicit game list: game g seats strategies table[seat_strategy[g*k+i]] with streams coords[g](seat i).
+ * rows: n_games * (4+28k) bytes (required). */
+int fk_play_games(fk_ctx *ctx, const fk_coord *coords, int64_t n_games, const fk_strategy *table, int32_t S,
+                  const int32_t *seat_strategy, int32_t k, int32_t target_score, int32_t max_rounds, void *rows);
+
+/* H2H block: attempts [state[0], min(max_attempts, state[0]+chunk_games)) of (root, pair, order) in
+ * attempt order until `target` completed games; state = {attempted, completed, safety, wins_seat1,
+ * wins_seat2} in/out (h2h_schedule.py:1165-1235). */
+int fk_h2h_run(fk_ctx *ctx, const fk_strategy seats[2], uint64_t root_seed, uint64_t pair_id, uint32_t order,
+               uint64_t target, uint64_t max_attempts, uint64_t chunk_games, int32_t target_score,
+               int32_t max_rounds, const fk_override *ov, int32_t n_ov, uint64_t state[5]);
+
+/* ---- single-op probes of the device functions (parity tests) ---- */
+/* n rolls: roll i scores faces[i*6 .. i*6+len[i]) for strategy[i] with turn_score_pre[i];
+ * out[i*5..] = score, used, reroll, d5, d1 (default_score(return_discards=True)). */
+int fk_debug_score(fk_ctx *ctx, int64_t n, const uint8_t *faces, const int32_t *len, const int32_t *turn_score_pre,
+                   const fk_strategy *strategy, int32_t *out);
+/* n decisions: args[i*6..] = turn_score, dice_left, has_scored, final_round, score_to_beat, player_score
+ * -> out[i] = FarklePlayer._should_continue (engine.py:156-205) */
+int fk_debug_should_continue(fk_ctx *ctx, int64_t n, const int32_t *args, const fk_strategy *strategy, int32_t *out);
+/* n streams: coordinate -> PCG64DXSM state; then n_calls dice rolls of sizes[c] each (same sizes for all
+ * streams); faces out: n * sum(sizes) bytes; raw64 (nullable): first 4 raw outputs of each stream. */
+int fk_debug_dice(fk_ctx *ctx, int64_t n, const fk_coord *coords, int32_t n_calls, const int32_t *sizes,
+                  uint8_t *faces, uint64_t *raw64);
+/* Same but from explicit generator states: state[i*6..] = state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger. */
+int fk_debug_dice_state(fk_ctx *ctx, int64_t n, const uint64_t *state, int32_t n_calls, const int32_t *sizes,
+                        uint8_t *faces, uint64_t *state_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -200,6 +200,19 @@ void fko_stream64(const fko_coord *c, int n, uint64_t *out) {
     for (int i = 0; i < n; ++i) out[i] = fko_next64(&r);
 }
 
+/* dice from an explicit generator state {state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger} */
+void fko_dice_from_state(const uint64_t st[6], int n_calls, const int32_t *sizes, uint8_t *faces, uint64_t out[6]) {
+    fko_rng r = {st[0], st[1], st[2], st[3], (uint32_t)st[4], (uint32_t)st[5]};
+    for (int i = 0; i < n_calls; ++i)
+        for (int j = 0; j < sizes[i]; ++j) *faces++ = (uint8_t)fko_integers(&r, 1, 7);
+    out[0] = r.state_hi;
+    out[1] = r.state_lo;
+    out[2] = r.inc_hi;
+    out[3] = r.inc_lo;
+    out[4] = r.has_uint32;
+    out[5] = r.uinteger;
+}
+
 void fko_dice_stream(const fko_coord *c, int n_calls, const int32_t *sizes, uint8_t *faces) {
     fko_rng r;
     fko_rng_init(&r, c);
@@ -371,6 +384,16 @@ static int should_continue(const player_t *p, int32_t turn_score, int32_t dice_l
                           running_total);
     if (final_round && running_total <= score_to_beat) keep = 1; /* :202 */
     return keep;
+}
+
+int32_t fko_should_continue(const fko_strategy *s, int32_t turn_score, int32_t dice_left, int32_t has_scored,
+                            int32_t final_round, int32_t score_to_beat, int32_t player_score) {
+    player_t p;
+    memset(&p, 0, sizeof(p));
+    p.strategy = s;
+    p.score = player_score;
+    p.has_scored = has_scored;
+    return should_continue(&p, turn_score, dice_left, final_round, score_to_beat);
 }
 
 static int take_turn(player_t *p, script_t *sc, int32_t final_round, int32_t score_to_beat) { /* :208-273 */
@@ -573,41 +596,51 @@ int fko_tournament(const fko_strategy *table, int32_t S, int32_t k, uint64_t roo
         char *rowbuf = (char *)malloc(row_bytes);
         int64_t *local = (int64_t *)calloc((size_t)S * FKO_TALLY_COLS, sizeof(int64_t));
         int64_t local_batch = -1;
-#pragma omp for schedule(static, 1)
-        for (int64_t b = 0; b < n_batches; ++b) {
-            memset(local, 0, sizeof(int64_t) * (size_t)S * FKO_TALLY_COLS);
-            local_batch = b;
-            int64_t lo = b * shuffles_per_batch, hi = lo + shuffles_per_batch;
-            if (hi > n_sh) hi = n_sh;
-            for (int64_t si = lo; si < hi; ++si) {
-                uint64_t shuffle = shuffle_begin + (uint64_t)si;
-                fko_coord pc = {FKO_NS_SHUFFLE_PERMUTATION, 0, root_seed, (uint64_t)k, shuffle, 0, 0, 0, 0, 0};
-                fko_rng prng;
-                fko_rng_init(&prng, &pc); /* :312-317 */
-                fko_permutation(&prng, S, perm); /* :318 */
-                if (perms) memcpy(perms + (size_t)si * S, perm, sizeof(int32_t) * (size_t)S);
-                for (int32_t g = 0; g < gps; ++g) {
-                    fko_coord gc = {FKO_NS_TOURNAMENT_PLAYER, 0, root_seed, (uint64_t)k, shuffle, 0, 0,
-                                    (uint64_t)g,              0, 0}; /* :366-372 */
-                    if (game_seeds) { /* :319-329 */
-                        fko_coord fc = gc;
-                        fc.purpose = FKO_NS_TOURNAMENT_GAME;
-                        game_seeds[(size_t)si * gps + g] = fko_coordinate_seed32(&fc);
-                    }
-                    uint32_t mr = lookup_override(ov, n_ov, root_seed, (uint32_t)k, shuffle, (uint64_t)g,
-                                                  (uint32_t)max_rounds);
-                    char *row = rows ? (char *)rows + ((size_t)si * gps + g) * row_bytes : rowbuf;
-                    int rc = fko_play_game(&gc, table, perm + (size_t)g * k, k, target_score, (int32_t)mr, row);
-                    if (rc) {
-#pragma omp critical
-                        err = rc;
-                        continue;
-                    }
-                    tally_row(local, row, k);
+        /* one shuffle per work item; a thread sees shuffles (hence batches) in increasing order and
+         * folds its private tally into the batch's slot whenever the batch changes (integer sums:
+         * order independent) */
+#pragma omp for schedule(dynamic, 1) nowait
+        for (int64_t si = 0; si < n_sh; ++si) {
+            const int64_t b = si / shuffles_per_batch;
+            if (b != local_batch) {
+                if (local_batch >= 0) {
+#pragma omp critical(fko_tally)
+                    for (size_t i = 0; i < (size_t)S * FKO_TALLY_COLS; ++i)
+                        tally[(size_t)local_batch * S * FKO_TALLY_COLS + i] += local[i];
                 }
+                memset(local, 0, sizeof(int64_t) * (size_t)S * FKO_TALLY_COLS);
+                local_batch = b;
             }
-            memcpy(tally + (size_t)local_batch * S * FKO_TALLY_COLS, local,
-                   sizeof(int64_t) * (size_t)S * FKO_TALLY_COLS);
+            uint64_t shuffle = shuffle_begin + (uint64_t)si;
+            fko_coord pc = {FKO_NS_SHUFFLE_PERMUTATION, 0, root_seed, (uint64_t)k, shuffle, 0, 0, 0, 0, 0};
+            fko_rng prng;
+            fko_rng_init(&prng, &pc);        /* :312-317 */
+            fko_permutation(&prng, S, perm); /* :318 */
+            if (perms) memcpy(perms + (size_t)si * S, perm, sizeof(int32_t) * (size_t)S);
+            for (int32_t g = 0; g < gps; ++g) {
+                fko_coord gc = {FKO_NS_TOURNAMENT_PLAYER, 0, root_seed, (uint64_t)k, shuffle, 0, 0,
+                                (uint64_t)g,              0, 0}; /* :366-372 */
+                if (game_seeds) { /* :319-329 */
+                    fko_coord fc = gc;
+                    fc.purpose = FKO_NS_TOURNAMENT_GAME;
+                    game_seeds[(size_t)si * gps + g] = fko_coordinate_seed32(&fc);
+                }
+                uint32_t mr = lookup_override(ov, n_ov, root_seed, (uint32_t)k, shuffle, (uint64_t)g,
+                                              (uint32_t)max_rounds);
+                char *row = rows ? (char *)rows + ((size_t)si * gps + g) * row_bytes : rowbuf;
+                int rc = fko_play_game(&gc, table, perm + (size_t)g * k, k, target_score, (int32_t)mr, row);
+                if (rc) {
+#pragma omp critical(fko_err)
+                    err = rc;
+                    continue;
+                }
+                tally_row(local, row, k);
+            }
+        }
+        if (local_batch >= 0) {
+#pragma omp critical(fko_tally)
+            for (size_t i = 0; i < (size_t)S * FKO_TALLY_COLS; ++i)
+                tally[(size_t)local_batch * S * FKO_TALLY_COLS + i] += local[i];
         }
         free(perm);
         free(rowbuf);

@@ -107,6 +107,8 @@ void fko_stream64(const fko_coord *c, int n, uint64_t *out);
 /* Generator.integers(1,7,size=sizes[i]) repeated; writes all faces consecutively */
 void fko_dice_stream(const fko_coord *c, int n_calls, const int32_t *sizes, uint8_t *faces);
 
+void fko_dice_from_state(const uint64_t st[6], int n_calls, const int32_t *sizes, uint8_t *faces, uint64_t out[6]);
+
 /* ---- scoring ---- */
 /* counts[6] -> score, used, single_fives, single_ones; src/farkle/game/scoring_lookup.py:123-172 */
 void fko_evaluate(const int32_t counts[6], int32_t *score, int32_t *used, int32_t *sf, int32_t *so);
@@ -116,6 +118,10 @@ void fko_default_score(const uint8_t *faces, int32_t n, int32_t turn_score_pre, 
 /* ThresholdStrategy.decide; src/farkle/simulation/strategies.py:212-275 */
 int32_t fko_decide(const fko_strategy *s, int32_t turn_score, int32_t dice_left, int32_t has_scored,
                    int32_t final_round, int32_t score_to_beat, int32_t running_total);
+
+/* FarklePlayer._should_continue; src/farkle/game/engine.py:156-205 */
+int32_t fko_should_continue(const fko_strategy *s, int32_t turn_score, int32_t dice_left, int32_t has_scored,
+                            int32_t final_round, int32_t score_to_beat, int32_t player_score);
 
 /* ---- game / tournament / h2h ---- */
 /* One game: seat i uses strategy table[seat_strategy[i]] and stream coord(seat_index=i).

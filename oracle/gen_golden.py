@@ -177,7 +177,20 @@ def gen_scoring():
                  score_to_beat=int(rs.integers(90, 110)) * 100, running_total=int(rs.integers(90, 110)) * 100)
         dec.append({"strategy": strat_tuple(s), **{k: int(v) for k, v in a.items()},
                     "out": int(s.decide(score_needed=0, **a))})
-    _dump({"table": table, "csv_rows": rows, "default_score": cases, "decide": dec},
+    # FarklePlayer._should_continue (engine.py:156-205) through a real player object
+    from farkle.game.engine import FarklePlayer
+
+    cont = []
+    for _ in range(1500):
+        s = grids[int(rs.integers(0, len(grids)))]
+        pl = FarklePlayer(name="P1", strategy=s, rng=None)
+        pl.score = int(rs.integers(0, 120)) * 100
+        pl.has_scored = bool(rs.integers(0, 2))
+        a = dict(turn_score=int(rs.integers(1, 40)) * 50, dice_left=int(rs.integers(1, 7)),
+                 final_round=bool(rs.integers(0, 2)), score_to_beat=int(rs.integers(95, 115)) * 100)
+        cont.append({"strategy": strat_tuple(s), "player_score": pl.score, "has_scored": int(pl.has_scored),
+                     **{k: int(v) for k, v in a.items()}, "out": int(pl._should_continue(target_score=10_000, **a))})
+    _dump({"table": table, "csv_rows": rows, "default_score": cases, "decide": dec, "should_continue": cont},
               open(OUT / "scoring_vectors.json", "w"))
 
 

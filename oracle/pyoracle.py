@@ -92,6 +92,7 @@ def lib() -> C.CDLL:
         _lib.fko_coordinate_seed64.restype = C.c_uint64
         _lib.fko_integers.restype = C.c_int64
         _lib.fko_decide.restype = C.c_int32
+        _lib.fko_should_continue.restype = C.c_int32
     return _lib
 
 
@@ -142,6 +143,20 @@ def dice_stream(c: np.ndarray, sizes) -> np.ndarray:
     out = np.zeros(int(sizes.sum()), dtype=np.uint8)
     lib().fko_dice_stream(_p(c), C.c_int(len(sizes)), _p(sizes), _p(out))
     return out
+
+
+def dice_from_state(state, sizes):
+    st = np.ascontiguousarray(state, dtype=np.uint64)
+    sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+    faces = np.zeros(int(sizes.sum()), dtype=np.uint8)
+    out = np.zeros(6, dtype=np.uint64)
+    lib().fko_dice_from_state(_p(st), C.c_int(len(sizes)), _p(sizes), _p(faces), _p(out))
+    return faces, out
+
+
+def should_continue(strategy, turn_score, dice_left, has_scored, final_round, score_to_beat, player_score) -> bool:
+    return bool(lib().fko_should_continue(_p(strategy), C.c_int32(turn_score), C.c_int32(dice_left), C.c_int32(bool(has_scored)),
+                                          C.c_int32(bool(final_round)), C.c_int32(score_to_beat), C.c_int32(player_score)))
 
 
 def permutation(c: np.ndarray, n: int) -> np.ndarray:

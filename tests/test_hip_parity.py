@@ -1,0 +1,388 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle and the golden
+vectors (reference outputs).  Bit-exact: everything on this path is integer work.
+
+Run on a MI355X box with ``python -m pytest tests -m gpu``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from farkle_ii_amd.backend import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def po():
+    import pyoracle
+
+    return pyoracle
+
+
+def _strats(tuples):
+    from farkle_ii_amd.strategies import STRATEGY_DTYPE
+
+    return gu.strategies_from_tuples(tuples, STRATEGY_DTYPE)
+
+
+def _coords(items):
+    from farkle_ii_amd.backend import COORD_DTYPE
+
+    out = np.zeros(len(items), dtype=COORD_DTYPE)
+    for i, it in enumerate(items):
+        out[i] = it
+    return out
+
+
+def _default_table():
+    from farkle_ii_amd.strategies import default_grid_tuples
+
+    return _strats(default_grid_tuples())
+
+
+def _rows_equal(a: np.ndarray, b: np.ndarray) -> bool:
+    return a.tobytes() == b.tobytes()
+
+
+# ------------------------------------------------------------------ device info / loud failures
+def test_device_is_gfx950(eng):
+    info = eng.device_info()
+    assert info["arch"].startswith("gfx950"), info
+    assert info["wavefront_size"] == 64 and info["compute_units"] >= 200
+
+
+# ------------------------------------------------------------------ RNG + dice
+def test_streams_and_dice_match_golden(eng):
+    data = gu.load("rng_vectors.json")
+    cases = data["cases"]
+    sizes = cases[0]["sizes"]
+    assert all(c["sizes"] == sizes for c in cases)
+    coords = _coords([(c["purpose"], 0, c["root_seed"], c["k"], c["shuffle_index"], c["pair_id"], c["order"],
+                       c["game_index"], c["seat_index"], 0) for c in cases])
+    faces, raw = eng.debug_dice(coords, sizes)
+    for i, c in enumerate(cases):
+        assert [int(v) for v in raw[i]] == c["raw64"][:4]
+        assert faces[i].tolist() == c["dice"]
+
+
+def test_dice_match_oracle_random_coordinates(eng, po):
+    rs = np.random.default_rng(11)
+    n = 4096
+    items = [(int(rs.choice([10, 103, 203])), 0, int(rs.integers(0, 2**63)), int(rs.integers(2, 13)), int(rs.integers(0, 2**40)),
+              int(rs.integers(0, 4000)), int(rs.integers(0, 2)), int(rs.integers(0, 2**34)), int(rs.integers(0, 12)), 0)
+             for _ in range(n)]
+    sizes = rs.integers(1, 7, size=64).astype(np.int32)
+    faces, raw = eng.debug_dice(_coords(items), sizes)
+    for i in range(0, n, 7):
+        c = po.coord(items[i][0], *items[i][2:9])
+        assert np.array_equal(po.dice_stream(c, sizes), faces[i])
+        assert np.array_equal(po.stream64(c, 4), raw[i])
+
+
+def _state_with_output(out64: int, lo: int) -> tuple[int, int]:
+    """Invert the DXSM output function: a (hi, lo) state whose next 64-bit output is ``out64``."""
+    M = 0xDA942042E4DD58B5
+    mask = (1 << 64) - 1
+    h = (out64 * pow(lo | 1, -1, 1 << 64)) & mask
+    h ^= h >> 48
+    h = (h * pow(M, -1, 1 << 64)) & mask
+    h ^= h >> 32
+    return h, lo
+
+
+def test_lemire_rejection_slow_path(eng, po):
+    """A die word r with low32(6r) < 4 must be redrawn (engine.py:101 -> Generator.integers).  Such words
+    appear once per ~2^30 dice, so states that emit them on demand are constructed by inverting DXSM."""
+    rejecting = [0, 715827883, 2147483648, 2863311531]
+    assert all(((r * 6) & 0xFFFFFFFF) < 4 for r in rejecting)
+    rs = np.random.default_rng(3)
+    states = []
+    for r in rejecting:
+        for other in rejecting + [12345, 0xFFFFFFFF]:
+            for has_buf in (0, 1):
+                for lo_half_first in (0, 1):
+                    out = (other << 32) | r if lo_half_first else (r << 32) | other
+                    hi, lo = _state_with_output(out, int(rs.integers(0, 2**63)))
+                    inc = int(rs.integers(0, 2**63)) * 2 + 1
+                    states.append([hi, lo, int(rs.integers(0, 2**63)), inc, has_buf, rejecting[int(rs.integers(0, 4))] if has_buf else 0])
+    states = np.array(states, dtype=np.uint64)
+    for sizes in ([6, 6, 6], [1, 2, 3, 4, 5, 6, 1], [5, 1, 1, 6], [2, 2, 2, 2, 3]):
+        faces, out = eng.debug_dice_state(states, sizes)
+        for i, st in enumerate(states):
+            f, o = po.dice_from_state(st, sizes)
+            assert np.array_equal(f, faces[i]), (i, sizes)
+            assert np.array_equal(o, out[i]), (i, sizes)
+        assert faces.min() >= 1 and faces.max() <= 6
+
+
+# ------------------------------------------------------------------ scoring / decisions
+def test_score_table_all_923_patterns(eng):
+    data = gu.load("scoring_vectors.json")
+    table = data["table"]
+    faces = np.zeros((len(table), 6), dtype=np.uint8)
+    lens = np.zeros(len(table), dtype=np.int32)
+    for i, row in enumerate(table):
+        roll = [f + 1 for f in range(6) for _ in range(row[f])]
+        faces[i, :len(roll)] = roll
+        lens[i] = len(roll)
+    plain = _strats([[300, 2, 0, 0, 1, 1, 0, 0, 0, 1, 0]] * len(table))
+    out = eng.debug_score(faces, lens, np.zeros(len(table), dtype=np.int32), plain)
+    for i, row in enumerate(table):
+        assert out[i, 0] == row[6] and out[i, 1] == row[7] and out[i, 3] == 0 and out[i, 4] == 0, row
+
+
+def test_default_score_matches_golden_and_oracle(eng, po):
+    data = gu.load("scoring_vectors.json")
+    cases = data["default_score"]
+    faces = np.zeros((len(cases), 6), dtype=np.uint8)
+    for i, c in enumerate(cases):
+        faces[i, :len(c["roll"])] = c["roll"]
+    lens = np.array([len(c["roll"]) for c in cases], dtype=np.int32)
+    pre = np.array([c["pre"] for c in cases], dtype=np.int32)
+    out = eng.debug_score(faces, lens, pre, _strats([c["strategy"] for c in cases]))
+    for i, c in enumerate(cases):
+        assert out[i].tolist() == c["out"], c
+    # exhaustive over the multiset table x a sample of the default grid x turn scores, against the oracle
+    table = data["table"]
+    grid = _default_table()
+    rs = np.random.default_rng(5)
+    pick = rs.choice(len(grid), size=48, replace=False)
+    rolls, ls, pres, ss = [], [], [], []
+    for row in table:
+        roll = [f + 1 for f in range(6) for _ in range(row[f])]
+        for gi in pick[: 12 if len(roll) < 3 else 48]:
+            for p in (0, 250, 950):
+                rolls.append(roll + [0] * (6 - len(roll)))
+                ls.append(len(roll))
+                pres.append(p)
+                ss.append(gi)
+    st = grid[np.array(ss)]
+    out = eng.debug_score(np.array(rolls, dtype=np.uint8), ls, pres, st)
+    for i in range(0, len(rolls), 5):
+        exp = po.default_score(rolls[i][: ls[i]], pres[i], st[i : i + 1])
+        assert tuple(out[i].tolist()) == exp, (rolls[i], pres[i], st[i])
+
+
+def test_should_continue_matches_golden(eng):
+    data = gu.load("scoring_vectors.json")
+    cases = data["should_continue"]
+    args = np.array([[c["turn_score"], c["dice_left"], c["has_scored"], c["final_round"], c["score_to_beat"],
+                      c["player_score"]] for c in cases], dtype=np.int32)
+    out = eng.debug_should_continue(args, _strats([c["strategy"] for c in cases]))
+    assert out.tolist() == [c["out"] for c in cases]
+
+
+# ------------------------------------------------------------------ single games
+def test_game_rows_match_reference_vectors(eng):
+    data = gu.load("game_vectors.json")
+    tables = {"g64": _strats(data["grids"]["g64"]), "default": _default_table()}
+    groups: dict = {}
+    for g in data["games"]:
+        groups.setdefault((g["grid"], g["k"], g["target"], g["max_rounds"]), []).append(g)
+    for (grid, k, target, max_rounds), games in groups.items():
+        table = tables[grid]
+        coords = _coords([(g["purpose"], 0, g["root_seed"], k, g["shuffle"], g["pair"], g["order"], g["game"], 0, 0)
+                          for g in games])
+        seat = np.array([g["strategies"] for g in games], dtype=np.int32)
+        rows = eng.play_games(coords, table, seat, k, target_score=target, max_rounds=max_rounds)
+        for row, g in zip(rows, games):
+            gu.assert_row_equal(gu.row_as_compact(row, k, lambda i: table[i]["strategy_id"]), g["row"], ctx=str(g["root_seed"]))
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 5, 6, 8, 12])
+def test_random_games_match_oracle(eng, po, k):
+    table = _default_table()
+    rs = np.random.default_rng(100 + k)
+    n = 3000 if k <= 4 else 1200
+    coords = _coords([(103, 0, int(rs.integers(0, 2**63)), k, int(rs.integers(0, 10**6)), 0, 0, int(rs.integers(0, 3000)), 0, 0)
+                      for _ in range(n)])
+    seat = np.stack([rs.choice(len(table), size=k, replace=False) for _ in range(n)]).astype(np.int32)
+    rows = eng.play_games(coords, table, seat, k)
+    ref = po.play_games(coords.view(po.COORD_DTYPE), table.view(po.STRATEGY_DTYPE), seat, k, n_threads=8)
+    assert _rows_equal(rows, ref.view(rows.dtype))
+
+
+def test_time_path_games(eng):
+    data = gu.load("time_path_vectors.json")
+    for block in [data["kat_counts"]] + data["many_games"]:
+        table = _strats(block["strategies"])
+        k = len(table)
+        n = block["n_games"]
+        coords = _coords([(10, 0, block["seed"], k, 0, 0, 0, i, 0, 0) for i in range(n)])
+        rows = eng.play_games(coords, table, np.tile(np.arange(k, dtype=np.int32), n), k,
+                              target_score=block.get("target", 10_000))
+        for i, (row, gold) in enumerate(zip(rows, block["rows"])):
+            gu.assert_row_equal(gu.row_as_compact(row, k, lambda j: table[j]["strategy_id"]), gold, ctx=f"game {i}")
+    kat = data["kat_counts"]  # tests/unit/simulation/test_simulation.py:184-199
+    table = _strats(kat["strategies"])
+    coords = _coords([(10, 0, 123, 3, 0, 0, 0, i, 0, 0) for i in range(10)])
+    rows = eng.play_games(coords, table, np.tile(np.arange(3, dtype=np.int32), 10), 3, target_score=5000)
+    counts: dict = {}
+    for row in rows:
+        key = f"P{int(row['winner_seat']) + 1}"
+        counts[key] = counts.get(key, 0) + 1
+    assert counts == kat["expected"]
+
+
+# ------------------------------------------------------------------ tournament
+def test_tournament_matches_reference_vectors(eng):
+    from farkle_ii_amd.backend import make_overrides
+
+    data = gu.load("tournament_vectors.json")
+    for case in data["cases"]:
+        table = _strats(case["strategies"])
+        ov = make_overrides([(11, 0, 0, 2, 0)]) if case["profile"] == "oracle" else None
+        res = eng.tournament(table, case["k"], case["root_seed"], case["shuffle"], case["shuffle"] + 1,
+                             target_score=case["target"], overrides=ov, want_rows=True, want_perms=True)
+        assert res["perms"][0].tolist() == case["perm"], case["name"]
+        ids = table["strategy_id"]
+        gu.assert_tally_matches(res["tally"][0], ids, case["tally"], ctx=case["name"])
+        for row, gold in zip(res["rows"], case["rows"]):
+            gu.assert_row_equal(gu.row_as_compact(row, case["k"], lambda i: ids[i]), gold, ctx=case["name"])
+
+
+def test_reference_expected_rows_on_gpu(eng):
+    """EXPECTED_ROWS (tests/integration/test_raw_simulation_oracle.py:45-58) straight from the HIP path."""
+    from farkle_ii_amd.backend import make_overrides
+
+    data = gu.load("tournament_vectors.json")
+    grid4 = _strats(gu.load("grid_vectors.json")["oracle4"])
+    ov = make_overrides([(11, 0, 0, 2, 0)])
+    for (root, k, shuffle, game), (seat_strats, status, winner_strategy, n_rounds, n_turns, scores) in data["EXPECTED_ROWS"]:
+        res = eng.tournament(grid4, k, root, shuffle, shuffle + 1, target_score=100, overrides=ov, want_rows=True)
+        row = res["rows"][game]
+        assert [int(row["seats"][i]["strategy"]) for i in range(k)] == seat_strats
+        assert ("completed", "safety_limit")[int(row["status"])] == status
+        w = int(row["winner_seat"])
+        assert (None if w < 0 else int(row["seats"][w]["strategy"])) == winner_strategy
+        assert int(row["n_rounds"]) == n_rounds
+        assert sum(int(row["seats"][i]["n_turns"]) for i in range(k)) == n_turns
+        assert [int(row["seats"][i]["score"]) for i in range(k)] == scores
+
+
+@pytest.mark.parametrize("k,n_shuffles", [(2, 600), (4, 300), (8, 150)])
+def test_tournament_g64_matches_oracle(eng, po, k, n_shuffles):
+    table = _strats(gu.load("grid_vectors.json")["g64"])
+    res = eng.tournament(table, k, 42, 0, n_shuffles, want_rows=True, want_perms=True)
+    ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 42, 0, n_shuffles, want_rows=True, want_perms=True, n_threads=8)
+    assert np.array_equal(res["perms"], ref["perms"])
+    assert _rows_equal(res["rows"], ref["rows"].view(res["rows"].dtype))
+    assert np.array_equal(res["tally"], ref["tally"])
+
+
+def test_tournament_default_grid_matches_oracle(eng, po):
+    table = _default_table()
+    for k, n_sh, root in [(4, 6, 0), (2, 4, 42), (6, 4, 9), (12, 3, 5)]:
+        res = eng.tournament(table, k, root, 10, 10 + n_sh, want_rows=True, want_perms=True)
+        ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, root, 10, 10 + n_sh, want_rows=True, want_perms=True, n_threads=8)
+        assert np.array_equal(res["perms"], ref["perms"]), k
+        assert _rows_equal(res["rows"], ref["rows"].view(res["rows"].dtype)), k
+        assert np.array_equal(res["tally"], ref["tally"]), k
+
+
+def test_tournament_batches_chunks_options_and_overrides(eng, po):
+    """Same results whatever the launch geometry: per-batch tallies, workspace chunking, LDS vs global
+    tally, hand-over threshold, block size; max_rounds overrides land on the right (shuffle, game)."""
+    from farkle_ii_amd.backend import make_overrides
+
+    table = _strats(gu.load("grid_vectors.json")["g64"])
+    ovs = [(42, 3, 5, 2, 0), (42, 17, 31, 2, 1), (42, 40, 0, 2, 7), (42, 40, 1, 4, 0), (7, 3, 5, 2, 0)]
+    ref = po.tournament(table.view(po.STRATEGY_DTYPE), 2, 42, 0, 50, shuffles_per_batch=7, overrides=po.make_overrides(ovs),
+                        want_rows=True, n_threads=8)
+    base = eng.tournament(table, 2, 42, 0, 50, shuffles_per_batch=7, overrides=make_overrides(ovs), want_rows=True)
+    assert np.array_equal(base["tally"], ref["tally"]) and base["tally"].shape[0] == 8
+    assert _rows_equal(base["rows"], ref["rows"].view(base["rows"].dtype))
+    try:
+        for name, value in [("chunk_bytes", 1 << 20), ("batch_threshold", 1), ("batch_threshold", 64), ("block", 256),
+                            ("block", 64), ("use_lds_tally", 0)]:
+            eng.set_option(name, value)
+            got = eng.tournament(table, 2, 42, 0, 50, shuffles_per_batch=7, overrides=make_overrides(ovs), want_rows=True)
+            assert np.array_equal(got["tally"], ref["tally"]), (name, value)
+            assert _rows_equal(got["rows"], base["rows"]), (name, value)
+            one = eng.tournament(table, 2, 42, 0, 50, overrides=make_overrides(ovs))
+            assert np.array_equal(one["tally"][0], ref["tally"].sum(axis=0)), (name, value)
+    finally:
+        for name, value in [("chunk_bytes", 24 << 30), ("batch_threshold", 6), ("block", 0), ("use_lds_tally", -1)]:
+            eng.set_option(name, value)
+
+
+def test_tournament_full_size_properties(eng):
+    """BASELINE config 2 at full size (k=2, 64-strategy grid, 10^7 games, seed 42): size-independent
+    properties of the tally (the oracle cannot play 10^7 games inside a test)."""
+    table = _strats(gu.load("grid_vectors.json")["g64"])
+    n_sh = 312_500
+    full = eng.tournament(table, 2, 42, 0, n_sh)["tally"][0]
+    assert np.all(full[:, 1] == n_sh)                              # every strategy seated once per shuffle
+    assert np.array_equal(full[:, 1], full[:, 2] + full[:, 3])     # attempted = completed + safety
+    assert full[:, 0].sum() * 2 == full[:, 2].sum()                # one winner per completed game
+    assert 0 < full[:, 3].sum() < 0.05 * full[:, 1].sum()          # never-bank pairings reach the safety limit
+    assert np.all(full[:, 14] == 0) and np.all(full[:, 25] == 0)   # winners never carry hit_max_rounds
+    mean_score = full[:, 4] / np.maximum(full[:, 0], 1)
+    assert np.all((mean_score >= 10_000) | (full[:, 0] == 0))      # winning_score >= target
+    assert np.all(full[:, 15] >= full[:, 4])                       # sum of squares dominates the sum
+    # additivity over a partition of the shuffle range + run-to-run determinism
+    a = eng.tournament(table, 2, 42, 0, 100_000)["tally"][0]
+    b = eng.tournament(table, 2, 42, 100_000, n_sh)["tally"][0]
+    assert np.array_equal(a + b, full)
+    again = eng.tournament(table, 2, 42, 0, n_sh)["tally"][0]
+    assert np.array_equal(again, full)
+
+
+# ------------------------------------------------------------------ H2H
+def test_h2h_blocks_match_goldens_and_oracle(eng, po):
+    from farkle_ii_amd.backend import make_overrides
+
+    data = gu.load("h2h_vectors.json")
+    grid4 = _strats(data["oracle4"])
+    ov = make_overrides([(11, 0, 0, 0, 0), (11, 1, 0, 0, 0), (11, 1, 1, 0, 0)])
+    expected = {tuple(k): v for k, v in data["EXPECTED_H2H_BLOCKS"]}
+    for b in data["blocks"]:
+        seats = grid4[[b["seat1_strategy"], b["seat2_strategy"]]]
+        st = eng.h2h(seats, b["root_seed"], b["pair_id"], b["order"], 1, 2, 5000, target_score=100, overrides=ov)
+        attempted, completed, safety, w1, w2 = (int(v) for v in st)
+        wins_a, wins_b = (w1, w2) if b["order"] == 0 else (w2, w1)
+        status = "complete" if completed >= 1 else ("unresolved_nonviable" if attempted >= 2 else "partial_resumable")
+        assert [attempted, completed, safety, wins_a, wins_b, max(0, attempted - 1), status] == \
+            expected[(b["pair_id"], b["root_seed"], b["order"])]
+    g64 = _strats(gu.load("grid_vectors.json")["g64"])
+    for b in data["g64_blocks"]:
+        seats = g64[[b["seat1_strategy"], b["seat2_strategy"]]]
+        state = None
+        for step in b["trace"]:
+            state = eng.h2h(seats, b["root_seed"], b["pair_id"], b["order"], b["n_completed_required"], b["max_attempts"],
+                            b["chunk"], state=state)
+            assert [int(v) for v in state] == step
+    # a never-bank pairing: many safety-limit replacements, larger block, against the oracle
+    never = [i for i, s in enumerate(g64) if s["dice_threshold"] == 0 and not s["require_both"]]
+    for seats_idx, target, max_att in [((never[0], 5), 3000, 6000), ((never[0], never[1]), 10, 400), ((3, 40), 20_000, 40_000)]:
+        seats = g64[list(seats_idx)]
+        got = eng.h2h(seats, 42, 9, 1, target, max_att, 10**9)
+        exp = po.h2h_block(seats.view(po.STRATEGY_DTYPE), 42, 9, 1, target, max_att, 10**9)
+        assert np.array_equal(got, exp), seats_idx
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_argument_errors(eng):
+    from farkle_ii_amd.backend import FarkleHipError
+
+    table = _strats(gu.load("grid_vectors.json")["g64"])
+    with pytest.raises(FarkleHipError, match="n_players must divide"):
+        eng.tournament(table, 3, 0, 0, 1)  # run_tournament.py:274
+    with pytest.raises(FarkleHipError):
+        eng.tournament(table, 2, 0, 0, 1, max_rounds=70_000)
+    bad = table.copy()
+    bad[0]["smart_one"], bad[0]["smart_five"] = 1, 0
+    with pytest.raises(FarkleHipError, match="smart_one"):
+        eng.tournament(bad, 2, 0, 0, 1)
+    empty = eng.tournament(table, 2, 0, 5, 5)
+    assert empty["tally"].shape[0] == 0

@@ -233,3 +233,12 @@ def test_oracle_argument_errors():
     table = _strats(gu.load("grid_vectors.json")["g64"])
     with pytest.raises(po.OracleError):
         po.tournament(table, 3, 0, 0, 1)  # 64 % 3 != 0 (run_tournament.py:274)
+
+
+def test_should_continue_cases():
+    data = gu.load("scoring_vectors.json")
+    for case in data["should_continue"]:
+        s = _strats([case["strategy"]])
+        got = po.should_continue(s, case["turn_score"], case["dice_left"], case["has_scored"], case["final_round"],
+                                 case["score_to_beat"], case["player_score"])
+        assert int(got) == case["out"], case
