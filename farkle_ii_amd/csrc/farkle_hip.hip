@@ -416,7 +416,7 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
         }
     };
 
-    // ---- one roll of the current turn (engine.py:241-263) ----
+    // ---- one roll of the current turn (engine.py:241-263), straight-line up to the turn hand-over ----
     auto roll_step = [&]() {
         if (rolls_this_turn >= 1000u) { // ROLL_LIMIT, engine.py:36,242
             raise(FK_ERR_ROLL_LIMIT);
@@ -424,32 +424,23 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
         }
         const uint32_t n = dice;
         const uint32_t counts = roll_counts(rng, n);
-        cA += 1u; // n_rolls (engine.py:98)
         rolls_this_turn += 1u;
         const RollResult rr = default_score(counts, (int32_t)n, turn_score, sp);
-        bool turn_over;
-        if (rr.score == 0) { // farkle (engine.py:135-137, 247-249)
-            cA += 0x10000u;
-            turn_score = 0;
-            turn_over = true;
-        } else {
-            if (rr.d5 > 0) cC += 1u + ((uint32_t)rr.d5 << 16); // engine.py:139-144
-            if (rr.d1 > 0) cD += 1u + ((uint32_t)rr.d1 << 16);
-            dice = (rr.used == (int32_t)n) ? 6u : (n - (uint32_t)rr.used); // engine.py:146
-            turn_score += rr.score;
-            if (turn_score > 0xffff) {
-                raise(FK_ERR_COUNTER_OVERFLOW);
-                return;
-            }
-            if (sp.has(SF_AUTO_HOT) && dice == 6u) { // _apply_hot_dice, engine.py:149-154, 253
-                cE += 1u;
-                turn_over = false;
-            } else {
-                turn_over = !should_continue(sp, turn_score, (int32_t)dice, (cE & CE_HAS_SCORED) != 0u,
-                                             final_round != 0u, score_to_beat, score);
-            }
+        const bool farkle = rr.score == 0;                          // engine.py:135-137, 247-249
+        cA += 1u + (farkle ? 0x10000u : 0u);                        // n_rolls (engine.py:98), n_farkles
+        cC += (rr.d5 > 0) ? (1u + ((uint32_t)rr.d5 << 16)) : 0u;    // engine.py:139-144
+        cD += (rr.d1 > 0) ? (1u + ((uint32_t)rr.d1 << 16)) : 0u;
+        dice = (rr.used == (int32_t)n) ? 6u : (n - (uint32_t)rr.used); // engine.py:146
+        turn_score = farkle ? 0 : (turn_score + rr.score);
+        const bool hot = !farkle & sp.has(SF_AUTO_HOT) & (dice == 6u); // _apply_hot_dice, engine.py:149-154, 253
+        cE += hot ? 1u : 0u;
+        const bool keep = should_continue(sp, turn_score, (int32_t)dice, (cE & CE_HAS_SCORED) != 0u, final_round != 0u,
+                                          score_to_beat, score);
+        if (turn_score > 0xffff) {
+            raise(FK_ERR_COUNTER_OVERFLOW);
+            return;
         }
-        if (turn_over) end_turn();
+        if (farkle | (!hot & !keep)) end_turn();
     };
 
     // ---- wave-level hand-over: finish ended games, deal new tickets ----

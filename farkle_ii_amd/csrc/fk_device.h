@@ -186,14 +186,27 @@ __host__ __device__ inline uint32_t roll_counts_sequential(Rng &r, uint32_t n, u
     return counts;
 }
 
+__host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
 // Converged fast path: all 64-bit outputs a roll can need (<= 3) are generated under per-lane
 // predicates, the six candidate words are selected with v_cndmask, and the (once in ~2^30 dice)
 // Lemire rejection falls back to the sequential form from the saved generator state.
+//   face index:   4*f = mulhi(w, 24) & 28          (mulhi(w,24) = floor(4 * 6w / 2^32) in [4f, 4f+3])
+//   count update: counts += on_i << 4f             (one v_lshl_add_u32; on_i = bit i of (1<<n)-1)
+//   rejection:    min over the six low words (6w mod 2^32) < 4.  Words that are generated but not
+//                 consumed can only cause a (harmless, exact) detour through the sequential path;
+//                 words that are not generated are the constant 1 (6 >= 4, never rejects).
 __device__ inline uint32_t roll_counts(Rng &r, uint32_t n, uint32_t *faces_out = nullptr) {
     const Rng saved = r;
     const uint32_t hb = r.has_buf;
     const uint32_t need = (n - hb + 1u) >> 1; // new 64-bit outputs: ceil((n - has_buf) / 2), 0..3
-    uint32_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0, last_hi = r.buf;
+    uint32_t lo0 = 1, hi0 = 1, lo1 = 1, hi1 = 1, lo2 = 1, hi2 = 1, last_hi = r.buf;
     if (need > 0u) {
         uint64_t o = pcg_next64(r);
         lo0 = (uint32_t)o;
@@ -219,19 +232,20 @@ __device__ inline uint32_t roll_counts(Rng &r, uint32_t n, uint32_t *faces_out =
     w[3] = hb ? lo1 : hi1;
     w[4] = hb ? hi1 : lo2;
     w[5] = hb ? lo2 : hi2;
-    uint32_t counts = 0, reject = 0, faces = 0;
+    const uint32_t onbits = (1u << n) - 1u;
+    uint32_t counts = 0, faces = 0, minleft = 0xffffffffu;
 #pragma unroll
     for (uint32_t i = 0; i < 6; ++i) {
-        uint32_t f = __umulhi(w[i], 6u);
-        uint32_t left = w[i] * 6u;
-        bool on = i < n;
-        reject |= (on && left < 4u) ? 1u : 0u;
-        counts += on ? (1u << (4u * f)) : 0u;
-        faces |= on ? ((f + 1u) << (4u * i)) : 0u;
+        const uint32_t f4 = mulhi32(w[i], 24u) & 28u;
+        const uint32_t on = (onbits >> i) & 1u;
+        counts += on << f4;
+        const uint32_t left = w[i] * 6u;
+        minleft = left < minleft ? left : minleft;
+        if (faces_out) faces |= on ? (((f4 >> 2) + 1u) << (4u * i)) : 0u;
     }
     r.has_buf = (n + hb) & 1u;
     r.buf = last_hi;
-    if (reject) { // rare: redo this roll exactly as NumPy would
+    if (minleft < 4u) { // rare: redo this roll exactly as NumPy would
         r = saved;
         faces = 0;
         counts = roll_counts_sequential(r, n, &faces);
@@ -271,36 +285,29 @@ __host__ __device__ inline int ctz32(uint32_t x) {
 }
 
 __host__ __device__ inline RawScore score_counts(uint32_t c) {
-    RawScore r;
+    // straight-line: every conditional below is a select, not a branch
     const uint32_t e2 = nibble_eq(c, 2u), e3 = nibble_eq(c, 3u), e4 = nibble_eq(c, 4u);
-    const bool straight = (c == 0x111111u);                 // _straight :28-38
-    const bool three_pairs = popc32(e2) == 3;               // _three_pairs :42-53
-    const bool two_triplets = popc32(e3) == 2;              // _two_triplets :57-68
-    const bool four_two = (e4 != 0u) && (e2 != 0u);         // _four_kind_plus_pair :72-82
-    if (straight || three_pairs || two_triplets || four_two) {
-        r.score = two_triplets && !(straight || three_pairs) ? 2500 : 1500;
-        r.used = 6;
-        r.sf = 0;
-        r.so = 0;
-        return r;
-    }
-    // n-of-a-kind (_apply_sets :86-115): nibble >= 3  <=>  bit 3 of (nibble + 5)
+    const uint32_t straight = (c == 0x111111u) ? 1u : 0u;                  // _straight :28-38
+    const uint32_t three_pairs = (popc32(e2) == 3) ? 1u : 0u;              // _three_pairs :42-53
+    const uint32_t two_triplets = (popc32(e3) == 2) ? 1u : 0u;             // _two_triplets :57-68
+    const uint32_t four_two = ((e4 != 0u) ? 1u : 0u) & ((e2 != 0u) ? 1u : 0u); // _four_kind_plus_pair :72-82
+    const uint32_t special = straight | three_pairs | two_triplets | four_two; // mutually exclusive (6 dice)
+    // n-of-a-kind (_apply_sets :86-115): nibble >= 3  <=>  bit 3 of (nibble + 5); at most one such face here
     const uint32_t ge3 = (c + 0x555555u) & 0x888888u;
-    int32_t set_pts = 0, set_n = 0;
-    uint32_t rest = c;
-    if (ge3) {
-        const int sh = ctz32(ge3) - 3; // 4 * face_index
-        const int32_t n = (int32_t)((c >> sh) & 7u);
-        const int32_t face = (sh >> 2) + 1;
-        set_pts = (n == 3) ? (face == 1 ? 300 : face * 100) : (n - 3) * 1000;
-        set_n = n;
-        rest = c & ~(0xFu << sh);
-    }
+    const bool has_set = ge3 != 0u;
+    const uint32_t sh = has_set ? (uint32_t)(ctz32(ge3 | 0x80000000u) - 3) : 0u; // 4 * face_index
+    const int32_t n = (int32_t)((c >> sh) & 7u);
+    const int32_t face = (int32_t)(sh >> 2) + 1;
+    const int32_t trip = (face == 1) ? 300 : face * 100;
+    const int32_t set_pts = has_set ? ((n == 3) ? trip : (n - 3) * 1000) : 0;
+    const int32_t set_n = has_set ? n : 0;
+    const uint32_t rest = has_set ? (c & ~(0xFu << sh)) : c;
     const int32_t ones = (int32_t)(rest & 7u), fives = (int32_t)((rest >> 16) & 7u);
-    r.score = set_pts + 100 * ones + 50 * fives; // :168-172
-    r.used = set_n + ones + fives;
-    r.sf = fives;
-    r.so = ones;
+    RawScore r;
+    r.score = special ? (two_triplets ? 2500 : 1500) : (set_pts + 100 * ones + 50 * fives); // :168-172
+    r.used = special ? 6 : (set_n + ones + fives);
+    r.sf = special ? 0 : fives;
+    r.so = special ? 0 : ones;
     return r;
 }
 
@@ -343,7 +350,9 @@ struct RollResult {
 // The reference enumerates re-scored sub-rolls (generate_sequences/score_lister/_select_candidate,
 // :197-366); every candidate that survives its `drop > singles` filter (:326-329) only removes lone
 // 1s/5s, so its score is raw - 50*d5 - 100*d1 and its used dice raw_used - d5 - d1 (closed form).
-__host__ __device__ inline RollResult default_score(uint32_t counts, int32_t n, int32_t turn_pre, const Strat &s) {
+//
+// Reference form (loops), kept as the readable statement of the rule and used by host-side checks:
+__host__ __device__ inline RollResult default_score_loops(uint32_t counts, int32_t n, int32_t turn_pre, const Strat &s) {
     const RawScore raw = score_counts(counts);
     RollResult out{raw.score, raw.used, 0, 0};
     if (!s.has(SF_SMART_FIVE) || raw.used == n || (raw.sf == 0 && raw.so == 0)) return out; // :433
@@ -353,11 +362,10 @@ __host__ __device__ inline RollResult default_score(uint32_t counts, int32_t n, 
     for (int32_t d5 = 0; d5 <= raw.sf; ++d5) {       // outer loop over fives (:224)
         for (int32_t d1 = 0; d1 <= max1; ++d1) {     // inner loop over ones (:225)
             const int32_t cs = raw.score - 50 * d5 - 100 * d1;
-            if (cs == 0) continue;                                   // score_lister :262
-            const int32_t score_after = turn_pre + cs;               // :331
+            if (cs == 0) continue;                                    // score_lister :262
+            const int32_t score_after = turn_pre + cs;                // :331
             const int32_t dice_left_after = n - (raw.used - d5 - d1); // :334
             if (must_bank(s, score_after, dice_left_after)) continue; // :337
-            // lexicographic key (:346-353) folded into one int: dice_left < 8, score_after < 2^20
             const int32_t key = favor_score ? (score_after * 8 + dice_left_after)
                                             : (dice_left_after * (1 << 20) + score_after);
             if (key > best_key) { // strict '>' keeps the first of equal keys (:354)
@@ -374,20 +382,85 @@ __host__ __device__ inline RollResult default_score(uint32_t counts, int32_t n, 
     return out;
 }
 
+// Branch-free form used by the kernels.  A candidate (d5, d1) != (0, 0) lives in one nibble of a 32-bit
+// word (8 candidates, d5, d1 in 0..2); per-candidate predicates are SWAR compares whose result is bit 3
+// of each nibble.  With v = d5 + 2*d1 (discarded points / 50) and cnt = d5 + d1 (dice returned):
+//     score_after < score_thr      <=>  v   >= vmin = floor((pre + raw - thr) / 50) + 1   (0 if already below)
+//     dice_left_after > dice_thr   <=>  cnt >= cmin = dice_thr - (n - used) + 1
+//     not must_bank (:283-300)     <=>  OR rule:  v >= vmin AND cnt >= cmin;   AND rule (require_both): either
+// The nibbles are laid out in preference order (best first), one layout per favor_dice_or_score value, so the
+// argmax of the reference's tuple key (:346-359) is a find-first-set.  (0, 0) is handled on the side: it is the
+// best candidate under SCORE preference and the worst under DICE preference.
+constexpr uint32_t pack8(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5, uint32_t a6, uint32_t a7) {
+    return a0 | (a1 << 4) | (a2 << 8) | (a3 << 12) | (a4 << 16) | (a5 << 20) | (a6 << 24) | (a7 << 28);
+}
+// SCORE preference: ascending v, ties by descending cnt:  (1,0) (2,0) (0,1) (1,1) (2,1) (0,2) (1,2) (2,2)
+constexpr uint32_t CS_D5 = pack8(1, 2, 0, 1, 2, 0, 1, 2), CS_D1 = pack8(0, 0, 1, 1, 1, 2, 2, 2);
+// DICE preference: descending cnt, ties by ascending v:   (2,2) (2,1) (1,2) (2,0) (1,1) (0,2) (1,0) (0,1)
+constexpr uint32_t CD_D5 = pack8(2, 2, 1, 2, 1, 0, 1, 0), CD_D1 = pack8(2, 1, 2, 0, 1, 2, 0, 1);
+constexpr uint32_t NIB_H = 0x88888888u, NIB_1 = 0x11111111u;
+
+__host__ __device__ inline RollResult default_score(uint32_t counts, int32_t n, int32_t turn_pre, const Strat &s) {
+    const RawScore raw = score_counts(counts);
+    const uint32_t sf = (uint32_t)raw.sf, so = (uint32_t)raw.so;
+    const uint32_t m1 = s.has(SF_SMART_ONE) ? so : 0u;
+    const bool eligible = s.has(SF_SMART_FIVE) & (raw.used != n) & ((sf | so) != 0u); // :433
+    const bool cs = s.has(SF_CONSIDER_SCORE), cd = s.has(SF_CONSIDER_DICE), rb = s.has(SF_REQUIRE_BOTH);
+    const bool fav = s.has(SF_FAVOR_SCORE);
+    // thresholds in candidate units
+    const int32_t x = turn_pre + raw.score - s.score_thr;
+    const uint32_t xq = ((uint32_t)(x < 1000 ? x : 1000) * 1311u) >> 16; // floor(x / 50) for 0 <= x <= 1000
+    uint32_t vmin = (x < 0) ? 0u : (xq + 1u < 7u ? xq + 1u : 7u);
+    vmin = cs ? vmin : 0u;
+    int32_t cm = s.dice_thr() - (n - raw.used) + 1;
+    cm = cm < 0 ? 0 : (cm > 5 ? 5 : cm);
+    const uint32_t cmin = cd ? (uint32_t)cm : 0u;
+    // candidate layout for this strategy's preference
+    const uint32_t D5 = fav ? CS_D5 : CD_D5, D1 = fav ? CS_D1 : CD_D1;
+    const uint32_t V = D5 + 2u * D1, CNT = D5 + D1; // nibble-wise (max 6 / 4: no carries)
+    const uint32_t ok5 = (sf * NIB_1 + (NIB_H - D5)) & NIB_H;  // d5 <= single fives (:326-329)
+    const uint32_t ok1 = (m1 * NIB_1 + (NIB_H - D1)) & NIB_H;  // d1 <= single ones (smart_one only)
+    const uint32_t mv = ((NIB_H + V) - vmin * NIB_1) & NIB_H;  // v >= vmin
+    const uint32_t mc = ((NIB_H + CNT) - cmin * NIB_1) & NIB_H; // cnt >= cmin
+    const uint32_t keep = rb ? (mv | mc) : (mv & mc);          // not must_bank
+    // candidate score 0 (score_lister :262): 50 * v == raw score
+    const uint32_t r50 = ((uint32_t)raw.score * 1311u) >> 16;   // raw.score / 50 (raw.score is a multiple of 50, < 2^16)
+    const uint32_t xr = V ^ ((r50 < 15u ? r50 : 15u) * NIB_1);
+    const uint32_t nz = (xr | (xr << 1) | (xr << 2) | (xr << 3)) & NIB_H; // nibble != 0
+    const uint32_t feas = ok5 & ok1 & keep & nz;
+    const bool f0 = rb ? ((vmin == 0u) | (cmin == 0u)) : ((vmin == 0u) & (cmin == 0u)); // (0,0) not must_bank
+    const bool any8 = feas != 0u;
+    const uint32_t l4 = any8 ? (uint32_t)(ctz32(feas | 0u) - 3) : 0u;
+    const bool take = eligible & any8 & !(fav & f0);
+    const int32_t d5 = take ? (int32_t)((D5 >> l4) & 3u) : 0;
+    const int32_t d1 = take ? (int32_t)((D1 >> l4) & 3u) : 0;
+    RollResult out;
+    out.d5 = d5; // == single_fives - best_sf (:467)
+    out.d1 = d1;
+    out.score = raw.score - 50 * d5 - 100 * d1; // apply_discards :575-578
+    out.used = raw.used - d5 - d1;
+    return out;
+}
+
 // FarklePlayer._should_continue (src/farkle/game/engine.py:156-205) with ThresholdStrategy.decide
-// (src/farkle/simulation/strategies.py:212-275) and _decide_continue (:125-162) inlined.
+// (src/farkle/simulation/strategies.py:212-275) and _decide_continue (:125-162) folded into boolean algebra:
+//   stop  = final & running > to_beat & !run_up                      (engine.py:189)
+//   force = final & running <= to_beat                               (engine.py:202, strategies.py:255)
+//   entry = !has_scored & turn < 500                                 (strategies.py:249)
+//   thr   = both considered ? (require_both ? want_s | want_d : want_s & want_d) : want_s | want_d   (:154-162)
+//   continue = !stop & (force | entry | thr)
 __host__ __device__ inline bool should_continue(const Strat &s, int32_t turn_score, int32_t dice_left, bool has_scored,
                                                 bool final_round, int32_t score_to_beat, int32_t player_score) {
     const int32_t running_total = player_score + turn_score;
-    if (final_round && running_total > score_to_beat && !s.has(SF_RUN_UP)) return false; // engine.py:189
-    if (final_round && running_total <= score_to_beat) return true;                       // engine.py:202 (overrides decide)
-    if (!has_scored && turn_score < 500) return true;                                     // strategies.py:249
-    // final_round here implies running_total > score_to_beat and run_up_score: fall through (:253-262)
+    const bool above = running_total > score_to_beat;
+    const bool stop = final_round & above & !s.has(SF_RUN_UP);
+    const bool force = final_round & !above;
+    const bool entry = !has_scored & (turn_score < 500);
     const bool cs = s.has(SF_CONSIDER_SCORE), cd = s.has(SF_CONSIDER_DICE);
-    const bool want_s = cs && turn_score < s.score_thr;
-    const bool want_d = cd && dice_left > s.dice_thr();
-    if (cs && cd) return s.has(SF_REQUIRE_BOTH) ? (want_s || want_d) : (want_s && want_d);
-    return cs ? want_s : (cd ? want_d : false);
+    const bool want_s = cs & (turn_score < s.score_thr);
+    const bool want_d = cd & (dice_left > s.dice_thr());
+    const bool thr = (cs & cd & !s.has(SF_REQUIRE_BOTH)) ? (want_s & want_d) : (want_s | want_d);
+    return !stop & (force | entry | thr);
 }
 
 } // namespace fk
