@@ -60,6 +60,13 @@ struct SeedArgs {
     uint32_t k;
     uint32_t n_games;
     uint4 *seeds;            // [n_games][k][2] = {state lo, state hi}, {inc lo, inc hi}
+    // longest-first scheduling (tournament mode): games whose seats ALL never bank run to the round
+    // limit (~13x the mean length); they are dealt first so that they do not form the tail of a wave.
+    const uint16_t *perm_T;  // nullable
+    const uint32_t *slow_bits; // bitmap over strategies: 1 = never banks voluntarily
+    uint32_t n_sh;
+    uint32_t *sched;         // [n_games] ticket -> game id
+    uint32_t *sched_ctr;     // [2] front / back cursors
 };
 
 struct PlayArgs {
@@ -67,6 +74,7 @@ struct PlayArgs {
     const uint16_t *perm_T;      // [S][n_sh] shuffle-minor permutations (MODE_PERM)
     const int32_t *seat_strategy; // [n_games][k] (MODE_LIST)
     const uint4 *seeds;
+    const uint32_t *sched;       // nullable: ticket -> game id (longest-first schedule)
     unsigned long long *tally;   // [n_batches][S][26]
     uint8_t *rows;               // nullable, [n_games] * (4 + 28k)
     uint32_t *ticket;
@@ -119,46 +127,91 @@ __global__ void fk_perm_kernel(SeedPool prefix, uint64_t shuffle0, uint32_t n_sh
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ void fk_seed_kernel(SeedArgs a) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= a.n_games) return;
-    SeedPool gp;
-    uint64_t seat0 = 0, replicate = 0;
-    if (a.coords) {
-        const fk_coord c = a.coords[id];
-        seat0 = c.seat_index;
-        replicate = c.replicate_index;
-        ss_begin(gp, 2u, c.purpose, (uint32_t)c.root_seed, (uint32_t)(c.root_seed >> 32));
-        ss_absorb64(gp, c.k);
-        ss_absorb64(gp, c.shuffle_index);
-        ss_absorb64(gp, c.pair_id);
-        ss_absorb64(gp, c.order);
-        ss_absorb64(gp, c.game_index);
-    } else {
-        gp = a.prefix;
-        gp.hc = HC_AFTER_6_WORDS;
-        uint64_t sh = a.shuffle0, g = a.game0 + id;
-        if (a.gps) {
-            const uint32_t q = id / a.gps;
-            sh = a.shuffle0 + q;
-            g = a.game0 + (id - q * a.gps);
-        }
-        ss_absorb64(gp, sh);
-        ss_absorb64(gp, a.pair);
-        ss_absorb64(gp, a.order);
-        ss_absorb64(gp, g);
+constexpr int SEED_BLOCK = 1024;
+
+__global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
+    __shared__ uint32_t wave_cnt[2][SEED_BLOCK / 64];
+    __shared__ uint32_t block_base[2];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = t < a.n_games;
+    // Tournament mode walks the games shuffle-minor (consecutive lanes = consecutive shuffles of one game
+    // slot) so that the shuffle-minor permutation is read coalesced; ids stay shuffle-major.
+    uint32_t id = t, sh_local = 0, g_local = t;
+    if (a.perm_T) {
+        g_local = t / a.n_sh;
+        sh_local = t - g_local * a.n_sh;
+        id = sh_local * a.gps + g_local;
+    } else if (a.gps) {
+        sh_local = t / a.gps;
+        g_local = t - sh_local * a.gps;
     }
-    for (uint32_t s = 0; s < a.k; ++s) {
-        SeedPool sp = gp;
-        ss_absorb64(sp, seat0 + s); // seat_index
-        ss_absorb64(sp, replicate); // replicate_index
-        uint32_t g8[8];
-        ss_generate<8>(sp, g8);
-        Rng r;
-        pcg_seed(r, g8);
-        uint4 *dst = a.seeds + ((size_t)id * a.k + s) * 2;
-        dst[0] = make_uint4((uint32_t)r.lo, (uint32_t)(r.lo >> 32), (uint32_t)r.hi, (uint32_t)(r.hi >> 32));
-        dst[1] = make_uint4((uint32_t)r.inc_lo, (uint32_t)(r.inc_lo >> 32), (uint32_t)r.inc_hi, (uint32_t)(r.inc_hi >> 32));
+    if (valid) {
+        SeedPool gp;
+        uint64_t seat0 = 0, replicate = 0;
+        if (a.coords) {
+            const fk_coord c = a.coords[id];
+            seat0 = c.seat_index;
+            replicate = c.replicate_index;
+            ss_begin(gp, 2u, c.purpose, (uint32_t)c.root_seed, (uint32_t)(c.root_seed >> 32));
+            ss_absorb64(gp, c.k);
+            ss_absorb64(gp, c.shuffle_index);
+            ss_absorb64(gp, c.pair_id);
+            ss_absorb64(gp, c.order);
+            ss_absorb64(gp, c.game_index);
+        } else {
+            gp = a.prefix;
+            gp.hc = HC_AFTER_6_WORDS;
+            ss_absorb64(gp, a.shuffle0 + sh_local);
+            ss_absorb64(gp, a.pair);
+            ss_absorb64(gp, a.order);
+            ss_absorb64(gp, a.game0 + g_local);
+        }
+        for (uint32_t s = 0; s < a.k; ++s) {
+            SeedPool sp = gp;
+            ss_absorb64(sp, seat0 + s); // seat_index
+            ss_absorb64(sp, replicate); // replicate_index
+            uint32_t g8[8];
+            ss_generate<8>(sp, g8);
+            Rng r;
+            pcg_seed(r, g8);
+            uint4 *dst = a.seeds + ((size_t)t * a.k + s) * 2; // slot = walk order (coalesced stores)
+            dst[0] = make_uint4((uint32_t)r.lo, (uint32_t)(r.lo >> 32), (uint32_t)r.hi, (uint32_t)(r.hi >> 32));
+            dst[1] = make_uint4((uint32_t)r.inc_lo, (uint32_t)(r.inc_lo >> 32), (uint32_t)r.inc_hi, (uint32_t)(r.inc_hi >> 32));
+        }
+    }
+    if (!a.sched) return; // uniform
+    // Longest-first schedule (scheduling only: results do not depend on the order games are dealt in).
+    // Never-banking pairings fill the schedule from the front, everything else from the back; positions come
+    // from one returning atomic per block and class (a single word sustains only ~90 returning atomics/us).
+    bool all_slow = valid;
+    if (valid) {
+        for (uint32_t s = 0; s < a.k; ++s) {
+            const uint32_t idx = a.perm_T[(size_t)(g_local * a.k + s) * a.n_sh + sh_local];
+            all_slow = all_slow && ((a.slow_bits[idx >> 5] >> (idx & 31u)) & 1u);
+        }
+    }
+    const uint64_t slow_m = __ballot(all_slow);
+    const uint64_t fast_m = __ballot(valid && !all_slow);
+    const uint32_t wave = threadIdx.x >> 6;
+    if (lane_id() == 0u) {
+        wave_cnt[0][wave] = (uint32_t)__popcll(slow_m);
+        wave_cnt[1][wave] = (uint32_t)__popcll(fast_m);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2u) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < SEED_BLOCK / 64; ++w) {
+            const uint32_t c = wave_cnt[threadIdx.x][w];
+            wave_cnt[threadIdx.x][w] = total; // exclusive prefix
+            total += c;
+        }
+        block_base[threadIdx.x] = total ? atomicAdd(&a.sched_ctr[threadIdx.x], total) : 0u;
+    }
+    __syncthreads();
+    if (valid) {
+        const uint32_t pos = all_slow ? (block_base[0] + wave_cnt[0][wave] + mbcnt(slow_m))
+                                      : (a.n_games - 1u - (block_base[1] + wave_cnt[1][wave] + mbcnt(fast_m)));
+        a.sched[pos] = id;
     }
 }
 
@@ -331,9 +384,14 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
         max_rounds = a.max_rounds;
         for (uint32_t i = 0; i < a.n_ov; ++i)
             if (a.ov[i].game == id) max_rounds = a.ov[i].max_rounds;
+        uint32_t slot = id; // seeds are stored in the seed kernel's walk order (shuffle-minor in tournament mode)
+        if (a.mode == MODE_PERM) {
+            const uint32_t sh = id / a.gps, g = id - sh * a.gps;
+            slot = g * a.n_sh + sh;
+        }
         for (uint32_t s = 0; s < K; ++s) {
             const uint2 pk = a.strat[strategy_index(id, s)];
-            const uint4 *src = a.seeds + ((size_t)id * K + s) * 2;
+            const uint4 *src = a.seeds + ((size_t)slot * K + s) * 2;
             const uint4 stv = src[0], inc = src[1];
             L(F_LO0, s) = stv.x;
             L(F_LO1, s) = stv.y;
@@ -464,8 +522,10 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
         }
         if (mine) {
             const uint32_t rank = mbcnt(waiting);
-            if (rank < avail) init_game(pool_next + rank);
-            else if (rank - avail < new_avail) init_game(new_base + (rank - avail));
+            uint32_t ticket = 0xffffffffu;
+            if (rank < avail) ticket = pool_next + rank;
+            else if (rank - avail < new_avail) ticket = new_base + (rank - avail);
+            if (ticket != 0xffffffffu) init_game(a.sched ? a.sched[ticket] : ticket);
             else st = ST_DONE;
         }
         if (n <= avail) {
@@ -591,7 +651,8 @@ struct fk_ctx {
     std::string err;
     fk_timing timing{};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, dbg[6];
+    DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, dbg[6];
+    int32_t longest_first = 1;
     int64_t chunk_bytes = (int64_t)24 << 30;
     int32_t batch_threshold = 6;
     int32_t use_lds_tally = -1;
@@ -666,7 +727,17 @@ int upload_strategies(fk_ctx *c, const fk_strategy *s, int32_t S) {
     rc = ensure(c, c->strat, sizeof(uint2) * (size_t)S);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->strat.p, packed.data(), sizeof(uint2) * (size_t)S, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream)); // `packed` goes out of scope
+    // Strategies that never bank voluntarily outside the final round: should_continue's threshold term is
+    // always true iff dice are considered with dice_threshold < 1 (dice_left >= 1 always exceeds it) and the
+    // score threshold cannot veto (require_both, or score not considered).  Used for scheduling only.
+    std::vector<uint32_t> slow(((size_t)S + 31) / 32, 0u);
+    for (int32_t i = 0; i < S; ++i)
+        if (s[i].consider_dice && s[i].dice_threshold < 1 && (s[i].require_both || !s[i].consider_score))
+            slow[(size_t)i >> 5] |= 1u << (i & 31);
+    rc = ensure(c, c->slow, slow.size() * 4);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->slow.p, slow.data(), slow.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); // host vectors go out of scope
     return FK_OK;
 }
 
@@ -775,9 +846,20 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 64, c->stream));
     sa.seeds = static_cast<uint4 *>(c->seeds.p);
+    if (sa.perm_T && c->longest_first) {
+        rc = ensure(c, c->order, (size_t)sa.n_games * 4);
+        if (rc) return rc;
+        sa.sched = static_cast<uint32_t *>(c->order.p);
+        sa.sched_ctr = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(c->misc.p) + 32);
+        sa.slow_bits = static_cast<const uint32_t *>(c->slow.p);
+        pa.sched = sa.sched;
+    } else {
+        sa.sched = nullptr;
+        pa.sched = nullptr;
+    }
     {
         Timer t(c, &c->timing.seed_ms, 0);
-        hipLaunchKernelGGL(fk_seed_kernel, dim3((sa.n_games + 255u) / 256u), dim3(256), 0, c->stream, sa);
+        hipLaunchKernelGGL(fk_seed_kernel, dim3((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK), dim3(SEED_BLOCK), 0, c->stream, sa);
         t.stop();
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, t.collect());
@@ -832,7 +914,7 @@ void fk_destroy(fk_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->strat, &c->perm, &c->seeds, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist, &c->coords})
+    for (DevBuf *b : {&c->strat, &c->perm, &c->seeds, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist, &c->coords, &c->order, &c->slow})
         release(*b);
     for (auto &b : c->dbg) release(b);
     for (auto &e : c->ev)
@@ -868,6 +950,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     if (n == "chunk_bytes") c->chunk_bytes = std::max<int64_t>(value, 1 << 20);
     else if (n == "batch_threshold") c->batch_threshold = (int32_t)value;
     else if (n == "use_lds_tally") c->use_lds_tally = (int32_t)value;
+    else if (n == "longest_first") c->longest_first = (int32_t)value;
     else if (n == "block") {
         if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
             return fail(c, FK_ERR_ARG, "block must be 0, 64, 128, 256, 512 or 1024");
@@ -971,6 +1054,8 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
         sa.gps = gps;
         sa.k = (uint32_t)k;
         sa.n_games = n_games;
+        sa.perm_T = static_cast<const uint16_t *>(c->perm.p);
+        sa.n_sh = n_sh;
 
         PlayArgs pa{};
         pa.strat = static_cast<const uint2 *>(c->strat.p);
@@ -1237,7 +1322,7 @@ static int debug_dice_common(fk_ctx *c, int64_t n, const fk_coord *coords, const
         sa.k = 1;
         sa.n_games = (uint32_t)n;
         sa.seeds = static_cast<uint4 *>(c->seeds.p);
-        hipLaunchKernelGGL(fk_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, sa);
+        hipLaunchKernelGGL(fk_seed_kernel, dim3((unsigned)((n + SEED_BLOCK - 1) / SEED_BLOCK)), dim3(SEED_BLOCK), 0, c->stream, sa);
         HIPCHK(c, hipGetLastError());
         d_seeds = sa.seeds;
     } else {
