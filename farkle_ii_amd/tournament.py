@@ -1,0 +1,326 @@
+"""Tournament shuffle/chunk functions on the GPU engine.
+
+Mirrors ``src/farkle/simulation/run_tournament.py``: ``TournamentConfig`` :78-94, ``ShuffleTask`` :97-105,
+``METRIC_LABELS`` :109-121, ``OutcomeCounter`` :165-245, ``_init_worker`` :265-277, ``_play_one_shuffle`` :301-393,
+``_play_shuffle`` :396-400, ``_run_chunk`` :403-457, ``_run_chunk_metrics`` :473-585.  A chunk (contiguous shuffles)
+is ONE kernel launch; the returned objects have the reference's types so its parent loop can absorb them.
+"""
+from __future__ import annotations
+
+from collections import Counter, defaultdict
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Any, Dict, List, Mapping, Sequence, Tuple
+
+import numpy as np
+
+from . import random as urandom
+from .backend import (COL_ATTEMPTED, COL_COMPLETED, COL_SAFETY, COL_SQ_SUMS, COL_SUMS, COL_WINS, FarkleHipError,
+                      FK_ERR_ROLL_LIMIT)
+from .engine import get_engine
+from .game_profile import GameProfile
+from .rows import OUTCOME_SCHEMA_VERSION, TOURNAMENT_METHOD_VERSION, row_to_dict, rows_to_table
+from .strategies import ThresholdStrategy, pack_strategies, prepare_public_helper_strategies
+
+NUM_SHUFFLES = 5_907
+DESIRED_SEC_PER_CHUNK = 10
+CKPT_EVERY_SEC = 30
+
+METRIC_LABELS: Tuple[str, ...] = (
+    "winning_score", "n_rounds", "winner_farkles", "winner_rolls", "winner_highest_turn", "winner_smart_five_uses",
+    "winner_n_smart_five_dice", "winner_smart_one_uses", "winner_n_smart_one_dice", "winner_hot_dice",
+    "winner_hit_max_rounds",
+)
+
+
+@dataclass
+class TournamentConfig:
+    n_players: int = 5
+    num_shuffles: int = NUM_SHUFFLES
+    desired_sec_per_chunk: int = DESIRED_SEC_PER_CHUNK
+    ckpt_every_sec: int = CKPT_EVERY_SEC
+    n_strategies: int = 7_140
+    mp_start_method: str | None = None
+    deterministic_batch_size: int = 30
+
+    @property
+    def games_per_shuffle(self) -> int:
+        return self.n_strategies // self.n_players
+
+
+@dataclass(frozen=True)
+class ShuffleTask:
+    """Stable coordinate identity for one complete tournament shuffle."""
+
+    root_seed: int
+    k: int
+    shuffle_index: int
+    shuffle_seed: int
+    deterministic_batch_id: int
+
+
+class OutcomeCounter(Counter):
+    """Win counter carrying additive attempted/completed exposure conservation."""
+
+    def __init__(self, *args: Any, **kwargs: Any) -> None:
+        self.attempted_exposures: Counter = Counter()
+        self.completed_exposures: Counter = Counter()
+        self.safety_limit_exposures: Counter = Counter()
+        self.games_attempted = 0
+        self.games_completed = 0
+        self.games_safety_limit = 0
+        super().__init__(*args, **kwargs)
+
+    def absorb(self, other: Counter) -> None:
+        super().update(other)
+        if isinstance(other, OutcomeCounter):
+            self.attempted_exposures.update(other.attempted_exposures)
+            self.completed_exposures.update(other.completed_exposures)
+            self.safety_limit_exposures.update(other.safety_limit_exposures)
+            self.games_attempted += other.games_attempted
+            self.games_completed += other.games_completed
+            self.games_safety_limit += other.games_safety_limit
+            return
+        completed = int(sum(other.values()))
+        self.attempted_exposures.update(other)
+        self.completed_exposures.update(other)
+        self.games_attempted += completed
+        self.games_completed += completed
+
+    def outcome_payload(self) -> dict[str, Any]:
+        return {"games_attempted": self.games_attempted, "games_completed": self.games_completed,
+                "games_safety_limit": self.games_safety_limit, "attempted_exposures": dict(self.attempted_exposures),
+                "completed_exposures": dict(self.completed_exposures),
+                "safety_limit_exposures": dict(self.safety_limit_exposures)}
+
+    def __reduce__(self):
+        return (_restore_outcome_counter, (dict(self), self.outcome_payload()))
+
+
+def _restore_outcome_counter(counts: dict, outcome_counts: dict) -> OutcomeCounter:
+    restored = OutcomeCounter(counts)
+    restored.attempted_exposures.update(outcome_counts.get("attempted_exposures", {}))
+    restored.completed_exposures.update(outcome_counts.get("completed_exposures", {}))
+    restored.safety_limit_exposures.update(outcome_counts.get("safety_limit_exposures", {}))
+    restored.games_attempted = int(outcome_counts.get("games_attempted", 0))
+    restored.games_completed = int(outcome_counts.get("games_completed", 0))
+    restored.games_safety_limit = int(outcome_counts.get("games_safety_limit", 0))
+    return restored
+
+
+@dataclass
+class WorkerState:
+    strats: list[ThresholdStrategy]
+    cfg: TournamentConfig
+    game_profile: GameProfile | None = None
+    table: np.ndarray = field(default=None, repr=False)  # type: ignore[assignment]
+
+
+_STATE: WorkerState | None = None
+
+
+def _init_worker(strategies: Sequence[ThresholdStrategy], config: TournamentConfig, game_profile: GameProfile | None = None,
+                 progress_endpoint: Any = None) -> None:
+    """Initialise per-process state (strategy table uploaded lazily with each launch)."""
+    del progress_endpoint
+    global _STATE
+    if len(strategies) % config.n_players != 0:
+        raise ValueError(f"n_players must divide {len(strategies):,}")
+    resolved = prepare_public_helper_strategies(strategies)
+    _STATE = WorkerState(resolved, config, game_profile, pack_strategies(resolved))
+
+
+def _coerce_shuffle_task(task: ShuffleTask | int) -> ShuffleTask:
+    if isinstance(task, ShuffleTask):
+        return task
+    k = _STATE.cfg.n_players if _STATE is not None else 0
+    return ShuffleTask(root_seed=int(task), k=k, shuffle_index=0, shuffle_seed=int(task), deterministic_batch_id=0)
+
+
+def tally_to_counters(tally: np.ndarray, ids: Sequence[int], k: int):
+    """``int64[S][26]`` -> (OutcomeCounter, sums, square sums) with the reference's dict shapes."""
+    wins = OutcomeCounter()
+    sums: Dict[str, Dict[int, float]] = {m: defaultdict(float) for m in METRIC_LABELS}
+    sqs: Dict[str, Dict[int, float]] = {m: defaultdict(float) for m in METRIC_LABELS}
+    for i, sid in enumerate(ids):
+        row = tally[i]
+        sid = int(sid)
+        if row[COL_ATTEMPTED]:
+            wins.attempted_exposures[sid] = int(row[COL_ATTEMPTED])
+        if row[COL_COMPLETED]:
+            wins.completed_exposures[sid] = int(row[COL_COMPLETED])
+        if row[COL_SAFETY]:
+            wins.safety_limit_exposures[sid] = int(row[COL_SAFETY])
+        if row[COL_WINS]:
+            wins[sid] = int(row[COL_WINS])
+            for j, label in enumerate(METRIC_LABELS):
+                sums[label][sid] = float(row[COL_SUMS + j])
+                sqs[label][sid] = float(row[COL_SQ_SUMS + j])
+    wins.games_attempted = int(tally[:, COL_ATTEMPTED].sum()) // k
+    wins.games_completed = int(tally[:, COL_COMPLETED].sum()) // k
+    wins.games_safety_limit = int(tally[:, COL_SAFETY].sum()) // k
+    return wins, sums, sqs
+
+
+def _limits(state: WorkerState) -> tuple[int, int, np.ndarray | None]:
+    gp = state.game_profile
+    if gp is None:
+        return 10_000, 200, None
+    return gp.default_target_score, gp.default_max_rounds, gp.tournament_overrides()
+
+
+def _launch(tasks: Sequence[ShuffleTask], *, want_rows: bool, per_shuffle: bool = False):
+    """Run the games of ``tasks`` (any shuffle indices of one (root, k) cell), grouped into contiguous launches."""
+    state = _STATE
+    if state is None:
+        raise RuntimeError("tournament worker state is not initialised (_init_worker)")
+    eng = get_engine()
+    target, max_rounds, ov = _limits(state)
+    out = []
+    i = 0
+    while i < len(tasks):
+        j = i
+        while (j + 1 < len(tasks) and tasks[j + 1].shuffle_index == tasks[j].shuffle_index + 1
+               and tasks[j + 1].root_seed == tasks[i].root_seed and tasks[j + 1].k == tasks[i].k):
+            j += 1
+        first, last = tasks[i], tasks[j]
+        try:
+            res = eng.tournament(state.table, first.k, first.root_seed, first.shuffle_index, last.shuffle_index + 1,
+                                 shuffles_per_batch=1 if per_shuffle else None, target_score=target, max_rounds=max_rounds,
+                                 overrides=ov, want_rows=want_rows)
+        except FarkleHipError as exc:
+            if exc.code == FK_ERR_ROLL_LIMIT:
+                raise RuntimeError(str(exc)) from exc
+            raise
+        out.append((tasks[i:j + 1], res))
+        i = j + 1
+    return out
+
+
+def _shuffle_rows(task: ShuffleTask, rows: np.ndarray, ids: Sequence[int]) -> List[Dict[str, Any]]:
+    k = task.k
+    gps = len(rows)
+    game_seeds = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=task.root_seed, k=k,
+                                          shuffle_index=task.shuffle_index, game_index=np.arange(gps, dtype=np.uint64),
+                                          dtype=np.uint32)
+    out = []
+    for g in range(gps):
+        out.append(row_to_dict(rows[g], k, ids, {
+            "root_seed": task.root_seed, "k": k, "shuffle_index": task.shuffle_index, "game_index": g,
+            "deterministic_batch_id": task.deterministic_batch_id, "shuffle_seed": task.shuffle_seed,
+            "game_seed": int(game_seeds[g]), "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
+            "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_GAME)}))
+    return out
+
+
+def _play_one_shuffle(task: ShuffleTask | int, *, collect_rows: bool = False):
+    """Play all games for one shuffle and aggregate the results: (wins, sums, sq_sums, rows)."""
+    work = _coerce_shuffle_task(task)
+    state = _STATE
+    (_, res), = _launch([work], want_rows=collect_rows)
+    ids = [int(s.strategy_id) for s in state.strats]  # type: ignore[union-attr]
+    wins, sums, sqs = tally_to_counters(res["tally"][0], ids, work.k)
+    rows = _shuffle_rows(work, res["rows"], ids) if collect_rows else []
+    return wins, sums, sqs, rows
+
+
+def _play_shuffle(task: ShuffleTask | int) -> Counter:
+    wins, _, _, _ = _play_one_shuffle(task, collect_rows=False)
+    return wins
+
+
+def _run_chunk(shuffle_tasks: Sequence[ShuffleTask | int]) -> Counter:
+    """Play a batch of shuffles and tally wins (one launch per contiguous shuffle range)."""
+    tasks = [_coerce_shuffle_task(t) for t in shuffle_tasks]
+    state = _STATE
+    total = OutcomeCounter()
+    ids = [int(s.strategy_id) for s in state.strats]  # type: ignore[union-attr]
+    for group, res in _launch(tasks, want_rows=False):
+        wins, _, _ = tally_to_counters(res["tally"].sum(axis=0), ids, group[0].k)
+        total.absorb(wins)
+    return total
+
+
+def _run_chunk_metrics(shuffle_tasks: Sequence[ShuffleTask | int], *, collect_rows: bool = False,
+                       row_dir: Path | None = None, manifest_path: Path | None = None, row_sidecar: Any = None):
+    """Play shuffles and accumulate metrics: (wins, sums, square_sums).  With ``collect_rows`` and ``row_dir``
+    one ``rows_{root}_{k}p_{shuffle:012d}.parquet`` shard per shuffle is written and recorded in ``manifest.jsonl``
+    (run_tournament.py:530-558; v3 sidecars are out of scope, ``row_sidecar`` must be None)."""
+    if row_sidecar is not None:
+        raise NotImplementedError("v3 artifact sidecars are outside this engine's scope")
+    tasks = [_coerce_shuffle_task(t) for t in shuffle_tasks]
+    state = _STATE
+    ids = [int(s.strategy_id) for s in state.strats]  # type: ignore[union-attr]
+    wins_total = OutcomeCounter()
+    sums_total: Dict[str, Dict[int, float]] = {m: defaultdict(float) for m in METRIC_LABELS}
+    sq_total: Dict[str, Dict[int, float]] = {m: defaultdict(float) for m in METRIC_LABELS}
+    for group, res in _launch(tasks, want_rows=collect_rows):
+        wins, sums, sqs = tally_to_counters(res["tally"].sum(axis=0), ids, group[0].k)
+        wins_total.absorb(wins)
+        for label in METRIC_LABELS:
+            for key, v in sums[label].items():
+                sums_total[label][key] += v
+            for key, v in sqs[label].items():
+                sq_total[label][key] += v
+        if row_dir is not None and collect_rows:
+            gps = len(res["rows"]) // len(group)
+            for n, task in enumerate(group):
+                write_row_shard(Path(row_dir), manifest_path, task, res["rows"][n * gps:(n + 1) * gps], ids)
+    return wins_total, sums_total, sq_total
+
+
+def write_row_shard(row_dir: Path, manifest_path: Path | None, task: ShuffleTask, rows: np.ndarray, ids: Sequence[int]) -> Path:
+    """One shuffle's rows -> parquet shard + manifest record (run_tournament.py:530-558)."""
+    import json
+    import os
+
+    import pyarrow.parquet as pq
+
+    gps = len(rows)
+    game_seeds = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=task.root_seed, k=task.k,
+                                          shuffle_index=task.shuffle_index, game_index=np.arange(gps, dtype=np.uint64),
+                                          dtype=np.uint32)
+    table = rows_to_table(rows, task.k, ids, root_seed=task.root_seed, shuffle_index=task.shuffle_index,
+                          game_index=np.arange(gps), deterministic_batch_id=task.deterministic_batch_id,
+                          shuffle_seed=task.shuffle_seed, game_seed=game_seeds.astype(np.int64),
+                          rng_purpose_namespace=int(urandom.RandomPurpose.TOURNAMENT_GAME))
+    row_dir.mkdir(parents=True, exist_ok=True)
+    out = row_dir / f"rows_{task.root_seed}_{task.k}p_{task.shuffle_index:012d}.parquet"
+    tmp = out.with_suffix(".parquet.tmp")
+    pq.write_table(table, tmp)
+    os.replace(tmp, out)
+    manifest = Path(manifest_path) if manifest_path else row_dir / "manifest.jsonl"
+    record = {"path": out.name, "rows": gps, "root_seed": task.root_seed, "n_players": task.k,
+              "shuffle_index": task.shuffle_index, "shuffle_seed": task.shuffle_seed,
+              "deterministic_batch_id": task.deterministic_batch_id, "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
+              "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
+              "outcome_schema_version": OUTCOME_SCHEMA_VERSION, "tournament_method_version": TOURNAMENT_METHOD_VERSION,
+              "pid": os.getpid()}
+    with open(manifest, "a", encoding="utf-8") as fh:
+        fh.write(json.dumps(record, sort_keys=True) + "\n")
+    return out
+
+
+def shuffle_tasks(root_seed: int, k: int, shuffle_begin: int, shuffle_end: int, deterministic_batch_size: int) -> list[ShuffleTask]:
+    """Stable ShuffleTask identities of a shuffle range (shuffle_seed = ns-100 uint32 fingerprint)."""
+    idx = np.arange(shuffle_begin, shuffle_end, dtype=np.uint64)
+    seeds = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_SHUFFLE, root_seed=root_seed, k=k, shuffle_index=idx,
+                                     dtype=np.uint32) if len(idx) else []
+    return [ShuffleTask(root_seed, k, int(i), int(s), int(i) // deterministic_batch_size) for i, s in zip(idx, seeds)]
+
+
+def _measure_throughput(sample_strategies: Sequence[ThresholdStrategy], sample_games: int = 2_000, seed: int = 0,
+                        game_profile: GameProfile | None = None) -> float:
+    """Quick benchmark returning games processed per second (run_tournament.py:593-619)."""
+    import time
+
+    from .simulation import PlayerRngCoordinates, play_coordinate_games
+
+    k = len(sample_strategies)
+    coords = [PlayerRngCoordinates(purpose=urandom.RandomPurpose.TOURNAMENT_PLAYER, root_seed=seed, k=k, game_index=i)
+              for i in range(sample_games)]
+    target = game_profile.default_target_score if game_profile else 10_000
+    t0 = time.perf_counter()
+    play_coordinate_games(coords, prepare_public_helper_strategies(sample_strategies),
+                          np.tile(np.arange(k, dtype=np.int32), (sample_games, 1)), target_score=target)
+    return sample_games / max(time.perf_counter() - t0, 1e-9)

@@ -384,7 +384,10 @@ def gen_grids():
     import hashlib
 
     digest = hashlib.sha256(json.dumps([strat_tuple(s) for s in d]).encode()).hexdigest()
-    _dump({"fast_kwargs": fast_kw, "fast": [strat_tuple(s) for s in fast_grid], "g64": [strat_tuple(s) for s in grid64()],
+    from farkle.utils.schema_helpers import raw_simulation_schema_for
+
+    schemas = {str(k): [[f.name, str(f.type), bool(f.nullable)] for f in raw_simulation_schema_for(k)] for k in (2, 4)}
+    _dump({"raw_schema": schemas, "fast_kwargs": fast_kw, "fast": [strat_tuple(s) for s in fast_grid], "g64": [strat_tuple(s) for s in grid64()],
                "oracle4": [strat_tuple(s) for s in grid_oracle4()], "default_size": len(d), "default_sha256": digest,
                "default_head": [strat_tuple(s) for s in d[:40]], "default_tail": [strat_tuple(s) for s in d[-40:]]},
               open(OUT / "grid_vectors.json", "w"))

@@ -1,0 +1,177 @@
+"""GPU tests of the host-side mirror of the reference's operator surface: these read like the reference's
+own tests (tests/unit/simulation/test_simulation.py, test_run_tournament.py, tests/unit/analysis/test_h2h_schedule.py)
+but every game runs in the HIP kernels."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _strategies(tuples):
+    from farkle_ii_amd.strategies import FavorDiceOrScore, ThresholdStrategy
+
+    out = []
+    for t in tuples:
+        out.append(ThresholdStrategy(t[0], t[1], bool(t[2]), bool(t[3]), bool(t[4]), bool(t[5]), bool(t[6]), bool(t[7]), bool(t[8]),
+                                     FavorDiceOrScore.SCORE if t[9] else FavorDiceOrScore.DICE, strategy_id=None if t[10] < 0 else t[10]))
+    return out
+
+
+def _compact(row: dict, k: int) -> dict:
+    seats = [[row[f"P{i}_{n}"] for n in ("score", "strategy", "farkles", "rolls", "n_turns", "highest_turn", "smart_five_uses",
+                                          "n_smart_five_dice", "smart_one_uses", "n_smart_one_dice", "hot_dice")]
+             + [0 if row[f"P{i}_rank"] is None else row[f"P{i}_rank"], int(row[f"P{i}_hit_max_rounds"])] for i in range(1, k + 1)]
+    return {"n_rounds": row["n_rounds"], "status": 0 if row["termination_status"] == "completed" else 1,
+            "winner_seat": -1 if row["winner_seat"] is None else int(row["winner_seat"][1:]) - 1, "seats": seats,
+            "winner_strategy": row["winner_strategy"], "winning_score": row["winning_score"], "victory_margin": row["victory_margin"],
+            "seat_ranks": row["seat_ranks"], "game_seed": row["game_seed"]}
+
+
+def test_simulate_many_games_deterministic_counts():
+    # tests/unit/simulation/test_simulation.py:184-199
+    from farkle_ii_amd.simulation import simulate_many_games
+    from farkle_ii_amd.strategies import ThresholdStrategy
+
+    strategies = [ThresholdStrategy(score_threshold=0, dice_threshold=6), ThresholdStrategy(score_threshold=500, dice_threshold=3),
+                  ThresholdStrategy(score_threshold=1000, dice_threshold=2)]
+    df = simulate_many_games(n_games=10, strategies=strategies, target_score=5000, seed=123, n_jobs=1)
+    assert df["winner_seat"].value_counts().to_dict() == {"P2": 6, "P1": 2, "P3": 2}
+    df2 = simulate_many_games(n_games=10, strategies=strategies, target_score=5000, seed=123, n_jobs=4)
+    assert df.equals(df2)
+    with pytest.raises(ValueError, match="explicit seed"):
+        simulate_many_games(n_games=1, strategies=strategies)
+
+
+def test_simulate_many_games_rows_match_reference():
+    from farkle_ii_amd.simulation import simulate_many_games
+
+    data = gu.load("time_path_vectors.json")
+    for block in data["many_games"]:
+        strategies = _strategies(block["strategies"])
+        df = simulate_many_games(n_games=block["n_games"], strategies=strategies, seed=block["seed"])
+        assert [int(v) for v in df["game_seed"]] == block["game_seeds"]
+        for got, gold in zip(df.to_dict(orient="records"), block["rows"]):
+            c = _compact(got, block["players"])
+            for key in gold:
+                assert c[key] == gold[key], key
+
+
+def test_play_game_single_rows_and_errors():
+    from farkle_ii_amd.random import RandomPurpose
+    from farkle_ii_amd.simulation import PlayerRngCoordinates, _play_game
+
+    data = gu.load("game_vectors.json")
+    g64 = _strategies(data["grids"]["g64"])
+    for g in [x for x in data["games"] if x["grid"] == "g64"][:25]:
+        coords = PlayerRngCoordinates(purpose=RandomPurpose(g["purpose"]), root_seed=g["root_seed"], k=g["k"],
+                                      shuffle_index=g["shuffle"], pair_id=g["pair"], order=g["order"], game_index=g["game"])
+        row = _play_game(0, [g64[i] for i in g["strategies"]], target_score=g["target"], max_rounds=g["max_rounds"],
+                         player_rng_coordinates=coords)
+        c = _compact(row, g["k"])
+        for key in ("n_rounds", "status", "winner_seat", "seats", "winner_strategy", "winning_score", "victory_margin", "seat_ranks"):
+            assert c[key] == g["row"][key], key
+    with pytest.raises(ValueError, match="coordinate k"):
+        _play_game(0, g64[:3], player_rng_coordinates=PlayerRngCoordinates(purpose=RandomPurpose.PLAYER, root_seed=1, k=2))
+
+
+def test_play_one_shuffle_matches_reference():
+    # the reference's _play_one_shuffle (run_tournament.py:301-393): wins, sums, square sums, rows with provenance
+    from farkle_ii_amd import tournament as rt
+    from farkle_ii_amd.game_profile import GameProfile, TournamentMaxRoundsOverride
+
+    data = gu.load("tournament_vectors.json")
+    for case in data["cases"]:
+        strategies = _strategies(case["strategies"])
+        profile = None
+        if case["profile"] == "oracle":
+            profile = GameProfile(default_target_score=100, tournament_max_rounds_overrides=(TournamentMaxRoundsOverride(11, 2, 0, 0, 0),))
+        rt._init_worker(strategies, rt.TournamentConfig(n_players=case["k"], n_strategies=len(strategies)), profile)
+        task = rt.ShuffleTask(case["root_seed"], case["k"], case["shuffle"], 0, 0)
+        wins, sums, sqs, rows = rt._play_one_shuffle(task, collect_rows=True)
+        gold = case["tally"]
+        assert {str(k): v for k, v in wins.items()} == gold["wins"]
+        assert {str(k): v for k, v in wins.safety_limit_exposures.items()} == gold["safety"]
+        assert [wins.games_attempted, wins.games_completed, wins.games_safety_limit] == gold["games"]
+        for m in rt.METRIC_LABELS:
+            assert {str(k): int(v) for k, v in sums[m].items()} == gold["sums"][m]
+            assert {str(k): int(v) for k, v in sqs[m].items()} == gold["sq_sums"][m]
+        assert len(rows) == len(case["rows"])
+        for got, g in zip(rows, case["rows"]):
+            c = _compact(got, case["k"])
+            for key in g:
+                assert c[key] == g[key], (case["name"], key)
+            assert got["shuffle_index"] == case["shuffle"] and got["rng_purpose_namespace"] == 102
+        assert rt._play_shuffle(task) == wins
+
+
+def test_run_chunk_and_row_shards(tmp_path):
+    import json
+
+    import pyarrow.parquet as pq
+
+    from farkle_ii_amd import tournament as rt
+    from farkle_ii_amd.rows import raw_simulation_schema_for, simulation_rows_to_table
+
+    strategies = _strategies(gu.load("grid_vectors.json")["g64"])
+    rt._init_worker(strategies, rt.TournamentConfig(n_players=2, n_strategies=64, deterministic_batch_size=4))
+    tasks = rt.shuffle_tasks(42, 2, 0, 10, 4)
+    total = rt._run_chunk(tasks)
+    per = rt.OutcomeCounter()
+    for t in tasks:
+        per.absorb(rt._play_shuffle(t))
+    assert total == per and total.attempted_exposures == per.attempted_exposures and total.games_attempted == 320
+    wins, sums, sqs = rt._run_chunk_metrics(tasks[2:6], collect_rows=True, row_dir=tmp_path / "rows")
+    assert wins.games_attempted == 4 * 32
+    records = [json.loads(line) for line in open(tmp_path / "rows" / "manifest.jsonl")]
+    assert [r["shuffle_index"] for r in records] == [2, 3, 4, 5] and records[0]["path"] == "rows_42_2p_000000000002.parquet"
+    table = pq.read_table(tmp_path / "rows" / records[0]["path"])
+    assert table.schema == raw_simulation_schema_for(2) and table.num_rows == 32
+    _, _, _, rows = rt._play_one_shuffle(tasks[2], collect_rows=True)
+    assert table.to_pylist() == simulation_rows_to_table(rows, 2).to_pylist()
+    # non-contiguous task lists are split into contiguous launches
+    odd = [tasks[0], tasks[2], tasks[3], tasks[7]]
+    got = rt._run_chunk(odd)
+    exp = rt.OutcomeCounter()
+    for t in odd:
+        exp.absorb(rt._play_shuffle(t))
+    assert got == exp
+
+
+def test_h2h_block_runner_matches_goldens(tmp_path):
+    import pandas as pd
+
+    from farkle_ii_amd.game_profile import GameProfile, H2HMaxRoundsOverride
+    from farkle_ii_amd.h2h import gpu_block_runner
+
+    data = gu.load("h2h_vectors.json")
+    strategies = _strategies(data["oracle4"])
+    manifest = pd.DataFrame([{"strategy_id": s.strategy_id, "score_threshold": s.score_threshold, "dice_threshold": s.dice_threshold,
+                              "smart_five": s.smart_five, "smart_one": s.smart_one, "consider_score": s.consider_score,
+                              "consider_dice": s.consider_dice, "require_both": s.require_both, "auto_hot_dice": s.auto_hot_dice,
+                              "run_up_score": s.run_up_score, "favor_dice_or_score": s.favor_dice_or_score.value} for s in strategies])
+    path = tmp_path / "strategy_manifest.parquet"
+    manifest.to_parquet(path)
+    profile = GameProfile(default_target_score=100, h2h_max_rounds_overrides=(H2HMaxRoundsOverride(11, 0, 0, 0, 0),
+                                                                              H2HMaxRoundsOverride(11, 1, 0, 0, 0),
+                                                                              H2HMaxRoundsOverride(11, 1, 0, 1, 0)))
+    runner = gpu_block_runner(profile)
+    expected = {tuple(k): v for k, v in data["EXPECTED_H2H_BLOCKS"]}
+    for b in data["blocks"]:
+        block = {k: b[k] for k in ("pair_id", "root_seed", "order", "seat1_strategy", "seat2_strategy", "n_completed_required", "max_attempts")}
+        out = runner(block, path, 5000)
+        got = [out["games_attempted"], out["games_completed"], out["games_safety_limit"], out["wins_a"], out["wins_b"],
+               out["replacement_attempt_count"], out["completion_status"]]
+        assert got == expected[(b["pair_id"], b["root_seed"], b["order"])]
+        assert out["games_attempted"] == out["games_completed"] + out["games_safety_limit"]
+        assert out["wins_seat1"] + out["wins_seat2"] == out["games_completed"]
+
+
+def test_farkle_time_path():
+    from farkle_ii_amd.time_farkle import measure_sim_times
+
+    out = measure_sim_times(n_games=200, players=2, seed=42, jobs=1)
+    assert sum(out["winners"].values()) <= 200 and out["games_per_sec"] > 0
