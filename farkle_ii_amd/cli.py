@@ -1,0 +1,97 @@
+"""``farkle`` command line for the simulation path: ``run`` and ``time``.
+
+Mirrors ``src/farkle/cli/main.py`` (:53-140 parser, :325-464 dispatch) for the two commands on this path; the
+analysis/orchestration commands of the reference are out of scope and are rejected with a clear message.
+
+    python -m farkle_ii_amd --config configs/fast.yaml --set sim.n_players_list=[2] --set sim.seed_list=[42] run --metrics
+    python -m farkle_ii_amd time --players 2 --n-games 1000 --seed 42
+    torchrun --nproc-per-node 8 -m farkle_ii_amd --config cfg.yaml run      (one process per GPU, RCCL tally reduce)
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import sys
+from pathlib import Path
+from typing import Sequence
+
+LOGGER = logging.getLogger("farkle_ii_amd.cli")
+_OUT_OF_SCOPE = ("watch", "analyze", "two-seed-pipeline")
+
+
+def build_parser() -> argparse.ArgumentParser:
+    parser = argparse.ArgumentParser(prog="farkle")
+    parser.add_argument("--config", type=Path, help="Path to YAML configuration")
+    parser.add_argument("--set", dest="overrides", action="append", default=[], metavar="KEY=VALUE",
+                        help="Override configuration values")
+    parser.add_argument("--log-level", default="INFO", help="Root logging level")
+    sub = parser.add_subparsers(dest="command", required=True)
+    run = sub.add_parser("run", help="Run a tournament")
+    run.add_argument("--metrics", action="store_true", help="Collect per-strategy metrics in addition to win counts")
+    run.add_argument("--row-dir", type=Path, help="Write full per-game rows to this directory")
+    run.add_argument("--force", action="store_true", help="Recompute even when existing run artifacts are available")
+    t = sub.add_parser("time", help="Benchmark simulation throughput")
+    t.add_argument("--players", type=int, default=5, help="Players per game (default: 5)")
+    t.add_argument("--n-games", dest="n_games", type=int, default=1000, help="Number of games to run (default: 1000)")
+    t.add_argument("--jobs", type=int, default=1, help="Parallel jobs (accepted for compatibility)")
+    t.add_argument("--seed", type=int, default=42, help="Seed (default: 42)")
+    for name in _OUT_OF_SCOPE:
+        sub.add_parser(name, help="(reference command outside the simulation path)")
+    return parser
+
+
+def _maybe_init_distributed() -> None:
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch
+        import torch.distributed as dist
+
+        if not dist.is_initialized():
+            local = int(os.environ.get("LOCAL_RANK", "0"))
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group("gloo")
+
+
+def main(argv: Sequence[str] | None = None) -> None:
+    args = build_parser().parse_args(argv)
+    logging.basicConfig(level=getattr(logging, str(args.log_level).upper(), logging.INFO),
+                        format="%(asctime)s %(levelname)s %(name)s: %(message)s")
+    if args.command in _OUT_OF_SCOPE:
+        raise SystemExit(f"farkle {args.command}: outside the simulation path this engine replaces; use the reference CLI")
+    if args.command == "time":
+        from .time_farkle import measure_sim_times
+
+        out = measure_sim_times(n_games=args.n_games, players=args.players, seed=args.seed, jobs=args.jobs)
+        print(f"{args.n_games} games, {args.players} players: {out['games_per_sec']:.1f} games/s; winners {out['winners']}")
+        return
+    from . import runner
+    from .config import AppConfig, apply_dot_overrides, load_app_config
+
+    cfg = load_app_config(args.config, seed_list_len=None) if args.config is not None else AppConfig()
+    cfg = apply_dot_overrides(cfg, list(args.overrides or []))
+    if cfg.sim.seed_list is not None and len(cfg.sim.seed_list) != 1:
+        raise ValueError(f"sim.seed_list must contain exactly 1 seeds, got {cfg.sim.seed_list!r}")
+    cfg.sim.populate_seed_list(1)
+    if args.metrics:
+        cfg.sim.expanded_metrics = True
+    if args.row_dir is not None:
+        cfg.sim.row_dir = args.row_dir
+    _maybe_init_distributed()
+    rank = int(os.environ.get("RANK", "0"))
+    if rank == 0:
+        runner.write_active_config(cfg, cfg.results_root)
+    LOGGER.info("Dispatching run command: seed=%s n_players_list=%s results_dir=%s", cfg.sim.seed, cfg.sim.n_players_list,
+                cfg.results_root)
+    if len(cfg.sim.n_players_list) > 1:
+        out = runner.run_multi(cfg, force=args.force)
+    else:
+        out = {cfg.sim.n_players_list[0]: runner.run_single_n(cfg, cfg.sim.n_players_list[0], force=args.force)}
+    if rank == 0:
+        print({f"{k}p_games": v for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

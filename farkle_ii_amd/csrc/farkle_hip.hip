@@ -653,6 +653,7 @@ struct fk_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, dbg[6];
     int32_t longest_first = 1;
+    int32_t blocks_per_cu = 0; // 0 = as many as fit
     int64_t chunk_bytes = (int64_t)24 << 30;
     int32_t batch_threshold = 6;
     int32_t use_lds_tally = -1;
@@ -782,6 +783,7 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int32_t S, bool single_batch) {
     int per_cu = (int)std::max<size_t>(1, LDS_LIMIT / std::max<size_t>(p.lds, 1));
     per_cu = std::min(per_cu, 2048 / block);
     per_cu = std::max(per_cu, 1);
+    if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
     p.grid = c->prop.multiProcessorCount * per_cu;
     return p;
 }
@@ -951,6 +953,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "batch_threshold") c->batch_threshold = (int32_t)value;
     else if (n == "use_lds_tally") c->use_lds_tally = (int32_t)value;
     else if (n == "longest_first") c->longest_first = (int32_t)value;
+    else if (n == "blocks_per_cu") c->blocks_per_cu = (int32_t)value;
     else if (n == "block") {
         if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
             return fail(c, FK_ERR_ARG, "block must be 0, 64, 128, 256, 512 or 1024");

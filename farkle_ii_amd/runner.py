@@ -1,0 +1,406 @@
+"""AppConfig front-end of the tournament: grid -> workload plan -> GPU batches -> artifacts.
+
+Mirrors ``src/farkle/simulation/runner.py`` (``run_single_n`` :1326-1752, ``run_multi`` :1757-1816) and the parent
+loop of ``src/farkle/simulation/run_tournament.py:1050-1839`` for the v2 (no-sidecar) artifact set:
+
+    <results_root>/strategy_manifest.parquet
+    <results_root>/<k>_players/simulation_workload_plan.json
+    <results_root>/<k>_players/<k>p_checkpoint.pkl        {win_totals, outcome_counts, metric_sums, metric_square_sums, meta}
+    <results_root>/<k>_players/<k>p_checkpoint.parquet    per-strategy summary (runner.py:1612-1648)
+    <results_root>/<k>_players/<k>p_metrics.parquet       expanded metrics (runner.py:1651-1712), with sim.expanded_metrics
+    <row_dir>/rows_<root>_<k>p_<shuffle:012d>.parquet + manifest.jsonl        (with sim.row_dir)
+    <metric_chunk_dir>/metrics_<batch:06d>.parquet + metrics_manifest.jsonl   (with sim.metric_chunk_dir)
+    <results_root>/<k>_players/simulation.done.json       plain completion marker (v3 sidecars are out of scope)
+
+Resume ownership is the deterministic batch, as in the reference (``completed_process_block_indices``).  With
+``torch.distributed`` initialised (one process per GPU) whole batches are partitioned over the ranks and the per-batch
+tallies are SUM-reduced to rank 0, which writes the artifacts.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import pickle
+import time
+from collections import Counter
+from pathlib import Path
+from typing import Any, Mapping, Sequence
+
+import numpy as np
+
+from . import random as urandom
+from . import tournament as rt
+from .config import AppConfig
+from .distributed import reduce_tally, shard_shuffle_range
+from .engine import get_engine
+from .game_profile import GameProfile
+from .rows import OUTCOME_SCHEMA_VERSION, TOURNAMENT_METHOD_VERSION
+from .strategies import (STRATEGY_TUPLE_FIELDS, FavorDiceOrScore, ThresholdStrategy, generate_strategy_grid,
+                         prepare_public_helper_strategies, strategy_tuple)
+from .workload_planner import TournamentWorkloadPlan, WorkloadCapExceeded, plan_tournament_workload, write_workload_plan
+
+LOGGER = logging.getLogger(__name__)
+MAX_GAMES_PER_LAUNCH = 200_000_000  # checkpoint cadence on the GPU: a launch group is at most this many games
+
+
+def _rank_world() -> tuple[int, int]:
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
+def _atomic_write_bytes(path: Path, content: bytes) -> None:
+    path.parent.mkdir(parents=True, exist_ok=True)
+    tmp = path.with_name(path.name + ".tmp")
+    tmp.write_bytes(content)
+    os.replace(tmp, path)
+
+
+def _write_parquet_atomic(table, path: Path) -> None:
+    import pyarrow.parquet as pq
+
+    path.parent.mkdir(parents=True, exist_ok=True)
+    tmp = path.with_name(path.name + ".tmp")
+    pq.write_table(table, tmp)
+    os.replace(tmp, path)
+
+
+def _resolve_strategies(cfg: AppConfig, strategies: list[ThresholdStrategy] | None) -> tuple[list[ThresholdStrategy], int]:
+    if strategies is None:
+        strategies, _ = generate_strategy_grid(
+            score_thresholds=cfg.sim.score_thresholds, dice_thresholds=cfg.sim.dice_thresholds,
+            smart_five_opts=cfg.sim.smart_five_opts, smart_one_opts=cfg.sim.smart_one_opts,
+            consider_score_opts=cfg.sim.consider_score_opts, consider_dice_opts=cfg.sim.consider_dice_opts,
+            auto_hot_dice_opts=cfg.sim.auto_hot_dice_opts, run_up_score_opts=cfg.sim.run_up_score_opts,
+            include_stop_at=cfg.sim.include_stop_at, include_stop_at_heuristic=cfg.sim.include_stop_at_heuristic)
+    strategies = prepare_public_helper_strategies(strategies)
+    LOGGER.info("Strategy grid prepared: %d strategies", len(strategies))
+    return strategies, len(strategies)
+
+
+def build_strategy_manifest(strategies: Sequence[ThresholdStrategy]):
+    """Manifest frame mapping strategy ids to attributes (strategies.py:725-748)."""
+    import pandas as pd
+
+    rows: dict[int, dict[str, Any]] = {}
+    for s in strategies:
+        if s.strategy_id is None or int(s.strategy_id) in rows:
+            continue
+        attrs = dict(zip(STRATEGY_TUPLE_FIELDS, strategy_tuple(s)))
+        attrs["strategy_id"] = int(s.strategy_id)
+        attrs["strategy_str"] = str(s)
+        if isinstance(attrs["favor_dice_or_score"], FavorDiceOrScore):
+            attrs["favor_dice_or_score"] = attrs["favor_dice_or_score"].value
+        rows[int(s.strategy_id)] = attrs
+    frame = pd.DataFrame(rows.values())
+    if not frame.empty:
+        frame["strategy_id"] = frame["strategy_id"].astype("Int32")
+        frame = frame.sort_values("strategy_id", kind="mergesort").reset_index(drop=True)
+    return frame
+
+
+def _plan_workload_from_config(cfg: AppConfig, n_strategies: int, n_players: int) -> TournamentWorkloadPlan:
+    return plan_tournament_workload(
+        root_seed=cfg.sim.seed, k=n_players, strategy_count=n_strategies, resolution_delta=cfg.screening.resolution_delta,
+        confidence=cfg.screening.interval_confidence, batch_count=cfg.batching.target_batches,
+        min_shuffles_per_batch=cfg.batching.min_shuffles_per_batch, shuffle_cap=cfg.screening.max_shuffles_per_root_k,
+        projected_games_per_second=cfg.screening.projected_games_per_second)
+
+
+def _filter_player_counts(player_counts: Sequence[int], grid_size: int) -> tuple[list[int], list[int]]:
+    valid = [n for n in player_counts if n > 0 and grid_size % n == 0]
+    invalid = [n for n in player_counts if n not in valid]
+    if invalid:
+        LOGGER.warning("Dropping incompatible player counts: %s", invalid)
+    return valid, invalid
+
+
+def simulation_done_path(cfg: AppConfig, n_players: int) -> Path:
+    return cfg.n_dir(n_players) / "simulation.done.json"
+
+
+def simulation_is_complete(cfg: AppConfig, n_players: int, plan: TournamentWorkloadPlan | None = None) -> bool:
+    path = simulation_done_path(cfg, n_players)
+    if not path.exists() or not cfg.checkpoint_path(n_players).exists():
+        return False
+    try:
+        meta = json.loads(path.read_text(encoding="utf-8"))["metadata"]
+    except (OSError, KeyError, json.JSONDecodeError):
+        return False
+    if plan is not None and (meta.get("num_shuffles") != plan.required_shuffles or meta.get("n_strategies") != plan.strategy_count
+                             or meta.get("shuffles_per_batch") != plan.shuffles_per_batch):
+        return False
+    return meta.get("root_seed") == cfg.sim.seed and meta.get("k") == n_players
+
+
+def _metric_chunk_table(batch_tally: np.ndarray, ids: Sequence[int], k: int):
+    """Rows of one ``metrics_<idx>.parquet`` (run_tournament.py:1603-1642)."""
+    import pyarrow as pa
+
+    wins, sums, sqs = rt.tally_to_counters(batch_tally, ids, k)
+    rows = []
+    for label in rt.METRIC_LABELS:
+        for strat in sorted(set(sums[label]) | set(wins.attempted_exposures), key=str):
+            rows.append({"metric": label, "strategy": strat, "sum": sums[label].get(strat, 0.0),
+                         "square_sum": sqs[label].get(strat, 0.0), "wins": int(wins.get(strat, 0)),
+                         "attempted_exposures": int(wins.attempted_exposures.get(strat, 0)),
+                         "completed_exposures": int(wins.completed_exposures.get(strat, 0)),
+                         "safety_limit_exposures": int(wins.safety_limit_exposures.get(strat, 0))})
+    return pa.Table.from_pylist(rows)
+
+
+def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[ThresholdStrategy], plan: TournamentWorkloadPlan,
+                   checkpoint_path: Path, collect_metrics: bool, row_dir: Path | None, metric_chunk_dir: Path | None,
+                   resume: bool, checkpoint_metadata: Mapping[str, Any], oracle_game_profile: GameProfile | None = None) -> dict:
+    """Play every deterministic batch not yet owned by the checkpoint and persist the aggregates."""
+    rank, world = _rank_world()
+    eng = get_engine()
+    k = n_players
+    S = len(strategies)
+    ids = [int(s.strategy_id) for s in strategies]
+    spb = plan.shuffles_per_batch
+    n_batches = plan.batch_count
+    meta = {
+        "n_players": k, "num_shuffles": plan.required_shuffles, "global_seed": cfg.sim.seed, "n_strategies": S,
+        "rng_scheme_version": urandom.RNG_SCHEME_VERSION, "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
+        "tournament_method_version": TOURNAMENT_METHOD_VERSION, "rng_bit_generator": "PCG64DXSM",
+        "coordinate_contract_version": 2, "shuffle_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
+        "shuffle_permutation_purpose_namespace": int(urandom.RandomPurpose.SHUFFLE_PERMUTATION),
+        "game_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_GAME),
+        "player_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_PLAYER), "deterministic_batch_size": spb,
+        **dict(checkpoint_metadata),
+        "workload_plan_version": plan.plan_version, "screening_resolution_delta": plan.resolution_delta,
+        "screening_interval_confidence": plan.confidence, "batch_count": plan.batch_count, "shuffles_per_batch": spb,
+        "batch_construction": plan.batch_construction, "backend": "farkle_ii_amd/hip-gfx950",
+    }
+    total = np.zeros((S, 26), dtype=np.int64)
+    done_batches: set[int] = set()
+    if resume and checkpoint_path.exists():
+        payload = pickle.loads(checkpoint_path.read_bytes())
+        old = payload.get("meta", {})
+        stale = [key for key in ("n_players", "num_shuffles", "global_seed", "n_strategies", "deterministic_batch_size",
+                                 "strategy_manifest_sha", "rng_scheme_version")
+                 if key in old and old.get(key) != meta.get(key)]
+        if stale:
+            raise ValueError(f"checkpoint {checkpoint_path} was written under a different contract: {stale}; use --force")
+        total = np.asarray(payload["tally_int64"], dtype=np.int64)
+        done_batches = set(int(b) for b in old.get("completed_process_block_indices", []))
+        LOGGER.info("Resuming: %d of %d batches already complete", len(done_batches), n_batches)
+    pending = [b for b in range(n_batches) if b not in done_batches]
+    target = oracle_game_profile.default_target_score if oracle_game_profile else 10_000
+    max_rounds = oracle_game_profile.default_max_rounds if oracle_game_profile else 200
+    ov = oracle_game_profile.tournament_overrides() if oracle_game_profile else None
+    table = rt.pack_strategies(strategies)
+    gps = S // k
+    group_batches = max(1, MAX_GAMES_PER_LAUNCH // max(spb * gps, 1))
+    want_rows = row_dir is not None
+    t_start = time.perf_counter()
+    games_done = 0
+
+    def save(final: bool) -> None:
+        wins, sums, sqs = rt.tally_to_counters(total, ids, k)
+        payload: dict[str, Any] = {"win_totals": Counter(dict(wins)), "outcome_counts": wins.outcome_payload(),
+                                   "tally_int64": total.copy()}
+        if collect_metrics:
+            payload["metric_sums"] = {m: dict(v) for m, v in sums.items()}
+            payload["metric_square_sums"] = {m: dict(v) for m, v in sqs.items()}
+        completed = sorted(done_batches)
+        payload["meta"] = {**meta, "completed_process_block_indices": completed,
+                           "completed_shuffle_indices": [s for b in completed for s in range(b * spb, (b + 1) * spb)],
+                           "complete": final}
+        _atomic_write_bytes(checkpoint_path, pickle.dumps(payload, protocol=pickle.HIGHEST_PROTOCOL))
+
+    i = 0
+    while i < len(pending):
+        # contiguous run of pending batches, capped by the launch-group size
+        j = i
+        while j + 1 < len(pending) and pending[j + 1] == pending[j] + 1 and (j + 1 - i) < group_batches:
+            j += 1
+        b0, b1 = pending[i], pending[j] + 1
+        lo, hi = shard_shuffle_range(b0 * spb, b1 * spb, rank, world, batch_size=spb)
+        local = np.zeros((b1 - b0, S, 26), dtype=np.int64)
+        if hi > lo:
+            res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=spb, target_score=target,
+                                 max_rounds=max_rounds, overrides=ov, want_rows=want_rows)
+            first = lo // spb - b0
+            local[first:first + len(res["tally"])] = res["tally"]
+            if want_rows:  # every rank writes the shards of its own shuffles
+                tasks = rt.shuffle_tasks(cfg.sim.seed, k, lo, hi, spb)
+                for n, task in enumerate(tasks):
+                    rt.write_row_shard(row_dir, None, task, res["rows"][n * gps:(n + 1) * gps], ids)
+        group = reduce_tally(local, dst=0)
+        if rank == 0:
+            for n, b in enumerate(range(b0, b1)):
+                if metric_chunk_dir is not None:
+                    _write_parquet_atomic(_metric_chunk_table(group[n], ids, k), metric_chunk_dir / f"metrics_{b:06d}.parquet")
+                    tasks = rt.shuffle_tasks(cfg.sim.seed, k, b * spb, (b + 1) * spb, spb)
+                    record = {"path": f"metrics_{b:06d}.parquet", "chunk_index": b, "process_block_index": b,
+                              "root_seed": cfg.sim.seed, "n_players": k, "deterministic_batch_id": b,
+                              "shuffle_index_start": b * spb, "shuffle_index_end": (b + 1) * spb - 1, "shuffle_count": spb,
+                              "shuffle_indices": [t.shuffle_index for t in tasks], "shuffle_seeds": [t.shuffle_seed for t in tasks],
+                              "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
+                              "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
+                              "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
+                              "tournament_method_version": TOURNAMENT_METHOD_VERSION}
+                    with open(metric_chunk_dir / "metrics_manifest.jsonl", "a", encoding="utf-8") as fh:
+                        fh.write(json.dumps(record, sort_keys=True) + "\n")
+                total += group[n]
+                done_batches.add(b)
+            games_done += (b1 - b0) * spb * gps
+            save(final=False)
+            LOGGER.info("Batches %d..%d done: %.3g games/s so far", b0, b1 - 1,
+                        games_done / max(time.perf_counter() - t_start, 1e-9))
+        i = j + 1
+    if rank == 0:
+        save(final=True)
+    return {"tally": total, "games": games_done, "seconds": time.perf_counter() - t_start}
+
+
+def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | None = None, *, force: bool = False,
+                 oracle_game_profile: GameProfile | None = None) -> int:
+    """Run a Farkle tournament for a single player count ``n``; returns the number of games of the plan."""
+    import hashlib
+
+    import pyarrow as pa
+
+    rank, _ = _rank_world()
+    strategies, grid_size = _resolve_strategies(cfg, strategies)
+    plan = _plan_workload_from_config(cfg, grid_size, n)
+    n_dir = cfg.n_dir(n)
+    n_dir.mkdir(parents=True, exist_ok=True)
+    if not force and simulation_is_complete(cfg, n, plan):
+        LOGGER.info("Simulation already complete; preserving published outputs for %sp", n)
+        return plan.required_games
+    plan_path = n_dir / "simulation_workload_plan.json"
+    row_dir = cfg.simulation_row_dir(n)
+    metric_chunk_dir = cfg.metric_chunk_dir(n)
+    if plan.cap_exceeded:
+        if rank == 0:
+            write_workload_plan(plan_path, plan)
+        raise WorkloadCapExceeded(plan)
+    ckpt_path = cfg.checkpoint_path(n)
+    manifest = build_strategy_manifest(strategies)
+    manifest_sha = hashlib.sha256(manifest.to_json(orient="records").encode()).hexdigest()
+    if rank == 0:
+        if force:
+            for path in (ckpt_path, n_dir / f"{n}p_checkpoint.parquet", cfg.metrics_path(n), simulation_done_path(cfg, n)):
+                path.unlink(missing_ok=True)
+            for d in (row_dir, metric_chunk_dir):
+                if d is not None and d.exists():
+                    for f in d.iterdir():
+                        if f.suffix in {".parquet", ".jsonl", ".tmp"}:
+                            f.unlink()
+        manifest_path = cfg.strategy_manifest_root_path()
+        table = pa.Table.from_pandas(manifest, preserve_index=False)
+        if manifest_path.exists():
+            import pyarrow.parquet as pq
+
+            if not pq.read_table(manifest_path).equals(table):
+                raise ValueError(f"Strategy manifest at {manifest_path} does not match the configured grid")
+        else:
+            _write_parquet_atomic(table, manifest_path)
+        write_workload_plan(plan_path, plan)
+    for d in (row_dir, metric_chunk_dir):
+        if d is not None:
+            d.mkdir(parents=True, exist_ok=True)
+    result = run_tournament(cfg=cfg, n_players=n, strategies=strategies, plan=plan, checkpoint_path=ckpt_path,
+                            collect_metrics=cfg.sim.expanded_metrics, row_dir=row_dir, metric_chunk_dir=metric_chunk_dir,
+                            resume=not force, checkpoint_metadata={"strategy_manifest_sha": manifest_sha},
+                            oracle_game_profile=oracle_game_profile)
+    if rank != 0:
+        return plan.required_games
+    ids = [int(s.strategy_id) for s in strategies]
+    wins, sums, sqs = rt.tally_to_counters(result["tally"], ids, n)
+    # (A) summary parquet, (B) expanded metrics parquet — column order as in runner.py:1612-1712
+    summary, metrics_rows = [], []
+    for strat in sorted(wins.attempted_exposures, key=str):
+        w = int(wins.get(strat, 0))
+        attempted = int(wins.attempted_exposures[strat])
+        if attempted <= 0:
+            continue
+        completed = int(wins.completed_exposures[strat])
+        safety = int(wins.safety_limit_exposures[strat])
+        row: dict[str, Any] = {"strategy": strat, "wins": float(w), "attempted_exposures": attempted, "completed_exposures": completed,
+                               "safety_limit_exposures": safety, "losses": attempted - w, "win_rate_per_attempt": w / attempted,
+                               "win_rate": w / attempted, "win_rate_given_completion": w / completed if completed else float("nan"),
+                               "safety_limit_exposure_rate": safety / attempted}
+        if cfg.sim.expanded_metrics:
+            for label in rt.METRIC_LABELS:
+                row[f"mean_{label}"] = (sums[label].get(strat, 0.0) / w) if w > 0 else 0.0
+        summary.append(row)
+        if cfg.sim.expanded_metrics:
+            base: dict[str, Any] = {"strategy": strat, "wins": w, "total_games_strat": attempted, "attempted_exposures": attempted,
+                                    "completed_exposures": completed, "safety_limit_exposures": safety, "losses": attempted - w,
+                                    "win_rate_per_attempt": w / attempted, "win_rate": w / attempted,
+                                    "win_rate_given_completion": w / completed if completed else float("nan"),
+                                    "safety_limit_exposure_rate": safety / attempted}
+            for label in rt.METRIC_LABELS:
+                s_val, q_val = sums[label].get(strat, 0.0), sqs[label].get(strat, 0.0)
+                mean = (s_val / w) if w > 0 else 0.0
+                base[f"sum_{label}"] = float(s_val)
+                base[f"sq_sum_{label}"] = float(q_val)
+                base[f"mean_{label}"] = float(mean)
+                base[f"var_{label}"] = float(max(q_val / w - mean**2, 0.0)) if w > 0 else 0.0
+            base["expected_score"] = sums["winning_score"].get(strat, 0.0) / attempted
+            metrics_rows.append(base)
+    if summary:
+        _write_parquet_atomic(pa.Table.from_pylist(summary), n_dir / f"{n}p_checkpoint.parquet")
+    if metrics_rows:
+        _write_parquet_atomic(pa.Table.from_pylist(metrics_rows), cfg.metrics_path(n))
+    done = {"stage": "simulation", "status": "success", "backend": "farkle_ii_amd/hip-gfx950",
+            "metadata": {"n_players": n, "seed": cfg.sim.seed, "root_seed": cfg.sim.seed, "k": n,
+                         "num_shuffles": plan.required_shuffles, "shuffle_index_start": 0,
+                         "shuffle_index_end": plan.required_shuffles - 1, "deterministic_batch_count": plan.batch_count,
+                         "shuffles_per_batch": plan.shuffles_per_batch, "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
+                         "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
+                         "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
+                         "tournament_method_version": TOURNAMENT_METHOD_VERSION, "n_strategies": grid_size},
+            "outputs": sorted(str(p.relative_to(cfg.results_root)) for p in n_dir.rglob("*") if p.is_file()
+                              and p.name != "simulation.done.json"),
+            "games": plan.required_games, "games_per_second_this_run": (result["games"] / result["seconds"]) if result["games"] else None}
+    _atomic_write_bytes(simulation_done_path(cfg, n), (json.dumps(done, indent=2, sort_keys=True) + "\n").encode())
+    return plan.required_games
+
+
+def run_multi(cfg: AppConfig, player_counts: Sequence[int] | None = None, *, force: bool = False,
+              oracle_game_profile: GameProfile | None = None) -> dict[int, int]:
+    """Run tournaments for several player counts (sequential over k, as in the reference)."""
+    counts = list(player_counts) if player_counts is not None else list(cfg.sim.n_players_list)
+    strategies, grid_size = _resolve_strategies(cfg, None)
+    valid, _ = _filter_player_counts(counts, grid_size)
+    results: dict[int, int] = {}
+    for n in valid:
+        results[n] = run_single_n(cfg, n, strategies=strategies, force=force, oracle_game_profile=oracle_game_profile)
+    return results
+
+
+def write_active_config(cfg: AppConfig, dest_dir: Path) -> Path:
+    """Persist the resolved simulation config next to the results (orchestration/seed_utils.py:86)."""
+    import dataclasses
+
+    import yaml
+
+    def plain(obj):
+        if dataclasses.is_dataclass(obj):
+            return {f.name: plain(getattr(obj, f.name)) for f in dataclasses.fields(obj)}
+        if isinstance(obj, Path):
+            return str(obj)
+        if isinstance(obj, (list, tuple)):
+            return [plain(v) for v in obj]
+        if isinstance(obj, dict):
+            return {str(k): plain(v) for k, v in obj.items()}
+        return obj
+
+    data = plain(cfg)
+    data.update(data.pop("opaque", {}))
+    dest_dir = Path(dest_dir)
+    dest_dir.mkdir(parents=True, exist_ok=True)
+    path = dest_dir / "active_config.yaml"
+    path.write_text(yaml.safe_dump(data, sort_keys=True), encoding="utf-8")
+    return path

@@ -393,7 +393,31 @@ def gen_grids():
               open(OUT / "grid_vectors.json", "w"))
 
 
+def gen_runner():
+    """Workload plans and config path resolution of the reference's run surface."""
+    from farkle.config import AppConfig, IOConfig, SimConfig
+    from farkle.simulation.workload_planner import plan_tournament_workload
+
+    plans = []
+    for kw in [dict(root_seed=42, k=2, strategy_count=80, resolution_delta=0.03),
+               dict(root_seed=0, k=4, strategy_count=5160, resolution_delta=0.03, batch_count=100, min_shuffles_per_batch=30),
+               dict(root_seed=11, k=2, strategy_count=4, resolution_delta=0.9, batch_count=2, min_shuffles_per_batch=1),
+               dict(root_seed=5, k=5, strategy_count=80, resolution_delta=0.1, confidence=0.9, batch_count=10, min_shuffles_per_batch=3, shuffle_cap=20),
+               dict(root_seed=5, k=8, strategy_count=64, resolution_delta=0.05, projected_games_per_second=1e6)]:
+        plans.append({"kwargs": kw, "plan": plan_tournament_workload(**kw).to_dict()})
+    paths = []
+    for prefix, seed, row_dir, n in [("results", 0, "rows", 5), ("results_x_seed_7", 7, "rows", 2), ("/abs/out", 3, "{n}p_rows", 4),
+                                     ("res", 1, None, 2), ("res", 1, "sub/rows", 6), ("res", 9, "/abs/rows_{p}", 2)]:
+        cfg = AppConfig(io=IOConfig(results_dir_prefix=Path(prefix)), sim=SimConfig(seed=seed, row_dir=None if row_dir is None else Path(row_dir)))
+        rd = cfg.simulation_row_dir(n)
+        paths.append({"prefix": prefix, "seed": seed, "row_dir": row_dir, "n": n, "results_root": str(cfg.results_root),
+                      "n_dir": str(cfg.n_dir(n)), "row": None if rd is None else str(rd), "checkpoint": str(cfg.checkpoint_path(n)),
+                      "manifest": str(cfg.strategy_manifest_root_path())})
+    _dump({"plans": plans, "paths": paths}, open(OUT / "runner_vectors.json", "w"))
+
+
 if __name__ == "__main__":
+    gen_runner()
     gen_rng()
     gen_scoring()
     gen_games()

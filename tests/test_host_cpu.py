@@ -166,3 +166,79 @@ def test_init_worker_requires_divisible_grid():
                                               auto_hot_dice_opts=[False, True], run_up_score_opts=[False])
     with pytest.raises(ValueError, match="n_players must divide"):
         rt._init_worker(strategies, rt.TournamentConfig(n_players=3, n_strategies=len(strategies)))
+
+
+# ------------------------------------------------------------------ run surface: planner, config, CLI parsing
+def test_workload_plans_match_reference():
+    from farkle_ii_amd.workload_planner import WorkloadCapExceeded, plan_tournament_workload
+
+    for case in gu.load("runner_vectors.json")["plans"]:
+        plan = plan_tournament_workload(**case["kwargs"])
+        got = plan.to_dict()
+        for key, val in case["plan"].items():
+            if isinstance(val, float):
+                assert got[key] == pytest.approx(val, rel=1e-12), key
+            else:
+                assert got[key] == val, key
+        if plan.cap_exceeded:
+            assert "Raise screening.max_shuffles_per_root_k" in str(WorkloadCapExceeded(plan))
+    with pytest.raises(ValueError, match="multiple of k"):
+        plan_tournament_workload(root_seed=0, k=3, strategy_count=80, resolution_delta=0.1)
+
+
+def test_config_paths_match_reference():
+    from pathlib import Path
+
+    from farkle_ii_amd.config import AppConfig, IOConfig, SimConfig
+
+    for case in gu.load("runner_vectors.json")["paths"]:
+        cfg = AppConfig(io=IOConfig(results_dir_prefix=Path(case["prefix"])),
+                        sim=SimConfig(seed=case["seed"], row_dir=None if case["row_dir"] is None else Path(case["row_dir"])))
+        rd = cfg.simulation_row_dir(case["n"])
+        assert str(cfg.results_root) == case["results_root"] and str(cfg.n_dir(case["n"])) == case["n_dir"]
+        assert (None if rd is None else str(rd)) == case["row"]
+        assert str(cfg.checkpoint_path(case["n"])) == case["checkpoint"]
+        assert str(cfg.strategy_manifest_root_path()) == case["manifest"]
+
+
+def test_config_loading_overrides_and_errors(tmp_path):
+    from pathlib import Path
+
+    from farkle_ii_amd.config import apply_dot_overrides, load_app_config
+
+    root = Path(__file__).resolve().parent.parent
+    cfg = load_app_config(root / "configs" / "fast_config.yaml", seed_list_len=1)
+    assert cfg.sim.seed == 42 and cfg.sim.n_players_list == [2, 4, 5] and cfg.sim.smart_five_opts == [True]
+    overlay = tmp_path / "o.yaml"
+    overlay.write_text("sim.n_players_list: [2]\nsim:\n  seed_list: [7]\nanalysis:\n  n_jobs: 1\n")
+    cfg = load_app_config(root / "configs" / "fast_config.yaml", overlay, seed_list_len=1)
+    assert cfg.sim.n_players_list == [2] and cfg.sim.seed == 7 and str(cfg.results_root).endswith("_seed_7")
+    apply_dot_overrides(cfg, ["sim.expanded_metrics=false", "screening.resolution_delta=0.5", "sim.n_players_list=[4]",
+                              "sim.row_dir=rows", "batching.target_batches=2"])
+    assert cfg.sim.expanded_metrics is False and cfg.screening.resolution_delta == 0.5 and cfg.sim.n_players_list == [4]
+    assert str(cfg.simulation_row_dir(4)).endswith("4_players/4p_rows") and cfg.batching.target_batches == 2
+    with pytest.raises(AttributeError, match="Unknown option"):
+        apply_dot_overrides(cfg, ["sim.nope=1"])
+    with pytest.raises(ValueError, match="Invalid override"):
+        apply_dot_overrides(cfg, ["sim.seed"])
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("sim:\n  n_players_list: [1]\n")
+    with pytest.raises(ValueError, match=">= 2"):
+        load_app_config(bad)
+    bad.write_text("sim:\n  seed_list: [1, 2]\n")
+    with pytest.raises(ValueError, match="exactly 1 seeds"):
+        load_app_config(bad, seed_list_len=1)
+    bad.write_text("sim:\n  bogus_key: 3\n")
+    with pytest.raises(ValueError, match="Unknown option"):
+        load_app_config(bad)
+
+
+def test_cli_parser_surface():
+    from farkle_ii_amd.cli import build_parser, main
+
+    args = build_parser().parse_args(["--config", "c.yaml", "--set", "sim.seed=3", "run", "--metrics", "--force"])
+    assert args.command == "run" and args.metrics and args.force and args.overrides == ["sim.seed=3"]
+    args = build_parser().parse_args(["time", "--players", "2", "--n-games", "1000", "--seed", "42"])
+    assert (args.players, args.n_games, args.seed, args.jobs) == (2, 1000, 42, 1)
+    with pytest.raises(SystemExit, match="outside the simulation path"):
+        main(["analyze"])

@@ -175,3 +175,105 @@ def test_farkle_time_path():
 
     out = measure_sim_times(n_games=200, players=2, seed=42, jobs=1)
     assert sum(out["winners"].values()) <= 200 and out["games_per_sec"] > 0
+
+
+def test_farkle_run_end_to_end_artifacts_resume_and_force(tmp_path):
+    """`farkle run` on a tiny grid: artifacts, checkpoint payload, per-batch metric chunks, row shards, resume, --force;
+    aggregates cross-checked against the CPU oracle."""
+    import json
+    import pickle
+
+    import pyarrow.parquet as pq
+    import pyoracle as po
+
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.cli import main
+    from farkle_ii_amd.strategies import pack_strategies
+
+    cfg_path = tmp_path / "tiny.yaml"
+    cfg_path.write_text(f"""
+io:
+  results_dir_prefix: "{tmp_path / 'out'}"
+sim:
+  n_players_list: [2, 4]
+  seed_list: [11]
+  expanded_metrics: true
+  row_dir: "rows"
+  metric_chunk_dir: "metric_chunks"
+  score_thresholds: [300, 500]
+  dice_thresholds: [2]
+  smart_five_opts: [false]
+  smart_one_opts: [false]
+  consider_score_opts: [true]
+  consider_dice_opts: [true]
+  auto_hot_dice_opts: [false, true]
+  run_up_score_opts: [false]
+screening:
+  resolution_delta: 0.5
+batching:
+  target_batches: 3
+  min_shuffles_per_batch: 2
+""")
+    main(["--config", str(cfg_path), "run"])
+    root = tmp_path / "out_seed_11"
+    assert (root / "strategy_manifest.parquet").exists() and (root / "active_config.yaml").exists()
+    manifest = pq.read_table(root / "strategy_manifest.parquet").to_pandas()
+    assert list(manifest["strategy_id"]) == list(range(8)) and manifest["strategy_str"][0].startswith("Strat(300,2)")
+    for k in (2, 4):
+        n_dir = root / f"{k}_players"
+        plan = json.loads((n_dir / "simulation_workload_plan.json").read_text())
+        assert plan["k"] == k and plan["batch_count"] == 3 and plan["required_shuffles"] == 3 * plan["shuffles_per_batch"]
+        payload = pickle.loads((n_dir / f"{k}p_checkpoint.pkl").read_bytes())
+        assert set(payload) >= {"win_totals", "outcome_counts", "metric_sums", "metric_square_sums", "meta"}
+        assert payload["meta"]["completed_process_block_indices"] == [0, 1, 2] and payload["meta"]["complete"]
+        n_sh = plan["required_shuffles"]
+        from farkle_ii_amd.config import load_app_config
+
+        strategies, _ = runner._resolve_strategies(load_app_config(cfg_path, seed_list_len=1), None)
+        ref = po.tournament(pack_strategies(strategies).view(po.STRATEGY_DTYPE), k, 11, 0, n_sh)["tally"][0]
+        assert {int(s): int(v) for s, v in payload["win_totals"].items()} == {i: int(ref[i, 0]) for i in range(8) if ref[i, 0]}
+        assert payload["outcome_counts"]["games_attempted"] == n_sh * (8 // k)
+        assert payload["metric_sums"]["winner_rolls"] == {i: float(ref[i, 7]) for i in range(8) if ref[i, 0]}
+        summary = pq.read_table(n_dir / f"{k}p_checkpoint.parquet").to_pandas()
+        assert list(summary["attempted_exposures"]) == [n_sh] * 8 and summary["wins"].sum() == ref[:, 0].sum()
+        metrics = pq.read_table(n_dir / f"{k}p_metrics.parquet")
+        assert "var_winning_score" in metrics.column_names and "expected_score" in metrics.column_names
+        chunks = sorted((n_dir / f"{k}p_metric_chunks").glob("metrics_*.parquet"))
+        assert [c.name for c in chunks] == ["metrics_000000.parquet", "metrics_000001.parquet", "metrics_000002.parquet"]
+        chunk_wins = sum(pq.read_table(c).to_pandas().query("metric == 'n_rounds'")["wins"].sum() for c in chunks)
+        assert chunk_wins == ref[:, 0].sum()
+        rows = sorted((n_dir / f"{k}p_rows").glob("rows_*.parquet"))
+        assert len(rows) == n_sh and sum(pq.read_table(r).num_rows for r in rows) == n_sh * (8 // k)
+        done = json.loads((n_dir / "simulation.done.json").read_text())
+        assert done["metadata"]["num_shuffles"] == n_sh and done["status"] == "success"
+    # second invocation: complete -> preserved untouched
+    before = (root / "2_players" / "2p_checkpoint.pkl").stat().st_mtime_ns
+    main(["--config", str(cfg_path), "run"])
+    assert (root / "2_players" / "2p_checkpoint.pkl").stat().st_mtime_ns == before
+    # interrupted run: drop the done marker and one batch from the checkpoint -> resume replays only that batch
+    n_dir = root / "2_players"
+    payload = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    full = payload["tally_int64"].copy()
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    strategies, _ = runner._resolve_strategies(cfg, None)
+    spb = payload["meta"]["shuffles_per_batch"]
+    last = po.tournament(pack_strategies(strategies).view(po.STRATEGY_DTYPE), 2, 11, 2 * spb, 3 * spb)["tally"][0]
+    payload["tally_int64"] = full - last
+    payload["meta"]["completed_process_block_indices"] = [0, 1]
+    (n_dir / "2p_checkpoint.pkl").write_bytes(pickle.dumps(payload))
+    (n_dir / "simulation.done.json").unlink()
+    main(["--config", str(cfg_path), "--set", "sim.n_players_list=[2]", "run"])
+    again = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    assert np.array_equal(again["tally_int64"], full) and again["meta"]["completed_process_block_indices"] == [0, 1, 2]
+    # --force recomputes from scratch to the same totals
+    main(["--config", str(cfg_path), "--set", "sim.n_players_list=[2]", "run", "--force"])
+    forced = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    assert np.array_equal(forced["tally_int64"], full)
+    assert len(list((n_dir / "2p_rows").glob("rows_*.parquet"))) == 3 * spb
+
+
+def test_farkle_time_cli(capsys):
+    from farkle_ii_amd.cli import main
+
+    main(["time", "--players", "2", "--n-games", "1000", "--seed", "42"])
+    assert "1000 games, 2 players" in capsys.readouterr().out
