@@ -224,13 +224,27 @@ __global__ void fk_finalize_tally(unsigned long long *tally, uint32_t n_rows) {
 }
 
 // ---------------------------------------------------------------------------------------
-template <int BLOCK>
+// One seat's context: the turn owner's copy lives in VGPRs between begin_turn / end_turn; every seat has a
+// field-major LDS slot.  With INCG the (read-only) PCG increment is not kept in LDS but re-read from the seed
+// buffer at the start of each turn: 52 instead of 68 bytes of LDS per seat, i.e. one more resident wave per SIMD
+// at k >= 3.  (Keeping both k = 2 seats in VGPRs and swapping registers at the turn boundary was measured 3 %
+// slower than the LDS slots and is not built.)
+struct Seat {
+    uint64_t lo, hi, inc_lo, inc_hi; // PCG64DXSM state / increment
+    uint32_t buf;                    // buffered half word (has_buf is bit 17 of cE)
+    int32_t score;
+    uint32_t cA, cB, cC, cD, cE;     // packed u16 counters + flags
+    Strat sp;
+};
+
+template <int BLOCK, bool INCG>
 __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
     extern __shared__ uint32_t lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t K = a.k;
-    const uint32_t fstride = K * BLOCK; // dwords between fields
-    unsigned long long *tl = reinterpret_cast<unsigned long long *>(lds + NF * fstride);
+    const uint32_t fstride = K * BLOCK; // dwords between LDS fields
+    constexpr uint32_t NFIELDS = INCG ? (uint32_t)NF - 4u : (uint32_t)NF;
+    unsigned long long *tl = reinterpret_cast<unsigned long long *>(lds + NFIELDS * fstride);
 
     if (a.use_lds_tally) {
         for (uint32_t i = tid; i < a.S * LT_COLS; i += BLOCK) tl[i] = 0ull;
@@ -242,19 +256,19 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
     uint32_t pool_next = 0, pool_end = 0, exhausted = 0; // wave-uniform ticket pool
 
     // game registers
-    uint32_t game_id = 0, seat = 0, rounds = 0, max_rounds = 0, trigger = 0;
+    uint32_t game_id = 0, seat = 0, rounds = 0, max_rounds = 0, trigger = 0, seed_slot = 0;
     uint32_t final_round = 0, safety = 0;
     int32_t score_to_beat = 0;
     // turn registers
-    uint32_t dice = 6, rolls_this_turn = 0;
+    uint32_t dice = 6, rolls_this_turn = 0, has_buf = 0;
     int32_t turn_score = 0;
-    // seat context
-    Rng rng{};
-    int32_t score = 0;
-    uint32_t cA = 0, cB = 0, cC = 0, cD = 0, cE = 0;
-    Strat sp{0, 0};
+    Seat cur{}; // the turn owner
 
-    auto L = [&](uint32_t field, uint32_t s) -> uint32_t & { return lds[field * fstride + s * BLOCK + tid]; };
+    // LDS field slots; with INCG the four increment dwords have no slot and later fields move up
+    auto L = [&](uint32_t field, uint32_t s) -> uint32_t & {
+        const uint32_t f = (INCG && field > F_INC_HI1) ? field - 4u : field;
+        return lds[f * fstride + s * BLOCK + tid];
+    };
 
     auto strategy_index = [&](uint32_t id, uint32_t s) -> uint32_t {
         if (a.mode == MODE_PERM) {
@@ -265,38 +279,64 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
         return s;
     };
 
+    // per-seat views used by the end-of-game code (seat s may be the turn owner or not)
+    auto seat_score = [&](uint32_t s) -> int32_t { return (int32_t)L(F_SCORE, s); };
+    auto seat_counter = [&](uint32_t s, uint32_t field) -> uint32_t { return L(field, s); }; // field in F_CA..F_CE
+
+    auto load_seat_from_global = [&](Seat &x, uint32_t id, uint32_t slot, uint32_t s) {
+        const uint2 pk = a.strat[strategy_index(id, s)];
+        const uint4 *src = a.seeds + ((size_t)slot * K + s) * 2;
+        const uint4 stv = src[0], inc = src[1];
+        x.lo = (uint64_t)stv.x | ((uint64_t)stv.y << 32);
+        x.hi = (uint64_t)stv.z | ((uint64_t)stv.w << 32);
+        x.inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
+        x.inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
+        x.buf = 0;
+        x.score = 0;
+        x.cA = x.cB = x.cC = x.cD = x.cE = 0;
+        x.sp = Strat{(int32_t)pk.x, pk.y};
+    };
+
     auto begin_turn = [&](uint32_t s) {
-        rng.lo = (uint64_t)L(F_LO0, s) | ((uint64_t)L(F_LO1, s) << 32);
-        rng.hi = (uint64_t)L(F_HI0, s) | ((uint64_t)L(F_HI1, s) << 32);
-        rng.inc_lo = (uint64_t)L(F_INC_LO0, s) | ((uint64_t)L(F_INC_LO1, s) << 32);
-        rng.inc_hi = (uint64_t)L(F_INC_HI0, s) | ((uint64_t)L(F_INC_HI1, s) << 32);
-        rng.buf = L(F_BUF, s);
-        score = (int32_t)L(F_SCORE, s);
-        cA = L(F_CA, s);
-        cB = L(F_CB, s) + 0x10000u; // n_turns += 1 (engine.py:236)
-        cC = L(F_CC, s);
-        cD = L(F_CD, s);
-        cE = L(F_CE, s);
-        rng.has_buf = (cE & CE_HAS_BUF) ? 1u : 0u;
-        sp.score_thr = (int32_t)L(F_SPX, s);
-        sp.bits = L(F_SPY, s);
+        if (INCG) {
+            const uint4 inc = a.seeds[((size_t)seed_slot * K + s) * 2 + 1];
+            cur.inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
+            cur.inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
+        } else {
+            cur.inc_lo = (uint64_t)L(F_INC_LO0, s) | ((uint64_t)L(F_INC_LO1, s) << 32);
+            cur.inc_hi = (uint64_t)L(F_INC_HI0, s) | ((uint64_t)L(F_INC_HI1, s) << 32);
+        }
+        cur.lo = (uint64_t)L(F_LO0, s) | ((uint64_t)L(F_LO1, s) << 32);
+        cur.hi = (uint64_t)L(F_HI0, s) | ((uint64_t)L(F_HI1, s) << 32);
+        cur.buf = L(F_BUF, s);
+        cur.score = (int32_t)L(F_SCORE, s);
+        cur.cA = L(F_CA, s);
+        cur.cB = L(F_CB, s);
+        cur.cC = L(F_CC, s);
+        cur.cD = L(F_CD, s);
+        cur.cE = L(F_CE, s);
+        cur.sp.score_thr = (int32_t)L(F_SPX, s);
+        cur.sp.bits = L(F_SPY, s);
+        cur.cB += 0x10000u; // n_turns += 1 (engine.py:236)
+        has_buf = (cur.cE & CE_HAS_BUF) ? 1u : 0u;
         dice = 6;
         turn_score = 0;
         rolls_this_turn = 0;
     };
 
     auto store_turn = [&](uint32_t s) {
-        L(F_LO0, s) = (uint32_t)rng.lo;
-        L(F_LO1, s) = (uint32_t)(rng.lo >> 32);
-        L(F_HI0, s) = (uint32_t)rng.hi;
-        L(F_HI1, s) = (uint32_t)(rng.hi >> 32);
-        L(F_BUF, s) = rng.buf;
-        L(F_SCORE, s) = (uint32_t)score;
-        L(F_CA, s) = cA;
-        L(F_CB, s) = cB;
-        L(F_CC, s) = cC;
-        L(F_CD, s) = cD;
-        L(F_CE, s) = (cE & ~CE_HAS_BUF) | (rng.has_buf ? CE_HAS_BUF : 0u);
+        cur.cE = (cur.cE & ~CE_HAS_BUF) | (has_buf ? CE_HAS_BUF : 0u);
+        L(F_LO0, s) = (uint32_t)cur.lo;
+        L(F_LO1, s) = (uint32_t)(cur.lo >> 32);
+        L(F_HI0, s) = (uint32_t)cur.hi;
+        L(F_HI1, s) = (uint32_t)(cur.hi >> 32);
+        L(F_BUF, s) = cur.buf;
+        L(F_SCORE, s) = (uint32_t)cur.score;
+        L(F_CA, s) = cur.cA;
+        L(F_CB, s) = cur.cB;
+        L(F_CC, s) = cur.cC;
+        L(F_CD, s) = cur.cD;
+        L(F_CE, s) = cur.cE;
     };
 
     auto raise = [&](int32_t code) {
@@ -308,9 +348,9 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
     auto finish_game = [&]() {
         const bool completed = (safety == 0u);
         uint32_t w = 0;
-        int32_t best = (int32_t)L(F_SCORE, 0);
+        int32_t best = seat_score(0);
         for (uint32_t s = 1; s < K; ++s) { // stable sort on score desc: first maximum wins (engine.py:477)
-            const int32_t sc = (int32_t)L(F_SCORE, s);
+            const int32_t sc = seat_score(s);
             if (sc > best) {
                 best = sc;
                 w = s;
@@ -326,7 +366,8 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
             else atomicAdd(&a.tally[((size_t)batch * a.S + idx) * FK_TALLY_COLS + (completed ? 2u : 3u)], 1ull);
         }
         if (completed) {
-            const uint32_t wa = L(F_CA, w), wb = L(F_CB, w), wc = L(F_CC, w), wd = L(F_CD, w), we = L(F_CE, w);
+            const uint32_t wa = seat_counter(w, F_CA), wb = seat_counter(w, F_CB), wc = seat_counter(w, F_CC),
+                           wd = seat_counter(w, F_CD), we = seat_counter(w, F_CE);
             const unsigned long long m[10] = {(unsigned long long)(uint32_t)best, rounds, wa >> 16, wa & 0xffffu,
                                               wb & 0xffffu, wc & 0xffffu, wc >> 16, wd & 0xffffu, wd >> 16, we & 0xffffu};
             if (a.use_lds_tally) {
@@ -356,16 +397,17 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
             hdr.winner_seat = completed ? (int8_t)w : (int8_t)-1;
             *reinterpret_cast<fk_row_hdr *>(row) = hdr;
             for (uint32_t s = 0; s < K; ++s) {
-                const int32_t sc = (int32_t)L(F_SCORE, s);
+                const int32_t sc = seat_score(s);
                 uint32_t rank = 0;
                 if (completed) {
                     rank = 1;
                     for (uint32_t j = 0; j < K; ++j) {
-                        const int32_t o = (int32_t)L(F_SCORE, j);
+                        const int32_t o = seat_score(j);
                         rank += (o > sc || (o == sc && j < s)) ? 1u : 0u;
                     }
                 }
-                const uint32_t xa = L(F_CA, s), xb = L(F_CB, s), xc = L(F_CC, s), xd = L(F_CD, s), xe = L(F_CE, s);
+                const uint32_t xa = seat_counter(s, F_CA), xb = seat_counter(s, F_CB), xc = seat_counter(s, F_CC),
+                               xd = seat_counter(s, F_CD), xe = seat_counter(s, F_CE);
                 uint32_t *d = reinterpret_cast<uint32_t *>(row + sizeof(fk_row_hdr) + sizeof(fk_seat) * s);
                 d[0] = (uint32_t)sc;
                 d[1] = strategy_index(game_id, s);
@@ -389,18 +431,20 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
             const uint32_t sh = id / a.gps, g = id - sh * a.gps;
             slot = g * a.n_sh + sh;
         }
+        seed_slot = slot;
         for (uint32_t s = 0; s < K; ++s) {
-            const uint2 pk = a.strat[strategy_index(id, s)];
-            const uint4 *src = a.seeds + ((size_t)slot * K + s) * 2;
-            const uint4 stv = src[0], inc = src[1];
-            L(F_LO0, s) = stv.x;
-            L(F_LO1, s) = stv.y;
-            L(F_HI0, s) = stv.z;
-            L(F_HI1, s) = stv.w;
-            L(F_INC_LO0, s) = inc.x;
-            L(F_INC_LO1, s) = inc.y;
-            L(F_INC_HI0, s) = inc.z;
-            L(F_INC_HI1, s) = inc.w;
+            Seat x;
+            load_seat_from_global(x, id, slot, s);
+            L(F_LO0, s) = (uint32_t)x.lo;
+            L(F_LO1, s) = (uint32_t)(x.lo >> 32);
+            L(F_HI0, s) = (uint32_t)x.hi;
+            L(F_HI1, s) = (uint32_t)(x.hi >> 32);
+            if (!INCG) {
+                L(F_INC_LO0, s) = (uint32_t)x.inc_lo;
+                L(F_INC_LO1, s) = (uint32_t)(x.inc_lo >> 32);
+                L(F_INC_HI0, s) = (uint32_t)x.inc_hi;
+                L(F_INC_HI1, s) = (uint32_t)(x.inc_hi >> 32);
+            }
             L(F_BUF, s) = 0u;
             L(F_SCORE, s) = 0u;
             L(F_CA, s) = 0u;
@@ -408,8 +452,8 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
             L(F_CC, s) = 0u;
             L(F_CD, s) = 0u;
             L(F_CE, s) = 0u;
-            L(F_SPX, s) = pk.x;
-            L(F_SPY, s) = pk.y;
+            L(F_SPX, s) = (uint32_t)x.sp.score_thr;
+            L(F_SPY, s) = x.sp.bits;
         }
         seat = 0;
         trigger = 0;
@@ -429,17 +473,18 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
 
     // ---- end of a turn: bank, write back, advance the table (engine.py:265-273, 453-472, 523-550) ----
     auto end_turn = [&]() {
-        if (!(cE & CE_HAS_SCORED) && turn_score >= 500) cE |= CE_HAS_SCORED;
-        if (cE & CE_HAS_SCORED) {
-            score += turn_score;
-            if ((uint32_t)turn_score > (cB & 0xffffu)) cB = (cB & 0xffff0000u) | (uint32_t)turn_score;
+        if (!(cur.cE & CE_HAS_SCORED) && turn_score >= 500) cur.cE |= CE_HAS_SCORED;
+        if (cur.cE & CE_HAS_SCORED) {
+            cur.score += turn_score;
+            if ((uint32_t)turn_score > (cur.cB & 0xffffu)) cur.cB = (cur.cB & 0xffff0000u) | (uint32_t)turn_score;
         }
         // u16 guard bands (a turn adds <= 1000 rolls / <= 2000 discarded dice)
-        if ((cA & 0xffffu) > 64000u || (cC >> 16) > 63000u || (cD >> 16) > 63000u) {
+        if ((cur.cA & 0xffffu) > 64000u || (cur.cC >> 16) > 63000u || (cur.cD >> 16) > 63000u) {
             raise(FK_ERR_COUNTER_OVERFLOW);
             return;
         }
         store_turn(seat);
+        const int32_t score = cur.score;
         uint32_t next;
         bool ended = false;
         if (!final_round) {
@@ -481,19 +526,25 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
             return;
         }
         const uint32_t n = dice;
+        Rng rng{cur.hi, cur.lo, cur.inc_hi, cur.inc_lo, cur.buf, has_buf};
         const uint32_t counts = roll_counts(rng, n);
+        cur.hi = rng.hi;
+        cur.lo = rng.lo;
+        cur.buf = rng.buf;
+        has_buf = rng.has_buf;
         rolls_this_turn += 1u;
+        const Strat sp = cur.sp;
         const RollResult rr = default_score(counts, (int32_t)n, turn_score, sp);
-        const bool farkle = rr.score == 0;                          // engine.py:135-137, 247-249
-        cA += 1u + (farkle ? 0x10000u : 0u);                        // n_rolls (engine.py:98), n_farkles
-        cC += (rr.d5 > 0) ? (1u + ((uint32_t)rr.d5 << 16)) : 0u;    // engine.py:139-144
-        cD += (rr.d1 > 0) ? (1u + ((uint32_t)rr.d1 << 16)) : 0u;
-        dice = (rr.used == (int32_t)n) ? 6u : (n - (uint32_t)rr.used); // engine.py:146
+        const bool farkle = rr.score == 0;                              // engine.py:135-137, 247-249
+        cur.cA += 1u + (farkle ? 0x10000u : 0u);                        // n_rolls (engine.py:98), n_farkles
+        cur.cC += (rr.d5 > 0) ? (1u + ((uint32_t)rr.d5 << 16)) : 0u;    // engine.py:139-144
+        cur.cD += (rr.d1 > 0) ? (1u + ((uint32_t)rr.d1 << 16)) : 0u;
+        dice = (rr.used == (int32_t)n) ? 6u : (n - (uint32_t)rr.used);  // engine.py:146
         turn_score = farkle ? 0 : (turn_score + rr.score);
-        const bool hot = !farkle & sp.has(SF_AUTO_HOT) & (dice == 6u); // _apply_hot_dice, engine.py:149-154, 253
-        cE += hot ? 1u : 0u;
-        const bool keep = should_continue(sp, turn_score, (int32_t)dice, (cE & CE_HAS_SCORED) != 0u, final_round != 0u,
-                                          score_to_beat, score);
+        const bool hot = !farkle & sp.has(SF_AUTO_HOT) & (dice == 6u);  // _apply_hot_dice, engine.py:149-154, 253
+        cur.cE += hot ? 1u : 0u;
+        const bool keep = should_continue(sp, turn_score, (int32_t)dice, (cur.cE & CE_HAS_SCORED) != 0u, final_round != 0u,
+                                          score_to_beat, cur.score);
         if (turn_score > 0xffff) {
             raise(FK_ERR_COUNTER_OVERFLOW);
             return;
@@ -654,6 +705,8 @@ struct fk_ctx {
     DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, dbg[6];
     int32_t longest_first = 1;
     int32_t blocks_per_cu = 0; // 0 = as many as fit
+    int32_t inc_global = -1;   // -1 auto, 0 increments in LDS, 1 increments re-read from the seed buffer
+    int32_t waves_per_cu = 16; // resident-wave target used to size the grid
     int64_t chunk_bytes = (int64_t)24 << 30;
     int32_t batch_threshold = 6;
     int32_t use_lds_tally = -1;
@@ -753,57 +806,80 @@ struct LaunchPlan {
     int block = 0, grid = 0;
     size_t lds = 0;
     bool lds_tally = false;
+    bool inc_global = false; // PCG increments re-read from the seed buffer each turn (52 B of LDS per seat)
 };
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-LaunchPlan plan_play(const fk_ctx *c, int32_t k, int32_t S, bool single_batch) {
-    LaunchPlan p;
-    const size_t per_lane = (size_t)NF * 4 * (size_t)k;
-    const size_t tally_bytes = (size_t)S * LT_COLS * 8;
-    int block = c->block;
-    if (block == 0) {
-        for (int b : {1024, 512, 256, 128, 64}) {
-            if (per_lane * (size_t)b <= LDS_LIMIT) {
-                block = b;
-                break;
-            }
-        }
-        if (block == 0) block = 64;
-        // prefer a block that leaves room for the privatised tally
-        if (single_batch && c->use_lds_tally != 0 && per_lane * (size_t)block + tally_bytes > LDS_LIMIT && block > 256 &&
-            per_lane * (size_t)(block / 2) + tally_bytes <= LDS_LIMIT)
-            block /= 2;
-    }
-    p.block = block;
-    size_t seat_bytes = per_lane * (size_t)block;
-    bool want = single_batch && (c->use_lds_tally != 0);
-    p.lds_tally = want && (seat_bytes + tally_bytes <= LDS_LIMIT);
-    p.lds = seat_bytes + (p.lds_tally ? tally_bytes : 0);
-    int per_cu = (int)std::max<size_t>(1, LDS_LIMIT / std::max<size_t>(p.lds, 1));
-    per_cu = std::min(per_cu, 2048 / block);
-    per_cu = std::max(per_cu, 1);
-    if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
-    p.grid = c->prop.multiProcessorCount * per_cu;
-    return p;
+size_t play_lds_bytes(int32_t k, int block, bool inc_global, bool lds_tally, int32_t S) {
+    const size_t per_lane = (size_t)(inc_global ? NF - 4 : NF) * 4 * (size_t)k;
+    return per_lane * (size_t)block + (lds_tally ? (size_t)S * LT_COLS * 8 : 0);
 }
 
-template <int BLOCK>
+// Pick block size / LDS layout for the most resident lanes per CU (ties: larger blocks, increments in LDS).
+LaunchPlan plan_play(const fk_ctx *c, int32_t k, int32_t S, bool single_batch) {
+    LaunchPlan best;
+    const bool want_tally = single_batch && (c->use_lds_tally != 0);
+    const int max_lanes = c->waves_per_cu * 64;
+    int best_lanes = -1;
+    for (int incg = 0; incg <= 1; ++incg) {
+        if (c->inc_global >= 0 && incg != c->inc_global) continue;
+        for (int block : {1024, 512, 256, 128, 64}) {
+            if (c->block != 0 && block != c->block) continue;
+            bool tally = want_tally && play_lds_bytes(k, block, incg != 0, true, S) <= LDS_LIMIT;
+            size_t lds = play_lds_bytes(k, block, incg != 0, tally, S);
+            if (lds > LDS_LIMIT) continue;
+            int per_cu = (int)(LDS_LIMIT / std::max<size_t>(lds, 1));
+            per_cu = std::min(per_cu, std::max(1, max_lanes / block));
+            if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
+            per_cu = std::max(per_cu, 1);
+            int lanes = per_cu * block + (tally ? 1 : 0); // a privatised tally breaks ties
+            if (lanes > best_lanes) {
+                best_lanes = lanes;
+                best.block = block;
+                best.lds = lds;
+                best.lds_tally = tally;
+                best.inc_global = incg != 0;
+                best.grid = c->prop.multiProcessorCount * per_cu;
+            }
+        }
+    }
+    if (best_lanes < 0) { // k too large even for one wave with increments in global memory
+        best.block = 64;
+        best.inc_global = true;
+        best.lds_tally = false;
+        best.lds = play_lds_bytes(k, 64, true, false, S);
+        best.grid = c->prop.multiProcessorCount;
+    }
+    return best;
+}
+
+template <int BLOCK, bool INCG>
 hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, INCG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(p.lds, 16));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fk_play_kernel<BLOCK>, dim3((unsigned)p.grid), dim3(BLOCK), p.lds, s, a);
+    hipLaunchKernelGGL((fk_play_kernel<BLOCK, INCG>), dim3((unsigned)p.grid), dim3(BLOCK), p.lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
+    if (p.lds > LDS_LIMIT) return hipErrorInvalidValue;
+    if (p.inc_global) {
+        switch (p.block) {
+        case 1024: return launch_play_t<1024, true>(p, a, s);
+        case 512: return launch_play_t<512, true>(p, a, s);
+        case 256: return launch_play_t<256, true>(p, a, s);
+        case 128: return launch_play_t<128, true>(p, a, s);
+        default: return launch_play_t<64, true>(p, a, s);
+        }
+    }
     switch (p.block) {
-    case 1024: return launch_play_t<1024>(p, a, s);
-    case 512: return launch_play_t<512>(p, a, s);
-    case 256: return launch_play_t<256>(p, a, s);
-    case 128: return launch_play_t<128>(p, a, s);
-    default: return launch_play_t<64>(p, a, s);
+    case 1024: return launch_play_t<1024, false>(p, a, s);
+    case 512: return launch_play_t<512, false>(p, a, s);
+    case 256: return launch_play_t<256, false>(p, a, s);
+    case 128: return launch_play_t<128, false>(p, a, s);
+    default: return launch_play_t<64, false>(p, a, s);
     }
 }
 
@@ -842,6 +918,9 @@ int check_device_error(fk_ctx *c, const int32_t *d_err, int64_t game_base, const
 // Run seeds + games for `n_games` games whose seeds/strategy sources are already described by the args.
 int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &plan, int64_t game_base, const char *what) {
     SeedArgs sa = sa_in;
+    if (plan.lds > LDS_LIMIT)
+        return fail(c, FK_ERR_ARG, "k=%u needs %zu bytes of LDS per wave; the seat contexts of at most 48 players fit a CU",
+                    sa.k, plan.lds);
     int rc = ensure(c, c->seeds, (size_t)sa.n_games * sa.k * 32);
     if (rc) return rc;
     rc = ensure(c, c->misc, 64);
@@ -954,6 +1033,8 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "use_lds_tally") c->use_lds_tally = (int32_t)value;
     else if (n == "longest_first") c->longest_first = (int32_t)value;
     else if (n == "blocks_per_cu") c->blocks_per_cu = (int32_t)value;
+    else if (n == "inc_global") c->inc_global = (int32_t)value;
+    else if (n == "waves_per_cu") c->waves_per_cu = (int32_t)std::max<int64_t>(1, std::min<int64_t>(32, value));
     else if (n == "block") {
         if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
             return fail(c, FK_ERR_ARG, "block must be 0, 64, 128, 256, 512 or 1024");
