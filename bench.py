@@ -166,11 +166,17 @@ def main() -> None:
         achieved_ops = kernel_games_per_s * wpg["ops_per_game"]
         # algorithmic HBM bytes of the game kernel in counts-only mode: seat seeds read once (32 B x k per game)
         # + 2 B x k permutation entries; the tally is [S][26] int64 written once per launch
-        hbm_bytes_per_game = 32 * K + 2 * K
+        hbm_bytes_per_game = 32 * K + 2 * K + 4
+        # HBM bytes per launch from the PMC passes of the same launch (rocprofv3 cannot run inside this process):
+        # profiles/r01_hbm_traffic.json, FETCH_SIZE x2-corrected per MI355X_MICROARCH.md
+        traffic = None
+        tpath = ROOT / "profiles" / "r01_hbm_traffic.json"
+        if tpath.exists() and args.shuffles == SHUFFLES_PER_STEP:
+            traffic = json.loads(tpath.read_text())["kernels"]["fk_play_kernel"]["hbm_bytes_corrected"]
         roofline = {
             "bound": "valu", "kernel": "fk_play_kernel",
             "achieved": achieved_ops / 1e12, "peak": peak_ops / 1e12, "unit": "Tlane-op/s (int32)", "frac": achieved_ops / peak_ops,
-            "traffic": None,
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate pass)",
             "kernel_ms": kernel_ms, "kernel_games_per_s": kernel_games_per_s, **wpg,
             "hbm": {"achieved": kernel_games_per_s * hbm_bytes_per_game / 1e9, "peak": 8000.0, "unit": "GB/s",
                     "frac": kernel_games_per_s * hbm_bytes_per_game / 8e12, "bytes_per_game": hbm_bytes_per_game},
