@@ -62,7 +62,8 @@ struct SeedArgs {
     uint4 *seeds;            // [n_games][k][2] = {state lo, state hi}, {inc lo, inc hi}
     // longest-first scheduling (tournament mode): games whose seats ALL never bank run to the round
     // limit (~13x the mean length); they are dealt first so that they do not form the tail of a wave.
-    const uint16_t *perm_T;  // nullable
+    const uint16_t *perm_T;  // nullable; blocked layout, see perm_at()
+    uint32_t perm_slots, S;
     const uint32_t *slow_bits; // bitmap over strategies: 1 = never banks voluntarily
     uint32_t n_sh;
     uint32_t *sched;         // [n_games] ticket -> game id
@@ -71,7 +72,8 @@ struct SeedArgs {
 
 struct PlayArgs {
     const uint2 *strat;          // [S] packed strategies
-    const uint16_t *perm_T;      // [S][n_sh] shuffle-minor permutations (MODE_PERM)
+    const uint16_t *perm_T;      // blocked permutations (MODE_PERM), see perm_at()
+    uint32_t perm_slots;
     const int32_t *seat_strategy; // [n_games][k] (MODE_LIST)
     const uint4 *seeds;
     const uint32_t *sched;       // nullable: ticket -> game id (longest-first schedule)
@@ -98,31 +100,74 @@ __device__ inline uint32_t mbcnt(uint64_t mask) { // lanes of `mask` below this 
 
 __device__ inline Strat unpack_strat(uint2 v) { return Strat{(int32_t)v.x, v.y}; }
 
+// Permutations are stored blocked: [n_sh / slots][S][slots] (u16), `slots` = shuffles one fk_perm_kernel block holds
+// in LDS.  A block writes one contiguous region; entry e of consecutive shuffles is contiguous inside a block.
+__device__ inline uint32_t perm_at(const uint16_t *perm, uint32_t S, uint32_t slots, uint32_t sh, uint32_t e) {
+    const uint32_t b = sh / slots, l = sh - b * slots;
+    return perm[((size_t)b * S + e) * slots + l];
+}
+
 // ---------------------------------------------------------------------------------------
-__global__ void fk_perm_kernel(SeedPool prefix, uint64_t shuffle0, uint32_t n_sh, uint32_t S, uint16_t *perm_T) {
-    const uint32_t sh = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sh >= n_sh) return;
-    SeedPool p = prefix;
-    p.hc = HC_AFTER_6_WORDS;
-    ss_absorb64(p, shuffle0 + sh); // shuffle_index
+// Each lane shuffles its own u16[S] array held in LDS (lane-private, contiguous), then the block writes the
+// arrays out shuffle-minor so that the writes — and every later read of entry i across shuffles — are coalesced.
+// Fisher-Yates is a dependent chain of S swaps per shuffle; in LDS a step costs two ds_read + two ds_write instead
+// of four scattered HBM/L2 transactions.  LDS capacity fixes the shuffles per CU (`slots` = min(512, 160 KiB / 2S):
+// 512 at S <= 160, 15 at the 5 160-strategy grid); because each chain is latency-bound the slots are spread over
+// the block's 8 waves (2 per SIMD) rather than packed into one.
+constexpr int PERM_BLOCK = 512, PERM_WAVES = PERM_BLOCK / 64;
+
+__global__ __launch_bounds__(PERM_BLOCK) void fk_perm_kernel(SeedPool prefix, uint64_t shuffle0, uint32_t n_sh, uint32_t S,
+                                                             uint32_t slots, uint16_t *perm_T) {
+    extern __shared__ uint16_t perm_lds[];
+    const uint32_t per_wave = (slots + PERM_WAVES - 1u) / PERM_WAVES;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t slot = wave * per_wave + lane;
+    const uint32_t sh = blockIdx.x * slots + slot;
+    const bool valid = lane < per_wave && slot < slots && sh < n_sh;
+    uint16_t *a = perm_lds + (size_t)(valid ? slot : 0u) * S;
+    if (valid) {
+        for (uint32_t e = 0; e < S; ++e) a[e] = (uint16_t)e;
+    }
+    // Fisher-Yates: for i = S-1 .. 1: j = random_interval(i) (masked rejection on the buffered 32-bit stream);
+    // swap(a[i], a[j]).  Every lane consumes exactly one 32-bit word per trip and only advances its own `i` when
+    // the word is accepted, so a lane never waits for another lane's rejections and the low/high half-word phase
+    // is uniform across the wave: one PCG64DXSM output per two trips, no divergence.
+    Rng r{};
+    if (valid) {
+        SeedPool p = prefix;
+        p.hc = HC_AFTER_6_WORDS;
+        ss_absorb64(p, shuffle0 + sh); // shuffle_index
 #pragma unroll
-    for (int i = 0; i < 5; ++i) ss_absorb64(p, 0); // pair_id, order, game_index, seat_index, replicate_index
-    uint32_t g8[8];
-    ss_generate<8>(p, g8);
-    Rng r;
-    pcg_seed(r, g8);
-    uint16_t *a = perm_T + sh;
-    for (uint32_t i = 0; i < S; ++i) a[(size_t)i * n_sh] = (uint16_t)i;
-    // Fisher-Yates: for i = S-1 .. 1: j = random_interval(i); swap(a[i], a[j])
-    for (uint32_t i = S - 1u; i >= 1u; --i) {
-        const uint32_t mask = 0xffffffffu >> __clz((int)i);
-        uint32_t j;
-        do {
-            j = pcg_next32(r) & mask;
-        } while (j > i);
-        const uint16_t ai = a[(size_t)i * n_sh], aj = a[(size_t)j * n_sh];
-        a[(size_t)i * n_sh] = aj;
-        a[(size_t)j * n_sh] = ai;
+        for (int w = 0; w < 5; ++w) ss_absorb64(p, 0); // pair_id, order, game_index, seat_index, replicate_index
+        uint32_t g8[8];
+        ss_generate<8>(p, g8);
+        pcg_seed(r, g8);
+    }
+    uint32_t i = valid ? S - 1u : 0u;
+    auto consume = [&](uint32_t w) {
+        if (i >= 1u) {
+            const uint32_t j = w & (0xffffffffu >> __clz((int)i));
+            if (j <= i) {
+                const uint16_t ai = a[i], aj = a[j];
+                a[i] = aj;
+                a[j] = ai;
+                i -= 1u;
+            }
+        }
+    };
+    while (__ballot(i >= 1u)) {
+        const uint64_t o = pcg_next64(r);
+        consume((uint32_t)o);         // low half first ...
+        consume((uint32_t)(o >> 32)); // ... then the buffered high half
+    }
+    __syncthreads();
+    // blocked store [block][e][slot]: one contiguous, fully coalesced region per block
+    const uint32_t first = blockIdx.x * slots;
+    const uint32_t count = min(slots, n_sh > first ? n_sh - first : 0u);
+    uint16_t *out = perm_T + (size_t)blockIdx.x * S * slots;
+    for (uint32_t idx = threadIdx.x; idx < S * slots; idx += PERM_BLOCK) {
+        const uint32_t e = idx / slots, l = idx - e * slots;
+        out[idx] = l < count ? perm_lds[(size_t)l * S + e] : (uint16_t)0;
     }
 }
 
@@ -186,7 +231,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
     bool all_slow = valid;
     if (valid) {
         for (uint32_t s = 0; s < a.k; ++s) {
-            const uint32_t idx = a.perm_T[(size_t)(g_local * a.k + s) * a.n_sh + sh_local];
+            const uint32_t idx = perm_at(a.perm_T, a.S, a.perm_slots, sh_local, g_local * a.k + s);
             all_slow = all_slow && ((a.slow_bits[idx >> 5] >> (idx & 31u)) & 1u);
         }
     }
@@ -273,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
     auto strategy_index = [&](uint32_t id, uint32_t s) -> uint32_t {
         if (a.mode == MODE_PERM) {
             const uint32_t sh = id / a.gps, g = id - sh * a.gps;
-            return a.perm_T[(size_t)(g * K + s) * a.n_sh + sh];
+            return perm_at(a.perm_T, a.S, a.perm_slots, sh, g * K + s);
         }
         if (a.mode == MODE_LIST) return (uint32_t)a.seat_strategy[(size_t)id * K + s];
         return s;
@@ -1090,23 +1135,28 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
         const uint64_t sh0 = shuffle_begin + done;
         const uint32_t n_games = n_sh * gps;
 
-        rc = ensure(c, c->perm, (size_t)S * n_sh * 2);
+        const uint32_t slots = (uint32_t)std::max<size_t>(1, std::min<size_t>(PERM_BLOCK, LDS_LIMIT / ((size_t)S * 2)));
+        const uint32_t perm_blocks = (n_sh + slots - 1u) / slots;
+        rc = ensure(c, c->perm, (size_t)perm_blocks * S * slots * 2);
         if (rc) return rc;
         {
             Timer t(c, &c->timing.perm_ms, 0);
-            hipLaunchKernelGGL(fk_perm_kernel, dim3((n_sh + 63u) / 64u), dim3(64), 0, c->stream, perm_prefix, sh0, n_sh,
-                               (uint32_t)S, static_cast<uint16_t *>(c->perm.p));
+            const size_t perm_lds = (size_t)slots * S * 2;
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)perm_lds));
+            hipLaunchKernelGGL(fk_perm_kernel, dim3(perm_blocks), dim3(PERM_BLOCK), perm_lds, c->stream,
+                               perm_prefix, sh0, n_sh, (uint32_t)S, slots, static_cast<uint16_t *>(c->perm.p));
             t.stop();
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, t.collect());
         }
         if (perms) {
-            perm_host.resize((size_t)S * n_sh);
+            perm_host.resize((size_t)perm_blocks * S * slots);
             HIPCHK(c, hipMemcpyAsync(perm_host.data(), c->perm.p, perm_host.size() * 2, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             for (uint32_t s = 0; s < n_sh; ++s)
                 for (int32_t i = 0; i < S; ++i)
-                    perms[(size_t)(done + s) * S + i] = perm_host[(size_t)i * n_sh + s];
+                    perms[(size_t)(done + s) * S + i] = perm_host[((size_t)(s / slots) * S + i) * slots + s % slots];
         }
 
         // overrides that fall into this chunk -> chunk-local game ids
@@ -1139,11 +1189,14 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
         sa.k = (uint32_t)k;
         sa.n_games = n_games;
         sa.perm_T = static_cast<const uint16_t *>(c->perm.p);
+        sa.perm_slots = slots;
+        sa.S = (uint32_t)S;
         sa.n_sh = n_sh;
 
         PlayArgs pa{};
         pa.strat = static_cast<const uint2 *>(c->strat.p);
         pa.perm_T = static_cast<const uint16_t *>(c->perm.p);
+        pa.perm_slots = slots;
         pa.seat_strategy = nullptr;
         pa.tally = static_cast<unsigned long long *>(c->tally.p);
         pa.rows = rows ? static_cast<uint8_t *>(c->rows.p) : nullptr;
