@@ -16,7 +16,21 @@ from .game_profile import GameProfile
 from .strategies import FavorDiceOrScore, ThresholdStrategy, pack_strategies
 
 _PROGRESS_KEYS = {"games_attempted", "games_completed", "games_safety_limit", "wins_seat1", "wins_seat2", "wins_a", "wins_b",
-                  "replacement_attempt_count", "completion_status", "completion_game_rate", "safety_limit_game_rate"}
+                  "replacement_attempt_count", "completion_status", "completion_game_rate", "safety_limit_game_rate",
+                  "authenticated_attempt_index_start", "authenticated_attempt_index_stop_exclusive",
+                  "attempt_coordinate_range_hash"}
+
+
+def attempt_coordinate_range_hash(block: Mapping[str, Any], stop_exclusive: int) -> str:
+    """SHA-256 of the contiguous semantic attempt-coordinate prefix (h2h_schedule.py:1072-1085)."""
+    import hashlib
+    import json
+
+    payload = {"rng_scheme_version": int(block.get("rng_scheme_version", 2)),
+               "purpose": int(block.get("rng_purpose_namespace", 203)), "root_seed": int(block["root_seed"]),
+               "pair_id": int(block["pair_id"]), "order": int(block["order"]), "attempt_index_start": 0,
+               "attempt_index_stop_exclusive": int(stop_exclusive)}
+    return hashlib.sha256(json.dumps(payload, sort_keys=True, separators=(",", ":")).encode("utf-8")).hexdigest()
 
 
 def block_progress(block: Mapping[str, Any], *, games_attempted: int, games_completed: int, games_safety_limit: int,
@@ -38,6 +52,8 @@ def block_progress(block: Mapping[str, Any], *, games_attempted: int, games_comp
         "completion_status": status,
         "completion_game_rate": games_completed / games_attempted if games_attempted else None,
         "safety_limit_game_rate": games_safety_limit / games_attempted if games_attempted else None,
+        "authenticated_attempt_index_start": 0, "authenticated_attempt_index_stop_exclusive": games_attempted,
+        "attempt_coordinate_range_hash": attempt_coordinate_range_hash(block, games_attempted),
     })
     return out
 

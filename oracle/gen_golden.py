@@ -315,6 +315,7 @@ def gen_h2h():
                          "n_completed_required": 1, "max_attempts": 2,
                          "rng_scheme_version": 2, "rng_purpose_namespace": 203}
                 res = h2h._simulate_block_from_manifest(dict(block), manifest, 5000, profile)
+                block["range_hash"] = res["attempt_coordinate_range_hash"]
                 blocks.append({**block, "out": [res["games_attempted"], res["games_completed"], res["games_safety_limit"],
                                                 res["wins_seat1"], res["wins_seat2"], res["wins_a"], res["wins_b"],
                                                 res["replacement_attempt_count"], res["completion_status"]]})

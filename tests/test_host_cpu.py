@@ -242,3 +242,34 @@ def test_cli_parser_surface():
     assert (args.players, args.n_games, args.seed, args.jobs) == (2, 1000, 42, 1)
     with pytest.raises(SystemExit, match="outside the simulation path"):
         main(["analyze"])
+
+
+def test_h2h_block_progress_and_range_hash():
+    from farkle_ii_amd.h2h import attempt_coordinate_range_hash, block_progress
+
+    data = gu.load("h2h_vectors.json")
+    for b in data["blocks"]:
+        block = {k: b[k] for k in ("pair_id", "root_seed", "order", "seat1_strategy", "seat2_strategy", "n_completed_required",
+                                   "max_attempts", "rng_scheme_version", "rng_purpose_namespace")}
+        a, c, s, w1, w2 = b["out"][:5]
+        out = block_progress({**block, "block_id": "x", "_private": 1}, games_attempted=a, games_completed=c,
+                             games_safety_limit=s, wins_seat1=w1, wins_seat2=w2)
+        assert [out["wins_a"], out["wins_b"], out["replacement_attempt_count"], out["completion_status"]] == b["out"][5:]
+        assert out["attempt_coordinate_range_hash"] == b["range_hash"] == attempt_coordinate_range_hash(block, a)
+        assert out["block_id"] == "x" and "_private" not in out and out["authenticated_attempt_index_stop_exclusive"] == a
+
+
+def test_c_header_is_plain_c(tmp_path):
+    """The drop-in boundary must be consumable from C (and C++): compile a translation unit that only includes it."""
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    src = tmp_path / "t.c"
+    src.write_text('#include "farkle_hip.h"\nint main(void){ fk_strategy s; fk_row_hdr h; (void)s; (void)h; '
+                   'return (int)(sizeof(fk_strategy) != 20 || sizeof(fk_seat) != 28 || sizeof(fk_row_hdr) != 4 || '
+                   'sizeof(fk_override) != 32 || sizeof(fk_coord) != 72); }\n')
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(root / "include"), str(src), "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", "-I", str(root / "include"), str(src)], check=True)
