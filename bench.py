@@ -156,9 +156,11 @@ def main() -> None:
         assert int(tot[:, 1].sum()) == total_games * K, "exposure conservation failed"
         assert np.array_equal(tot[:, 1], tot[:, 2] + tot[:, 3]) and int(tot[:, 0].sum()) * K == int(tot[:, 2].sum())
 
-        # live per-game work from a row sample of the same workload
-        sample = eng.tournament(table, K, ROOT_SEED, 0, 2000, want_rows=True)
+        # live per-game work (R, T of SURVEY section 8d) from the rows of one launch of the SAME size, so that every
+        # fk_play_kernel launch of this process has the step's shape (the rocprofv3 per-kernel average stays comparable)
+        sample = eng.tournament(table, K, ROOT_SEED, 0, args.shuffles, want_rows=True)
         wpg = work_per_game(sample["rows"], K)
+        del sample
         kernel_ms = play_ms / max(launches, 1)
         kernel_games_per_s = games_per_rank_step / (kernel_ms * 1e-3)
         # VALU roof: CUs x 4 SIMD x 32 lanes/clk x clock (MI355X_MICROARCH.md: wave64 issues over 2 cycles on a SIMD-32)
@@ -188,7 +190,11 @@ def main() -> None:
             cpu = cpu_baseline(table)
             n_sh = cpu.pop("_n_sh")
             ref_tally = cpu.pop("_tally")
-            got = eng.tournament(table, K, ROOT_SEED, 0, n_sh)["tally"][0]
+            if n_sh == args.shuffles:
+                got = eng.tournament(table, K, ROOT_SEED, 0, n_sh)["tally"][0]
+            else:  # slower host: compare on the sample's shuffles only (per-batch tallies of one same-size launch)
+                spb = n_sh
+                got = eng.tournament(table, K, ROOT_SEED, 0, (args.shuffles // spb) * spb, shuffles_per_batch=spb)["tally"][0]
             assert np.array_equal(got, ref_tally), "GPU tally differs from the CPU oracle on the baseline sample"
             cpu["parity"] = f"GPU tally == oracle tally on the sample ({n_sh * 32} games)"
         line = {
@@ -200,6 +206,9 @@ def main() -> None:
                        "k": K, "n_strategies": S, "games_per_gpu_per_step": games_per_rank_step, "parallelism": f"shuffle-range split x{n_gpus}",
                        "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
             "roofline": roofline, "cpu_baseline": cpu,
+            # not `vs_baseline` (BASELINE.json publishes nothing for this exact config): the reference's own report of the
+            # k=2 tournament path on its 80-strategy grid, Ryzen 7 3700X, 12 workers = 1 142.9 games/s
+            "vs_reference_published_12_workers": value / 1142.9,
         }
         print(json.dumps(line))
     eng.close()
