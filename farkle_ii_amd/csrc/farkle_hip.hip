@@ -261,11 +261,22 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
 }
 
 // attempted = completed + safety for every (batch, strategy) row
-__global__ void fk_finalize_tally(unsigned long long *tally, uint32_t n_rows) {
+// Tournament mode: every strategy is seated exactly once per shuffle (S % k == 0), so its attempted exposures in a
+// batch equal the batch's shuffle count and only the (rare) safety-limit exposures are counted by the game kernel:
+// completed = attempted - safety.  Other modes count completed explicitly: attempted = completed + safety.
+__global__ void fk_finalize_tally(unsigned long long *tally, uint32_t n_rows, uint32_t S, uint32_t spb, uint64_t n_sh_total,
+                                  uint32_t derive_completed) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     unsigned long long *t = tally + (size_t)i * FK_TALLY_COLS;
-    t[1] = t[2] + t[3];
+    if (derive_completed) {
+        const uint64_t batch = i / S, first = batch * spb;
+        const uint64_t in_batch = first + spb <= n_sh_total ? spb : n_sh_total - first;
+        t[1] = in_batch;
+        t[2] = in_batch - t[3];
+    } else {
+        t[1] = t[2] + t[3];
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -404,12 +415,16 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
         uint32_t batch = 0;
         if (a.mode == MODE_PERM) batch = (a.sh_offset + game_id / a.gps) / a.spb;
         uint32_t widx = 0;
-        for (uint32_t s = 0; s < K; ++s) {
-            const uint32_t idx = strategy_index(game_id, s);
-            if (s == w) widx = idx;
-            if (a.use_lds_tally) atomicAdd(&tl[idx * LT_COLS + (completed ? 1u : 2u)], 1ull);
-            else atomicAdd(&a.tally[((size_t)batch * a.S + idx) * FK_TALLY_COLS + (completed ? 2u : 3u)], 1ull);
+        // exposures: tournament mode counts only safety-limit exposures (completed is derived in fk_finalize_tally)
+        const bool count_exposures = !completed || a.mode != MODE_PERM;
+        if (count_exposures) {
+            for (uint32_t s = 0; s < K; ++s) {
+                const uint32_t idx = strategy_index(game_id, s);
+                if (a.use_lds_tally) atomicAdd(&tl[idx * LT_COLS + (completed ? 1u : 2u)], 1ull);
+                else atomicAdd(&a.tally[((size_t)batch * a.S + idx) * FK_TALLY_COLS + (completed ? 2u : 3u)], 1ull);
+            }
         }
+        if (completed) widx = strategy_index(game_id, w);
         if (completed) {
             const uint32_t wa = seat_counter(w, F_CA), wb = seat_counter(w, F_CB), wc = seat_counter(w, F_CC),
                            wd = seat_counter(w, F_CD), we = seat_counter(w, F_CE);
@@ -420,16 +435,20 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
                 atomicAdd(&t[0], 1ull);
 #pragma unroll
                 for (int j = 0; j < 10; ++j) {
-                    atomicAdd(&t[3 + j], m[j]);
-                    atomicAdd(&t[13 + j], m[j] * m[j]);
+                    if (m[j]) { // zero-valued metrics (e.g. smart-discard counters of non-smart winners) add nothing
+                        atomicAdd(&t[3 + j], m[j]);
+                        atomicAdd(&t[13 + j], m[j] * m[j]);
+                    }
                 }
             } else {
                 unsigned long long *t = a.tally + ((size_t)batch * a.S + widx) * FK_TALLY_COLS;
                 atomicAdd(&t[0], 1ull);
 #pragma unroll
                 for (int j = 0; j < 10; ++j) {
-                    atomicAdd(&t[4 + j], m[j]);
-                    atomicAdd(&t[15 + j], m[j] * m[j]);
+                    if (m[j]) {
+                        atomicAdd(&t[4 + j], m[j]);
+                        atomicAdd(&t[15 + j], m[j] * m[j]);
+                    }
                 }
             }
         }
@@ -1223,7 +1242,7 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
     }
     const uint32_t n_rows = (uint32_t)(n_batches * (uint64_t)S);
     hipLaunchKernelGGL(fk_finalize_tally, dim3((n_rows + 255u) / 256u), dim3(256), 0, c->stream,
-                       static_cast<unsigned long long *>(c->tally.p), n_rows);
+                       static_cast<unsigned long long *>(c->tally.p), n_rows, (uint32_t)S, shuffles_per_batch, n_sh_total, 1u);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(t1, c->stream));
     HIPCHK(c, hipMemcpyAsync(tally, c->tally.p, tally_bytes, hipMemcpyDeviceToHost, c->stream));
