@@ -33,7 +33,7 @@ constexpr uint32_t HC_AFTER_6_WORDS = ss_hc(24); // 4 + 12 (all pairs) + 2*4 has
 
 enum : uint32_t { MODE_PERM = 0, MODE_LIST = 1, MODE_FIXED = 2 };
 
-// LDS seat-context fields (dwords), layout lds[(field * K + seat) * BLOCK + tid]
+// LDS seat-context fields (dwords), record layout lds[(seat * BLOCK + tid) * NFIELDS + field]
 enum : uint32_t {
     F_LO0 = 0, F_LO1, F_HI0, F_HI1, F_INC_LO0, F_INC_LO1, F_INC_HI0, F_INC_HI1,
     F_BUF, F_SCORE, F_CA, F_CB, F_CC, F_CD, F_CE, F_SPX, F_SPY, NF
@@ -298,9 +298,8 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
     extern __shared__ uint32_t lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t K = a.k;
-    const uint32_t fstride = K * BLOCK; // dwords between LDS fields
-    constexpr uint32_t NFIELDS = INCG ? (uint32_t)NF - 4u : (uint32_t)NF;
-    unsigned long long *tl = reinterpret_cast<unsigned long long *>(lds + NFIELDS * fstride);
+    constexpr uint32_t NFIELDS = INCG ? (uint32_t)NF - 4u : (uint32_t)NF; // 13 or 17 dwords per seat record
+    unsigned long long *tl = reinterpret_cast<unsigned long long *>(lds + NFIELDS * K * BLOCK);
 
     if (a.use_lds_tally) {
         for (uint32_t i = tid; i < a.S * LT_COLS; i += BLOCK) tl[i] = 0ull;
@@ -320,10 +319,13 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
     int32_t turn_score = 0;
     Seat cur{}; // the turn owner
 
-    // LDS field slots; with INCG the four increment dwords have no slot and later fields move up
+    // Seat records are contiguous per (seat, lane): record base = (seat * BLOCK + tid) * NFIELDS, field = immediate
+    // offset (one address VGPR per turn boundary, ds_read2/ds_write2 pairs).  The odd record stride (13 / 17 dwords)
+    // maps the 32 lanes of an LDS lane group to 32 distinct banks whatever seat each lane is on (BLOCK % 32 == 0).
+    // With INCG the four increment dwords have no slot and later fields move up.
     auto L = [&](uint32_t field, uint32_t s) -> uint32_t & {
         const uint32_t f = (INCG && field > F_INC_HI1) ? field - 4u : field;
-        return lds[f * fstride + s * BLOCK + tid];
+        return lds[(s * BLOCK + tid) * NFIELDS + f];
     };
 
     auto strategy_index = [&](uint32_t id, uint32_t s) -> uint32_t {
