@@ -383,3 +383,49 @@ def test_argument_errors(eng):
         eng.tournament(bad, 2, 0, 0, 1)
     empty = eng.tournament(table, 2, 0, 5, 5)
     assert empty["tally"].shape[0] == 0
+
+
+# ------------------------------------------------------------------ BASELINE configs 3-5 at full size: properties
+def test_config3_full_size_properties(eng):
+    """BASELINE config 3 (k=4, 5 160-strategy grid, 10^8 games = 77 520 shuffles x 1 290, root seed 0): conservation,
+    additivity over a partition of the shuffle range, per-batch tallies summing to the single-batch tally."""
+    table = _default_table()
+    n_sh = 77_520
+    full = eng.tournament(table, 4, 0, 0, n_sh)["tally"][0]
+    assert np.all(full[:, 1] == n_sh) and np.array_equal(full[:, 1], full[:, 2] + full[:, 3])
+    assert full[:, 0].sum() * 4 == full[:, 2].sum() and full[:, 2].sum() + full[:, 3].sum() == n_sh * 5160
+    assert np.all(full[:, 14] == 0) and np.all(full[:, 15] >= full[:, 4])
+    won = full[:, 0] > 0
+    assert np.all(full[won, 4] >= 10_000 * full[won, 0])                     # every winning score reaches the target
+    assert np.all(full[won, 5] <= 200 * full[won, 0])                        # n_rounds <= max_rounds
+    a = eng.tournament(table, 4, 0, 0, 30_000)["tally"][0]
+    b = eng.tournament(table, 4, 0, 30_000, n_sh, shuffles_per_batch=10_000)["tally"]
+    assert b.shape[0] == 5 and np.array_equal(a + b.sum(axis=0), full)
+
+
+def test_config4_player_count_sweep_properties(eng):
+    """BASELINE config 4 shape (k in {2,4,6,8} on the 5 160 grid) at 1/100 scale: exposure conservation per k."""
+    table = _default_table()
+    for k in (2, 4, 6, 8):
+        n_sh = 2_500_000 // (5160 // k)
+        t = eng.tournament(table, k, 7, 0, n_sh)["tally"][0]
+        assert np.all(t[:, 1] == n_sh) and np.array_equal(t[:, 1], t[:, 2] + t[:, 3]), k
+        assert t[:, 0].sum() * k == t[:, 2].sum(), k
+
+
+def test_config5_h2h_full_size_block(eng):
+    """BASELINE config 5 shape: one pairing at 10^8 completed games; chunked execution reaches the same state."""
+    g64 = _strats(gu.load("grid_vectors.json")["g64"])
+    seats = g64[[3, 40]]
+    target = 100_000_000
+    one = eng.h2h(seats, 42, 5, 0, target, 2 * target, 10**12)
+    attempted, completed, safety, w1, w2 = (int(v) for v in one)
+    assert completed == target and attempted == completed + safety and w1 + w2 == completed
+    state = None
+    for _ in range(8):
+        state = eng.h2h(seats, 42, 5, 0, target, 2 * target, 15_000_000, state=state)
+    assert np.array_equal(state, one)
+    swapped = eng.h2h(seats[::-1].copy(), 42, 5, 1, target, 2 * target, 10**12)  # order 1: strategy b in seat 1
+    assert int(swapped[1]) == target and int(swapped[3]) + int(swapped[4]) == target
+    # strategy a keeps winning the majority from either seat (it wins 76 % from seat 1)
+    assert w1 > w2 and int(swapped[4]) > int(swapped[3])
