@@ -767,7 +767,7 @@ struct fk_ctx {
     hipDeviceProp_t prop{};
     std::string err;
     fk_timing timing{};
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // [0..3] kernel timers, [4..5] whole call
     DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, dbg[6];
     int32_t longest_first = 1;
     int32_t blocks_per_cu = 0; // 0 = as many as fit
@@ -1035,6 +1035,8 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
 
 extern "C" {
 
+void fk_destroy(fk_ctx *c);
+
 int fk_init(int device_ordinal, fk_ctx **out) {
     if (!out) return FK_ERR_ARG;
     *out = nullptr;
@@ -1045,12 +1047,12 @@ int fk_init(int device_ordinal, fk_ctx **out) {
     c->device = device_ordinal;
     if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&c->prop, device_ordinal) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete c;
+        fk_destroy(c); // releases whatever was created
         return FK_ERR_HIP;
     }
     for (auto &e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) {
-            delete c;
+            fk_destroy(c);
             return FK_ERR_HIP;
         }
     *out = c;
@@ -1145,9 +1147,7 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
     const SeedPool perm_prefix = seed_prefix(101u /* SHUFFLE_PERMUTATION */, root_seed, (uint64_t)k);
     const SeedPool seat_prefix = seed_prefix(103u /* TOURNAMENT_PLAYER */, root_seed, (uint64_t)k);
 
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    HIPCHK(c, hipEventCreate(&t0));
-    HIPCHK(c, hipEventCreate(&t1));
+    const hipEvent_t t0 = c->ev[4], t1 = c->ev[5];
     HIPCHK(c, hipEventRecord(t0, c->stream));
 
     std::vector<uint16_t> perm_host;
@@ -1250,8 +1250,6 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
     HIPCHK(c, hipMemcpyAsync(tally, c->tally.p, tally_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipEventElapsedTime(&c->timing.total_ms, t0, t1));
-    (void)hipEventDestroy(t0);
-    (void)hipEventDestroy(t1);
     return FK_OK;
 }
 
