@@ -43,6 +43,7 @@ enum : uint32_t {
 //   cC = sf_uses | sf_dice << 16      cD = so_uses | so_dice << 16
 //   cE = hot_dice | flags << 16       flags: bit0 has_scored, bit1 has_buf
 constexpr uint32_t CE_HAS_SCORED = 1u << 16, CE_HAS_BUF = 1u << 17;
+constexpr uint32_t CE_IDX_SHIFT = 18; // LEAN records: strategy index in cE[31:18] (S <= 16384)
 
 constexpr uint32_t LT_COLS = 24; // LDS tally columns: wins, completed, safety, 10 sums, 10 square sums, pad
 constexpr uint32_t TICKET_CHUNK = 64;
@@ -281,9 +282,10 @@ __global__ void fk_finalize_tally(unsigned long long *tally, uint32_t n_rows, ui
 
 // ---------------------------------------------------------------------------------------
 // One seat's context: the turn owner's copy lives in VGPRs between begin_turn / end_turn; every seat has a
-// field-major LDS slot.  With INCG the (read-only) PCG increment is not kept in LDS but re-read from the seed
-// buffer at the start of each turn: 52 instead of 68 bytes of LDS per seat, i.e. one more resident wave per SIMD
-// at k >= 3.  (Keeping both k = 2 seats in VGPRs and swapping registers at the turn boundary was measured 3 %
+// contiguous LDS record.  LEAN records keep only what a turn mutates (PCG state, buffered half word, score, counters:
+// 11 dwords = 44 bytes instead of 68): the read-only PCG increment and the packed strategy are re-read from the seed
+// buffer / strategy table (L2-resident) at the start of each turn, the strategy index riding in the spare bits of cE.
+// Fewer LDS bytes per lane = more resident waves per SIMD (k=2: 4 -> 6 with the 80-VGPR instance, k=4: 2 -> 3.5).  (Keeping both k = 2 seats in VGPRs and swapping registers at the turn boundary was measured 3 %
 // slower than the LDS slots and is not built.)
 struct Seat {
     uint64_t lo, hi, inc_lo, inc_hi; // PCG64DXSM state / increment
@@ -293,12 +295,12 @@ struct Seat {
     Strat sp;
 };
 
-template <int BLOCK, bool INCG>
-__global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
+template <int BLOCK, bool LEAN, int WPE>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void fk_play_kernel(PlayArgs a) {
     extern __shared__ uint32_t lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t K = a.k;
-    constexpr uint32_t NFIELDS = INCG ? (uint32_t)NF - 4u : (uint32_t)NF; // 13 or 17 dwords per seat record
+    constexpr uint32_t NFIELDS = LEAN ? (uint32_t)NF - 6u : (uint32_t)NF; // 11 or 17 dwords per seat record
     unsigned long long *tl = reinterpret_cast<unsigned long long *>(lds + NFIELDS * K * BLOCK);
 
     if (a.use_lds_tally) {
@@ -322,9 +324,9 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
     // Seat records are contiguous per (seat, lane): record base = (seat * BLOCK + tid) * NFIELDS, field = immediate
     // offset (one address VGPR per turn boundary, ds_read2/ds_write2 pairs).  The odd record stride (13 / 17 dwords)
     // maps the 32 lanes of an LDS lane group to 32 distinct banks whatever seat each lane is on (BLOCK % 32 == 0).
-    // With INCG the four increment dwords have no slot and later fields move up.
+    // LEAN records have no increment / strategy slots: fields after the increment move up by four.
     auto L = [&](uint32_t field, uint32_t s) -> uint32_t & {
-        const uint32_t f = (INCG && field > F_INC_HI1) ? field - 4u : field;
+        const uint32_t f = (LEAN && field > F_INC_HI1) ? field - 4u : field;
         return lds[(s * BLOCK + tid) * NFIELDS + f];
     };
 
@@ -338,11 +340,17 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
     };
 
     // per-seat views used by the end-of-game code (seat s may be the turn owner or not)
+    auto seat_strategy = [&](uint32_t s) -> uint32_t { // strategy-table index of seat s of the lane's current game
+        if (LEAN) return L(F_CE, s) >> CE_IDX_SHIFT;
+        return strategy_index(game_id, s);
+    };
     auto seat_score = [&](uint32_t s) -> int32_t { return (int32_t)L(F_SCORE, s); };
     auto seat_counter = [&](uint32_t s, uint32_t field) -> uint32_t { return L(field, s); }; // field in F_CA..F_CE
 
+    uint32_t x_idx = 0; // strategy index of the seat last loaded by load_seat_from_global
     auto load_seat_from_global = [&](Seat &x, uint32_t id, uint32_t slot, uint32_t s) {
-        const uint2 pk = a.strat[strategy_index(id, s)];
+        x_idx = strategy_index(id, s);
+        const uint2 pk = a.strat[x_idx];
         const uint4 *src = a.seeds + ((size_t)slot * K + s) * 2;
         const uint4 stv = src[0], inc = src[1];
         x.lo = (uint64_t)stv.x | ((uint64_t)stv.y << 32);
@@ -356,13 +364,11 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
     };
 
     auto begin_turn = [&](uint32_t s) {
-        if (INCG) {
-            const uint4 inc = a.seeds[((size_t)seed_slot * K + s) * 2 + 1];
-            cur.inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
-            cur.inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
-        } else {
+        if (!LEAN) {
             cur.inc_lo = (uint64_t)L(F_INC_LO0, s) | ((uint64_t)L(F_INC_LO1, s) << 32);
             cur.inc_hi = (uint64_t)L(F_INC_HI0, s) | ((uint64_t)L(F_INC_HI1, s) << 32);
+            cur.sp.score_thr = (int32_t)L(F_SPX, s);
+            cur.sp.bits = L(F_SPY, s);
         }
         cur.lo = (uint64_t)L(F_LO0, s) | ((uint64_t)L(F_LO1, s) << 32);
         cur.hi = (uint64_t)L(F_HI0, s) | ((uint64_t)L(F_HI1, s) << 32);
@@ -373,8 +379,13 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
         cur.cC = L(F_CC, s);
         cur.cD = L(F_CD, s);
         cur.cE = L(F_CE, s);
-        cur.sp.score_thr = (int32_t)L(F_SPX, s);
-        cur.sp.bits = L(F_SPY, s);
+        if (LEAN) { // read-only per-seat data comes from HBM/L2; the loads overlap the first dice of the turn
+            const uint4 inc = a.seeds[((size_t)seed_slot * K + s) * 2 + 1];
+            const uint2 pk = a.strat[cur.cE >> CE_IDX_SHIFT];
+            cur.inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
+            cur.inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
+            cur.sp = Strat{(int32_t)pk.x, pk.y};
+        }
         cur.cB += 0x10000u; // n_turns += 1 (engine.py:236)
         has_buf = (cur.cE & CE_HAS_BUF) ? 1u : 0u;
         dice = 6;
@@ -421,12 +432,12 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
         const bool count_exposures = !completed || a.mode != MODE_PERM;
         if (count_exposures) {
             for (uint32_t s = 0; s < K; ++s) {
-                const uint32_t idx = strategy_index(game_id, s);
+                const uint32_t idx = seat_strategy(s);
                 if (a.use_lds_tally) atomicAdd(&tl[idx * LT_COLS + (completed ? 1u : 2u)], 1ull);
                 else atomicAdd(&a.tally[((size_t)batch * a.S + idx) * FK_TALLY_COLS + (completed ? 2u : 3u)], 1ull);
             }
         }
-        if (completed) widx = strategy_index(game_id, w);
+        if (completed) widx = seat_strategy(w);
         if (completed) {
             const uint32_t wa = seat_counter(w, F_CA), wb = seat_counter(w, F_CB), wc = seat_counter(w, F_CC),
                            wd = seat_counter(w, F_CD), we = seat_counter(w, F_CE);
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
                                xd = seat_counter(s, F_CD), xe = seat_counter(s, F_CE);
                 uint32_t *d = reinterpret_cast<uint32_t *>(row + sizeof(fk_row_hdr) + sizeof(fk_seat) * s);
                 d[0] = (uint32_t)sc;
-                d[1] = strategy_index(game_id, s);
+                d[1] = seat_strategy(s);
                 d[2] = (xa >> 16) | (xa << 16);                    // farkles, rolls
                 d[3] = (xb >> 16) | (xb << 16);                    // n_turns, highest_turn
                 d[4] = xc;                                         // sf_uses, sf_dice
@@ -505,11 +516,13 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
             L(F_LO1, s) = (uint32_t)(x.lo >> 32);
             L(F_HI0, s) = (uint32_t)x.hi;
             L(F_HI1, s) = (uint32_t)(x.hi >> 32);
-            if (!INCG) {
+            if (!LEAN) {
                 L(F_INC_LO0, s) = (uint32_t)x.inc_lo;
                 L(F_INC_LO1, s) = (uint32_t)(x.inc_lo >> 32);
                 L(F_INC_HI0, s) = (uint32_t)x.inc_hi;
                 L(F_INC_HI1, s) = (uint32_t)(x.inc_hi >> 32);
+                L(F_SPX, s) = (uint32_t)x.sp.score_thr;
+                L(F_SPY, s) = x.sp.bits;
             }
             L(F_BUF, s) = 0u;
             L(F_SCORE, s) = 0u;
@@ -517,9 +530,7 @@ __global__ __launch_bounds__(BLOCK) void fk_play_kernel(PlayArgs a) {
             L(F_CB, s) = 0u;
             L(F_CC, s) = 0u;
             L(F_CD, s) = 0u;
-            L(F_CE, s) = 0u;
-            L(F_SPX, s) = (uint32_t)x.sp.score_thr;
-            L(F_SPY, s) = x.sp.bits;
+            L(F_CE, s) = LEAN ? (x_idx << CE_IDX_SHIFT) : 0u;
         }
         seat = 0;
         trigger = 0;
@@ -771,7 +782,7 @@ struct fk_ctx {
     DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, dbg[6];
     int32_t longest_first = 1;
     int32_t blocks_per_cu = 0; // 0 = as many as fit
-    int32_t inc_global = -1;   // -1 auto, 0 increments in LDS, 1 increments re-read from the seed buffer
+    int32_t lean = -1;         // -1 auto, 0 full 17-dword seat records, 1 lean 11-dword records
     int32_t waves_per_cu = 16; // resident-wave target used to size the grid
     int64_t chunk_bytes = (int64_t)24 << 30;
     int32_t batch_threshold = 6;
@@ -872,68 +883,75 @@ struct LaunchPlan {
     int block = 0, grid = 0;
     size_t lds = 0;
     bool lds_tally = false;
-    bool inc_global = false; // PCG increments re-read from the seed buffer each turn (52 B of LDS per seat)
+    bool lean = false; // 11-dword seat records (increment + strategy re-read from HBM/L2 each turn)
+    int wpe = 4;       // waves per SIMD the chosen instance is compiled for
 };
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-size_t play_lds_bytes(int32_t k, int block, bool inc_global, bool lds_tally, int32_t S) {
-    const size_t per_lane = (size_t)(inc_global ? NF - 4 : NF) * 4 * (size_t)k;
+size_t play_lds_bytes(int32_t k, int block, bool lean, bool lds_tally, int32_t S) {
+    const size_t per_lane = (size_t)(lean ? NF - 6 : NF) * 4 * (size_t)k;
     return per_lane * (size_t)block + (lds_tally ? (size_t)S * LT_COLS * 8 : 0);
 }
 
-// Pick block size / LDS layout for the most resident lanes per CU (ties: larger blocks, increments in LDS).
+// Pick block size / record layout for the most resident lanes per CU (ties: full records, larger blocks).
+// Instances are compiled for 4 waves/SIMD (<= 128 VGPRs); the 768-thread LEAN instance for 6 (80 VGPRs): its 12 waves
+// split evenly over the 4 SIMDs, so two blocks (24 waves) co-reside.
 LaunchPlan plan_play(const fk_ctx *c, int32_t k, int32_t S, bool single_batch) {
     LaunchPlan best;
     const bool want_tally = single_batch && (c->use_lds_tally != 0);
-    const int max_lanes = c->waves_per_cu * 64;
     int best_lanes = -1;
-    for (int incg = 0; incg <= 1; ++incg) {
-        if (c->inc_global >= 0 && incg != c->inc_global) continue;
-        for (int block : {1024, 512, 256, 128, 64}) {
+    for (int lean = 0; lean <= 1; ++lean) {
+        if (c->lean >= 0 && lean != c->lean) continue;
+        if (lean && S > (1 << (32 - CE_IDX_SHIFT))) continue; // strategy index must fit cE[31:18]
+        for (int block : {1024, 768, 512, 256, 128, 64}) {
             if (c->block != 0 && block != c->block) continue;
-            bool tally = want_tally && play_lds_bytes(k, block, incg != 0, true, S) <= LDS_LIMIT;
-            size_t lds = play_lds_bytes(k, block, incg != 0, tally, S);
+            if (block == 768 && !lean) continue;
+            const int wpe = (block == 768) ? 6 : 4;
+            bool tally = want_tally && play_lds_bytes(k, block, lean != 0, true, S) <= LDS_LIMIT;
+            size_t lds = play_lds_bytes(k, block, lean != 0, tally, S);
             if (lds > LDS_LIMIT) continue;
             int per_cu = (int)(LDS_LIMIT / std::max<size_t>(lds, 1));
-            per_cu = std::min(per_cu, std::max(1, max_lanes / block));
+            per_cu = std::min(per_cu, std::max(1, wpe * 4 * 64 / block));
             if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
             per_cu = std::max(per_cu, 1);
-            int lanes = per_cu * block + (tally ? 1 : 0); // a privatised tally breaks ties
+            int lanes = (per_cu * block) * 4 + (tally ? 2 : 0) + (lean ? 0 : 1); // tie-breaks: tally, then full records
             if (lanes > best_lanes) {
                 best_lanes = lanes;
                 best.block = block;
                 best.lds = lds;
                 best.lds_tally = tally;
-                best.inc_global = incg != 0;
+                best.lean = lean != 0;
+                best.wpe = wpe;
                 best.grid = c->prop.multiProcessorCount * per_cu;
             }
         }
     }
-    if (best_lanes < 0) { // k too large even for one wave with increments in global memory
+    if (best_lanes < 0) { // k too large for one wave: reported by run_chunk
         best.block = 64;
-        best.inc_global = true;
+        best.lean = S <= (1 << (32 - CE_IDX_SHIFT));
         best.lds_tally = false;
-        best.lds = play_lds_bytes(k, 64, true, false, S);
+        best.lds = play_lds_bytes(k, 64, best.lean, false, S);
         best.grid = c->prop.multiProcessorCount;
     }
     return best;
 }
 
-template <int BLOCK, bool INCG>
+template <int BLOCK, bool LEAN, int WPE = 4>
 hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, INCG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, LEAN, WPE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(p.lds, 16));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fk_play_kernel<BLOCK, INCG>), dim3((unsigned)p.grid), dim3(BLOCK), p.lds, s, a);
+    hipLaunchKernelGGL((fk_play_kernel<BLOCK, LEAN, WPE>), dim3((unsigned)p.grid), dim3(BLOCK), p.lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     if (p.lds > LDS_LIMIT) return hipErrorInvalidValue;
-    if (p.inc_global) {
+    if (p.lean) {
         switch (p.block) {
         case 1024: return launch_play_t<1024, true>(p, a, s);
+        case 768: return launch_play_t<768, true, 6>(p, a, s);
         case 512: return launch_play_t<512, true>(p, a, s);
         case 256: return launch_play_t<256, true>(p, a, s);
         case 128: return launch_play_t<128, true>(p, a, s);
@@ -985,7 +1003,7 @@ int check_device_error(fk_ctx *c, const int32_t *d_err, int64_t game_base, const
 int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &plan, int64_t game_base, const char *what) {
     SeedArgs sa = sa_in;
     if (plan.lds > LDS_LIMIT)
-        return fail(c, FK_ERR_ARG, "k=%u needs %zu bytes of LDS per wave; the seat contexts of at most 48 players fit a CU",
+        return fail(c, FK_ERR_ARG, "k=%u needs %zu bytes of LDS per wave; the seat contexts of at most 58 players fit a CU",
                     sa.k, plan.lds);
     int rc = ensure(c, c->seeds, (size_t)sa.n_games * sa.k * 32);
     if (rc) return rc;
@@ -1101,11 +1119,11 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "use_lds_tally") c->use_lds_tally = (int32_t)value;
     else if (n == "longest_first") c->longest_first = (int32_t)value;
     else if (n == "blocks_per_cu") c->blocks_per_cu = (int32_t)value;
-    else if (n == "inc_global") c->inc_global = (int32_t)value;
+    else if (n == "lean") c->lean = (int32_t)value;
     else if (n == "waves_per_cu") c->waves_per_cu = (int32_t)std::max<int64_t>(1, std::min<int64_t>(32, value));
     else if (n == "block") {
-        if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
-            return fail(c, FK_ERR_ARG, "block must be 0, 64, 128, 256, 512 or 1024");
+        if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 768 && value != 1024)
+            return fail(c, FK_ERR_ARG, "block must be 0, 64, 128, 256, 512, 768 (lean records only) or 1024");
         c->block = (int32_t)value;
     } else return fail(c, FK_ERR_ARG, "unknown option %s", name);
     return FK_OK;
