@@ -88,11 +88,19 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    # FK_DIST_BACKEND=gloo rehearses the multi-rank path on a one-GPU box (ranks share GPU 0, tallies reduced on CPU);
+    # the real runs use nccl = RCCL over xGMI with one GPU per rank.
+    backend = os.environ.get("FK_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if distributed:
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world if distributed else 1
     if args.gpus != n_gpus and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
@@ -104,7 +112,8 @@ def main() -> None:
     eng = Engine(local_rank)
     info = eng.device_info()
     dev = torch.device("cuda", local_rank)
-    total = torch.zeros((S, 26), dtype=torch.int64, device=dev)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the tally reduction runs
+    total = torch.zeros((S, 26), dtype=torch.int64, device=red_dev)
 
     def sync() -> None:
         if distributed:
@@ -115,15 +124,15 @@ def main() -> None:
         first = (index * n_gpus + rank) * args.shuffles
         res = eng.tournament(table, K, ROOT_SEED, first, first + args.shuffles)
         t = eng.timing()
-        tally = torch.from_numpy(res["tally"][0]).to(dev)
+        tally = torch.from_numpy(res["tally"][0]).to(red_dev)
         if distributed:
             dist.reduce(tally, dst=0, op=dist.ReduceOp.SUM)  # RCCL sum of win counts (the only exchange)
         return tally, t
 
     # one-time initialisation outside any step: device workspace, lazily loaded torch kernels, RCCL communicator
     eng.tournament(table, K, ROOT_SEED, 0, args.shuffles)
-    warm = torch.zeros((S, 26), dtype=torch.int64, device=dev)
-    warm += torch.from_numpy(np.zeros((S, 26), dtype=np.int64)).to(dev)
+    warm = torch.zeros((S, 26), dtype=torch.int64, device=red_dev)
+    warm += torch.from_numpy(np.zeros((S, 26), dtype=np.int64)).to(red_dev)
     if distributed:
         dist.reduce(warm, dst=0, op=dist.ReduceOp.SUM)
     for i in range(args.warmup):
@@ -143,7 +152,7 @@ def main() -> None:
     sync()
     elapsed = time.perf_counter() - t0
     if distributed:
-        e = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        e = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = float(e.item())
 
