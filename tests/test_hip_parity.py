@@ -431,3 +431,36 @@ def test_config5_h2h_full_size_block(eng):
     assert int(swapped[1]) == target and int(swapped[3]) + int(swapped[4]) == target
     # strategy a keeps winning the majority from either seat (it wins 76 % from seat 1)
     assert w1 > w2 and int(swapped[4]) > int(swapped[3])
+
+
+# ------------------------------------------------------------------ randomized differential test
+def test_fuzz_random_tables_limits_and_player_counts(eng, po):
+    """Random legal strategy tables (extreme thresholds, every flag combination), player counts 1..12, targets and round
+    limits, small and large shuffle counts: rows, permutations and tallies bit-identical to the oracle."""
+    from farkle_ii_amd.strategies import STRATEGY_DTYPE
+
+    rs = np.random.default_rng(2026)
+    for trial in range(40):
+        k = int(rs.choice([1, 2, 2, 3, 4, 5, 6, 7, 8, 10, 12]))
+        S = k * int(rs.integers(1, 9))
+        table = np.zeros(S, dtype=STRATEGY_DTYPE)
+        for i in range(S):
+            sf = int(rs.integers(0, 2))
+            so = int(rs.integers(0, 2)) if sf else 0
+            cs, cd = int(rs.integers(0, 2)), int(rs.integers(0, 2))
+            rb = int(rs.integers(0, 2)) if (cs and cd) else 0
+            table[i] = (int(rs.choice([0, 50, 199, 250, 300, 500, 1000, 1350, 10_000])), int(rs.integers(-1, 7)), sf, so, cs, cd, rb,
+                        int(rs.integers(0, 2)), int(rs.integers(0, 2)), int(rs.integers(0, 2)), 1000 + i)
+        target = int(rs.choice([100, 500, 2000, 10_000, 20_000]))
+        max_rounds = int(rs.choice([0, 1, 3, 50, 200, 300]))
+        n_sh = int(rs.choice([1, 2, 7, 40]))
+        root = int(rs.integers(0, 2**63))
+        first = int(rs.integers(0, 2**40))
+        got = eng.tournament(table, k, root, first, first + n_sh, shuffles_per_batch=3, target_score=target, max_rounds=max_rounds,
+                             want_rows=True, want_perms=True)
+        ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, root, first, first + n_sh, shuffles_per_batch=3, target_score=target,
+                            max_rounds=max_rounds, want_rows=True, want_perms=True, n_threads=4)
+        ctx = (trial, k, S, target, max_rounds, n_sh)
+        assert np.array_equal(got["perms"], ref["perms"]), ctx
+        assert _rows_equal(got["rows"], ref["rows"].view(got["rows"].dtype)), ctx
+        assert np.array_equal(got["tally"], ref["tally"]), ctx
