@@ -394,6 +394,29 @@ def gen_grids():
               open(OUT / "grid_vectors.json", "w"))
 
 
+def gen_fuzz():
+    """Games on random legal strategy tables (extreme thresholds, every flag combination, k = 1..8, odd limits)."""
+    rs = np.random.default_rng(77)
+    games = []
+    for _ in range(160):
+        k = int(rs.choice([1, 2, 2, 3, 4, 5, 6, 8]))
+        strats = []
+        for i in range(k):
+            sf = bool(rs.integers(0, 2))
+            so = bool(rs.integers(0, 2)) if sf else False
+            cs, cd = bool(rs.integers(0, 2)), bool(rs.integers(0, 2))
+            rb = bool(rs.integers(0, 2)) if (cs and cd) else False
+            strats.append(ThresholdStrategy(int(rs.choice([0, 50, 199, 250, 300, 500, 1000, 1350, 10000])), int(rs.integers(-1, 7)),
+                                            sf, so, cs, cd, rb, bool(rs.integers(0, 2)), bool(rs.integers(0, 2)),
+                                            FavorDiceOrScore.SCORE if rs.integers(0, 2) else FavorDiceOrScore.DICE, strategy_id=i))
+        root, sh, gi = int(rs.integers(0, 2**63)), int(rs.integers(0, 10**6)), int(rs.integers(0, 3000))
+        tgt, mr = int(rs.choice([100, 500, 2000, 10000, 20000])), int(rs.choice([0, 1, 3, 50, 200, 300]))
+        row = play(strats, 103, root, k, shuffle=sh, game=gi, target=tgt, max_rounds=mr)
+        games.append({"strategies": [strat_tuple(s) for s in strats], "k": k, "root_seed": root, "shuffle": sh, "game": gi,
+                      "target": tgt, "max_rounds": mr, "row": row_to_compact(row, k)})
+    _dump({"games": games}, open(OUT / "fuzz_vectors.json", "w"))
+
+
 def gen_runner():
     """Workload plans and config path resolution of the reference's run surface."""
     from farkle.config import AppConfig, IOConfig, SimConfig
@@ -419,6 +442,7 @@ def gen_runner():
 
 if __name__ == "__main__":
     gen_runner()
+    gen_fuzz()
     gen_rng()
     gen_scoring()
     gen_games()

@@ -464,3 +464,13 @@ def test_fuzz_random_tables_limits_and_player_counts(eng, po):
         assert np.array_equal(got["perms"], ref["perms"]), ctx
         assert _rows_equal(got["rows"], ref["rows"].view(got["rows"].dtype)), ctx
         assert np.array_equal(got["tally"], ref["tally"]), ctx
+
+
+def test_random_table_games_match_reference_vectors(eng):
+    for g in gu.load("fuzz_vectors.json")["games"]:
+        table = _strats(g["strategies"])
+        k = g["k"]
+        coords = _coords([(103, 0, g["root_seed"], k, g["shuffle"], 0, 0, g["game"], 0, 0)])
+        row = eng.play_games(coords, table, np.arange(k, dtype=np.int32)[None, :], k, target_score=g["target"],
+                             max_rounds=g["max_rounds"])[0]
+        gu.assert_row_equal(gu.row_as_compact(row, k, lambda i: table[i]["strategy_id"]), g["row"], ctx=str(g["root_seed"]))

@@ -242,3 +242,12 @@ def test_should_continue_cases():
         got = po.should_continue(s, case["turn_score"], case["dice_left"], case["has_scored"], case["final_round"],
                                  case["score_to_beat"], case["player_score"])
         assert int(got) == case["out"], case
+
+
+def test_random_table_games_match_reference():
+    """Games on random legal strategy tables (k = 1..8, extreme thresholds, odd limits) from the Python reference."""
+    for g in gu.load("fuzz_vectors.json")["games"]:
+        table = _strats(g["strategies"])
+        c = po.coord(103, g["root_seed"], g["k"], g["shuffle"], game_index=g["game"])
+        row = po.play_game(c, table, list(range(g["k"])), g["target"], g["max_rounds"])[0]
+        gu.assert_row_equal(gu.row_as_compact(row, g["k"], lambda i: table[i]["strategy_id"]), g["row"], ctx=str(g["root_seed"]))
