@@ -317,15 +317,20 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     uint32_t final_round = 0, safety = 0;
     int32_t score_to_beat = 0;
     // turn registers
-    uint32_t dice = 6, rolls_this_turn = 0, has_buf = 0;
+    uint32_t dice = 6, rolls_this_turn = 0;
     int32_t turn_score = 0;
-    Seat cur{}; // the turn owner
+    // read-only data of the turn owner (PCG increment, packed strategy): the only per-seat values carried in registers
+    // across roll iterations.  The mutable seat record (generator state, score, counters) is loaded from and stored to
+    // LDS inside every roll step, so the hot loop carries no per-seat PHIs through its divergent turn hand-over.
+    uint64_t own_inc_lo = 0, own_inc_hi = 0;
+    int32_t own_thr = 0;
+    uint32_t own_bits = 0;
 
     // Seat records are contiguous per (seat, lane): record base = (seat * BLOCK + tid) * NFIELDS, field = immediate
     // offset (one address VGPR per turn boundary, ds_read2/ds_write2 pairs).  The odd record stride (13 / 17 dwords)
     // maps the 32 lanes of an LDS lane group to 32 distinct banks whatever seat each lane is on (BLOCK % 32 == 0).
     // LEAN records have no increment / strategy slots: fields after the increment move up by four.
-    auto L = [&](uint32_t field, uint32_t s) -> uint32_t & {
+    auto L = [&](uint32_t field, uint32_t s) __attribute__((always_inline)) -> uint32_t & {
         const uint32_t f = (LEAN && field > F_INC_HI1) ? field - 4u : field;
         return lds[(s * BLOCK + tid) * NFIELDS + f];
     };
@@ -363,49 +368,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         x.sp = Strat{(int32_t)pk.x, pk.y};
     };
 
-    auto begin_turn = [&](uint32_t s) {
-        if (!LEAN) {
-            cur.inc_lo = (uint64_t)L(F_INC_LO0, s) | ((uint64_t)L(F_INC_LO1, s) << 32);
-            cur.inc_hi = (uint64_t)L(F_INC_HI0, s) | ((uint64_t)L(F_INC_HI1, s) << 32);
-            cur.sp.score_thr = (int32_t)L(F_SPX, s);
-            cur.sp.bits = L(F_SPY, s);
-        }
-        cur.lo = (uint64_t)L(F_LO0, s) | ((uint64_t)L(F_LO1, s) << 32);
-        cur.hi = (uint64_t)L(F_HI0, s) | ((uint64_t)L(F_HI1, s) << 32);
-        cur.buf = L(F_BUF, s);
-        cur.score = (int32_t)L(F_SCORE, s);
-        cur.cA = L(F_CA, s);
-        cur.cB = L(F_CB, s);
-        cur.cC = L(F_CC, s);
-        cur.cD = L(F_CD, s);
-        cur.cE = L(F_CE, s);
+    // turn owner := seat s (engine.py:236-240): n_turns += 1 in its record, fresh turn registers, read-only data
+    auto begin_turn = [&](uint32_t s) __attribute__((always_inline)) {
+        L(F_CB, s) += 0x10000u; // n_turns += 1 (engine.py:236)
         if (LEAN) { // read-only per-seat data comes from HBM/L2; the loads overlap the first dice of the turn
             const uint4 inc = a.seeds[((size_t)seed_slot * K + s) * 2 + 1];
-            const uint2 pk = a.strat[cur.cE >> CE_IDX_SHIFT];
-            cur.inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
-            cur.inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
-            cur.sp = Strat{(int32_t)pk.x, pk.y};
+            const uint2 pk = a.strat[L(F_CE, s) >> CE_IDX_SHIFT];
+            own_inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
+            own_inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
+            own_thr = (int32_t)pk.x;
+            own_bits = pk.y;
+        } else {
+            own_inc_lo = (uint64_t)L(F_INC_LO0, s) | ((uint64_t)L(F_INC_LO1, s) << 32);
+            own_inc_hi = (uint64_t)L(F_INC_HI0, s) | ((uint64_t)L(F_INC_HI1, s) << 32);
+            own_thr = (int32_t)L(F_SPX, s);
+            own_bits = L(F_SPY, s);
         }
-        cur.cB += 0x10000u; // n_turns += 1 (engine.py:236)
-        has_buf = (cur.cE & CE_HAS_BUF) ? 1u : 0u;
         dice = 6;
         turn_score = 0;
         rolls_this_turn = 0;
-    };
-
-    auto store_turn = [&](uint32_t s) {
-        cur.cE = (cur.cE & ~CE_HAS_BUF) | (has_buf ? CE_HAS_BUF : 0u);
-        L(F_LO0, s) = (uint32_t)cur.lo;
-        L(F_LO1, s) = (uint32_t)(cur.lo >> 32);
-        L(F_HI0, s) = (uint32_t)cur.hi;
-        L(F_HI1, s) = (uint32_t)(cur.hi >> 32);
-        L(F_BUF, s) = cur.buf;
-        L(F_SCORE, s) = (uint32_t)cur.score;
-        L(F_CA, s) = cur.cA;
-        L(F_CB, s) = cur.cB;
-        L(F_CC, s) = cur.cC;
-        L(F_CD, s) = cur.cD;
-        L(F_CE, s) = cur.cE;
     };
 
     auto raise = [&](int32_t code) {
@@ -548,20 +529,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         }
     };
 
-    // ---- end of a turn: bank, write back, advance the table (engine.py:265-273, 453-472, 523-550) ----
-    auto end_turn = [&]() {
-        if (!(cur.cE & CE_HAS_SCORED) && turn_score >= 500) cur.cE |= CE_HAS_SCORED;
-        if (cur.cE & CE_HAS_SCORED) {
-            cur.score += turn_score;
-            if ((uint32_t)turn_score > (cur.cB & 0xffffu)) cur.cB = (cur.cB & 0xffff0000u) | (uint32_t)turn_score;
-        }
-        // u16 guard bands (a turn adds <= 1000 rolls / <= 2000 discarded dice)
-        if ((cur.cA & 0xffffu) > 64000u || (cur.cC >> 16) > 63000u || (cur.cD >> 16) > 63000u) {
-            raise(FK_ERR_COUNTER_OVERFLOW);
-            return;
-        }
-        store_turn(seat);
-        const int32_t score = cur.score;
+    // ---- after a turn: advance the table (engine.py:453-472, 523-550); `score` is the owner's banked total ----
+    auto advance = [&](int32_t score) __attribute__((always_inline)) {
         uint32_t next;
         bool ended = false;
         if (!final_round) {
@@ -596,37 +565,61 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         }
     };
 
-    // ---- one roll of the current turn (engine.py:241-263), straight-line up to the turn hand-over ----
-    auto roll_step = [&]() {
+    // ---- one roll of the current turn (engine.py:241-273): record in, roll, score, decide, record out ----
+    auto roll_step = [&]() __attribute__((always_inline)) {
         if (rolls_this_turn >= 1000u) { // ROLL_LIMIT, engine.py:36,242
             raise(FK_ERR_ROLL_LIMIT);
             return;
         }
+        const uint32_t s = seat;
+        uint32_t cA = L(F_CA, s), cB = L(F_CB, s), cC = L(F_CC, s), cD = L(F_CD, s), cE = L(F_CE, s);
+        int32_t score = (int32_t)L(F_SCORE, s);
+        Rng rng{(uint64_t)L(F_HI0, s) | ((uint64_t)L(F_HI1, s) << 32), (uint64_t)L(F_LO0, s) | ((uint64_t)L(F_LO1, s) << 32),
+                own_inc_hi, own_inc_lo, L(F_BUF, s), (cE & CE_HAS_BUF) ? 1u : 0u};
         const uint32_t n = dice;
-        Rng rng{cur.hi, cur.lo, cur.inc_hi, cur.inc_lo, cur.buf, has_buf};
         const uint32_t counts = roll_counts(rng, n);
-        cur.hi = rng.hi;
-        cur.lo = rng.lo;
-        cur.buf = rng.buf;
-        has_buf = rng.has_buf;
         rolls_this_turn += 1u;
-        const Strat sp = cur.sp;
+        const Strat sp{own_thr, own_bits};
         const RollResult rr = default_score(counts, (int32_t)n, turn_score, sp);
         const bool farkle = rr.score == 0;                              // engine.py:135-137, 247-249
-        cur.cA += 1u + (farkle ? 0x10000u : 0u);                        // n_rolls (engine.py:98), n_farkles
-        cur.cC += (rr.d5 > 0) ? (1u + ((uint32_t)rr.d5 << 16)) : 0u;    // engine.py:139-144
-        cur.cD += (rr.d1 > 0) ? (1u + ((uint32_t)rr.d1 << 16)) : 0u;
+        cA += 1u + (farkle ? 0x10000u : 0u);                            // n_rolls (engine.py:98), n_farkles
+        cC += (rr.d5 > 0) ? (1u + ((uint32_t)rr.d5 << 16)) : 0u;        // engine.py:139-144
+        cD += (rr.d1 > 0) ? (1u + ((uint32_t)rr.d1 << 16)) : 0u;
         dice = (rr.used == (int32_t)n) ? 6u : (n - (uint32_t)rr.used);  // engine.py:146
         turn_score = farkle ? 0 : (turn_score + rr.score);
         const bool hot = !farkle & sp.has(SF_AUTO_HOT) & (dice == 6u);  // _apply_hot_dice, engine.py:149-154, 253
-        cur.cE += hot ? 1u : 0u;
-        const bool keep = should_continue(sp, turn_score, (int32_t)dice, (cur.cE & CE_HAS_SCORED) != 0u, final_round != 0u,
-                                          score_to_beat, cur.score);
+        cE += hot ? 1u : 0u;
+        const bool keep = should_continue(sp, turn_score, (int32_t)dice, (cE & CE_HAS_SCORED) != 0u, final_round != 0u,
+                                          score_to_beat, score);
         if (turn_score > 0xffff) {
             raise(FK_ERR_COUNTER_OVERFLOW);
             return;
         }
-        if (farkle | (!hot & !keep)) end_turn();
+        const bool over = farkle | (!hot & !keep);
+        // bank (engine.py:265-273), branch-free: a farkled turn has turn_score 0 and changes nothing
+        const uint32_t ts = over ? (uint32_t)turn_score : 0u;
+        cE |= (ts >= 500u) ? CE_HAS_SCORED : 0u;
+        const uint32_t banked = (cE & CE_HAS_SCORED) ? ts : 0u;
+        score += (int32_t)banked;
+        cB = (banked > (cB & 0xffffu)) ? ((cB & 0xffff0000u) | banked) : cB;
+        // u16 guard bands (a turn adds <= 1000 rolls / <= 2000 discarded dice)
+        if ((cA & 0xffffu) > 64000u || (cC >> 16) > 63000u || (cD >> 16) > 63000u) {
+            raise(FK_ERR_COUNTER_OVERFLOW);
+            return;
+        }
+        cE = (cE & ~CE_HAS_BUF) | (rng.has_buf ? CE_HAS_BUF : 0u);
+        L(F_LO0, s) = (uint32_t)rng.lo;
+        L(F_LO1, s) = (uint32_t)(rng.lo >> 32);
+        L(F_HI0, s) = (uint32_t)rng.hi;
+        L(F_HI1, s) = (uint32_t)(rng.hi >> 32);
+        L(F_BUF, s) = rng.buf;
+        L(F_SCORE, s) = (uint32_t)score;
+        L(F_CA, s) = cA;
+        L(F_CB, s) = cB;
+        L(F_CC, s) = cC;
+        L(F_CD, s) = cD;
+        L(F_CE, s) = cE;
+        if (over) advance(score);
     };
 
     // ---- wave-level hand-over: finish ended games, deal new tickets ----
@@ -637,9 +630,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         const uint32_t avail = pool_end - pool_next;
         uint32_t new_base = 0, new_avail = 0;
         if (avail < n && !exhausted) {
+            // v_readlane makes the pool registers provably wave-uniform, so the loops below branch on SGPRs
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(__ffsll((long long)waiting) - 1);
             uint32_t base = 0;
-            if (mine && lane_id() == (uint32_t)(__ffsll((long long)waiting) - 1)) base = atomicAdd(a.ticket, TICKET_CHUNK);
-            base = (uint32_t)__shfl((int)base, __ffsll((long long)waiting) - 1);
+            if (mine && lane_id() == first) base = atomicAdd(a.ticket, TICKET_CHUNK);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
             if (base >= a.n_games) {
                 exhausted = 1;
             } else {
@@ -665,15 +660,25 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         }
     };
 
+    // Two nested loops.  The inner one is the hot roll loop: a bottom-tested loop with a single back edge whose exit
+    // test is wave-uniform (ballots and the v_readlane'd ticket pool), so its loop-carried registers stay put (no PHI
+    // copies, no full s_waitcnt at a merge point).  The rare hand-over sits on the outer back edge.
+    auto handover_due = [&](uint64_t waiting, uint64_t active) -> bool {
+        return waiting && (!active || (uint32_t)__popcll(waiting) >= a.batch_threshold || exhausted);
+    };
     while (true) {
-        const uint64_t waiting = __ballot(st == ST_FRESH || st == ST_ENDED);
-        const uint64_t active = __ballot(st == ST_ACTIVE);
-        if (!waiting && !active) break;
-        if (waiting && ((uint32_t)__popcll(waiting) >= a.batch_threshold || !active || exhausted)) {
+        uint64_t waiting = __ballot(st == ST_FRESH || st == ST_ENDED);
+        uint64_t active = __ballot(st == ST_ACTIVE);
+        if (!(waiting | active)) break; // no lane is active and none waits: the wave has drained
+        if (handover_due(waiting, active)) {
             handover(waiting);
             continue;
         }
-        if (st == ST_ACTIVE) roll_step();
+        do {
+            if (st == ST_ACTIVE) roll_step();
+            waiting = __ballot(st == ST_ENDED);
+            active = __ballot(st == ST_ACTIVE);
+        } while (active && !handover_due(waiting, active));
     }
 
     if (a.use_lds_tally) {
