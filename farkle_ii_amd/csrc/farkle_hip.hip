@@ -529,48 +529,34 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         }
     };
 
-    // ---- after a turn: advance the table (engine.py:453-472, 523-550); `score` is the owner's banked total ----
+    // ---- after a turn: advance the table (engine.py:453-472, 523-550); `score` is the owner's banked total.
+    // Written as selects: one predicated region per roll step instead of a tree of them. ----
     auto advance = [&](int32_t score) __attribute__((always_inline)) {
-        uint32_t next;
-        bool ended = false;
-        if (!final_round) {
-            if (score >= a.target) { // first trigger starts the final round (engine.py:462-468)
-                final_round = 1;
-                score_to_beat = score;
-                trigger = seat;
-                next = (seat == 0u) ? 1u : 0u;
-            } else {
-                next = seat + 1u;
-                if (next == K) {
-                    if (rounds >= max_rounds) { // engine.py:453, 472
-                        safety = 1;
-                        ended = true;
-                    } else {
-                        rounds += 1u;
-                        next = 0u;
-                    }
-                }
-            }
-        } else {
-            if (score > score_to_beat) score_to_beat = score; // engine.py:547
-            next = seat + 1u;
-            if (next == trigger) next += 1u;
-        }
-        if (final_round && next >= K) ended = true;
+        const bool fr = final_round != 0u;
+        const bool trig = !fr & (score >= a.target);           // first trigger starts the final round (engine.py:462-468)
+        const bool normal = !fr & !trig;
+        const uint32_t n1 = seat + 1u;
+        const bool wrap = n1 == K;
+        const bool last = normal & wrap & (rounds >= max_rounds); // `while rounds < max_rounds` ends (engine.py:453, 472)
+        const uint32_t next_fr = n1 + ((n1 == trigger) ? 1u : 0u); // final round skips the trigger seat (engine.py:523-550)
+        const uint32_t next = fr ? next_fr : trig ? ((seat == 0u) ? 1u : 0u) : wrap ? 0u : n1;
+        rounds += (normal & wrap & !last) ? 1u : 0u;
+        safety = last ? 1u : safety;
+        score_to_beat = trig ? score : (fr & (score > score_to_beat)) ? score : score_to_beat; // engine.py:464, 547
+        trigger = trig ? seat : trigger;
+        final_round = (fr | trig) ? 1u : 0u;
+        const bool ended = last | ((fr | trig) & (next >= K));
         if (ended) {
             st = ST_ENDED;
         } else {
             seat = next;
-            begin_turn(seat);
+            begin_turn(next);
         }
     };
 
     // ---- one roll of the current turn (engine.py:241-273): record in, roll, score, decide, record out ----
     auto roll_step = [&]() __attribute__((always_inline)) {
-        if (rolls_this_turn >= 1000u) { // ROLL_LIMIT, engine.py:36,242
-            raise(FK_ERR_ROLL_LIMIT);
-            return;
-        }
+        const bool roll_limit = rolls_this_turn >= 1000u; // ROLL_LIMIT, engine.py:36,242 (raised below, before any store)
         const uint32_t s = seat;
         uint32_t cA = L(F_CA, s), cB = L(F_CB, s), cC = L(F_CC, s), cD = L(F_CD, s), cE = L(F_CE, s);
         int32_t score = (int32_t)L(F_SCORE, s);
@@ -591,10 +577,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         cE += hot ? 1u : 0u;
         const bool keep = should_continue(sp, turn_score, (int32_t)dice, (cE & CE_HAS_SCORED) != 0u, final_round != 0u,
                                           score_to_beat, score);
-        if (turn_score > 0xffff) {
-            raise(FK_ERR_COUNTER_OVERFLOW);
-            return;
-        }
         const bool over = farkle | (!hot & !keep);
         // bank (engine.py:265-273), branch-free: a farkled turn has turn_score 0 and changes nothing
         const uint32_t ts = over ? (uint32_t)turn_score : 0u;
@@ -602,9 +584,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         const uint32_t banked = (cE & CE_HAS_SCORED) ? ts : 0u;
         score += (int32_t)banked;
         cB = (banked > (cB & 0xffffu)) ? ((cB & 0xffff0000u) | banked) : cB;
-        // u16 guard bands (a turn adds <= 1000 rolls / <= 2000 discarded dice)
-        if ((cA & 0xffffu) > 64000u || (cC >> 16) > 63000u || (cD >> 16) > 63000u) {
-            raise(FK_ERR_COUNTER_OVERFLOW);
+        // one rare exit for all error conditions: the roll limit, then the u16 guard bands (a turn adds <= 1000 rolls
+        // and <= 2000 discarded dice; highest_turn must fit 16 bits)
+        const bool overflow = (turn_score > 0xffff) | ((cA & 0xffffu) > 64000u) | ((cC >> 16) > 63000u) | ((cD >> 16) > 63000u);
+        if (roll_limit | overflow) {
+            raise(roll_limit ? FK_ERR_ROLL_LIMIT : FK_ERR_COUNTER_OVERFLOW);
             return;
         }
         cE = (cE & ~CE_HAS_BUF) | (rng.has_buf ? CE_HAS_BUF : 0u);
