@@ -142,12 +142,12 @@ __host__ __device__ inline uint64_t pcg_next64(Rng &r) {
     h *= PCG_CHEAP_MULT;
     h ^= h >> 48;
     h *= l;
-    uint64_t nlo = r.lo * PCG_CHEAP_MULT;
-    uint64_t nhi = mulhi64(r.lo, PCG_CHEAP_MULT) + r.hi * PCG_CHEAP_MULT;
-    nlo += r.inc_lo;
-    nhi += r.inc_hi + (nlo < r.inc_lo ? 1u : 0u);
-    r.hi = nhi;
-    r.lo = nlo;
+    // one 128-bit multiply-add: the compiler's lowering (5 v_mad_u64_u32 + a 4-word carry chain) is 6 VALU
+    // instructions shorter than the lo/mulhi/hi split with its explicit carry compare
+    typedef unsigned __int128 u128;
+    const u128 st = (((u128)r.hi << 64) | r.lo) * PCG_CHEAP_MULT + (((u128)r.inc_hi << 64) | r.inc_lo);
+    r.hi = (uint64_t)(st >> 64);
+    r.lo = (uint64_t)st;
     return h;
 }
 
@@ -199,9 +199,10 @@ __host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) {
 // Lemire rejection falls back to the sequential form from the saved generator state.
 //   face index:   4*f = mulhi(w, 24) & 28          (mulhi(w,24) = floor(4 * 6w / 2^32) in [4f, 4f+3])
 //   count update: counts += on_i << 4f             (one v_lshl_add_u32; on_i = bit i of (1<<n)-1)
-//   rejection:    min over the six low words (6w mod 2^32) < 4.  Words that are generated but not
-//                 consumed can only cause a (harmless, exact) detour through the sequential path;
-//                 words that are not generated are the constant 1 (6 >= 4, never rejects).
+//   rejection:    6w mod 2^32 < 4 implies 24w mod 2^32 < 16, so the test is min over the six low words of
+//                 24w < 16 (the low half of the same 64-bit product).  False positives (6w mod 2^30 < 4) and
+//                 words that are generated but not consumed only cause a harmless, exact detour through the
+//                 sequential path; words that are not generated are the constant 1 (24 >= 16, never detours).
 __device__ inline uint32_t roll_counts(Rng &r, uint32_t n, uint32_t *faces_out = nullptr) {
     const Rng saved = r;
     const uint32_t hb = r.has_buf;
@@ -236,16 +237,17 @@ __device__ inline uint32_t roll_counts(Rng &r, uint32_t n, uint32_t *faces_out =
     uint32_t counts = 0, faces = 0, minleft = 0xffffffffu;
 #pragma unroll
     for (uint32_t i = 0; i < 6; ++i) {
-        const uint32_t f4 = mulhi32(w[i], 24u) & 28u;
+        const uint64_t p24 = (uint64_t)w[i] * 24u; // one v_mad_u64_u32: face index above, 4 * (6w mod 2^30) below
+        const uint32_t f4 = (uint32_t)(p24 >> 32) & 28u;
         const uint32_t on = (onbits >> i) & 1u;
         counts += on << f4;
-        const uint32_t left = w[i] * 6u;
+        const uint32_t left = (uint32_t)p24;
         minleft = left < minleft ? left : minleft;
         if (faces_out) faces |= on ? (((f4 >> 2) + 1u) << (4u * i)) : 0u;
     }
     r.has_buf = (n + hb) & 1u;
     r.buf = last_hi;
-    if (minleft < 4u) { // rare: redo this roll exactly as NumPy would
+    if (minleft < 16u) { // rare (a superset of the rejections, see above): redo this roll exactly as NumPy would
         r = saved;
         faces = 0;
         counts = roll_counts_sequential(r, n, &faces);
