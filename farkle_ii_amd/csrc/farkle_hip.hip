@@ -73,6 +73,7 @@ struct SeedArgs {
 
 struct PlayArgs {
     const uint2 *strat;          // [S] packed strategies
+    const uint16_t *score_lut;   // [SCORE_LUT_KEYS] score table (fk_device.h)
     const uint16_t *perm_T;      // blocked permutations (MODE_PERM), see perm_at()
     uint32_t perm_slots;
     const int32_t *seat_strategy; // [n_games][k] (MODE_LIST)
@@ -563,10 +564,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         Rng rng{(uint64_t)L(F_HI0, s) | ((uint64_t)L(F_HI1, s) << 32), (uint64_t)L(F_LO0, s) | ((uint64_t)L(F_LO1, s) << 32),
                 own_inc_hi, own_inc_lo, L(F_BUF, s), (cE & CE_HAS_BUF) ? 1u : 0u};
         const uint32_t n = dice;
-        const uint32_t counts = roll_counts(rng, n);
+        const uint32_t key = roll_counts<3>(rng, n);
         rolls_this_turn += 1u;
         const Strat sp{own_thr, own_bits};
-        const RollResult rr = default_score(counts, (int32_t)n, turn_score, sp);
+        const RollResult rr = default_score_lut(a.score_lut, key, (int32_t)n, turn_score, sp);
         const bool farkle = rr.score == 0;                              // engine.py:135-137, 247-249
         cA += 1u + (farkle ? 0x10000u : 0u);                            // n_rolls (engine.py:98), n_farkles
         cC += (rr.d5 > 0) ? (1u + ((uint32_t)rr.d5 << 16)) : 0u;        // engine.py:139-144
@@ -687,12 +688,18 @@ __device__ inline uint32_t pack_faces(const uint8_t *f, int32_t n) {
     return c;
 }
 
+__global__ void fk_score_lut_kernel(uint16_t *lut) { // the score table of fk_device.h, built on the device once per context
+    const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key < SCORE_LUT_KEYS) lut[key] = score_lut_entry(key);
+}
+
 __global__ void fk_dbg_score_kernel(int64_t n, const uint8_t *faces, const int32_t *len, const int32_t *pre,
-                                    const uint2 *strat, int32_t *out) {
+                                    const uint2 *strat, const uint16_t *lut, int32_t *out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Strat s = unpack_strat(strat[i]);
-    const RollResult r = default_score(pack_faces(faces + i * 6, len[i]), len[i], pre[i], s);
+    // the game kernel's path: 3-bit count key -> score table -> discard choice
+    const RollResult r = default_score_lut(lut, nibbles_to_lut_key(pack_faces(faces + i * 6, len[i])), len[i], pre[i], s);
     out[i * 5 + 0] = r.score;
     out[i * 5 + 1] = r.used;
     out[i * 5 + 2] = len[i] - r.used;
@@ -768,7 +775,7 @@ struct fk_ctx {
     std::string err;
     fk_timing timing{};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // [0..3] kernel timers, [4..5] whole call
-    DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, dbg[6];
+    DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, score_lut, dbg[6];
     int32_t longest_first = 1;
     int32_t blocks_per_cu = 0; // 0 = as many as fit
     int32_t lean = -1;         // -1 auto, 0 full 17-dword seat records, 1 lean 11-dword records
@@ -1062,6 +1069,17 @@ int fk_init(int device_ordinal, fk_ctx **out) {
             fk_destroy(c);
             return FK_ERR_HIP;
         }
+    // score table (fk_device.h): 512 KiB, built by one small kernel, read by every roll of the game kernel
+    if (ensure(c, c->score_lut, SCORE_LUT_KEYS * sizeof(uint16_t)) != FK_OK) {
+        fk_destroy(c);
+        return FK_ERR_HIP;
+    }
+    hipLaunchKernelGGL(fk_score_lut_kernel, dim3(SCORE_LUT_KEYS / 256), dim3(256), 0, c->stream,
+                       static_cast<uint16_t *>(c->score_lut.p));
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        fk_destroy(c);
+        return FK_ERR_HIP;
+    }
     *out = c;
     return FK_OK;
 }
@@ -1070,7 +1088,7 @@ void fk_destroy(fk_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->strat, &c->perm, &c->seeds, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist, &c->coords, &c->order, &c->slow})
+    for (DevBuf *b : {&c->strat, &c->perm, &c->seeds, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist, &c->coords, &c->order, &c->slow, &c->score_lut})
         release(*b);
     for (auto &b : c->dbg) release(b);
     for (auto &e : c->ev)
@@ -1223,6 +1241,7 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
 
         PlayArgs pa{};
         pa.strat = static_cast<const uint2 *>(c->strat.p);
+        pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
         pa.perm_T = static_cast<const uint16_t *>(c->perm.p);
         pa.perm_slots = slots;
         pa.seat_strategy = nullptr;
@@ -1300,6 +1319,7 @@ int fk_play_games(fk_ctx *c, const fk_coord *coords, int64_t n_games, const fk_s
 
     PlayArgs pa{};
     pa.strat = static_cast<const uint2 *>(c->strat.p);
+    pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
     pa.seat_strategy = static_cast<const int32_t *>(c->seatlist.p);
     pa.tally = static_cast<unsigned long long *>(c->tally.p);
     pa.rows = static_cast<uint8_t *>(c->rows.p);
@@ -1373,6 +1393,7 @@ int fk_h2h_run(fk_ctx *c, const fk_strategy seats[2], uint64_t root_seed, uint64
         sa.n_games = (uint32_t)n;
         PlayArgs pa{};
         pa.strat = static_cast<const uint2 *>(c->strat.p);
+        pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
         pa.tally = static_cast<unsigned long long *>(c->tally.p);
         pa.ov = static_cast<const DevOverride *>(c->ov.p);
         pa.n_ov = (uint32_t)dov.size();
@@ -1433,7 +1454,7 @@ int fk_debug_score(fk_ctx *c, int64_t n, const uint8_t *faces, const int32_t *le
     hipLaunchKernelGGL(fk_dbg_score_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n,
                        static_cast<const uint8_t *>(c->dbg[0].p), static_cast<const int32_t *>(c->dbg[1].p),
                        static_cast<const int32_t *>(c->dbg[2].p), static_cast<const uint2 *>(c->dbg[3].p),
-                       static_cast<int32_t *>(c->dbg[4].p));
+                       static_cast<const uint16_t *>(c->score_lut.p), static_cast<int32_t *>(c->dbg[4].p));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->dbg[4].p, sz[4], hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

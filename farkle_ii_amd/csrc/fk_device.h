@@ -168,6 +168,7 @@ __host__ __device__ inline uint32_t pcg_next32(Rng &r) {
 // = per die Lemire's bounded draw on the buffered 32-bit stream; rejection iff low32(r*6) < 4.
 // Returns the roll as nibble-packed face counts: count(face f) at bits [4(f-1), 4(f-1)+3).
 // ----------------------------------------------------------------------------------------
+template <uint32_t STRIDE = 4>
 __host__ __device__ inline uint32_t roll_counts_sequential(Rng &r, uint32_t n, uint32_t *faces_out) {
     uint32_t counts = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -180,7 +181,7 @@ __host__ __device__ inline uint32_t roll_counts_sequential(Rng &r, uint32_t n, u
             }
         }
         uint32_t f = (uint32_t)(m >> 32); // face - 1
-        counts += 1u << (4u * f);
+        counts += 1u << (STRIDE * f);
         if (faces_out) *faces_out |= (f + 1u) << (4u * i);
     }
     return counts;
@@ -203,6 +204,9 @@ __host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) {
 //                 24w < 16 (the low half of the same 64-bit product).  False positives (6w mod 2^30 < 4) and
 //                 words that are generated but not consumed only cause a harmless, exact detour through the
 //                 sequential path; words that are not generated are the constant 1 (24 >= 16, never detours).
+// STRIDE = width of one face's count field in the result: 4 (nibbles, the SWAR scorer's input) or 3 (the 18-bit key
+// of the score table, SCORE_LUT below; a count is at most 6).
+template <uint32_t STRIDE = 4>
 __device__ inline uint32_t roll_counts(Rng &r, uint32_t n, uint32_t *faces_out = nullptr) {
     const Rng saved = r;
     const uint32_t hb = r.has_buf;
@@ -237,20 +241,24 @@ __device__ inline uint32_t roll_counts(Rng &r, uint32_t n, uint32_t *faces_out =
     uint32_t counts = 0, faces = 0, minleft = 0xffffffffu;
 #pragma unroll
     for (uint32_t i = 0; i < 6; ++i) {
-        const uint64_t p24 = (uint64_t)w[i] * 24u; // one v_mad_u64_u32: face index above, 4 * (6w mod 2^30) below
-        const uint32_t f4 = (uint32_t)(p24 >> 32) & 28u;
+        // one v_mad_u64_u32 per die: field shift from the high word, rejection test on the low word.
+        //   STRIDE 4: 24w -> 4*face = hi & 28, low word 4 * (6w mod 2^30);   STRIDE 3: 6w -> face = hi, 3*face = hi + 2*hi
+        const uint64_t pw = (uint64_t)w[i] * (STRIDE == 4u ? 24u : 6u);
+        const uint32_t hiw = (uint32_t)(pw >> 32);
+        const uint32_t fsh = (STRIDE == 4u) ? (hiw & 28u) : (hiw + 2u * hiw);
+        const uint32_t face = (STRIDE == 4u) ? (fsh >> 2) : hiw;
         const uint32_t on = (onbits >> i) & 1u;
-        counts += on << f4;
-        const uint32_t left = (uint32_t)p24;
+        counts += on << fsh;
+        const uint32_t left = (uint32_t)pw;
         minleft = left < minleft ? left : minleft;
-        if (faces_out) faces |= on ? (((f4 >> 2) + 1u) << (4u * i)) : 0u;
+        if (faces_out) faces |= on ? ((face + 1u) << (4u * i)) : 0u;
     }
     r.has_buf = (n + hb) & 1u;
     r.buf = last_hi;
-    if (minleft < 16u) { // rare (a superset of the rejections, see above): redo this roll exactly as NumPy would
+    if (minleft < (STRIDE == 4u ? 16u : 4u)) { // rare (STRIDE 4: a superset of the rejections): redo this roll exactly as NumPy would
         r = saved;
         faces = 0;
-        counts = roll_counts_sequential(r, n, &faces);
+        counts = roll_counts_sequential<STRIDE>(r, n, &faces);
     }
     if (faces_out) *faces_out = faces;
     return counts;
@@ -310,6 +318,50 @@ __host__ __device__ inline RawScore score_counts(uint32_t c) {
     r.used = special ? 6 : (set_n + ones + fives);
     r.sf = special ? 0 : fives;
     r.so = special ? 0 : ones;
+    return r;
+}
+
+// ----------------------------------------------------------------------------------------
+// Score table.  _evaluate_nb depends on the count multiset only (923 multisets of <= 6 dice), so the game kernel
+// reads it from a table built once per context by running score_counts() above on every key:
+//   key   = six 3-bit face counts (what roll_counts<3> accumulates), 18 bits
+//   entry = u16: [5:0] score / 50, [8:6] dice used, [11:9] lone fives, [14:12] lone ones, [15] all dice used
+// 512 KiB in HBM, L2/L1-resident; ~10 VALU + one load per roll instead of the ~45 VALU of the SWAR scorer.
+// ----------------------------------------------------------------------------------------
+constexpr uint32_t SCORE_LUT_KEYS = 1u << 18;
+
+__host__ __device__ inline uint32_t lut_key_to_nibbles(uint32_t key) {
+    uint32_t c = 0;
+    for (uint32_t f = 0; f < 6; ++f) c |= ((key >> (3u * f)) & 7u) << (4u * f);
+    return c;
+}
+
+__host__ __device__ inline uint32_t nibbles_to_lut_key(uint32_t c) {
+    uint32_t k = 0;
+    for (uint32_t f = 0; f < 6; ++f) k |= ((c >> (4u * f)) & 7u) << (3u * f);
+    return k;
+}
+
+// entry of one key; keys that are not a roll (a count of 7, or more than 6 dice) map to 0 and are never read
+__host__ __device__ inline uint16_t score_lut_entry(uint32_t key) {
+    uint32_t n = 0;
+    for (uint32_t f = 0; f < 6; ++f) {
+        const uint32_t cf = (key >> (3u * f)) & 7u;
+        if (cf == 7u) return 0;
+        n += cf;
+    }
+    if (n == 0u || n > 6u) return 0;
+    const RawScore r = score_counts(lut_key_to_nibbles(key));
+    return (uint16_t)((uint32_t)(r.score / 50) | ((uint32_t)r.used << 6) | ((uint32_t)r.sf << 9) | ((uint32_t)r.so << 12) |
+                      (((uint32_t)r.used == n ? 1u : 0u) << 15));
+}
+
+__host__ __device__ inline RawScore raw_from_lut(uint32_t e) {
+    RawScore r;
+    r.score = (int32_t)((e & 63u) * 50u);
+    r.used = (int32_t)((e >> 6) & 7u);
+    r.sf = (int32_t)((e >> 9) & 7u);
+    r.so = (int32_t)((e >> 12) & 7u);
     return r;
 }
 
@@ -402,8 +454,7 @@ constexpr uint32_t CS_D5 = pack8(1, 2, 0, 1, 2, 0, 1, 2), CS_D1 = pack8(0, 0, 1,
 constexpr uint32_t CD_D5 = pack8(2, 2, 1, 2, 1, 0, 1, 0), CD_D1 = pack8(2, 1, 2, 0, 1, 2, 0, 1);
 constexpr uint32_t NIB_H = 0x88888888u, NIB_1 = 0x11111111u;
 
-__host__ __device__ inline RollResult default_score(uint32_t counts, int32_t n, int32_t turn_pre, const Strat &s) {
-    const RawScore raw = score_counts(counts);
+__host__ __device__ inline RollResult default_score_raw(const RawScore raw, int32_t n, int32_t turn_pre, const Strat &s) {
     const uint32_t sf = (uint32_t)raw.sf, so = (uint32_t)raw.so;
     const uint32_t m1 = s.has(SF_SMART_ONE) ? so : 0u;
     const bool eligible = s.has(SF_SMART_FIVE) & (raw.used != n) & ((sf | so) != 0u); // :433
@@ -442,6 +493,16 @@ __host__ __device__ inline RollResult default_score(uint32_t counts, int32_t n, 
     out.score = raw.score - 50 * d5 - 100 * d1; // apply_discards :575-578
     out.used = raw.used - d5 - d1;
     return out;
+}
+
+// nibble-packed counts -> SWAR scorer (host checks, table construction)
+__host__ __device__ inline RollResult default_score(uint32_t counts, int32_t n, int32_t turn_pre, const Strat &s) {
+    return default_score_raw(score_counts(counts), n, turn_pre, s);
+}
+
+// 3-bit-packed counts -> score table (the kernels)
+__device__ inline RollResult default_score_lut(const uint16_t *lut, uint32_t key, int32_t n, int32_t turn_pre, const Strat &s) {
+    return default_score_raw(raw_from_lut(lut[key]), n, turn_pre, s);
 }
 
 // FarklePlayer._should_continue (src/farkle/game/engine.py:156-205) with ThresholdStrategy.decide
