@@ -92,6 +92,7 @@ struct PlayArgs {
     uint32_t max_rounds;
     uint32_t batch_threshold;
     uint32_t use_lds_tally;
+    uint32_t uflags;             // the flag bits (8..15) every strategy of the table shares, see MIXED below
 };
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -296,7 +297,11 @@ struct Seat {
     Strat sp;
 };
 
-template <int BLOCK, bool LEAN, int WPE>
+// MIXED: the strategy flag bits that may differ between strategies of the table.  The other flags are the same for
+// the whole table (threshold grids fix most of them): they arrive as a kernel argument, so their tests run on the
+// scalar unit and the constants they select become s_cselects.  Instances: all flags mixed (generic), none, and
+// require_both | favor_score (the pair the reference's grid always enumerates).
+template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void fk_play_kernel(PlayArgs a) {
     extern __shared__ uint32_t lds[];
     const uint32_t tid = threadIdx.x;
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         const uint32_t n = dice;
         const uint32_t key = roll_counts<3>(rng, n);
         rolls_this_turn += 1u;
-        const Strat sp{own_thr, own_bits};
+        const Strat sp{own_thr, (own_bits & (0xffu | MIXED)) | (a.uflags & (0xff00u & ~MIXED))};
         const RollResult rr = default_score_lut(a.score_lut, key, (int32_t)n, turn_score, sp);
         const bool farkle = rr.score == 0;                              // engine.py:135-137, 247-249
         cA += 1u + (farkle ? 0x10000u : 0u);                            // n_rolls (engine.py:98), n_farkles
@@ -779,6 +784,9 @@ struct fk_ctx {
     int32_t longest_first = 1;
     int32_t blocks_per_cu = 0; // 0 = as many as fit
     int32_t lean = -1;         // -1 auto, 0 full 17-dword seat records, 1 lean 11-dword records
+    int32_t uniform_flags_opt = -1; // -1 auto (scalar-flag instance when the table allows it), 0 never
+    uint32_t table_flags = 0;            // set by upload_strategies: flag bits shared by the whole table ...
+    uint32_t table_mixed_flags = 0xff00u; // ... and the flag bits that differ between its strategies
     int32_t waves_per_cu = 16; // resident-wave target used to size the grid
     int64_t chunk_bytes = (int64_t)24 << 30;
     int32_t batch_threshold = 6;
@@ -854,6 +862,13 @@ int upload_strategies(fk_ctx *c, const fk_strategy *s, int32_t S) {
     rc = ensure(c, c->strat, sizeof(uint2) * (size_t)S);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->strat.p, packed.data(), sizeof(uint2) * (size_t)S, hipMemcpyHostToDevice, c->stream));
+    uint32_t f_and = 0xff00u, f_or = 0u;
+    for (int32_t i = 0; i < S; ++i) {
+        f_and &= packed[(size_t)i].y;
+        f_or |= packed[(size_t)i].y & 0xff00u;
+    }
+    c->table_mixed_flags = f_or & ~f_and;
+    c->table_flags = f_and;
     // Strategies that never bank voluntarily outside the final round: should_continue's threshold term is
     // always true iff dice are considered with dice_threshold < 1 (dice_left >= 1 always exceeds it) and the
     // score threshold cannot veto (require_both, or score not considered).  Used for scheduling only.
@@ -881,6 +896,7 @@ struct LaunchPlan {
     bool lds_tally = false;
     bool lean = false; // 11-dword seat records (increment + strategy re-read from HBM/L2 each turn)
     int wpe = 4;       // waves per SIMD the chosen instance is compiled for
+    uint32_t mixed_flags = 0xff00u; // flag bits that differ between strategies of the table (selects the kernel instance)
 };
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
@@ -933,13 +949,23 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int32_t S, bool single_batch) {
     return best;
 }
 
-template <int BLOCK, bool LEAN, int WPE = 4>
-hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, LEAN, WPE>),
+template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED>
+hipError_t launch_play_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, LEAN, WPE, MIXED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(p.lds, 16));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fk_play_kernel<BLOCK, LEAN, WPE>), dim3((unsigned)p.grid), dim3(BLOCK), p.lds, s, a);
+    hipLaunchKernelGGL((fk_play_kernel<BLOCK, LEAN, WPE, MIXED>), dim3((unsigned)p.grid), dim3(BLOCK), p.lds, s, a);
     return hipGetLastError();
+}
+
+constexpr uint32_t MIXED_ALL = 0xff00u, MIXED_NONE = 0u, MIXED_RB_FAV = SF_REQUIRE_BOTH | SF_FAVOR_SCORE;
+
+template <int BLOCK, bool LEAN, int WPE = 4>
+hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
+    // the narrowest instance whose MIXED set covers the flags that actually vary in this table
+    if (p.mixed_flags == MIXED_NONE) return launch_play_u<BLOCK, LEAN, WPE, MIXED_NONE>(p, a, s);
+    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_u<BLOCK, LEAN, WPE, MIXED_RB_FAV>(p, a, s);
+    return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL>(p, a, s);
 }
 
 hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
@@ -1032,7 +1058,10 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
     pa.use_lds_tally = plan.lds_tally ? 1u : 0u;
     {
         Timer t(c, &c->timing.play_ms, 2);
-        hipError_t e = launch_play(plan, pa, c->stream);
+        LaunchPlan lp = plan;
+        lp.mixed_flags = (c->uniform_flags_opt != 0) ? c->table_mixed_flags : 0xff00u;
+        pa.uflags = c->table_flags;
+        hipError_t e = launch_play(lp, pa, c->stream);
         t.stop();
         HIPCHK(c, e);
         HIPCHK(c, t.collect());
@@ -1127,6 +1156,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "longest_first") c->longest_first = (int32_t)value;
     else if (n == "blocks_per_cu") c->blocks_per_cu = (int32_t)value;
     else if (n == "lean") c->lean = (int32_t)value;
+    else if (n == "uniform_flags") c->uniform_flags_opt = (int32_t)value;
     else if (n == "waves_per_cu") c->waves_per_cu = (int32_t)std::max<int64_t>(1, std::min<int64_t>(32, value));
     else if (n == "block") {
         if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 768 && value != 1024)

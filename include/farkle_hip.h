@@ -118,7 +118,8 @@ int fk_get_device_info(fk_ctx *ctx, fk_device_info *out);
 int fk_get_timing(fk_ctx *ctx, fk_timing *out);
 /* Tunables: "chunk_bytes" (device workspace budget per chunk), "batch_threshold" (lanes that must be waiting
  * before a wave runs its game hand-over), "use_lds_tally" (0/1/-1 auto), "block" (0 auto), "lean" (seat-record layout:
- * -1 auto, 0 full, 1 lean), "blocks_per_cu", "longest_first" (1 = deal never-banking pairings first).  All of them are
+ * -1 auto, 0 full, 1 lean), "blocks_per_cu", "longest_first" (1 = deal never-banking pairings first), "uniform_flags" (-1 auto: tables whose
+ * strategies share all flag bits run the scalar-flag kernel instance, 0 never).  All of them are
  * scheduling / layout choices: results are identical for every setting. */
 int fk_set_option(fk_ctx *ctx, const char *name, int64_t value);
 
