@@ -60,7 +60,9 @@ struct SeedArgs {
     uint32_t gps;            // games per shuffle (affine id -> (shuffle, game)); 0 = no split
     uint32_t k;
     uint32_t n_games;
-    uint4 *seeds;            // [n_games][k][2] = {state lo, state hi}, {inc lo, inc hi}
+    uint4 *seeds;            // [2][n_games][k]: plane 0 = PCG state {lo, hi} (read once per game), plane 1 = increment
+                             // {lo, hi} (re-read at every turn start by lean-record kernels: a compact plane keeps
+                             // the increments of all resident games in L2)
     // longest-first scheduling (tournament mode): games whose seats ALL never bank run to the round
     // limit (~13x the mean length); they are dealt first so that they do not form the tail of a wave.
     const uint16_t *perm_T;  // nullable; blocked layout, see perm_at()
@@ -222,9 +224,10 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
             ss_generate<8>(sp, g8);
             Rng r;
             pcg_seed(r, g8);
-            uint4 *dst = a.seeds + ((size_t)t * a.k + s) * 2; // slot = walk order (coalesced stores)
+            uint4 *dst = a.seeds + ((size_t)t * a.k + s); // slot = walk order (coalesced stores)
             dst[0] = make_uint4((uint32_t)r.lo, (uint32_t)(r.lo >> 32), (uint32_t)r.hi, (uint32_t)(r.hi >> 32));
-            dst[1] = make_uint4((uint32_t)r.inc_lo, (uint32_t)(r.inc_lo >> 32), (uint32_t)r.inc_hi, (uint32_t)(r.inc_hi >> 32));
+            dst[(size_t)a.n_games * a.k] =
+                make_uint4((uint32_t)r.inc_lo, (uint32_t)(r.inc_lo >> 32), (uint32_t)r.inc_hi, (uint32_t)(r.inc_hi >> 32));
         }
     }
     if (!a.sched) return; // uniform
@@ -362,8 +365,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     auto load_seat_from_global = [&](Seat &x, uint32_t id, uint32_t slot, uint32_t s) {
         x_idx = strategy_index(id, s);
         const uint2 pk = a.strat[x_idx];
-        const uint4 *src = a.seeds + ((size_t)slot * K + s) * 2;
-        const uint4 stv = src[0], inc = src[1];
+        const uint4 *src = a.seeds + ((size_t)slot * K + s);
+        const uint4 stv = src[0], inc = src[(size_t)a.n_games * K];
         x.lo = (uint64_t)stv.x | ((uint64_t)stv.y << 32);
         x.hi = (uint64_t)stv.z | ((uint64_t)stv.w << 32);
         x.inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     auto begin_turn = [&](uint32_t s) __attribute__((always_inline)) {
         L(F_CB, s) += 0x10000u; // n_turns += 1 (engine.py:236)
         if (LEAN) { // read-only per-seat data comes from HBM/L2; the loads overlap the first dice of the turn
-            const uint4 inc = a.seeds[((size_t)seed_slot * K + s) * 2 + 1];
+            const uint4 inc = a.seeds[(size_t)a.n_games * K + (size_t)seed_slot * K + s];
             const uint2 pk = a.strat[L(F_CE, s) >> CE_IDX_SHIFT];
             own_inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
             own_inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
@@ -726,7 +729,7 @@ __global__ void fk_dbg_dice_kernel(int64_t n, const uint4 *seeds, const uint64_t
     if (i >= n) return;
     Rng r;
     if (seeds) {
-        const uint4 s = seeds[i * 2], c = seeds[i * 2 + 1];
+        const uint4 s = seeds[i], c = seeds[n + i]; // state plane, increment plane (k = 1)
         r.lo = (uint64_t)s.x | ((uint64_t)s.y << 32);
         r.hi = (uint64_t)s.z | ((uint64_t)s.w << 32);
         r.inc_lo = (uint64_t)c.x | ((uint64_t)c.y << 32);
