@@ -219,6 +219,15 @@ def main() -> None:
             # k=2 tournament path on its 80-strategy grid, Ryzen 7 3700X, 12 workers = 1 142.9 games/s
             "vs_reference_published_12_workers": value / 1142.9,
         }
+        # the Python reference itself timed on this same workload in the build container (oracle/time_reference.py; the
+        # reference cannot travel to the GPU box, so this is a committed fixture, not a measurement of this run)
+        fixture = ROOT / "tests" / "golden" / "reference_cpu_timing.json"
+        if fixture.exists():
+            ref = json.loads(fixture.read_text())
+            line["reference_python_fixture"] = {
+                "tournament_loop_games_per_s_1_process": ref["tournament_loop_1_process"]["games_per_s"],
+                "tournament_loop_games_per_s_8_processes": ref["tournament_loop_8_processes"]["games_per_s"],
+                "where": ref["host"]["note"]}
         print(json.dumps(line))
     eng.close()
     if distributed:
