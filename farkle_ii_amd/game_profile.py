@@ -1,11 +1,16 @@
 """Limit-only game settings (target score, max_rounds overrides) for deterministic workflow oracles.
 
-Mirrors ``src/farkle/simulation/game_profile.py:24-191`` minus the authentication hash; ``to_overrides``
-flattens a profile into the ``fk_override[]`` records of ``include/farkle_hip.h``.
+Mirrors ``src/farkle/simulation/game_profile.py:24-191`` including the canonical identity hash that checkpoints and
+manifests carry (``game_profile_sha256``); ``tournament_overrides`` / ``h2h_overrides`` flatten a profile into the
+``fk_override[]`` records of ``include/farkle_hip.h``.
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+import hashlib
+import json
+from dataclasses import asdict, dataclass
+
+GAME_PROFILE_CONTRACT_VERSION = 1
 
 import numpy as np
 
@@ -81,6 +86,22 @@ class GameProfile:
             if len(set(coords)) != len(coords):
                 kind = "tournament" if name.startswith("tournament") else "H2H"
                 raise ValueError(f"{kind} max-round overrides contain duplicate coordinates")
+
+    def canonical_payload(self) -> dict:
+        """Order-independent identity payload (game_profile.py:113-134)."""
+        return {"game_profile_contract_version": GAME_PROFILE_CONTRACT_VERSION,
+                "default_target_score": self.default_target_score, "default_max_rounds": self.default_max_rounds,
+                "tournament_max_rounds_overrides": [asdict(o) for o in sorted(self.tournament_max_rounds_overrides,
+                                                                              key=lambda o: o.coordinate)],
+                "h2h_max_rounds_overrides": [asdict(o) for o in sorted(self.h2h_max_rounds_overrides,
+                                                                       key=lambda o: o.coordinate)]}
+
+    @property
+    def sha256(self) -> str:
+        """SHA-256 of the canonical JSON of the payload: sorted keys, compact separators
+        (utils/authenticated_contract.py:100-114)."""
+        text = json.dumps(self.canonical_payload(), sort_keys=True, separators=(",", ":"), ensure_ascii=False, allow_nan=False)
+        return hashlib.sha256(text.encode("utf-8")).hexdigest()
 
     def tournament_limits(self, *, root_seed: int, k: int, shuffle_index: int, game_index: int) -> GameLimits:
         for o in self.tournament_max_rounds_overrides:

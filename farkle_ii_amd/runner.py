@@ -170,10 +170,11 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         "n_players": k, "num_shuffles": plan.required_shuffles, "global_seed": cfg.sim.seed, "n_strategies": S,
         "rng_scheme_version": urandom.RNG_SCHEME_VERSION, "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
         "tournament_method_version": TOURNAMENT_METHOD_VERSION, "rng_bit_generator": "PCG64DXSM",
-        "coordinate_contract_version": 2, "shuffle_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
+        "coordinate_contract_version": 1, "shuffle_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
         "shuffle_permutation_purpose_namespace": int(urandom.RandomPurpose.SHUFFLE_PERMUTATION),
         "game_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_GAME),
         "player_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_PLAYER), "deterministic_batch_size": spb,
+        **({"game_profile_sha256": oracle_game_profile.sha256} if oracle_game_profile is not None else {}),  # run_tournament.py:1156
         **dict(checkpoint_metadata),
         "workload_plan_version": plan.plan_version, "screening_resolution_delta": plan.resolution_delta,
         "screening_interval_confidence": plan.confidence, "batch_count": plan.batch_count, "shuffles_per_batch": spb,
@@ -190,7 +191,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         if stale:
             raise ValueError(f"checkpoint {checkpoint_path} was written under a different contract: {stale}; use --force")
         total = np.asarray(payload["tally_int64"], dtype=np.int64)
-        done_batches = set(int(b) for b in old.get("completed_process_block_indices", []))
+        done_batches = set(int(b) - 1 for b in old.get("completed_process_block_indices", []))  # recorded 1-based
         LOGGER.info("Resuming: %d of %d batches already complete", len(done_batches), n_batches)
     pending = [b for b in range(n_batches) if b not in done_batches]
     target = oracle_game_profile.default_target_score if oracle_game_profile else 10_000
@@ -204,16 +205,17 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
     games_done = 0
 
     def save(final: bool) -> None:
-        wins, sums, sqs = rt.tally_to_counters(total, ids, k)
-        payload: dict[str, Any] = {"win_totals": Counter(dict(wins)), "outcome_counts": wins.outcome_payload(),
+        wins, sums, sqs = rt.tally_to_counters(total, ids, k, dense=metric_chunk_dir is not None)
+        # the OutcomeCounter itself is pickled, exposures included (run_tournament.py:622-651)
+        payload: dict[str, Any] = {"win_totals": wins, "outcome_counts": wins.outcome_payload(),
                                    "tally_int64": total.copy()}
         if collect_metrics:
             payload["metric_sums"] = {m: dict(v) for m, v in sums.items()}
             payload["metric_square_sums"] = {m: dict(v) for m, v in sqs.items()}
         completed = sorted(done_batches)
-        payload["meta"] = {**meta, "completed_process_block_indices": completed,
-                           "completed_shuffle_indices": [s for b in completed for s in range(b * spb, (b + 1) * spb)],
-                           "complete": final}
+        # process blocks are numbered from 1 (run_tournament.py:1576-1586); one block = one deterministic batch here
+        payload["meta"] = {**meta, "completed_shuffle_indices": [s for b in completed for s in range(b * spb, (b + 1) * spb)],
+                           "completed_process_block_indices": [b + 1 for b in completed], "complete": final}
         _atomic_write_bytes(checkpoint_path, pickle.dumps(payload, protocol=pickle.HIGHEST_PROTOCOL))
 
     i = 0
@@ -233,14 +235,17 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             if want_rows:  # every rank writes the shards of its own shuffles
                 tasks = rt.shuffle_tasks(cfg.sim.seed, k, lo, hi, spb)
                 for n, task in enumerate(tasks):
-                    rt.write_row_shard(row_dir, None, task, res["rows"][n * gps:(n + 1) * gps], ids)
+                    rt.write_row_shard(row_dir, None, task, res["rows"][n * gps:(n + 1) * gps], ids,
+                                       game_profile_sha256=oracle_game_profile.sha256 if oracle_game_profile else None)
         group = reduce_tally(local, dst=0)
         if rank == 0:
             for n, b in enumerate(range(b0, b1)):
                 if metric_chunk_dir is not None:
-                    _write_parquet_atomic(_metric_chunk_table(group[n], ids, k), metric_chunk_dir / f"metrics_{b:06d}.parquet")
+                    chunk = _metric_chunk_table(group[n], ids, k)
+                    name = f"metrics_{b + 1:06d}.parquet"  # chunk / process-block indices count from 1 (run_tournament.py:1603-1642)
+                    _write_parquet_atomic(chunk, metric_chunk_dir / name)
                     tasks = rt.shuffle_tasks(cfg.sim.seed, k, b * spb, (b + 1) * spb, spb)
-                    record = {"path": f"metrics_{b:06d}.parquet", "chunk_index": b, "process_block_index": b,
+                    record = {"path": name, "rows": chunk.num_rows, "chunk_index": b + 1, "process_block_index": b + 1,
                               "root_seed": cfg.sim.seed, "n_players": k, "deterministic_batch_id": b,
                               "shuffle_index_start": b * spb, "shuffle_index_end": (b + 1) * spb - 1, "shuffle_count": spb,
                               "shuffle_indices": [t.shuffle_index for t in tasks], "shuffle_seeds": [t.shuffle_seed for t in tasks],
@@ -248,6 +253,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                               "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
                               "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
                               "tournament_method_version": TOURNAMENT_METHOD_VERSION}
+                    if oracle_game_profile is not None:  # run_tournament.py:1668
+                        record["game_profile_sha256"] = oracle_game_profile.sha256
                     with open(metric_chunk_dir / "metrics_manifest.jsonl", "a", encoding="utf-8") as fh:
                         fh.write(json.dumps(record, sort_keys=True) + "\n")
                 total += group[n]
@@ -286,7 +293,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         raise WorkloadCapExceeded(plan)
     ckpt_path = cfg.checkpoint_path(n)
     manifest = build_strategy_manifest(strategies)
-    manifest_sha = hashlib.sha256(manifest.to_json(orient="records").encode()).hexdigest()
+    manifest_sha = hashlib.sha256(manifest.to_csv(index=False).encode("utf-8")).hexdigest()  # runner.py:790-800
     if rank == 0:
         if force:
             for path in (ckpt_path, n_dir / f"{n}p_checkpoint.parquet", cfg.metrics_path(n), simulation_done_path(cfg, n)):

@@ -137,21 +137,27 @@ def _coerce_shuffle_task(task: ShuffleTask | int) -> ShuffleTask:
     return ShuffleTask(root_seed=int(task), k=k, shuffle_index=0, shuffle_seed=int(task), deterministic_batch_id=0)
 
 
-def tally_to_counters(tally: np.ndarray, ids: Sequence[int], k: int):
-    """``int64[S][26]`` -> (OutcomeCounter, sums, square sums) with the reference's dict shapes."""
+def tally_to_counters(tally: np.ndarray, ids: Sequence[int], k: int, *, dense: bool = False):
+    """``int64[S][26]`` -> (OutcomeCounter, sums, square sums) with the reference's dict shapes.
+
+    ``dense``: every strategy that was seated gets explicit zero entries, which is what the reference's totals look
+    like when they are rebuilt from metric chunk files (``_reduce_metric_chunk_payloads``, run_tournament.py:905-922:
+    each chunk row is added with ``+=``, zeros included); worker-side counters (``dense=False``) only hold what was
+    incremented."""
     wins = OutcomeCounter()
     sums: Dict[str, Dict[int, float]] = {m: defaultdict(float) for m in METRIC_LABELS}
     sqs: Dict[str, Dict[int, float]] = {m: defaultdict(float) for m in METRIC_LABELS}
     for i, sid in enumerate(ids):
         row = tally[i]
         sid = int(sid)
+        seated = dense and row[COL_ATTEMPTED]
         if row[COL_ATTEMPTED]:
             wins.attempted_exposures[sid] = int(row[COL_ATTEMPTED])
-        if row[COL_COMPLETED]:
+        if row[COL_COMPLETED] or seated:
             wins.completed_exposures[sid] = int(row[COL_COMPLETED])
-        if row[COL_SAFETY]:
+        if row[COL_SAFETY] or seated:
             wins.safety_limit_exposures[sid] = int(row[COL_SAFETY])
-        if row[COL_WINS]:
+        if row[COL_WINS] or seated:
             wins[sid] = int(row[COL_WINS])
             for j, label in enumerate(METRIC_LABELS):
                 sums[label][sid] = float(row[COL_SUMS + j])
@@ -269,7 +275,8 @@ def _run_chunk_metrics(shuffle_tasks: Sequence[ShuffleTask | int], *, collect_ro
     return wins_total, sums_total, sq_total
 
 
-def write_row_shard(row_dir: Path, manifest_path: Path | None, task: ShuffleTask, rows: np.ndarray, ids: Sequence[int]) -> Path:
+def write_row_shard(row_dir: Path, manifest_path: Path | None, task: ShuffleTask, rows: np.ndarray, ids: Sequence[int],
+                    game_profile_sha256: str | None = None) -> Path:
     """One shuffle's rows -> parquet shard + manifest record (run_tournament.py:530-558)."""
     import json
     import os
@@ -296,6 +303,8 @@ def write_row_shard(row_dir: Path, manifest_path: Path | None, task: ShuffleTask
               "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
               "outcome_schema_version": OUTCOME_SCHEMA_VERSION, "tournament_method_version": TOURNAMENT_METHOD_VERSION,
               "pid": os.getpid()}
+    if game_profile_sha256 is not None:  # run_tournament.py:549-553
+        record["game_profile_sha256"] = game_profile_sha256
     with open(manifest, "a", encoding="utf-8") as fh:
         fh.write(json.dumps(record, sort_keys=True) + "\n")
     return out

@@ -440,7 +440,94 @@ def gen_runner():
     _dump({"plans": plans, "paths": paths}, open(OUT / "runner_vectors.json", "w"))
 
 
+ARTIFACT_CONFIG = {
+    # the reference's tiny oracle config (tests/helpers/raw_simulation_oracle.py:80-190) with a finer screening
+    # resolution (more shuffles) and three deterministic batches; artifact_contract v3 sidecars are out of scope
+    "sim": {"n_players_list": [2, 4], "seed": 11, "seed_list": [11], "n_jobs": 1, "expanded_metrics": True, "row_dir": "rows",
+            "metric_chunk_dir": "metric_chunks", "desired_sec_per_chunk": 1, "ckpt_every_sec": 1, "score_thresholds": [500],
+            "dice_thresholds": [2], "smart_five_opts": [False], "smart_one_opts": [False], "consider_score_opts": [True],
+            "consider_dice_opts": [True], "auto_hot_dice_opts": [False, True], "run_up_score_opts": [False],
+            "include_stop_at": False, "include_stop_at_heuristic": False},
+    "screening": {"resolution_delta": 0.4, "interval_confidence": 0.95},
+    "batching": {"target_batches": 3, "min_shuffles_per_batch": 2},
+}
+
+
+def _jsonable(obj):
+    """Checkpoint payloads use int keys and Counter/defaultdict values: JSON wants string keys."""
+    if isinstance(obj, dict):
+        return {str(k): _jsonable(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_jsonable(v) for v in obj]
+    return obj
+
+
+def gen_artifacts():
+    """Run the reference's ``run_single_n`` (runner.py:1326) on a tiny config and freeze every artifact it writes:
+    parquet schemas + records, manifest records, workload plan, checkpoint payload.  The authenticated v3 sidecars
+    and the stage-done stamp need the reference's Git identity and are not produced here (the run stops there)."""
+    import dataclasses
+    import pickle
+    import shutil
+    import tempfile
+
+    import pyarrow.parquet as pq
+    import yaml
+    from farkle.config import load_app_config
+    from farkle.simulation import runner
+    from farkle.utils.authenticated_contract import CodeIdentityError
+
+    tmp = Path(tempfile.mkdtemp(prefix="fk_artifacts_"))
+    try:
+        payload = dict(ARTIFACT_CONFIG)
+        payload["io"] = {"results_dir_prefix": str(tmp / "out"), "analysis_subdir": "analysis"}
+        cfg_path = tmp / "tiny.yaml"
+        cfg_path.write_text(yaml.safe_dump(payload))
+        cfg = load_app_config(cfg_path, seed_list_len=1)
+        # plain (pre-v3) write path: same bytes minus the authenticated sidecars
+        cfg.artifact_contract = dataclasses.replace(cfg.artifact_contract, artifact_contract_version=2)
+        gp = GameProfile(default_target_score=100, default_max_rounds=200,
+                         tournament_max_rounds_overrides=(TournamentMaxRoundsOverride(11, 2, 0, 0, 0),))
+        out = {"config": ARTIFACT_CONFIG, "game_profile": {"target": 100, "max_rounds": 200, "overrides": [[11, 2, 0, 0, 0]]},
+               "runs": {}}
+        volatile = {"ts", "pid"}
+        for k in (2, 4):
+            try:
+                runner.run_single_n(cfg, k, oracle_game_profile=gp)
+                stamp = "written"
+            except CodeIdentityError:
+                stamp = "needs the reference's Git identity (not produced here)"
+            root = cfg.results_root
+            n_dir = root / f"{k}_players"
+            run = {"done_stamp": stamp, "files": sorted(str(f.relative_to(root)) for f in root.rglob("*")
+                                                        if f.is_file() and (f.parent == root or n_dir in f.parents)),
+                   "parquet": {}, "jsonl": {}}
+            for f in sorted(root.rglob("*.parquet")):
+                if f.parent == root or n_dir in f.parents:
+                    t = pq.read_table(f)
+                    run["parquet"][str(f.relative_to(root))] = {
+                        "schema": [[fld.name, str(fld.type)] for fld in t.schema], "records": t.to_pylist()}
+            for f in sorted(n_dir.rglob("*.jsonl")):
+                run["jsonl"][str(f.relative_to(root))] = [
+                    {kk: vv for kk, vv in json.loads(line).items() if kk not in volatile} for line in f.read_text().splitlines()]
+            run["workload_plan"] = json.loads((n_dir / "simulation_workload_plan.json").read_text())
+            ck = pickle.loads((n_dir / f"{k}p_checkpoint.pkl").read_bytes())
+            run["checkpoint"] = {"win_totals": _jsonable(dict(ck["win_totals"])), "outcome_counts": _jsonable(ck["outcome_counts"]),
+                                 "metric_sums": _jsonable({m: dict(v) for m, v in ck["metric_sums"].items()}),
+                                 "metric_square_sums": _jsonable({m: dict(v) for m, v in ck["metric_square_sums"].items()}),
+                                 "meta": _jsonable(ck["meta"])}
+            out["runs"][str(k)] = run
+        _dump(out, open(OUT / "artifact_vectors.json", "w"))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # e.g. `python oracle/gen_golden.py gen_artifacts`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
+    gen_artifacts()
     gen_runner()
     gen_fuzz()
     gen_rng()
