@@ -37,3 +37,62 @@ def reduce_tally(tally: np.ndarray, dst: int = 0, device=None) -> np.ndarray:
         t = t.to(device)
     dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+def h2h_block_distributed(h2h, seats, root_seed: int, pair_id: int, order: int, target: int, max_attempts: int,
+                          chunk_games: int, *, state, device=None, **limits) -> np.ndarray:
+    """One H2H block advanced by all ranks together; the result equals the single-process ``h2h(...)`` call.
+
+    ``h2h`` is ``Engine.h2h`` (same signature).  The stop rule of a block is a PREFIX (the first ``target`` completed
+    games in attempt order, h2h_schedule.py:1165-1235), while attempts themselves are independent, so:
+      1. the chunk's attempt range ``[attempted, min(max_attempts, attempted + chunk_games))`` is cut into one
+         contiguous sub-range per rank and every rank plays its sub-range to the end (no stop rule);
+      2. one all-gather of the five per-range counts; every rank takes the exclusive scan of the completed counts and
+         finds the first sub-range in which the running total reaches ``target``;
+      3. only that rank replays its sub-range with the remaining target, which stops it at the exact attempt the serial
+         loop would have stopped at; a second all-gather publishes the cut.
+    Sub-ranges after the cut are discarded (their attempts were never consumed by the serial loop)."""
+    import torch
+    import torch.distributed as dist
+
+    state = np.ascontiguousarray(state, dtype=np.uint64).copy()
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not distributed:
+        return h2h(seats, root_seed, pair_id, order, target, max_attempts, chunk_games, state=state, **limits)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    attempted, completed = int(state[0]), int(state[1])
+    end = min(int(max_attempts), attempted + int(chunk_games))
+    if completed >= target or end <= attempted:
+        return state
+    span = end - attempted
+    lo = attempted + (span * rank) // world
+    hi = attempted + (span * (rank + 1)) // world
+
+    def play(first: int, last: int, remaining: int) -> np.ndarray:
+        """Counts of attempts [first, last) stopped after `remaining` completed games: attempted, completed, safety, w1, w2."""
+        if last <= first or remaining <= 0:
+            return np.zeros(5, dtype=np.int64)
+        # a consistent block state whose next attempt index is `first` (attempted = completed + safety, wins = completed)
+        base = np.array([first, first, 0, first, 0], dtype=np.uint64)
+        out = h2h(seats, root_seed, pair_id, order, first + remaining, last, last - first, state=base, **limits)
+        return out.astype(np.int64) - base.astype(np.int64)
+
+    def gather(vec: np.ndarray) -> np.ndarray:
+        t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.int64))
+        if device is not None:
+            t = t.to(device)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        return np.stack([p.cpu().numpy() for p in parts])
+
+    need = target - completed
+    full = gather(play(lo, hi, 1 << 62))  # [world][5]
+    before = np.concatenate([[0], np.cumsum(full[:, 1])[:-1]])  # exclusive scan of completed games
+    cut = next((r for r in range(world) if before[r] + full[r, 1] >= need), None)
+    if cut is None:  # target not reached inside this chunk: every sub-range counts in full
+        total = full.sum(axis=0)
+    else:
+        mine = play(lo, hi, int(need - before[cut])) if rank == cut else np.zeros(5, dtype=np.int64)
+        partial = gather(mine)[cut]
+        total = full[:cut].sum(axis=0) + partial
+    return (state.astype(np.int64) + total).astype(np.uint64)

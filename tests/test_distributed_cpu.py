@@ -48,3 +48,51 @@ def test_two_rank_tally_reduce_matches_single_process(tmp_path):
     table = gu.strategies_from_tuples(gu.load("grid_vectors.json")["g64"], po.STRATEGY_DTYPE)
     full = po.tournament(table, 2, 42, 0, 96, shuffles_per_batch=8)["tally"]
     assert np.array_equal(np.load(out), full)
+
+
+def _h2h_worker(rank: int, world: int, port: int, out_path: str) -> None:
+    for p in (ROOT, ROOT / "oracle", ROOT / "tests"):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    import pyoracle as po
+    from farkle_ii_amd.distributed import h2h_block_distributed
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seats = np.zeros(2, dtype=po.STRATEGY_DTYPE)
+    seats[0] = (300, 2, 1, 1, 1, 1, 0, 1, 1, 1, 0)
+    seats[1] = (0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1)  # never banks: every game it does not lose early runs to the round limit
+    results = []
+    # (target, max_attempts, chunk, start state): cut inside rank 0 / rank 1 / not reached / attempt cap / resumed block
+    for target, max_attempts, chunk, start in [(40, 400, 400, None), (150, 400, 200, None), (10_000, 300, 120, None),
+                                               (90, 100, 1000, None), (120, 500, 77, (60, 55, 5, 30, 25))]:
+        st = np.zeros(5, dtype=np.uint64) if start is None else np.array(start, dtype=np.uint64)
+        got = h2h_block_distributed(po.h2h_block, seats, 7, 3, 1, target, max_attempts, chunk, state=st, max_rounds=12)
+        results.append(got.astype(np.int64))
+    if rank == 0:
+        np.save(out_path, np.stack(results))
+    dist.destroy_process_group()
+
+
+def test_two_rank_h2h_prefix_cut_matches_serial_block(tmp_path):
+    """contiguous attempt ranges per rank + exclusive scan of completed counts reproduces the serial prefix."""
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import pyoracle as po
+
+    out = str(tmp_path / "h2h.npy")
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_h2h_worker, args=(2, port, out), nprocs=2, join=True)
+    seats = np.zeros(2, dtype=po.STRATEGY_DTYPE)
+    seats[0] = (300, 2, 1, 1, 1, 1, 0, 1, 1, 1, 0)
+    seats[1] = (0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1)
+    want = []
+    for target, max_attempts, chunk, start in [(40, 400, 400, None), (150, 400, 200, None), (10_000, 300, 120, None),
+                                               (90, 100, 1000, None), (120, 500, 77, (60, 55, 5, 30, 25))]:
+        st = np.zeros(5, dtype=np.uint64) if start is None else np.array(start, dtype=np.uint64)
+        want.append(po.h2h_block(seats, 7, 3, 1, target, max_attempts, chunk, max_rounds=12, state=st).astype(np.int64))
+    got = np.load(out)
+    assert np.array_equal(got, np.stack(want)), (got, want)
+    assert (np.stack(want)[:, 2] > 0).any()  # the cases include safety-limit games (attempted != completed)

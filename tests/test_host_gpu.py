@@ -388,3 +388,53 @@ def test_farkle_run_artifacts_match_reference_run(tmp_path):
         if type(ck["win_totals"]).__name__ != "OutcomeCounter":
             diffs.append(f"k={k} checkpoint win_totals is a {type(ck['win_totals']).__name__}")
     assert not diffs, "\n".join(diffs)
+
+
+def _h2h_gpu_worker(rank: int, world: int, port: int, out_path: str) -> None:
+    import os
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import numpy as np
+    import torch.distributed as dist
+
+    from farkle_ii_amd.backend import STRATEGY_DTYPE, Engine
+    from farkle_ii_amd.distributed import h2h_block_distributed
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = Engine(0)  # both ranks share the one GPU of the test box; on a node each rank opens its own device
+    seats = np.zeros(2, dtype=STRATEGY_DTYPE)
+    seats[0] = (300, 2, 1, 1, 1, 1, 0, 1, 1, 1, 0)
+    seats[1] = (450, 1, 1, 0, 1, 1, 1, 0, 1, 0, 1)
+    st = np.zeros(5, dtype=np.uint64)
+    for _ in range(3):  # three chunks of a 200 000-game block, the last one holds the cut
+        st = h2h_block_distributed(eng.h2h, seats, 42, 5, 0, 200_000, 300_000, 90_000, state=st)
+    if rank == 0:
+        np.save(out_path, st.astype(np.int64))
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_h2h_block_two_ranks_matches_single_engine(tmp_path):
+    """Two gloo ranks cut one H2H block's attempt range in two and reproduce the single-engine prefix exactly."""
+    import os
+
+    import torch.multiprocessing as mp
+
+    from farkle_ii_amd.backend import STRATEGY_DTYPE
+    from farkle_ii_amd.engine import get_engine
+
+    out = str(tmp_path / "h2h.npy")
+    mp.spawn(_h2h_gpu_worker, args=(2, 33500 + os.getpid() % 2000, out), nprocs=2, join=True)
+    seats = np.zeros(2, dtype=STRATEGY_DTYPE)
+    seats[0] = (300, 2, 1, 1, 1, 1, 0, 1, 1, 1, 0)
+    seats[1] = (450, 1, 1, 0, 1, 1, 1, 0, 1, 0, 1)
+    eng = get_engine()
+    st = np.zeros(5, dtype=np.uint64)
+    for _ in range(3):
+        st = eng.h2h(seats, 42, 5, 0, 200_000, 300_000, 90_000, state=st)
+    got = np.load(out)
+    assert np.array_equal(got, st.astype(np.int64)) and got[1] == 200_000 and got[0] >= got[1]
