@@ -195,7 +195,7 @@ def main() -> None:
             "launch": {k2: t[k2] for k2 in ("play_block", "play_grid", "play_lds_bytes")},
         }
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and n_gpus == 1:  # the CPU leg runs on rank 0 of the single-GPU run only
             cpu = cpu_baseline(table)
             n_sh = cpu.pop("_n_sh")
             ref_tally = cpu.pop("_tally")
