@@ -59,70 +59,81 @@ class WorkloadCapExceeded(RuntimeError):
                          f"{plan.required_shuffles} and resume.")
 
 
-def worst_case_wilson_width(n: int, *, confidence: float = 0.95) -> float:
-    """Maximum full Wilson interval width for a binomial sample of size ``n``."""
-    from scipy.stats import norm
+def _is_int(value, minimum: int) -> bool:
+    return isinstance(value, int) and not isinstance(value, bool) and value >= minimum
 
-    if isinstance(n, bool) or not isinstance(n, int) or n < 1:
-        raise ValueError("n must be a positive integer")
+
+def _check_level(confidence: float) -> None:
     if not 0.0 < confidence < 1.0:
         raise ValueError("confidence must be between 0 and 1")
+
+
+def worst_case_wilson_width(n: int, *, confidence: float = 0.95) -> float:
+    """Widest full Wilson score interval any success count can produce at sample size ``n``: the interval is widest at
+    p = 1/2, i.e. at floor(n/2) or ceil(n/2) successes (workload_planner.py:88-108)."""
+    from scipy.stats import norm
+
+    if not _is_int(n, 1):
+        raise ValueError("n must be a positive integer")
+    _check_level(confidence)
     z = float(norm.ppf(0.5 + confidence / 2.0))
-    z2 = z * z
-
-    def width(successes: int) -> float:
-        p = successes / n
-        return 2.0 * z * math.sqrt(p * (1.0 - p) / n + z2 / (4.0 * n * n)) / (1.0 + z2 / n)
-
-    return max(width(n // 2), width((n + 1) // 2))
+    zz_over_n = z * z / n
+    widths = []
+    for successes in {n // 2, n - n // 2}:
+        p_hat = successes / n
+        half = z * math.sqrt(p_hat * (1.0 - p_hat) / n + zz_over_n / (4.0 * n))
+        widths.append(2.0 * half / (1.0 + zz_over_n))
+    return max(widths)
 
 
 def minimum_shuffles_for_resolution(resolution_delta: float, *, confidence: float = 0.95) -> int:
+    """Smallest n whose worst-case Wilson width is <= ``resolution_delta`` (the width is decreasing in n)."""
     if not 0.0 < resolution_delta < 1.0:
         raise ValueError("resolution_delta must be between 0 and 1")
-    if not 0.0 < confidence < 1.0:
-        raise ValueError("confidence must be between 0 and 1")
-    lower, upper = 0, 1
-    while worst_case_wilson_width(upper, confidence=confidence) > resolution_delta:
-        lower, upper = upper, upper * 2
-    while lower + 1 < upper:
-        mid = (lower + upper) // 2
-        if worst_case_wilson_width(mid, confidence=confidence) <= resolution_delta:
-            upper = mid
-        else:
-            lower = mid
-    return upper
+    _check_level(confidence)
+
+    def fine_enough(n: int) -> bool:
+        return worst_case_wilson_width(n, confidence=confidence) <= resolution_delta
+
+    hi = 1
+    while not fine_enough(hi):  # gallop to an upper bracket, then bisect (lo fails, hi passes)
+        hi *= 2
+    lo = hi // 2
+    while hi - lo > 1:
+        mid = (lo + hi) >> 1
+        lo, hi = (lo, mid) if fine_enough(mid) else (mid, hi)
+    return hi
 
 
 def plan_tournament_workload(*, root_seed: int, k: int, strategy_count: int, resolution_delta: float, confidence: float = 0.95,
                              batch_count: int = 100, min_shuffles_per_batch: int = 30, shuffle_cap: int | None = None,
                              projected_games_per_second: float | None = None) -> TournamentWorkloadPlan:
-    if isinstance(k, bool) or not isinstance(k, int) or k < 2:
+    """Shuffles per (root, k) from the screening resolution, rounded up to ``batch_count`` equal contiguous batches
+    (workload_planner.py:130-193)."""
+    if not _is_int(k, 2):
         raise ValueError("k must be an integer of at least 2")
-    if isinstance(strategy_count, bool) or not isinstance(strategy_count, int) or strategy_count < k or strategy_count % k:
+    if not _is_int(strategy_count, k) or strategy_count % k:
         raise ValueError("strategy_count must be a positive multiple of k")
-    if isinstance(batch_count, bool) or not isinstance(batch_count, int) or batch_count < 2:
+    if not _is_int(batch_count, 2):
         raise ValueError("batch_count must be an integer of at least 2")
-    if isinstance(min_shuffles_per_batch, bool) or not isinstance(min_shuffles_per_batch, int) or min_shuffles_per_batch < 1:
+    if not _is_int(min_shuffles_per_batch, 1):
         raise ValueError("min_shuffles_per_batch must be a positive integer")
-    if shuffle_cap is not None and (isinstance(shuffle_cap, bool) or not isinstance(shuffle_cap, int) or shuffle_cap < 1):
+    if shuffle_cap is not None and not _is_int(shuffle_cap, 1):
         raise ValueError("shuffle_cap must be positive when configured")
-    unrounded = minimum_shuffles_for_resolution(resolution_delta, confidence=confidence)
-    spb = max(min_shuffles_per_batch, math.ceil(unrounded / batch_count))
-    required = batch_count * spb
-    gps = strategy_count // k
-    capped = shuffle_cap is not None and required > shuffle_cap
-    plan = TournamentWorkloadPlan(
-        root_seed=int(root_seed), k=k, strategy_count=strategy_count, confidence=float(confidence),
-        resolution_delta=float(resolution_delta), required_shuffles_unrounded=unrounded, required_shuffles=required,
-        batch_count=batch_count, shuffles_per_batch=spb, batch_construction="equal_contiguous", games_per_shuffle=gps,
-        required_games=required * gps, achieved_resolution=worst_case_wilson_width(required, confidence=confidence),
-        shuffle_cap=shuffle_cap, cap_exceeded=capped,
-        achieved_resolution_at_cap=(worst_case_wilson_width(shuffle_cap, confidence=confidence)
-                                    if capped and shuffle_cap is not None else None))
-    if projected_games_per_second is not None:
-        plan = plan.with_games_per_second(projected_games_per_second)
-    return plan
+    needed = minimum_shuffles_for_resolution(resolution_delta, confidence=confidence)
+    per_batch = max(min_shuffles_per_batch, -(-needed // batch_count))
+    total = per_batch * batch_count
+    games_per_shuffle = strategy_count // k
+    over_cap = shuffle_cap is not None and total > shuffle_cap
+    fields = dict(root_seed=int(root_seed), k=k, strategy_count=strategy_count, confidence=float(confidence),
+                  resolution_delta=float(resolution_delta), required_shuffles_unrounded=needed, required_shuffles=total,
+                  batch_count=batch_count, shuffles_per_batch=per_batch, batch_construction="equal_contiguous",
+                  games_per_shuffle=games_per_shuffle, required_games=total * games_per_shuffle,
+                  achieved_resolution=worst_case_wilson_width(total, confidence=confidence), shuffle_cap=shuffle_cap,
+                  cap_exceeded=over_cap,
+                  achieved_resolution_at_cap=worst_case_wilson_width(shuffle_cap, confidence=confidence) if over_cap else None)
+    plan = TournamentWorkloadPlan(**fields)
+    return plan if projected_games_per_second is None else plan.with_games_per_second(projected_games_per_second)
 
 
 def write_workload_plan(path: Path, plan: TournamentWorkloadPlan) -> None:
