@@ -367,7 +367,8 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
                          "shuffles_per_batch": plan.shuffles_per_batch, "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
                          "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
                          "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
-                         "tournament_method_version": TOURNAMENT_METHOD_VERSION, "n_strategies": grid_size},
+                         "tournament_method_version": TOURNAMENT_METHOD_VERSION, "n_strategies": grid_size,
+                         **({"game_profile_sha256": oracle_game_profile.sha256} if oracle_game_profile is not None else {})},
             "outputs": sorted(str(p.relative_to(cfg.results_root)) for p in n_dir.rglob("*") if p.is_file()
                               and p.name != "simulation.done.json"),
             "games": plan.required_games, "games_per_second_this_run": (result["games"] / result["seconds"]) if result["games"] else None}
