@@ -68,8 +68,17 @@ def cpu_baseline(table: np.ndarray, seconds_target: float = 12.0) -> dict:
     t0 = time.perf_counter()
     res = po.tournament(t, K, ROOT_SEED, 0, n_sh, n_threads=threads)
     dt = time.perf_counter() - t0
+    # the same oracle on ONE core (SURVEY section 8d asks for both): first shuffles of the workload, about 3 s
+    t0 = time.perf_counter()
+    po.tournament(t, K, ROOT_SEED, 0, 200, n_threads=1)
+    n1 = int(max(200, min(n_sh, 200 * 3.0 / (time.perf_counter() - t0))))
+    t0 = time.perf_counter()
+    po.tournament(t, K, ROOT_SEED, 0, n1, n_threads=1)
+    dt1 = time.perf_counter() - t0
     return {"value": n_sh * 32 / dt, "unit": "games/s", "cores": threads, "kind": "port",
             "sample": f"shuffles 0..{n_sh - 1} of the same workload ({n_sh * 32} games, {dt:.1f} s, OpenMP over shuffles)",
+            "single_core": {"value": n1 * 32 / dt1, "unit": "games/s", "cores": 1,
+                            "sample": f"shuffles 0..{n1 - 1} ({n1 * 32} games, {dt1:.1f} s)"},
             "_tally": res["tally"][0], "_n_sh": n_sh}
 
 
