@@ -76,6 +76,7 @@ struct SeedArgs {
 struct PlayArgs {
     const uint2 *strat;          // [S] packed strategies
     const uint16_t *score_lut;   // [SCORE_LUT_KEYS] score table (fk_device.h)
+    const uint8_t *discard_lut;  // [DISCARD_LUT_KEYS] discard table (fk_device.h)
     const uint16_t *perm_T;      // blocked permutations (MODE_PERM), see perm_at()
     uint32_t perm_slots;
     const int32_t *seat_strategy; // [n_games][k] (MODE_LIST)
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         const uint32_t key = roll_counts<3>(rng, n);
         rolls_this_turn += 1u;
         const Strat sp{own_thr, (own_bits & (0xffu | MIXED)) | (a.uflags & (0xff00u & ~MIXED))};
-        const RollResult rr = default_score_lut(a.score_lut, key, (int32_t)n, turn_score, sp);
+        const RollResult rr = default_score_lut(a.score_lut, a.discard_lut, key, (int32_t)n, turn_score, sp);
         const bool farkle = rr.score == 0;                              // engine.py:135-137, 247-249
         cA += 1u + (farkle ? 0x10000u : 0u);                            // n_rolls (engine.py:98), n_farkles
         cC += (rr.d5 > 0) ? (1u + ((uint32_t)rr.d5 << 16)) : 0u;        // engine.py:139-144
@@ -705,13 +706,18 @@ __global__ void fk_score_lut_kernel(uint16_t *lut) { // the score table of fk_de
     if (key < SCORE_LUT_KEYS) lut[key] = score_lut_entry(key);
 }
 
+__global__ void fk_discard_lut_kernel(uint8_t *lut) { // the discard table of fk_device.h
+    const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key < DISCARD_LUT_KEYS) lut[key] = discard_lut_entry(key);
+}
+
 __global__ void fk_dbg_score_kernel(int64_t n, const uint8_t *faces, const int32_t *len, const int32_t *pre,
-                                    const uint2 *strat, const uint16_t *lut, int32_t *out) {
+                                    const uint2 *strat, const uint16_t *lut, const uint8_t *dlut, int32_t *out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Strat s = unpack_strat(strat[i]);
     // the game kernel's path: 3-bit count key -> score table -> discard choice
-    const RollResult r = default_score_lut(lut, nibbles_to_lut_key(pack_faces(faces + i * 6, len[i])), len[i], pre[i], s);
+    const RollResult r = default_score_lut(lut, dlut, nibbles_to_lut_key(pack_faces(faces + i * 6, len[i])), len[i], pre[i], s);
     out[i * 5 + 0] = r.score;
     out[i * 5 + 1] = r.used;
     out[i * 5 + 2] = len[i] - r.used;
@@ -787,7 +793,7 @@ struct fk_ctx {
     std::string err;
     fk_timing timing{};
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // [0..3] kernel timers, [4..5] whole call
-    DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, score_lut, dbg[6];
+    DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, score_lut, discard_lut, dbg[6];
     int32_t longest_first = 1;
     int32_t blocks_per_cu = 0; // 0 = as many as fit
     int32_t lean = -1;         // -1 auto, 0 full 17-dword seat records, 1 lean 11-dword records
@@ -1110,8 +1116,14 @@ int fk_init(int device_ordinal, fk_ctx **out) {
         fk_destroy(c);
         return FK_ERR_HIP;
     }
+    if (ensure(c, c->discard_lut, DISCARD_LUT_KEYS) != FK_OK) {
+        fk_destroy(c);
+        return FK_ERR_HIP;
+    }
     hipLaunchKernelGGL(fk_score_lut_kernel, dim3(SCORE_LUT_KEYS / 256), dim3(256), 0, c->stream,
                        static_cast<uint16_t *>(c->score_lut.p));
+    hipLaunchKernelGGL(fk_discard_lut_kernel, dim3(DISCARD_LUT_KEYS / 256), dim3(256), 0, c->stream,
+                       static_cast<uint8_t *>(c->discard_lut.p));
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
         fk_destroy(c);
         return FK_ERR_HIP;
@@ -1124,7 +1136,7 @@ void fk_destroy(fk_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->strat, &c->perm, &c->seeds, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist, &c->coords, &c->order, &c->slow, &c->score_lut})
+    for (DevBuf *b : {&c->strat, &c->perm, &c->seeds, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist, &c->coords, &c->order, &c->slow, &c->score_lut, &c->discard_lut})
         release(*b);
     for (auto &b : c->dbg) release(b);
     for (auto &e : c->ev)
@@ -1279,6 +1291,7 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
         PlayArgs pa{};
         pa.strat = static_cast<const uint2 *>(c->strat.p);
         pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
+        pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
         pa.perm_T = static_cast<const uint16_t *>(c->perm.p);
         pa.perm_slots = slots;
         pa.seat_strategy = nullptr;
@@ -1357,6 +1370,7 @@ int fk_play_games(fk_ctx *c, const fk_coord *coords, int64_t n_games, const fk_s
     PlayArgs pa{};
     pa.strat = static_cast<const uint2 *>(c->strat.p);
     pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
+        pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
     pa.seat_strategy = static_cast<const int32_t *>(c->seatlist.p);
     pa.tally = static_cast<unsigned long long *>(c->tally.p);
     pa.rows = static_cast<uint8_t *>(c->rows.p);
@@ -1431,6 +1445,7 @@ int fk_h2h_run(fk_ctx *c, const fk_strategy seats[2], uint64_t root_seed, uint64
         PlayArgs pa{};
         pa.strat = static_cast<const uint2 *>(c->strat.p);
         pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
+        pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
         pa.tally = static_cast<unsigned long long *>(c->tally.p);
         pa.ov = static_cast<const DevOverride *>(c->ov.p);
         pa.n_ov = (uint32_t)dov.size();
@@ -1491,7 +1506,8 @@ int fk_debug_score(fk_ctx *c, int64_t n, const uint8_t *faces, const int32_t *le
     hipLaunchKernelGGL(fk_dbg_score_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n,
                        static_cast<const uint8_t *>(c->dbg[0].p), static_cast<const int32_t *>(c->dbg[1].p),
                        static_cast<const int32_t *>(c->dbg[2].p), static_cast<const uint2 *>(c->dbg[3].p),
-                       static_cast<const uint16_t *>(c->score_lut.p), static_cast<int32_t *>(c->dbg[4].p));
+                       static_cast<const uint16_t *>(c->score_lut.p), static_cast<const uint8_t *>(c->discard_lut.p),
+                       static_cast<int32_t *>(c->dbg[4].p));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->dbg[4].p, sz[4], hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

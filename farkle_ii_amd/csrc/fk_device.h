@@ -454,20 +454,38 @@ constexpr uint32_t CS_D5 = pack8(1, 2, 0, 1, 2, 0, 1, 2), CS_D1 = pack8(0, 0, 1,
 constexpr uint32_t CD_D5 = pack8(2, 2, 1, 2, 1, 0, 1, 0), CD_D1 = pack8(2, 1, 2, 0, 1, 2, 0, 1);
 constexpr uint32_t NIB_H = 0x88888888u, NIB_1 = 0x11111111u;
 
-__host__ __device__ inline RollResult default_score_raw(const RawScore raw, int32_t n, int32_t turn_pre, const Strat &s) {
+// The inputs of the discard choice, reduced to the few values it really depends on.
+struct DiscardQuery {
+    uint32_t sf, m1;     // lone fives / lone ones that may be returned (0..2 each; ones only with smart_one)
+    uint32_t vmin, cmin; // thresholds in candidate units (0..7 / 0..5), see above
+    uint32_t r15;        // min(raw score / 50, 15): the candidate with v == raw score / 50 would score 0 (score_lister :262)
+    bool rb, fav;        // require_both, favor score
+    bool eligible;       // smart_five, dice left over, something to return (:433)
+};
+
+__host__ __device__ inline DiscardQuery discard_query(const RawScore raw, int32_t n, int32_t turn_pre, const Strat &s) {
+    DiscardQuery q;
     const uint32_t sf = (uint32_t)raw.sf, so = (uint32_t)raw.so;
-    const uint32_t m1 = s.has(SF_SMART_ONE) ? so : 0u;
-    const bool eligible = s.has(SF_SMART_FIVE) & (raw.used != n) & ((sf | so) != 0u); // :433
-    const bool cs = s.has(SF_CONSIDER_SCORE), cd = s.has(SF_CONSIDER_DICE), rb = s.has(SF_REQUIRE_BOTH);
-    const bool fav = s.has(SF_FAVOR_SCORE);
-    // thresholds in candidate units
+    q.sf = sf;
+    q.m1 = s.has(SF_SMART_ONE) ? so : 0u;
+    q.eligible = s.has(SF_SMART_FIVE) & (raw.used != n) & ((sf | so) != 0u); // :433
+    const bool cs = s.has(SF_CONSIDER_SCORE), cd = s.has(SF_CONSIDER_DICE);
+    q.rb = s.has(SF_REQUIRE_BOTH);
+    q.fav = s.has(SF_FAVOR_SCORE);
     const int32_t x = turn_pre + raw.score - s.score_thr;
     const uint32_t xq = ((uint32_t)(x < 1000 ? x : 1000) * 1311u) >> 16; // floor(x / 50) for 0 <= x <= 1000
-    uint32_t vmin = (x < 0) ? 0u : (xq + 1u < 7u ? xq + 1u : 7u);
-    vmin = cs ? vmin : 0u;
+    const uint32_t vmin = (x < 0) ? 0u : (xq + 1u < 7u ? xq + 1u : 7u);
+    q.vmin = cs ? vmin : 0u;
     int32_t cm = s.dice_thr() - (n - raw.used) + 1;
     cm = cm < 0 ? 0 : (cm > 5 ? 5 : cm);
-    const uint32_t cmin = cd ? (uint32_t)cm : 0u;
+    q.cmin = cd ? (uint32_t)cm : 0u;
+    const uint32_t r50 = ((uint32_t)raw.score * 1311u) >> 16; // raw.score / 50 (raw.score is a multiple of 50, < 2^16)
+    q.r15 = r50 < 15u ? r50 : 15u;
+    return q;
+}
+
+// SWAR search over the eight candidates; returns d5 | d1 << 2 of the best one, 0 if (0, 0) stays (eligibility aside).
+__host__ __device__ inline uint32_t discard_choice(uint32_t sf, uint32_t m1, uint32_t vmin, uint32_t cmin, uint32_t r15, bool rb, bool fav) {
     // candidate layout for this strategy's preference
     const uint32_t D5 = fav ? CS_D5 : CD_D5, D1 = fav ? CS_D1 : CD_D1;
     const uint32_t V = D5 + 2u * D1, CNT = D5 + D1; // nibble-wise (max 6 / 4: no carries)
@@ -476,17 +494,33 @@ __host__ __device__ inline RollResult default_score_raw(const RawScore raw, int3
     const uint32_t mv = ((NIB_H + V) - vmin * NIB_1) & NIB_H;  // v >= vmin
     const uint32_t mc = ((NIB_H + CNT) - cmin * NIB_1) & NIB_H; // cnt >= cmin
     const uint32_t keep = rb ? (mv | mc) : (mv & mc);          // not must_bank
-    // candidate score 0 (score_lister :262): 50 * v == raw score
-    const uint32_t r50 = ((uint32_t)raw.score * 1311u) >> 16;   // raw.score / 50 (raw.score is a multiple of 50, < 2^16)
-    const uint32_t xr = V ^ ((r50 < 15u ? r50 : 15u) * NIB_1);
-    const uint32_t nz = (xr | (xr << 1) | (xr << 2) | (xr << 3)) & NIB_H; // nibble != 0
+    const uint32_t xr = V ^ (r15 * NIB_1);
+    const uint32_t nz = (xr | (xr << 1) | (xr << 2) | (xr << 3)) & NIB_H; // nibble != 0: candidate score != 0
     const uint32_t feas = ok5 & ok1 & keep & nz;
     const bool f0 = rb ? ((vmin == 0u) | (cmin == 0u)) : ((vmin == 0u) & (cmin == 0u)); // (0,0) not must_bank
     const bool any8 = feas != 0u;
     const uint32_t l4 = any8 ? (uint32_t)(ctz32(feas | 0u) - 3) : 0u;
-    const bool take = eligible & any8 & !(fav & f0);
-    const int32_t d5 = take ? (int32_t)((D5 >> l4) & 3u) : 0;
-    const int32_t d1 = take ? (int32_t)((D1 >> l4) & 3u) : 0;
+    const bool take = any8 & !(fav & f0);
+    return take ? (((D5 >> l4) & 3u) | (((D1 >> l4) & 3u) << 2)) : 0u;
+}
+
+// Discard table: the choice above for every (sf, m1, vmin, cmin, r15, rb, fav), 2^16 one-byte entries (64 KiB, built on
+// the device once per context by running discard_choice on every key).  Key layout:
+//   [1:0] min(sf, 2)  [3:2] min(m1, 2)  [6:4] vmin  [9:7] cmin  [13:10] r15  [14] require_both  [15] favor score
+constexpr uint32_t DISCARD_LUT_KEYS = 1u << 16;
+
+__host__ __device__ inline uint32_t discard_key(const DiscardQuery &q) {
+    return (q.sf < 2u ? q.sf : 2u) | ((q.m1 < 2u ? q.m1 : 2u) << 2) | (q.vmin << 4) | (q.cmin << 7) | (q.r15 << 10) |
+           ((q.rb ? 1u : 0u) << 14) | ((q.fav ? 1u : 0u) << 15);
+}
+
+__host__ __device__ inline uint8_t discard_lut_entry(uint32_t key) {
+    return (uint8_t)discard_choice(key & 3u, (key >> 2) & 3u, (key >> 4) & 7u, (key >> 7) & 7u, (key >> 10) & 15u,
+                                   ((key >> 14) & 1u) != 0u, ((key >> 15) & 1u) != 0u);
+}
+
+__host__ __device__ inline RollResult apply_discards(const RawScore raw, uint32_t choice) {
+    const int32_t d5 = (int32_t)(choice & 3u), d1 = (int32_t)((choice >> 2) & 3u);
     RollResult out;
     out.d5 = d5; // == single_fives - best_sf (:467)
     out.d1 = d1;
@@ -495,14 +529,22 @@ __host__ __device__ inline RollResult default_score_raw(const RawScore raw, int3
     return out;
 }
 
+__host__ __device__ inline RollResult default_score_raw(const RawScore raw, int32_t n, int32_t turn_pre, const Strat &s) {
+    const DiscardQuery q = discard_query(raw, n, turn_pre, s);
+    return apply_discards(raw, q.eligible ? discard_choice(q.sf, q.m1, q.vmin, q.cmin, q.r15, q.rb, q.fav) : 0u);
+}
+
 // nibble-packed counts -> SWAR scorer (host checks, table construction)
 __host__ __device__ inline RollResult default_score(uint32_t counts, int32_t n, int32_t turn_pre, const Strat &s) {
     return default_score_raw(score_counts(counts), n, turn_pre, s);
 }
 
 // 3-bit-packed counts -> score table (the kernels)
-__device__ inline RollResult default_score_lut(const uint16_t *lut, uint32_t key, int32_t n, int32_t turn_pre, const Strat &s) {
-    return default_score_raw(raw_from_lut(lut[key]), n, turn_pre, s);
+__device__ inline RollResult default_score_lut(const uint16_t *lut, const uint8_t *dlut, uint32_t key, int32_t n, int32_t turn_pre,
+                                               const Strat &s) {
+    const RawScore raw = raw_from_lut(lut[key]);
+    const DiscardQuery q = discard_query(raw, n, turn_pre, s);
+    return apply_discards(raw, q.eligible ? (uint32_t)dlut[discard_key(q)] : 0u);
 }
 
 // FarklePlayer._should_continue (src/farkle/game/engine.py:156-205) with ThresholdStrategy.decide
