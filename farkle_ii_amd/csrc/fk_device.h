@@ -485,6 +485,8 @@ __host__ __device__ inline DiscardQuery discard_query(const RawScore raw, int32_
 }
 
 // SWAR search over the eight candidates; returns d5 | d1 << 2 of the best one, 0 if (0, 0) stays (eligibility aside).
+// Relies on the ThresholdStrategy invariant require_both => consider_score && consider_dice (strategies.py:201-207,
+// enforced by validate_strategies at the C-ABI): `rb` alone then selects the AND rule of _must_bank (:283-300).
 __host__ __device__ inline uint32_t discard_choice(uint32_t sf, uint32_t m1, uint32_t vmin, uint32_t cmin, uint32_t r15, bool rb, bool fav) {
     // candidate layout for this strategy's preference
     const uint32_t D5 = fav ? CS_D5 : CD_D5, D1 = fav ? CS_D1 : CD_D1;

@@ -1,0 +1,58 @@
+// Host-side check of the __host__ __device__ scoring code in farkle_ii_amd/csrc/fk_device.h (no GPU calls):
+//   1. SWAR default_score == the readable loop form default_score_loops on every multiset of 1..6 dice, every flag
+//      combination a ThresholdStrategy can have, a grid of thresholds and turn scores;
+//   2. the score-table entry of every key decodes to score_counts of that multiset;
+//   3. the discard-table entry, applied through discard_query/discard_key, equals the loop form as well.
+// Built and run by tests/test_device_header_host.py with hipcc (host compilation only).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#include "../../farkle_ii_amd/csrc/fk_device.h"
+
+using namespace fk;
+
+int main() {
+    std::vector<uint8_t> dlut(DISCARD_LUT_KEYS);
+    for (uint32_t k = 0; k < DISCARD_LUT_KEYS; ++k) dlut[k] = discard_lut_entry(k);
+    long cases = 0, bad_swar = 0, bad_table = 0, bad_lut = 0, multisets = 0;
+    for (uint32_t key = 1; key < SCORE_LUT_KEYS; ++key) {
+        uint32_t n = 0;
+        bool ok = true;
+        for (int f = 0; f < 6; ++f) {
+            const uint32_t c = (key >> (3 * f)) & 7u;
+            ok &= c <= 6u;
+            n += c;
+        }
+        if (!ok || n == 0 || n > 6) continue;
+        ++multisets;
+        const uint32_t nib = lut_key_to_nibbles(key);
+        if (nibbles_to_lut_key(nib) != key) ++bad_lut;
+        const RawScore raw = score_counts(nib), dec = raw_from_lut(score_lut_entry(key));
+        if (raw.score != dec.score || raw.used != dec.used || raw.sf != dec.sf || raw.so != dec.so) ++bad_lut;
+        for (uint32_t flags = 0; flags < 256; ++flags) {
+            // the two combinations ThresholdStrategy.__post_init__ rejects (strategies.py:196-207) never reach a kernel:
+            // fk_* entry points return FK_ERR_ARG for them (validate_strategies)
+            const uint32_t bits = flags << 8;
+            if ((bits & SF_SMART_ONE) && !(bits & SF_SMART_FIVE)) continue;
+            if ((bits & SF_REQUIRE_BOTH) && !((bits & SF_CONSIDER_SCORE) && (bits & SF_CONSIDER_DICE))) continue;
+            for (int32_t thr : {0, 200, 300, 350, 500, 1000}) {
+                for (int32_t dthr : {-1, 0, 1, 2, 3, 4, 6}) {
+                    const Strat s{thr, ((uint32_t)(uint8_t)(int8_t)dthr) | (flags << 8)};
+                    for (int32_t pre : {0, 50, 250, 300, 450, 950, 3000}) {
+                        const RollResult want = default_score_loops(nib, (int32_t)n, pre, s);
+                        const RollResult swar = default_score(nib, (int32_t)n, pre, s);
+                        const DiscardQuery q = discard_query(raw, (int32_t)n, pre, s);
+                        const RollResult tab = apply_discards(raw, q.eligible ? (uint32_t)dlut[discard_key(q)] : 0u);
+                        ++cases;
+                        if (swar.score != want.score || swar.used != want.used || swar.d5 != want.d5 || swar.d1 != want.d1) ++bad_swar;
+                        if (tab.score != want.score || tab.used != want.used || tab.d5 != want.d5 || tab.d1 != want.d1) ++bad_table;
+                    }
+                }
+            }
+        }
+    }
+    printf("multisets %ld cases %ld bad_swar %ld bad_table %ld bad_lut %ld\n", multisets, cases, bad_swar, bad_table, bad_lut);
+    return (multisets == 923 && bad_swar == 0 && bad_table == 0 && bad_lut == 0) ? 0 : 1;
+}

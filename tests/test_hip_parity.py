@@ -383,6 +383,17 @@ def test_argument_errors(eng):
     bad[0]["smart_one"], bad[0]["smart_five"] = 1, 0
     with pytest.raises(FarkleHipError, match="smart_one"):
         eng.tournament(bad, 2, 0, 0, 1)
+    # require_both without both considerations: ThresholdStrategy.__post_init__ raises (strategies.py:201-207); the
+    # branch-free discard search relies on this invariant, so every entry point must refuse the record
+    for field in ("consider_score", "consider_dice"):
+        bad = table.copy()
+        bad[5]["require_both"], bad[5][field] = 1, 0
+        with pytest.raises(FarkleHipError, match="require_both"):
+            eng.tournament(bad, 2, 0, 0, 1)
+        with pytest.raises(FarkleHipError, match="require_both"):
+            eng.h2h(bad[4:6], 1, 0, 0, 10, 20, 20)
+        with pytest.raises(FarkleHipError, match="require_both"):
+            eng.debug_score(np.ones((1, 6), np.uint8), [6], [0], bad[5:6])
     empty = eng.tournament(table, 2, 0, 5, 5)
     assert empty["tally"].shape[0] == 0
 
