@@ -7,8 +7,9 @@ A "step" is one pass of the hot path over one batch of synthetic input: at N=1 t
 BASELINE.json configs[1] — k=2, the 64-strategy grid, 10^7 games (312 500 shuffles x 32 games),
 root seed 42, counts-only tallies ([S][26] int64 resident in HBM).  For N>1 (one rank per GPU,
 launched by torch.distributed.run) every rank plays its own range of 312 500 shuffles per step
-(weak scaling: the shuffle space is partitioned, no data-path collective) and one RCCL reduce of
-the int64 tally per step plays the role of OutcomeCounter.absorb (run_tournament.py:197-213).
+(weak scaling: the shuffle space is partitioned, no data-path collective); ranks add their step tallies locally
+and ONE RCCL reduce of the [S][26] int64 tally to rank 0 at the end of the job, inside the timed region, plays the
+role of OutcomeCounter.absorb (run_tournament.py:197-213).
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (fk_play_kernel): the path is
 integer VALU work, so the bound is the vector-ALU issue roof, not HBM or MFMA; `cpu_baseline` is the
@@ -122,7 +123,6 @@ def main() -> None:
     info = eng.device_info()
     dev = torch.device("cuda", local_rank)
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the tally reduction runs
-    total = torch.zeros((S, 26), dtype=torch.int64, device=red_dev)
 
     def sync() -> None:
         if distributed:
@@ -132,11 +132,15 @@ def main() -> None:
     def step(index: int):
         first = (index * n_gpus + rank) * args.shuffles
         res = eng.tournament(table, K, ROOT_SEED, first, first + args.shuffles)
-        t = eng.timing()
-        tally = torch.from_numpy(res["tally"][0]).to(red_dev)
+        return res["tally"][0], eng.timing()
+
+    def reduce_to_rank0(local: np.ndarray):
+        """The path's only exchange: one SUM of the per-strategy int64 tally to rank 0 at the end of the
+        job, the analogue of OutcomeCounter.absorb — RCCL over xGMI when there is more than one rank."""
+        t = torch.from_numpy(local).to(red_dev)
         if distributed:
-            dist.reduce(tally, dst=0, op=dist.ReduceOp.SUM)  # RCCL sum of win counts (the only exchange)
-        return tally, t
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        return t
 
     # one-time initialisation outside any step: device workspace, lazily loaded torch kernels, RCCL communicator
     eng.tournament(table, K, ROOT_SEED, 0, args.shuffles)
@@ -144,20 +148,23 @@ def main() -> None:
     warm += torch.from_numpy(np.zeros((S, 26), dtype=np.int64)).to(red_dev)
     if distributed:
         dist.reduce(warm, dst=0, op=dist.ReduceOp.SUM)
+    local = np.zeros((S, 26), dtype=np.int64)
     for i in range(args.warmup):
         tally, _ = step(i)
-        total += tally
-    total.zero_()
+        local += tally
+    reduce_to_rank0(local)
+    local[:] = 0
     play_ms, seed_ms, perm_ms, launches = 0.0, 0.0, 0.0, 0
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         tally, t = step(args.warmup + i)
-        total += tally
+        local += tally  # [64][26] int64 host add
         play_ms += t["play_ms"]
         seed_ms += t["seed_ms"]
         perm_ms += t["perm_ms"]
         launches += t["play_launches"]
+    total = reduce_to_rank0(local)  # inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
     if distributed:
