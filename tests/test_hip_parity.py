@@ -315,6 +315,27 @@ def test_tournament_batches_chunks_options_and_overrides(eng, po):
             eng.set_option(name, value)
 
 
+def test_scalar_flag_kernel_instances_match_oracle(eng, po):
+    """The three flag-dispatch instances of the game kernel (no flag varies / only require_both and favor vary / any
+    flag varies) against the oracle, plus the generic instance forced on the same tables."""
+    base = _strats(gu.load("grid_vectors.json")["g64"])
+    uniform = base.copy()                      # every strategy shares all eight flags: scalar-flag instance
+    uniform["require_both"], uniform["favor_score"] = 1, 0
+    uniform["score_threshold"] = 250 + 25 * (np.arange(64) // 4)
+    uniform["dice_threshold"] = np.arange(64) % 4
+    mixed = base.copy()                        # a third flag varies: generic instance
+    mixed["auto_hot_dice"][::3] = 0
+    mixed["run_up_score"][::5] = 0
+    for name, table in (("uniform", uniform), ("rb_fav", base), ("mixed", mixed)):
+        ref = po.tournament(table.view(po.STRATEGY_DTYPE), 2, 9, 0, 40, n_threads=8)["tally"]
+        assert np.array_equal(eng.tournament(table, 2, 9, 0, 40)["tally"], ref), name
+        try:
+            eng.set_option("uniform_flags", 0)
+            assert np.array_equal(eng.tournament(table, 2, 9, 0, 40)["tally"], ref), name
+        finally:
+            eng.set_option("uniform_flags", -1)
+
+
 def test_tournament_full_size_properties(eng):
     """BASELINE config 2 at full size (k=2, 64-strategy grid, 10^7 games, seed 42): size-independent
     properties of the tally (the oracle cannot play 10^7 games inside a test)."""
