@@ -336,6 +336,36 @@ def test_scalar_flag_kernel_instances_match_oracle(eng, po):
             eng.set_option("uniform_flags", -1)
 
 
+def _random_valid_table(n: int, seed: int) -> np.ndarray:
+    from farkle_ii_amd.strategies import STRATEGY_DTYPE
+
+    rng = np.random.default_rng(seed)
+    t = np.zeros(n, dtype=STRATEGY_DTYPE)
+    t["score_threshold"] = rng.integers(2, 21, n) * 50
+    t["dice_threshold"] = rng.integers(0, 5, n)
+    for name in ("smart_five", "consider_score", "consider_dice", "auto_hot_dice", "run_up_score", "favor_score"):
+        t[name] = rng.integers(0, 2, n)
+    t["smart_one"] = t["smart_five"] & rng.integers(0, 2, n).astype(np.uint8)                     # strategies.py:198
+    t["require_both"] = t["consider_score"] & t["consider_dice"] & rng.integers(0, 2, n).astype(np.uint8)  # :202
+    t["strategy_id"] = np.arange(n)
+    return t
+
+
+def test_strategy_table_size_limits(eng, po):
+    """Largest table the ABI accepts (S = 65 534 at k = 2), the sizes either side of the lean-record limit
+    (strategy index in 14 bits: S <= 16 384) and one strategy too many."""
+    from farkle_ii_amd.backend import FarkleHipError
+
+    for S, k, n_sh in ((65_534, 2, 2), (16_384, 2, 3), (16_386, 2, 3), (16_386, 6, 4)):
+        table = _random_valid_table(S, S + k)
+        ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 5, 0, n_sh, want_rows=True, n_threads=8)
+        got = eng.tournament(table, k, 5, 0, n_sh, want_rows=True)
+        assert np.array_equal(got["tally"], ref["tally"]), (S, k)
+        assert _rows_equal(got["rows"], ref["rows"].view(got["rows"].dtype)), (S, k)
+    with pytest.raises(FarkleHipError):
+        eng.tournament(_random_valid_table(65_536, 1), 2, 5, 0, 1)
+
+
 def test_tournament_full_size_properties(eng):
     """BASELINE config 2 at full size (k=2, 64-strategy grid, 10^7 games, seed 42): size-independent
     properties of the tally (the oracle cannot play 10^7 games inside a test)."""
