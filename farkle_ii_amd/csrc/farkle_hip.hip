@@ -33,7 +33,7 @@ constexpr uint32_t HC_AFTER_6_WORDS = ss_hc(24); // 4 + 12 (all pairs) + 2*4 has
 
 enum : uint32_t { MODE_PERM = 0, MODE_LIST = 1, MODE_FIXED = 2 };
 
-// LDS seat-context fields (dwords), record layout lds[(seat * BLOCK + tid) * NFIELDS + field]
+// LDS seat-record fields (dwords), record layout lds[(seat * BLOCK + tid) * NFIELDS + field]
 enum : uint32_t {
     F_LO0 = 0, F_LO1, F_HI0, F_HI1, F_INC_LO0, F_INC_LO1, F_INC_HI0, F_INC_HI1,
     F_BUF, F_SCORE, F_CA, F_CB, F_CC, F_CD, F_CE, F_SPX, F_SPY, NF
@@ -287,12 +287,13 @@ __global__ void fk_finalize_tally(unsigned long long *tally, uint32_t n_rows, ui
 }
 
 // ---------------------------------------------------------------------------------------
-// One seat's context: the turn owner's copy lives in VGPRs between begin_turn / end_turn; every seat has a
-// contiguous LDS record.  LEAN records keep only what a turn mutates (PCG state, buffered half word, score, counters:
-// 11 dwords = 44 bytes instead of 68): the read-only PCG increment and the packed strategy are re-read from the seed
-// buffer / strategy table (L2-resident) at the start of each turn, the strategy index riding in the spare bits of cE.
-// Fewer LDS bytes per lane = more resident waves per SIMD (k=2: 4 -> 6 with the 80-VGPR instance, k=4: 2 -> 3.5).  (Keeping both k = 2 seats in VGPRs and swapping registers at the turn boundary was measured 3 %
-// slower than the LDS slots and is not built.)
+// One seat's context.  Every seat has a contiguous LDS record that each roll step loads, updates and stores; nothing
+// but the turn registers and the owner's read-only data (increment, strategy) is carried in VGPRs across rolls.
+// LEAN records keep only what a turn mutates (PCG state, buffered half word, score, counters: 11 dwords = 44 bytes
+// instead of 68): the read-only PCG increment and the packed strategy are re-read from the seed buffer's increment
+// plane / the strategy table (L2-resident) at the start of each turn, the strategy index riding in the spare bits of
+// cE.  Fewer LDS bytes per lane = more resident waves per SIMD (k=2: 4 -> 6, k=4: 2 -> 3.5).  `Seat` is the in-register
+// form used while a fresh game is set up.
 struct Seat {
     uint64_t lo, hi, inc_lo, inc_hi; // PCG64DXSM state / increment
     uint32_t buf;                    // buffered half word (has_buf is bit 17 of cE)

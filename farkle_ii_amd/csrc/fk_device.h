@@ -265,7 +265,8 @@ __device__ inline uint32_t roll_counts(Rng &r, uint32_t n, uint32_t *faces_out =
 }
 
 // ----------------------------------------------------------------------------------------
-// Scoring: _evaluate_nb (src/farkle/game/scoring_lookup.py:123-172) on nibble-packed counts.
+// Scoring: _evaluate_nb (src/farkle/game/scoring_lookup.py:123-172) on nibble-packed counts (the generator of the
+// score table the kernels read, and the host-side statement of the rule).
 // With <= 6 dice at most ONE face can form a set outside the four 6-dice patterns, so the
 // set is found with one SWAR compare + ffs instead of a per-face loop.
 // ----------------------------------------------------------------------------------------
