@@ -148,11 +148,30 @@ def gen_rng():
                "spawn_seeds_42": spawn}, open(OUT / "rng_vectors.json", "w"))
 
 
+def scoring_csv_rows():
+    """Data fixtures the reference holds for the scorer: its test CSV (tests/data/test_farkle_scores_data.csv, used by
+    tests/unit/game/test_scoring.py:76) and the three data/*.csv tables that list explicit rolls."""
+    rows = []
+    for path in ("tests/data/test_farkle_scores_data.csv", "data/farkle_all_scoring_combos.csv",
+                 "data/farkle_scores_data.csv", "data/farkle_missing_patterns_1.csv"):
+        for row in csv.DictReader(open(f"/root/reference/{path}")):
+            rows.append({"source": path, **{k: row[k] for k in ("Score", "Number_of_Dice", "Dice_Roll", "Used_Dice", "Reroll_Dice",
+                                                               "Single_Fives", "Single_Ones")}})
+    return rows
+
+
+def gen_scoring_csv():
+    """Refresh only the CSV part of scoring_vectors.json."""
+    path = OUT / "scoring_vectors.json"
+    data = json.load(open(path))
+    data["csv_rows"] = scoring_csv_rows()
+    _dump(data, open(path, "w"))
+
+
 def gen_scoring():
     table = [[int(x) for x in (*key, v[0], v[1], v[3], v[4])] for key, v in SCORE_TABLE.items()]
     assert len(table) == 923
-    # the reference's own 152-roll CSV (tests/data/test_farkle_scores_data.csv): data fixture
-    rows = list(csv.DictReader(open("/root/reference/tests/data/test_farkle_scores_data.csv")))
+    rows = scoring_csv_rows()
     rs = np.random.default_rng(7)
     grids = grid_default()
     cases = []

@@ -138,6 +138,25 @@ def test_score_table_all_923_patterns(eng):
         assert out[i, 0] == row[6] and out[i, 1] == row[7] and out[i, 3] == 0 and out[i, 4] == 0, row
 
 
+def test_score_matches_reference_csv_tables(eng):
+    """The scoring tables the reference keeps as data files (its test CSV and the three data/*.csv files with explicit
+    rolls, 448 rows): score, used and re-roll dice of every listed roll through the device score table."""
+    import json
+
+    rows = gu.load("scoring_vectors.json")["csv_rows"]
+    assert len(rows) >= 448
+    faces = np.zeros((len(rows), 6), dtype=np.uint8)
+    lens = np.zeros(len(rows), dtype=np.int32)
+    for i, row in enumerate(rows):
+        roll = json.loads(row["Dice_Roll"])
+        faces[i, :len(roll)] = roll
+        lens[i] = len(roll)
+    plain = _strats([[300, 2, 0, 0, 1, 1, 0, 0, 0, 1, 0]] * len(rows))
+    out = eng.debug_score(faces, lens, np.zeros(len(rows), dtype=np.int32), plain)
+    for i, row in enumerate(rows):
+        assert (out[i, 0], out[i, 1], out[i, 2]) == (int(row["Score"]), int(row["Used_Dice"]), int(row["Reroll_Dice"])), row
+
+
 def test_default_score_matches_golden_and_oracle(eng, po):
     data = gu.load("scoring_vectors.json")
     cases = data["default_score"]
