@@ -438,3 +438,63 @@ def test_h2h_block_two_ranks_matches_single_engine(tmp_path):
         st = eng.h2h(seats, 42, 5, 0, 200_000, 300_000, 90_000, state=st)
     got = np.load(out)
     assert np.array_equal(got, st.astype(np.int64)) and got[1] == 200_000 and got[0] >= got[1]
+
+
+def test_farkle_run_without_metric_chunks_uses_one_tally_per_group(tmp_path):
+    """No metric chunk directory -> the runner asks the engine for one tally per launch group (LDS tally path); totals,
+    checkpoint ownership and resume are the same as with per-batch tallies."""
+    import pickle
+
+    import pyoracle as po
+
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.cli import main
+    from farkle_ii_amd.config import load_app_config
+    from farkle_ii_amd.strategies import pack_strategies
+
+    cfg_path = tmp_path / "tiny.yaml"
+    cfg_path.write_text(f"""
+io:
+  results_dir_prefix: "{tmp_path / 'out'}"
+sim:
+  n_players_list: [2]
+  seed_list: [7]
+  expanded_metrics: true
+  row_dir: null
+  metric_chunk_dir: null
+  score_thresholds: [300, 500]
+  dice_thresholds: [1, 2]
+  smart_five_opts: [true]
+  smart_one_opts: [true, false]
+  consider_score_opts: [true]
+  consider_dice_opts: [true]
+  auto_hot_dice_opts: [true]
+  run_up_score_opts: [false]
+screening:
+  resolution_delta: 0.3
+batching:
+  target_batches: 4
+  min_shuffles_per_batch: 2
+""")
+    main(["--config", str(cfg_path), "run"])
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    n_dir = cfg.n_dir(2)
+    assert not (n_dir / "2p_metric_chunks").exists() and not (n_dir / "2p_rows").exists()
+    payload = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    strategies, _ = runner._resolve_strategies(cfg, None)
+    n_sh = payload["meta"]["num_shuffles"]
+    ref = po.tournament(pack_strategies(strategies).view(po.STRATEGY_DTYPE), 2, 7, 0, n_sh)["tally"][0]
+    assert np.array_equal(payload["tally_int64"], ref)
+    assert payload["meta"]["completed_process_block_indices"] == [1, 2, 3, 4] and payload["meta"]["complete"]
+    # worker-style counters (no chunk files to rebuild from): only what was incremented is present
+    assert {int(s): int(v) for s, v in payload["win_totals"].items()} == {i: int(ref[i, 0]) for i in range(len(ref)) if ref[i, 0]}
+    # resume after losing the last batch
+    spb = payload["meta"]["shuffles_per_batch"]
+    last = po.tournament(pack_strategies(strategies).view(po.STRATEGY_DTYPE), 2, 7, 3 * spb, 4 * spb)["tally"][0]
+    payload["tally_int64"] = ref - last
+    payload["meta"]["completed_process_block_indices"] = [1, 2, 3]
+    (n_dir / "2p_checkpoint.pkl").write_bytes(pickle.dumps(payload))
+    (n_dir / "simulation.done.json").unlink()
+    main(["--config", str(cfg_path), "run"])
+    again = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    assert np.array_equal(again["tally_int64"], ref) and again["meta"]["completed_process_block_indices"] == [1, 2, 3, 4]
