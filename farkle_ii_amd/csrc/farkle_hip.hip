@@ -793,7 +793,12 @@ struct fk_ctx {
     hipDeviceProp_t prop{};
     std::string err;
     fk_timing timing{};
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // [0..3] kernel timers, [4..5] whole call
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // see TimerSlot
+    struct PendingTimer {
+        float *acc;
+        hipEvent_t a, b;
+    };
+    std::vector<PendingTimer> pending; // kernel timers recorded on the stream, read after the chunk's one sync
     DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, score_lut, discard_lut, dbg[6];
     int32_t longest_first = 1;
     int32_t blocks_per_cu = 0; // 0 = as many as fit
@@ -1003,6 +1008,10 @@ hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     }
 }
 
+// Event pairs: kernels of one chunk are enqueued back to back (no host wait between them); their timers are read
+// after the stream sync that ends the chunk (collect_timers).
+enum TimerSlot : int { SLOT_PERM = 0, SLOT_SEED = 2, SLOT_PLAY = 4, SLOT_CALL = 6 };
+
 struct Timer {
     fk_ctx *c;
     float *acc;
@@ -1010,16 +1019,23 @@ struct Timer {
     Timer(fk_ctx *ctx, float *dst, int slot) : c(ctx), acc(dst), a(ctx->ev[slot]), b(ctx->ev[slot + 1]) {
         (void)hipEventRecord(a, c->stream);
     }
-    void stop() { (void)hipEventRecord(b, c->stream); }
-    hipError_t collect() {
-        hipError_t e = hipEventSynchronize(b);
-        if (e != hipSuccess) return e;
-        float ms = 0.f;
-        e = hipEventElapsedTime(&ms, a, b);
-        if (e == hipSuccess) *acc += ms;
-        return e;
+    void stop() {
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({acc, a, b});
     }
 };
+
+hipError_t collect_timers(fk_ctx *c) { // the stream has been synchronised
+    hipError_t first = hipSuccess;
+    for (const auto &t : c->pending) {
+        float ms = 0.f;
+        const hipError_t e = hipEventElapsedTime(&ms, t.a, t.b);
+        if (e == hipSuccess) *t.acc += ms;
+        else if (first == hipSuccess) first = e;
+    }
+    c->pending.clear();
+    return first;
+}
 
 int check_device_error(fk_ctx *c, const int32_t *d_err, int64_t game_base, const char *what) {
     int32_t h[2] = {0, 0};
@@ -1059,11 +1075,10 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
         pa.sched = nullptr;
     }
     {
-        Timer t(c, &c->timing.seed_ms, 0);
+        Timer t(c, &c->timing.seed_ms, SLOT_SEED);
         hipLaunchKernelGGL(fk_seed_kernel, dim3((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK), dim3(SEED_BLOCK), 0, c->stream, sa);
         t.stop();
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, t.collect());
     }
     pa.seeds = sa.seeds;
     pa.ticket = static_cast<uint32_t *>(c->misc.p);
@@ -1071,21 +1086,22 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
     pa.batch_threshold = (uint32_t)std::max(1, std::min(64, c->batch_threshold));
     pa.use_lds_tally = plan.lds_tally ? 1u : 0u;
     {
-        Timer t(c, &c->timing.play_ms, 2);
+        Timer t(c, &c->timing.play_ms, SLOT_PLAY);
         LaunchPlan lp = plan;
         lp.mixed_flags = (c->uniform_flags_opt != 0) ? c->table_mixed_flags : 0xff00u;
         pa.uflags = c->table_flags;
         hipError_t e = launch_play(lp, pa, c->stream);
         t.stop();
         HIPCHK(c, e);
-        HIPCHK(c, t.collect());
     }
     c->timing.play_launches += 1;
     c->timing.play_block = plan.block;
     c->timing.play_grid = plan.grid;
     c->timing.play_lds_bytes = (int32_t)plan.lds;
     c->timing.games += sa.n_games;
-    return check_device_error(c, pa.err, game_base, what);
+    const int rc_dev = check_device_error(c, pa.err, game_base, what); // synchronises the stream
+    HIPCHK(c, collect_timers(c));
+    return rc_dev;
 }
 
 } // namespace
@@ -1198,6 +1214,7 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
     if (n_ov < 0 || (n_ov > 0 && !ov)) return fail(c, FK_ERR_ARG, "bad override list");
     HIPCHK(c, hipSetDevice(c->device));
     c->timing = fk_timing{};
+    c->pending.clear();
 
     const uint64_t n_sh_total = shuffle_end - shuffle_begin;
     const uint32_t gps = (uint32_t)(S / k);
@@ -1222,7 +1239,7 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
     const SeedPool perm_prefix = seed_prefix(101u /* SHUFFLE_PERMUTATION */, root_seed, (uint64_t)k);
     const SeedPool seat_prefix = seed_prefix(103u /* TOURNAMENT_PLAYER */, root_seed, (uint64_t)k);
 
-    const hipEvent_t t0 = c->ev[4], t1 = c->ev[5];
+    const hipEvent_t t0 = c->ev[SLOT_CALL], t1 = c->ev[SLOT_CALL + 1];
     HIPCHK(c, hipEventRecord(t0, c->stream));
 
     std::vector<uint16_t> perm_host;
@@ -1236,7 +1253,7 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
         rc = ensure(c, c->perm, (size_t)perm_blocks * S * slots * 2);
         if (rc) return rc;
         {
-            Timer t(c, &c->timing.perm_ms, 0);
+            Timer t(c, &c->timing.perm_ms, SLOT_PERM);
             const size_t perm_lds = (size_t)slots * S * 2;
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)perm_lds));
@@ -1244,7 +1261,6 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
                                perm_prefix, sh0, n_sh, (uint32_t)S, slots, static_cast<uint16_t *>(c->perm.p));
             t.stop();
             HIPCHK(c, hipGetLastError());
-            HIPCHK(c, t.collect());
         }
         if (perms) {
             perm_host.resize((size_t)perm_blocks * S * slots);
@@ -1345,6 +1361,7 @@ int fk_play_games(fk_ctx *c, const fk_coord *coords, int64_t n_games, const fk_s
     }
     HIPCHK(c, hipSetDevice(c->device));
     c->timing = fk_timing{};
+    c->pending.clear();
     if (n_games == 0) return FK_OK;
     int rc = upload_strategies(c, table, S);
     if (rc) return rc;
@@ -1402,6 +1419,7 @@ int fk_h2h_run(fk_ctx *c, const fk_strategy seats[2], uint64_t root_seed, uint64
     if (n_ov < 0 || (n_ov > 0 && !ov)) return fail(c, FK_ERR_ARG, "bad override list");
     HIPCHK(c, hipSetDevice(c->device));
     c->timing = fk_timing{};
+    c->pending.clear();
     uint64_t attempted = state[0], completed = state[1], safety = state[2], w1 = state[3], w2 = state[4];
     if (!(completed <= target) || !(attempted <= max_attempts) || completed + safety != attempted || w1 + w2 != completed)
         return fail(c, FK_ERR_ARG, "inconsistent block state"); // h2h_schedule.py:1366, 1422-1468
