@@ -69,8 +69,9 @@ struct SeedArgs {
     uint32_t perm_slots, S;
     const uint32_t *slow_bits; // bitmap over strategies: 1 = never banks voluntarily
     uint32_t n_sh;
-    uint32_t *sched;         // [n_games] ticket -> game id
-    uint32_t *sched_ctr;     // [2] front / back cursors
+    uint32_t *sched;         // [n_games] ticket -> game id (classes all-slow / none-slow), see the kernel
+    uint32_t *sched_mid;     // [n_games] tickets of the some-slow class
+    uint32_t *sched_ctr;     // [3] per-class cursors = class sizes once the kernel is done
 };
 
 struct PlayArgs {
@@ -81,7 +82,9 @@ struct PlayArgs {
     uint32_t perm_slots;
     const int32_t *seat_strategy; // [n_games][k] (MODE_LIST)
     const uint4 *seeds;
-    const uint32_t *sched;       // nullable: ticket -> game id (longest-first schedule)
+    const uint32_t *sched;       // nullable: ticket -> game id (longest-first schedule, see fk_seed_kernel)
+    const uint32_t *sched_mid;   // tickets of the middle class
+    const uint32_t *sched_ctr;   // [3] class sizes
     unsigned long long *tally;   // [n_batches][S][26]
     uint8_t *rows;               // nullable, [n_games] * (4 + 28k)
     uint32_t *ticket;
@@ -181,8 +184,8 @@ __global__ __launch_bounds__(PERM_BLOCK) void fk_perm_kernel(SeedPool prefix, ui
 constexpr int SEED_BLOCK = 1024;
 
 __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
-    __shared__ uint32_t wave_cnt[2][SEED_BLOCK / 64];
-    __shared__ uint32_t block_base[2];
+    __shared__ uint32_t wave_cnt[3][SEED_BLOCK / 64];
+    __shared__ uint32_t block_base[3];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = t < a.n_games;
     // Tournament mode walks the games shuffle-minor (consecutive lanes = consecutive shuffles of one game
@@ -233,24 +236,28 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
     }
     if (!a.sched) return; // uniform
     // Longest-first schedule (scheduling only: results do not depend on the order games are dealt in).
-    // Never-banking pairings fill the schedule from the front, everything else from the back; positions come
-    // from one returning atomic per block and class (a single word sustains only ~90 returning atomics/us).
-    bool all_slow = valid;
+    // Three classes by the number of seats that never bank voluntarily: all of them (the game runs to the round limit,
+    // ~13x the mean length), some (the banking seats decide the game but every turn of a never-banking seat runs to
+    // its farkle: 1.6x the mean, tail to 9x), none.  Games are dealt in that order so that the launch drains on the
+    // shortest class.  Class 0 fills `sched` from the front, class 1 (none) from the back, class 2 (some) fills
+    // `sched_mid` from the front; the game kernel reads tickets [0, n0) from sched, [n0, n0 + n2) from sched_mid and
+    // the rest from sched again (its back region starts exactly at n0 + n2).  Positions come from one returning atomic
+    // per block and class (a single word sustains only ~90 returning atomics/us).
+    uint32_t n_slow = 0;
     if (valid) {
         for (uint32_t s = 0; s < a.k; ++s) {
             const uint32_t idx = perm_at(a.perm_T, a.S, a.perm_slots, sh_local, g_local * a.k + s);
-            all_slow = all_slow && ((a.slow_bits[idx >> 5] >> (idx & 31u)) & 1u);
+            n_slow += (a.slow_bits[idx >> 5] >> (idx & 31u)) & 1u;
         }
     }
-    const uint64_t slow_m = __ballot(all_slow);
-    const uint64_t fast_m = __ballot(valid && !all_slow);
+    const uint32_t cls = (n_slow == a.k) ? 0u : (n_slow == 0u ? 1u : 2u);
+    uint64_t cls_m[3];
+    for (uint32_t cidx = 0; cidx < 3u; ++cidx) cls_m[cidx] = __ballot(valid && cls == cidx);
     const uint32_t wave = threadIdx.x >> 6;
-    if (lane_id() == 0u) {
-        wave_cnt[0][wave] = (uint32_t)__popcll(slow_m);
-        wave_cnt[1][wave] = (uint32_t)__popcll(fast_m);
-    }
+    if (lane_id() == 0u)
+        for (uint32_t cidx = 0; cidx < 3u; ++cidx) wave_cnt[cidx][wave] = (uint32_t)__popcll(cls_m[cidx]);
     __syncthreads();
-    if (threadIdx.x < 2u) {
+    if (threadIdx.x < 3u) {
         uint32_t total = 0;
         for (uint32_t w = 0; w < SEED_BLOCK / 64; ++w) {
             const uint32_t c = wave_cnt[threadIdx.x][w];
@@ -261,9 +268,10 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
     }
     __syncthreads();
     if (valid) {
-        const uint32_t pos = all_slow ? (block_base[0] + wave_cnt[0][wave] + mbcnt(slow_m))
-                                      : (a.n_games - 1u - (block_base[1] + wave_cnt[1][wave] + mbcnt(fast_m)));
-        a.sched[pos] = id;
+        const uint32_t rank = block_base[cls] + wave_cnt[cls][wave] + mbcnt(cls == 0u ? cls_m[0] : cls == 1u ? cls_m[1] : cls_m[2]);
+        if (cls == 0u) a.sched[rank] = id;
+        else if (cls == 1u) a.sched[a.n_games - 1u - rank] = id;
+        else a.sched_mid[rank] = id;
     }
 }
 
@@ -647,7 +655,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             uint32_t ticket = 0xffffffffu;
             if (rank < avail) ticket = pool_next + rank;
             else if (rank - avail < new_avail) ticket = new_base + (rank - avail);
-            if (ticket != 0xffffffffu) init_game(a.sched ? a.sched[ticket] : ticket);
+            if (ticket != 0xffffffffu) {
+                uint32_t id = ticket;
+                if (a.sched) { // classes in dealing order: all-slow (front of sched), some-slow (sched_mid), none (back of sched)
+                    const uint32_t n_all = a.sched_ctr[0], n_some = a.sched_ctr[2];
+                    id = (ticket >= n_all && ticket - n_all < n_some) ? a.sched_mid[ticket - n_all] : a.sched[ticket];
+                }
+                init_game(id);
+            }
             else st = ST_DONE;
         }
         if (n <= avail) {
@@ -1059,20 +1074,27 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
                     sa.k, plan.lds);
     int rc = ensure(c, c->seeds, (size_t)sa.n_games * sa.k * 32);
     if (rc) return rc;
-    rc = ensure(c, c->misc, 64);
+    // misc: [0] ticket counter (hammered by atomics), [16] error record, [256] schedule class sizes (read by every
+    // hand-over of the game kernel: kept off the ticket counter's cache line)
+    rc = ensure(c, c->misc, 512);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 64, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 512, c->stream));
     sa.seeds = static_cast<uint4 *>(c->seeds.p);
     if (sa.perm_T && c->longest_first) {
-        rc = ensure(c, c->order, (size_t)sa.n_games * 4);
+        rc = ensure(c, c->order, (size_t)sa.n_games * 8);
         if (rc) return rc;
         sa.sched = static_cast<uint32_t *>(c->order.p);
-        sa.sched_ctr = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(c->misc.p) + 32);
+        sa.sched_mid = sa.sched + sa.n_games;
+        sa.sched_ctr = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(c->misc.p) + 256);
         sa.slow_bits = static_cast<const uint32_t *>(c->slow.p);
         pa.sched = sa.sched;
+        pa.sched_mid = sa.sched_mid;
+        pa.sched_ctr = sa.sched_ctr;
     } else {
         sa.sched = nullptr;
         pa.sched = nullptr;
+        pa.sched_mid = nullptr;
+        pa.sched_ctr = nullptr;
     }
     {
         Timer t(c, &c->timing.seed_ms, SLOT_SEED);
