@@ -69,9 +69,9 @@ struct SeedArgs {
     uint32_t perm_slots, S;
     const uint32_t *slow_bits; // bitmap over strategies: 1 = never banks voluntarily
     uint32_t n_sh;
-    uint32_t *sched;         // [n_games] ticket -> game id (classes all-slow / none-slow), see the kernel
-    uint32_t *sched_mid;     // [n_games] tickets of the some-slow class
-    uint32_t *sched_ctr;     // [3] per-class cursors = class sizes once the kernel is done
+    uint32_t *sched;         // [n_games] ticket -> game id, in dealing order (see the kernel)
+    const uint32_t *class_ctr; // [2] games whose seats all / partly never bank (fk_class_count_kernel)
+    uint32_t *sched_ctr;     // [3] per-class cursors
 };
 
 struct PlayArgs {
@@ -82,9 +82,7 @@ struct PlayArgs {
     uint32_t perm_slots;
     const int32_t *seat_strategy; // [n_games][k] (MODE_LIST)
     const uint4 *seeds;
-    const uint32_t *sched;       // nullable: ticket -> game id (longest-first schedule, see fk_seed_kernel)
-    const uint32_t *sched_mid;   // tickets of the middle class
-    const uint32_t *sched_ctr;   // [3] class sizes
+    const uint32_t *sched;       // nullable: ticket -> game id (longest-first schedule; seeds are stored by ticket)
     unsigned long long *tally;   // [n_batches][S][26]
     uint8_t *rows;               // nullable, [n_games] * (4 + 28k)
     uint32_t *ticket;
@@ -183,6 +181,31 @@ __global__ __launch_bounds__(PERM_BLOCK) void fk_perm_kernel(SeedPool prefix, ui
 // ---------------------------------------------------------------------------------------
 constexpr int SEED_BLOCK = 1024;
 
+// Sizes of the first two schedule classes of fk_seed_kernel (games whose seats all / partly never bank): one lane per
+// game in the seed kernel's walk order (coalesced permutation reads), one atomic per block and class.
+__global__ __launch_bounds__(SEED_BLOCK) void fk_class_count_kernel(const uint16_t *perm_T, uint32_t perm_slots, uint32_t S,
+                                                                    uint32_t k, uint32_t n_sh, uint32_t n_games,
+                                                                    const uint32_t *slow_bits, uint32_t *class_ctr) {
+    __shared__ uint32_t cnt[2];
+    if (threadIdx.x < 2u) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t n_all = 0, n_some = 0; // grid-stride: few blocks, so few same-address global atomics at the end
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_games; t += gridDim.x * blockDim.x) {
+        const uint32_t g_local = t / n_sh, sh_local = t - g_local * n_sh;
+        uint32_t n_slow = 0;
+        for (uint32_t s = 0; s < k; ++s) {
+            const uint32_t idx = perm_at(perm_T, S, perm_slots, sh_local, g_local * k + s);
+            n_slow += (slow_bits[idx >> 5] >> (idx & 31u)) & 1u;
+        }
+        n_all += (n_slow == k) ? 1u : 0u;
+        n_some += (n_slow != 0u && n_slow != k) ? 1u : 0u;
+    }
+    if (n_all) atomicAdd(&cnt[0], n_all);
+    if (n_some) atomicAdd(&cnt[1], n_some);
+    __syncthreads();
+    if (threadIdx.x < 2u && cnt[threadIdx.x]) atomicAdd(&class_ctr[threadIdx.x], cnt[threadIdx.x]);
+}
+
 __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
     __shared__ uint32_t wave_cnt[3][SEED_BLOCK / 64];
     __shared__ uint32_t block_base[3];
@@ -198,6 +221,47 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
     } else if (a.gps) {
         sh_local = t / a.gps;
         g_local = t - sh_local * a.gps;
+    }
+    // Longest-first schedule (tournament mode; scheduling only: results do not depend on the order games are dealt
+    // in).  Three classes by the number of seats that never bank voluntarily: all of them (the game runs to the round
+    // limit, ~13x the mean length), some (the banking seats decide the game but every turn of a never-banking seat runs
+    // to its farkle: 1.6x the mean, tail to 9x), none.  Games are dealt in that order so that the launch drains on the
+    // shortest class.  fk_class_count_kernel has counted the first two classes, so a game's ticket is class offset + its rank
+    // in the class; ranks come from one returning atomic per block and class (a single word sustains only ~90
+    // returning atomics/us).  The seeds are stored at the TICKET position: a wave's 64 consecutive tickets then read
+    // 64 consecutive seed records whatever the class mix (stored in walk order, a sparse class dragged a full 128-B line
+    // per game through L2: 3.7 GB of HBM fetches per 10^7 games instead of 1.1).
+    uint32_t slot = t;
+    if (a.sched) {
+        uint32_t n_slow = 0;
+        if (valid) {
+            for (uint32_t s = 0; s < a.k; ++s) {
+                const uint32_t idx = perm_at(a.perm_T, a.S, a.perm_slots, sh_local, g_local * a.k + s);
+                n_slow += (a.slow_bits[idx >> 5] >> (idx & 31u)) & 1u;
+            }
+        }
+        const uint32_t cls = (n_slow == a.k) ? 0u : (n_slow != 0u ? 1u : 2u); // all / some / none
+        uint64_t cls_m[3];
+        for (uint32_t cidx = 0; cidx < 3u; ++cidx) cls_m[cidx] = __ballot(valid && cls == cidx);
+        const uint32_t wave = threadIdx.x >> 6;
+        if (lane_id() == 0u)
+            for (uint32_t cidx = 0; cidx < 3u; ++cidx) wave_cnt[cidx][wave] = (uint32_t)__popcll(cls_m[cidx]);
+        __syncthreads();
+        if (threadIdx.x < 3u) {
+            uint32_t total = 0;
+            for (uint32_t w = 0; w < SEED_BLOCK / 64; ++w) {
+                const uint32_t c = wave_cnt[threadIdx.x][w];
+                wave_cnt[threadIdx.x][w] = total; // exclusive prefix
+                total += c;
+            }
+            const uint32_t offset = threadIdx.x == 0u ? 0u : threadIdx.x == 1u ? a.class_ctr[0] : a.class_ctr[0] + a.class_ctr[1];
+            block_base[threadIdx.x] = offset + (total ? atomicAdd(&a.sched_ctr[threadIdx.x], total) : 0u);
+        }
+        __syncthreads();
+        if (valid) {
+            slot = block_base[cls] + wave_cnt[cls][wave] + mbcnt(cls == 0u ? cls_m[0] : cls == 1u ? cls_m[1] : cls_m[2]);
+            a.sched[slot] = id;
+        }
     }
     if (valid) {
         SeedPool gp;
@@ -228,50 +292,11 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
             ss_generate<8>(sp, g8);
             Rng r;
             pcg_seed(r, g8);
-            uint4 *dst = a.seeds + ((size_t)t * a.k + s); // slot = walk order (coalesced stores)
+            uint4 *dst = a.seeds + ((size_t)slot * a.k + s); // ticket position (walk order without a schedule)
             dst[0] = make_uint4((uint32_t)r.lo, (uint32_t)(r.lo >> 32), (uint32_t)r.hi, (uint32_t)(r.hi >> 32));
             dst[(size_t)a.n_games * a.k] =
                 make_uint4((uint32_t)r.inc_lo, (uint32_t)(r.inc_lo >> 32), (uint32_t)r.inc_hi, (uint32_t)(r.inc_hi >> 32));
         }
-    }
-    if (!a.sched) return; // uniform
-    // Longest-first schedule (scheduling only: results do not depend on the order games are dealt in).
-    // Three classes by the number of seats that never bank voluntarily: all of them (the game runs to the round limit,
-    // ~13x the mean length), some (the banking seats decide the game but every turn of a never-banking seat runs to
-    // its farkle: 1.6x the mean, tail to 9x), none.  Games are dealt in that order so that the launch drains on the
-    // shortest class.  Class 0 fills `sched` from the front, class 1 (none) from the back, class 2 (some) fills
-    // `sched_mid` from the front; the game kernel reads tickets [0, n0) from sched, [n0, n0 + n2) from sched_mid and
-    // the rest from sched again (its back region starts exactly at n0 + n2).  Positions come from one returning atomic
-    // per block and class (a single word sustains only ~90 returning atomics/us).
-    uint32_t n_slow = 0;
-    if (valid) {
-        for (uint32_t s = 0; s < a.k; ++s) {
-            const uint32_t idx = perm_at(a.perm_T, a.S, a.perm_slots, sh_local, g_local * a.k + s);
-            n_slow += (a.slow_bits[idx >> 5] >> (idx & 31u)) & 1u;
-        }
-    }
-    const uint32_t cls = (n_slow == a.k) ? 0u : (n_slow == 0u ? 1u : 2u);
-    uint64_t cls_m[3];
-    for (uint32_t cidx = 0; cidx < 3u; ++cidx) cls_m[cidx] = __ballot(valid && cls == cidx);
-    const uint32_t wave = threadIdx.x >> 6;
-    if (lane_id() == 0u)
-        for (uint32_t cidx = 0; cidx < 3u; ++cidx) wave_cnt[cidx][wave] = (uint32_t)__popcll(cls_m[cidx]);
-    __syncthreads();
-    if (threadIdx.x < 3u) {
-        uint32_t total = 0;
-        for (uint32_t w = 0; w < SEED_BLOCK / 64; ++w) {
-            const uint32_t c = wave_cnt[threadIdx.x][w];
-            wave_cnt[threadIdx.x][w] = total; // exclusive prefix
-            total += c;
-        }
-        block_base[threadIdx.x] = total ? atomicAdd(&a.sched_ctr[threadIdx.x], total) : 0u;
-    }
-    __syncthreads();
-    if (valid) {
-        const uint32_t rank = block_base[cls] + wave_cnt[cls][wave] + mbcnt(cls == 0u ? cls_m[0] : cls == 1u ? cls_m[1] : cls_m[2]);
-        if (cls == 0u) a.sched[rank] = id;
-        else if (cls == 1u) a.sched[a.n_games - 1u - rank] = id;
-        else a.sched_mid[rank] = id;
     }
 }
 
@@ -502,13 +527,15 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     };
 
     // ---- fresh game for this lane ----
-    auto init_game = [&](uint32_t id) {
+    auto init_game = [&](uint32_t id, uint32_t ticket) {
         game_id = id;
         max_rounds = a.max_rounds;
         for (uint32_t i = 0; i < a.n_ov; ++i)
             if (a.ov[i].game == id) max_rounds = a.ov[i].max_rounds;
-        uint32_t slot = id; // seeds are stored in the seed kernel's walk order (shuffle-minor in tournament mode)
-        if (a.mode == MODE_PERM) {
+        // seed records sit at the ticket position when there is a schedule, else in the seed kernel's walk order
+        // (shuffle-minor in tournament mode)
+        uint32_t slot = a.sched ? ticket : id;
+        if (!a.sched && a.mode == MODE_PERM) {
             const uint32_t sh = id / a.gps, g = id - sh * a.gps;
             slot = g * a.n_sh + sh;
         }
@@ -655,14 +682,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             uint32_t ticket = 0xffffffffu;
             if (rank < avail) ticket = pool_next + rank;
             else if (rank - avail < new_avail) ticket = new_base + (rank - avail);
-            if (ticket != 0xffffffffu) {
-                uint32_t id = ticket;
-                if (a.sched) { // classes in dealing order: all-slow (front of sched), some-slow (sched_mid), none (back of sched)
-                    const uint32_t n_all = a.sched_ctr[0], n_some = a.sched_ctr[2];
-                    id = (ticket >= n_all && ticket - n_all < n_some) ? a.sched_mid[ticket - n_all] : a.sched[ticket];
-                }
-                init_game(id);
-            }
+            if (ticket != 0xffffffffu) init_game(a.sched ? a.sched[ticket] : ticket, ticket);
             else st = ST_DONE;
         }
         if (n <= avail) {
@@ -814,7 +834,7 @@ struct fk_ctx {
         hipEvent_t a, b;
     };
     std::vector<PendingTimer> pending; // kernel timers recorded on the stream, read after the chunk's one sync
-    DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, score_lut, discard_lut, dbg[6];
+    DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, score_lut, discard_lut, classes, dbg[6];
     int32_t longest_first = 1;
     int32_t blocks_per_cu = 0; // 0 = as many as fit
     int32_t lean = -1;         // -1 auto, 0 full 17-dword seat records, 1 lean 11-dword records
@@ -1074,30 +1094,32 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
                     sa.k, plan.lds);
     int rc = ensure(c, c->seeds, (size_t)sa.n_games * sa.k * 32);
     if (rc) return rc;
-    // misc: [0] ticket counter (hammered by atomics), [16] error record, [256] schedule class sizes (read by every
-    // hand-over of the game kernel: kept off the ticket counter's cache line)
+    // misc: [0] ticket counter (hammered by atomics), [16] error record, [256] schedule class cursors of the seed kernel
     rc = ensure(c, c->misc, 512);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 512, c->stream));
     sa.seeds = static_cast<uint4 *>(c->seeds.p);
     if (sa.perm_T && c->longest_first) {
-        rc = ensure(c, c->order, (size_t)sa.n_games * 8);
+        rc = ensure(c, c->order, (size_t)sa.n_games * 4);
         if (rc) return rc;
         sa.sched = static_cast<uint32_t *>(c->order.p);
-        sa.sched_mid = sa.sched + sa.n_games;
         sa.sched_ctr = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(c->misc.p) + 256);
+        rc = ensure(c, c->classes, 64);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(c->classes.p, 0, 64, c->stream));
+        sa.class_ctr = static_cast<const uint32_t *>(c->classes.p);
         sa.slow_bits = static_cast<const uint32_t *>(c->slow.p);
         pa.sched = sa.sched;
-        pa.sched_mid = sa.sched_mid;
-        pa.sched_ctr = sa.sched_ctr;
     } else {
         sa.sched = nullptr;
         pa.sched = nullptr;
-        pa.sched_mid = nullptr;
-        pa.sched_ctr = nullptr;
     }
     {
         Timer t(c, &c->timing.seed_ms, SLOT_SEED);
+        if (sa.sched) // class sizes first: a game's ticket is class offset + rank
+            hipLaunchKernelGGL(fk_class_count_kernel, dim3(std::min<uint32_t>((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK, 1024u)), dim3(SEED_BLOCK), 0,
+                               c->stream, sa.perm_T, sa.perm_slots, sa.S, sa.k, sa.n_sh, sa.n_games, sa.slow_bits,
+                               static_cast<uint32_t *>(c->classes.p));
         hipLaunchKernelGGL(fk_seed_kernel, dim3((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK), dim3(SEED_BLOCK), 0, c->stream, sa);
         t.stop();
         HIPCHK(c, hipGetLastError());
@@ -1175,7 +1197,7 @@ void fk_destroy(fk_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->strat, &c->perm, &c->seeds, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist, &c->coords, &c->order, &c->slow, &c->score_lut, &c->discard_lut})
+    for (DevBuf *b : {&c->strat, &c->perm, &c->seeds, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist, &c->coords, &c->order, &c->slow, &c->score_lut, &c->discard_lut, &c->classes})
         release(*b);
     for (auto &b : c->dbg) release(b);
     for (auto &e : c->ev)
