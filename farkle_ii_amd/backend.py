@@ -83,7 +83,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
 
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
-            "fk_tournament_run", "fk_play_games", "fk_h2h_run", "fk_debug_score", "fk_debug_should_continue",
+            "fk_tournament_run", "fk_play_games", "fk_h2h_run", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
             "fk_debug_dice", "fk_debug_dice_state"]
 _lib = None
 
@@ -231,6 +231,15 @@ class Engine:
                                          C.c_uint64(target), C.c_uint64(max_attempts), C.c_uint64(chunk_games),
                                          C.c_int32(target_score), C.c_int32(max_rounds), _p(ov), C.c_int32(len(ov)), _p(st)))
         return st
+
+    def coordinate_seeds(self, coords: np.ndarray, want32: bool = True, want64: bool = False):
+        """SeedSequence fingerprints of whole coordinates (``coordinate_seed``, utils/random.py:190-232)."""
+        coords = np.ascontiguousarray(coords, dtype=COORD_DTYPE)
+        n = len(coords)
+        s32 = np.zeros(n, dtype=np.uint32) if want32 else None
+        s64 = np.zeros(n, dtype=np.uint64) if want64 else None
+        self._check(self._lib.fk_coordinate_seeds(self._ctx, C.c_int64(n), _p(coords), _p(s32), _p(s64)))
+        return s32, s64
 
     # -- single-op probes ------------------------------------------------------------------
     def debug_score(self, faces: np.ndarray, lens, pre, strategies: np.ndarray) -> np.ndarray:

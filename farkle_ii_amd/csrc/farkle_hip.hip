@@ -761,6 +761,28 @@ __global__ void fk_dbg_score_kernel(int64_t n, const uint8_t *faces, const int32
     out[i * 5 + 4] = r.d1;
 }
 
+// SeedSequence fingerprints of whole coordinates: generate_state(1, uint32)[0] and generate_state(1, uint64)[0]
+// (utils/random.py:190-232; the ns-100 shuffle_seed and ns-102 game_seed columns of the row contract, the ns-1 seed of
+// simulate_many_games).  All 18 entropy words are absorbed, including seat_index and replicate_index of the record.
+__global__ void fk_coordinate_seed_kernel(int64_t n, const fk_coord *coords, uint32_t *out32, uint64_t *out64) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fk_coord c = coords[i];
+    SeedPool p;
+    ss_begin(p, 2u, c.purpose, (uint32_t)c.root_seed, (uint32_t)(c.root_seed >> 32));
+    ss_absorb64(p, c.k);
+    ss_absorb64(p, c.shuffle_index);
+    ss_absorb64(p, c.pair_id);
+    ss_absorb64(p, c.order);
+    ss_absorb64(p, c.game_index);
+    ss_absorb64(p, c.seat_index);
+    ss_absorb64(p, c.replicate_index);
+    uint32_t w[2];
+    ss_generate<2>(p, w);
+    if (out32) out32[i] = w[0];
+    if (out64) out64[i] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+}
+
 __global__ void fk_dbg_continue_kernel(int64_t n, const int32_t *args, const uint2 *strat, int32_t *out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1644,6 +1666,25 @@ static int debug_dice_common(fk_ctx *c, int64_t n, const fk_coord *coords, const
     if (total) HIPCHK(c, hipMemcpyAsync(faces, c->dbg[2].p, (size_t)n * total, hipMemcpyDeviceToHost, c->stream));
     if (raw64) HIPCHK(c, hipMemcpyAsync(raw64, c->dbg[3].p, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
     if (state_out) HIPCHK(c, hipMemcpyAsync(state_out, c->dbg[4].p, (size_t)n * 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FK_OK;
+}
+
+int fk_coordinate_seeds(fk_ctx *c, int64_t n, const fk_coord *coords, uint32_t *seed32, uint64_t *seed64) {
+    if (!c || n < 0 || !coords || (!seed32 && !seed64)) return c ? fail(c, FK_ERR_ARG, "bad arguments") : FK_ERR_ARG;
+    if (n == 0) return FK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure(c, c->coords, sizeof(fk_coord) * (size_t)n);
+    if (rc) return rc;
+    if ((rc = ensure(c, c->dbg[0], (size_t)n * 4))) return rc;
+    if ((rc = ensure(c, c->dbg[1], (size_t)n * 8))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->coords.p, coords, sizeof(fk_coord) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(fk_coordinate_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n,
+                       static_cast<const fk_coord *>(c->coords.p), seed32 ? static_cast<uint32_t *>(c->dbg[0].p) : nullptr,
+                       seed64 ? static_cast<uint64_t *>(c->dbg[1].p) : nullptr);
+    HIPCHK(c, hipGetLastError());
+    if (seed32) HIPCHK(c, hipMemcpyAsync(seed32, c->dbg[0].p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (seed64) HIPCHK(c, hipMemcpyAsync(seed64, c->dbg[1].p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FK_OK;
 }

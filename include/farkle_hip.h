@@ -12,6 +12,7 @@
  *                          :658-722, _measure_throughput run_tournament.py:593-619)
  *   fk_h2h_run         <-  _simulate_block_from_manifest attempt loop (the BlockRunner contract)
  *                          src/farkle/analysis/h2h_schedule.py:1149-1243, 1521
+ *   fk_coordinate_seeds <- coordinate_seed (src/farkle/utils/random.py:190-232)
  *   fk_debug_*         <-  FarklePlayer._roll (src/farkle/game/engine.py:85-101) and
  *                          default_score / decide (src/farkle/game/scoring.py:618-693,
  *                          src/farkle/simulation/strategies.py:212-275): single-op probes of the
@@ -144,6 +145,13 @@ int fk_play_games(fk_ctx *ctx, const fk_coord *coords, int64_t n_games, const fk
 int fk_h2h_run(fk_ctx *ctx, const fk_strategy seats[2], uint64_t root_seed, uint64_t pair_id, uint32_t order,
                uint64_t target, uint64_t max_attempts, uint64_t chunk_games, int32_t target_score,
                int32_t max_rounds, const fk_override *ov, int32_t n_ov, uint64_t state[5]);
+
+/* SeedSequence fingerprints of n coordinates (all nine coordinate words of the record, seat_index included):
+ * seed32[i] = generate_state(1, uint32)[0], seed64[i] = generate_state(1, uint64)[0]; either may be NULL.
+ * Replaces coordinate_seed (src/farkle/utils/random.py:190-232): the shuffle_seed (namespace 100) and game_seed
+ * (namespace 102) columns of rows and manifests (run_tournament.py:318-351), the per-game seed of
+ * simulate_many_games (namespace 1, simulation.py:700-713). */
+int fk_coordinate_seeds(fk_ctx *ctx, int64_t n, const fk_coord *coords, uint32_t *seed32, uint64_t *seed64);
 
 /* ---- single-op probes of the device functions (parity tests) ---- */
 /* n rolls: roll i scores faces[i*6 .. i*6+len[i]) for strategy[i] with turn_score_pre[i];

@@ -86,6 +86,33 @@ def test_dice_match_oracle_random_coordinates(eng, po):
         assert np.array_equal(po.stream64(c, 4), raw[i])
 
 
+def test_coordinate_seeds_match_golden_oracle_and_host(eng, po):
+    """fk_coordinate_seeds = coordinate_seed (utils/random.py:190-232): NumPy-generated goldens, the oracle on random
+    coordinates of every purpose namespace (replicate_index included) and the host's vectorised fingerprints."""
+    from farkle_ii_amd import random as urandom
+
+    data = gu.load("rng_vectors.json")
+    gold = _coords([(c["purpose"], 0, c["root_seed"], c["k"], c["shuffle_index"], c["pair_id"], c["order"], c["game_index"],
+                     c["seat_index"], 0) for c in data["cases"]])
+    s32, s64 = eng.coordinate_seeds(gold, want32=True, want64=True)
+    assert s32.tolist() == [c["seed32"] for c in data["cases"]] and s64.tolist() == [c["seed64"] for c in data["cases"]]
+    rs = np.random.default_rng(5)
+    n = 2000
+    items = [(int(rs.choice([1, 10, 11, 100, 101, 102, 103, 202, 203])), 0, int(rs.integers(0, 2**63)), int(rs.integers(0, 13)),
+              int(rs.integers(0, 2**40)), int(rs.integers(0, 4000)), int(rs.integers(0, 2)), int(rs.integers(0, 2**34)),
+              int(rs.integers(0, 12)), int(rs.integers(0, 3))) for _ in range(n)]
+    s32, s64 = eng.coordinate_seeds(_coords(items), want32=True, want64=True)
+    for i in range(0, n, 5):
+        c = po.coord(items[i][0], *items[i][2:10])
+        assert po.coordinate_seed32(c) == s32[i] and po.coordinate_seed64(c) == s64[i], items[i]
+    # the game_seed column of a shuffle's rows (namespace 102), as the host computes it for row shards
+    idx = np.arange(500, dtype=np.uint64)
+    host = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=42, k=2, shuffle_index=17, game_index=idx,
+                                    dtype=np.uint32)
+    dev, _ = eng.coordinate_seeds(_coords([(102, 0, 42, 2, 17, 0, 0, int(g), 0, 0) for g in idx]))
+    assert np.array_equal(host, dev)
+
+
 def _state_with_output(out64: int, lo: int) -> tuple[int, int]:
     """Invert the DXSM output function: a (hi, lo) state whose next 64-bit output is ``out64``."""
     M = 0xDA942042E4DD58B5
