@@ -865,7 +865,7 @@ struct fk_ctx {
     uint32_t table_mixed_flags = 0xff00u; // ... and the flag bits that differ between its strategies
     int32_t waves_per_cu = 16; // resident-wave target used to size the grid
     int64_t chunk_bytes = (int64_t)24 << 30;
-    int32_t batch_threshold = 6;
+    int32_t batch_threshold = 8;
     int32_t use_lds_tally = -1;
     int32_t block = 0;
 };

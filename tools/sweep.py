@@ -19,7 +19,7 @@ def run(label):
     print(f"{label:40s} play {min(ts):8.3f} ms  block {t['play_block']} grid {t['play_grid']} lds {t['play_lds_bytes']}", flush=True)
 for thr in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
     eng.set_option("batch_threshold", thr); run(f"threshold {thr}")
-eng.set_option("batch_threshold", 6)
+eng.set_option("batch_threshold", 8)
 for blk in (1024, 512, 256):
     eng.set_option("block", blk); run(f"block {blk} lds-tally")
 eng.set_option("use_lds_tally", 0)
