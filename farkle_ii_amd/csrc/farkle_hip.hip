@@ -124,16 +124,18 @@ int upload_strategies(fk_ctx *c, const fk_strategy *s, int32_t S) {
     }
     c->table_mixed_flags = f_or & ~f_and;
     c->table_flags = f_and;
-    // Strategies that never bank voluntarily outside the final round: should_continue's threshold term is
-    // always true iff dice are considered with dice_threshold < 1 (dice_left >= 1 always exceeds it) and the
-    // score threshold cannot veto (require_both, or score not considered).  Used for scheduling only.
-    std::vector<uint32_t> slow(((size_t)S + 31) / 32, 0u);
+    // Patience of a strategy, for the longest-first schedule only (fk_kernels.h, schedule_class).  It never banks
+    // voluntarily outside the final round (3) iff should_continue's threshold term is always true: dice are considered
+    // with dice_threshold < 1 (dice_left >= 1 always exceeds it) and the score threshold cannot veto (require_both, or
+    // score not considered).  With the same "either condition keeps rolling" rule and dice_threshold 1 / 2 it rolls
+    // down to one / two dice before it may bank (2 / 1).
+    std::vector<uint8_t> patience((size_t)S, 0);
     for (int32_t i = 0; i < S; ++i)
-        if (s[i].consider_dice && s[i].dice_threshold < 1 && (s[i].require_both || !s[i].consider_score))
-            slow[(size_t)i >> 5] |= 1u << (i & 31);
-    rc = ensure(c, c->slow, slow.size() * 4);
+        if (s[i].consider_dice && (s[i].require_both || !s[i].consider_score))
+            patience[(size_t)i] = s[i].dice_threshold < 1 ? 3 : s[i].dice_threshold == 1 ? 2 : s[i].dice_threshold == 2 ? 1 : 0;
+    rc = ensure(c, c->slow, patience.size());
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->slow.p, slow.data(), slow.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->slow.p, patience.data(), patience.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream)); // host vectors go out of scope
     return FK_OK;
 }
@@ -309,7 +311,7 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
         if (rc) return rc;
         HIPCHK(c, hipMemsetAsync(c->classes.p, 0, 64, c->stream));
         sa.class_ctr = static_cast<const uint32_t *>(c->classes.p);
-        sa.slow_bits = static_cast<const uint32_t *>(c->slow.p);
+        sa.patience = static_cast<const uint8_t *>(c->slow.p);
         pa.sched = sa.sched;
     } else {
         sa.sched = nullptr;
@@ -319,7 +321,7 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
         Timer t(c, &c->timing.seed_ms, SLOT_SEED);
         if (sa.sched) // class sizes first: a game's ticket is class offset + rank
             hipLaunchKernelGGL(fk_class_count_kernel, dim3(std::min<uint32_t>((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK, 1024u)), dim3(SEED_BLOCK), 0,
-                               c->stream, sa.perm_T, sa.perm_slots, sa.S, sa.k, sa.n_sh, sa.n_games, sa.slow_bits,
+                               c->stream, sa.perm_T, sa.perm_slots, sa.S, sa.k, sa.n_sh, sa.n_games, sa.patience,
                                static_cast<uint32_t *>(c->classes.p));
         hipLaunchKernelGGL(fk_seed_kernel, dim3((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK), dim3(SEED_BLOCK), 0, c->stream, sa);
         t.stop();

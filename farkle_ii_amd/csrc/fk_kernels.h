@@ -60,11 +60,11 @@ struct SeedArgs {
     // limit (~13x the mean length); they are dealt first so that they do not form the tail of a wave.
     const uint16_t *perm_T;  // nullable; blocked layout, see perm_at()
     uint32_t perm_slots, S;
-    const uint32_t *slow_bits; // bitmap over strategies: 1 = never banks voluntarily
+    const uint8_t *patience;   // per strategy: 3 = never banks voluntarily ... 0 = banks readily (scheduling only)
     uint32_t n_sh;
     uint32_t *sched;         // [n_games] ticket -> game id, in dealing order (see the kernel)
-    const uint32_t *class_ctr; // [2] games whose seats all / partly never bank (fk_class_count_kernel)
-    uint32_t *sched_ctr;     // [3] per-class cursors
+    const uint32_t *class_ctr; // [SCHED_CLASSES] class sizes (fk_class_count_kernel)
+    uint32_t *sched_ctr;     // [SCHED_CLASSES] per-class cursors
 };
 
 struct PlayArgs {
@@ -174,34 +174,52 @@ __global__ __launch_bounds__(PERM_BLOCK) void fk_perm_kernel(SeedPool prefix, ui
 // ---------------------------------------------------------------------------------------
 constexpr int SEED_BLOCK = 1024;
 
-// Sizes of the first two schedule classes of fk_seed_kernel (games whose seats all / partly never bank): one lane per
-// game in the seed kernel's walk order (coalesced permutation reads), one atomic per block and class.
+// Longest-first schedule classes (scheduling only: results do not depend on the order games are dealt in).
+// A strategy's patience is 3 if it never banks voluntarily (its games against other such seats run to the round
+// limit, ~13x the mean length), 2 / 1 if it rolls on until one / two dice are left unless BOTH of its conditions say
+// bank (long turns, many farkles: 1.6x / 1.2x the mean game length on the reference grid), else 0.  A game's class is 0
+// when every seat has patience 3, otherwise 7 - min(sum of patience, 6): class 0 is dealt first, class 7 last, so the
+// launch drains on the games that are shortest in expectation.
+constexpr uint32_t SCHED_CLASSES = 8;
+
+__device__ inline uint32_t schedule_class(const uint16_t *perm_T, uint32_t perm_slots, uint32_t S, uint32_t k,
+                                          const uint8_t *patience, uint32_t sh_local, uint32_t g_local) {
+    uint32_t sum = 0, n_never = 0;
+    for (uint32_t s = 0; s < k; ++s) {
+        const uint32_t p = patience[perm_at(perm_T, S, perm_slots, sh_local, g_local * k + s)];
+        sum += p;
+        n_never += (p == 3u) ? 1u : 0u;
+    }
+    return n_never == k ? 0u : (SCHED_CLASSES - 1u) - min(sum, SCHED_CLASSES - 2u);
+}
+
+// Class sizes: one lane per game in the seed kernel's walk order (coalesced permutation reads), grid-stride so that few
+// blocks add to the same global words at the end.
 __global__ __launch_bounds__(SEED_BLOCK) void fk_class_count_kernel(const uint16_t *perm_T, uint32_t perm_slots, uint32_t S,
                                                                     uint32_t k, uint32_t n_sh, uint32_t n_games,
-                                                                    const uint32_t *slow_bits, uint32_t *class_ctr) {
-    __shared__ uint32_t cnt[2];
-    if (threadIdx.x < 2u) cnt[threadIdx.x] = 0u;
+                                                                    const uint8_t *patience, uint32_t *class_ctr) {
+    __shared__ uint32_t cnt[SCHED_CLASSES];
+    if (threadIdx.x < SCHED_CLASSES) cnt[threadIdx.x] = 0u;
     __syncthreads();
-    uint32_t n_all = 0, n_some = 0; // grid-stride: few blocks, so few same-address global atomics at the end
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_games; t += gridDim.x * blockDim.x) {
-        const uint32_t g_local = t / n_sh, sh_local = t - g_local * n_sh;
-        uint32_t n_slow = 0;
-        for (uint32_t s = 0; s < k; ++s) {
-            const uint32_t idx = perm_at(perm_T, S, perm_slots, sh_local, g_local * k + s);
-            n_slow += (slow_bits[idx >> 5] >> (idx & 31u)) & 1u;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n_games; base += gridDim.x * blockDim.x) { // wave-uniform trip count
+        const uint32_t t = base + threadIdx.x;
+        uint32_t cls = SCHED_CLASSES;
+        if (t < n_games) {
+            const uint32_t g_local = t / n_sh, sh_local = t - g_local * n_sh;
+            cls = schedule_class(perm_T, perm_slots, S, k, patience, sh_local, g_local);
         }
-        n_all += (n_slow == k) ? 1u : 0u;
-        n_some += (n_slow != 0u && n_slow != k) ? 1u : 0u;
+        for (uint32_t cidx = 0; cidx < SCHED_CLASSES; ++cidx) {
+            const uint64_t m = __ballot(cls == cidx);
+            if (m && lane_id() == 0u) atomicAdd(&cnt[cidx], (uint32_t)__popcll(m));
+        }
     }
-    if (n_all) atomicAdd(&cnt[0], n_all);
-    if (n_some) atomicAdd(&cnt[1], n_some);
     __syncthreads();
-    if (threadIdx.x < 2u && cnt[threadIdx.x]) atomicAdd(&class_ctr[threadIdx.x], cnt[threadIdx.x]);
+    if (threadIdx.x < SCHED_CLASSES && cnt[threadIdx.x]) atomicAdd(&class_ctr[threadIdx.x], cnt[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
-    __shared__ uint32_t wave_cnt[3][SEED_BLOCK / 64];
-    __shared__ uint32_t block_base[3];
+    __shared__ uint32_t wave_cnt[SCHED_CLASSES][SEED_BLOCK / 64];
+    __shared__ uint32_t block_base[SCHED_CLASSES];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = t < a.n_games;
     // Tournament mode walks the games shuffle-minor (consecutive lanes = consecutive shuffles of one game
@@ -215,44 +233,36 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
         sh_local = t / a.gps;
         g_local = t - sh_local * a.gps;
     }
-    // Longest-first schedule (tournament mode; scheduling only: results do not depend on the order games are dealt
-    // in).  Three classes by the number of seats that never bank voluntarily: all of them (the game runs to the round
-    // limit, ~13x the mean length), some (the banking seats decide the game but every turn of a never-banking seat runs
-    // to its farkle: 1.6x the mean, tail to 9x), none.  Games are dealt in that order so that the launch drains on the
-    // shortest class.  fk_class_count_kernel has counted the first two classes, so a game's ticket is class offset + its rank
-    // in the class; ranks come from one returning atomic per block and class (a single word sustains only ~90
-    // returning atomics/us).  The seeds are stored at the TICKET position: a wave's 64 consecutive tickets then read
-    // 64 consecutive seed records whatever the class mix (stored in walk order, a sparse class dragged a full 128-B line
-    // per game through L2: 3.7 GB of HBM fetches per 10^7 games instead of 1.1).
+    // Longest-first schedule (tournament mode; classes above).  fk_class_count_kernel has sized the classes, so a game's
+    // ticket is class offset + its rank in the class; ranks come from one returning atomic per block and class (a single
+    // word sustains only ~90 returning atomics/us).  The seeds are stored at the TICKET position: a wave's 64
+    // consecutive tickets then read 64 consecutive seed records whatever the class mix (stored in walk order, a sparse
+    // class dragged a full 128-B line per game through L2: 3.7 GB of HBM fetches per 10^7 games instead of 0.5).
     uint32_t slot = t;
     if (a.sched) {
-        uint32_t n_slow = 0;
-        if (valid) {
-            for (uint32_t s = 0; s < a.k; ++s) {
-                const uint32_t idx = perm_at(a.perm_T, a.S, a.perm_slots, sh_local, g_local * a.k + s);
-                n_slow += (a.slow_bits[idx >> 5] >> (idx & 31u)) & 1u;
-            }
-        }
-        const uint32_t cls = (n_slow == a.k) ? 0u : (n_slow != 0u ? 1u : 2u); // all / some / none
-        uint64_t cls_m[3];
-        for (uint32_t cidx = 0; cidx < 3u; ++cidx) cls_m[cidx] = __ballot(valid && cls == cidx);
+        const uint32_t cls = valid ? schedule_class(a.perm_T, a.perm_slots, a.S, a.k, a.patience, sh_local, g_local) : SCHED_CLASSES;
         const uint32_t wave = threadIdx.x >> 6;
-        if (lane_id() == 0u)
-            for (uint32_t cidx = 0; cidx < 3u; ++cidx) wave_cnt[cidx][wave] = (uint32_t)__popcll(cls_m[cidx]);
+        uint64_t mine_m = 0;
+        for (uint32_t cidx = 0; cidx < SCHED_CLASSES; ++cidx) {
+            const uint64_t m = __ballot(cls == cidx);
+            if (cls == cidx) mine_m = m;
+            if (lane_id() == 0u) wave_cnt[cidx][wave] = (uint32_t)__popcll(m);
+        }
         __syncthreads();
-        if (threadIdx.x < 3u) {
+        if (threadIdx.x < SCHED_CLASSES) {
             uint32_t total = 0;
             for (uint32_t w = 0; w < SEED_BLOCK / 64; ++w) {
                 const uint32_t c = wave_cnt[threadIdx.x][w];
                 wave_cnt[threadIdx.x][w] = total; // exclusive prefix
                 total += c;
             }
-            const uint32_t offset = threadIdx.x == 0u ? 0u : threadIdx.x == 1u ? a.class_ctr[0] : a.class_ctr[0] + a.class_ctr[1];
+            uint32_t offset = 0;
+            for (uint32_t cidx = 0; cidx < threadIdx.x; ++cidx) offset += a.class_ctr[cidx];
             block_base[threadIdx.x] = offset + (total ? atomicAdd(&a.sched_ctr[threadIdx.x], total) : 0u);
         }
         __syncthreads();
         if (valid) {
-            slot = block_base[cls] + wave_cnt[cls][wave] + mbcnt(cls == 0u ? cls_m[0] : cls == 1u ? cls_m[1] : cls_m[2]);
+            slot = block_base[cls] + wave_cnt[cls][wave] + mbcnt(mine_m);
             a.sched[slot] = id;
         }
     }
