@@ -178,9 +178,9 @@ constexpr int SEED_BLOCK = 1024;
 // A strategy's patience is 3 if it never banks voluntarily (its games against other such seats run to the round
 // limit, ~13x the mean length), 2 / 1 if it rolls on until one / two dice are left unless BOTH of its conditions say
 // bank (long turns, many farkles: 1.6x / 1.2x the mean game length on the reference grid), else 0.  A game's class is 0
-// when every seat has patience 3, otherwise 7 - min(sum of patience, 6): class 0 is dealt first, class 7 last, so the
+// when every seat has patience 3, otherwise 15 - min(sum of patience, 14): class 0 is dealt first, class 15 last, so the
 // launch drains on the games that are shortest in expectation.
-constexpr uint32_t SCHED_CLASSES = 8;
+constexpr uint32_t SCHED_CLASSES = 16;
 
 __device__ inline uint32_t schedule_class(const uint16_t *perm_T, uint32_t perm_slots, uint32_t S, uint32_t k,
                                           const uint8_t *patience, uint32_t sh_local, uint32_t g_local) {
