@@ -1,25 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — simulated Farkle games/sec on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {2,3,4,5}]
 
-A "step" is one pass of the hot path over one batch of synthetic input: at N=1 the workload is
-BASELINE.json configs[1] — k=2, the 64-strategy grid, 10^7 games (312 500 shuffles x 32 games),
-root seed 42, counts-only tallies ([S][26] int64 resident in HBM).  For N>1 (one rank per GPU,
-launched by torch.distributed.run) every rank plays its own range of 312 500 shuffles per step
-(weak scaling: the shuffle space is partitioned, no data-path collective); ranks add their step tallies locally
-and ONE RCCL reduce of the [S][26] int64 tally to rank 0 at the end of the job, inside the timed region, plays the
-role of OutcomeCounter.absorb (run_tournament.py:197-213).
+A "step" is one pass of the hot path over one batch of synthetic input.  `--config` picks the BASELINE.json workload
+(default 2 = configs[1], the configuration the metric is quoted on):
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (fk_play_kernel): the path is
-integer VALU work, so the bound is the vector-ALU issue roof, not HBM or MFMA; `cpu_baseline` is the
-CPU oracle (a C port of the reference's algorithm, test infrastructure) timed on the host's cores.
+  2  k=2, 64-strategy grid, 10^7 games per GPU per step (312 500 shuffles x 32 games), root seed 42, counts-only
+  3  k=4, default 5 160-strategy grid, 10^8 games per GPU per step (77 520 shuffles x 1 290 games), root seed 0
+  4  k in {2,4,6,8} on the 5 160 grid, 2.5*10^8 games per k per step (10^9 in all), every k's shuffle range split over
+     the ranks (strong scaling), one tally reduce per k
+  5  H2H: all 66 pairs of 12 candidate strategies x orders {0,1}, 10^8 completed games per pair, blocks dealt over
+     the ranks, one reduce of the block results
+
+One process per GPU.  Under `torch.distributed.run` the ranks come from the environment; WITHOUT it, `--gpus N` (N > 1)
+makes this process start N rank processes itself — before anything here touches the GPU — and wait for them (the
+reference's scaling table is likewise one command per worker count, run_tournament.py:1576-1586).  Ranks add their step
+tallies locally and ONE int64 SUM reduce of the tally to rank 0 at the end of the job (RCCL over xGMI), inside the timed
+region, plays the role of OutcomeCounter.absorb (run_tournament.py:197-213).
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (fk_play_kernel): the path is integer VALU work,
+so the bound is the vector-ALU issue roof, not HBM or MFMA; `cpu_baseline` is the CPU oracle (a C port of the
+reference's algorithm, test infrastructure) timed on the host's cores on a bounded sample of the same workload.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -32,6 +42,7 @@ sys.path.insert(0, str(ROOT))
 SHUFFLES_PER_STEP = 312_500  # x 32 games = 10^7 games (BASELINE.json configs[1])
 ROOT_SEED = 42
 K = 2
+METRIC = "simulated games/sec (whole node) at k=2, fixed strategy-grid size"
 
 
 def grid64():
@@ -45,6 +56,17 @@ def grid64():
     return table
 
 
+def grid5160():
+    from farkle_ii_amd.strategies import STRATEGY_DTYPE, default_grid_tuples
+
+    tuples = default_grid_tuples()
+    table = np.zeros(len(tuples), dtype=STRATEGY_DTYPE)
+    for i, t in enumerate(tuples):
+        table[i] = tuple(t)
+    assert len(table) == 5160
+    return table
+
+
 def work_per_game(rows: np.ndarray, k: int) -> dict:
     """W(game) = 229*R + 30*T + 850*k int32 lane-ops, R = sum of seat rolls, T = sum of seat turns."""
     R = rows["seats"]["rolls"].astype(np.int64).sum(axis=1)
@@ -53,44 +75,333 @@ def work_per_game(rows: np.ndarray, k: int) -> dict:
     return {"rolls_per_game": float(R.mean()), "turns_per_game": float(T.mean()), "ops_per_game": float(W.mean())}
 
 
-def cpu_baseline(table: np.ndarray, seconds_target: float = 12.0) -> dict:
-    """Time the CPU oracle (checker, never the product) on a bounded sample of the same workload."""
+def add_timing(acc: dict, t: dict) -> dict:
+    """Accumulate fk_timing records (HIP events on the engine's stream) over the engine calls of a step."""
+    for key in ("play_ms", "seed_ms", "perm_ms", "play_launches", "games"):
+        acc[key] = acc.get(key, 0) + t.get(key, 0)
+    for key in ("play_block", "play_grid", "play_lds_bytes"):
+        acc[key] = t.get(key)
+    return acc
+
+
+def _oracle():
     sys.path.insert(0, str(ROOT / "oracle"))
     import pyoracle as po
 
+    return po
+
+
+def _cpu_threads() -> int:
     # a 1-GPU box gives this job a 16-core CPU share however many hardware threads the host shows
-    threads = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("FK_CPU_THREADS", "16"))))
-    t = table.view(po.STRATEGY_DTYPE)
-    po.tournament(t, K, ROOT_SEED, 0, 64, n_threads=threads)  # warm the thread pool
-    t0 = time.perf_counter()
-    po.tournament(t, K, ROOT_SEED, 0, 400, n_threads=threads)
-    rate = 400 * 32 / (time.perf_counter() - t0)
-    n_sh = int(max(400, min(SHUFFLES_PER_STEP, rate * seconds_target / 32)))
-    t0 = time.perf_counter()
-    res = po.tournament(t, K, ROOT_SEED, 0, n_sh, n_threads=threads)
-    dt = time.perf_counter() - t0
-    # the same oracle on ONE core (SURVEY section 8d asks for both): first shuffles of the workload, about 3 s
-    t0 = time.perf_counter()
-    po.tournament(t, K, ROOT_SEED, 0, 200, n_threads=1)
-    n1 = int(max(200, min(n_sh, 200 * 3.0 / (time.perf_counter() - t0))))
-    t0 = time.perf_counter()
-    po.tournament(t, K, ROOT_SEED, 0, n1, n_threads=1)
-    dt1 = time.perf_counter() - t0
-    return {"value": n_sh * 32 / dt, "unit": "games/s", "cores": threads, "kind": "port",
-            "sample": f"shuffles 0..{n_sh - 1} of the same workload ({n_sh * 32} games, {dt:.1f} s, OpenMP over shuffles)",
-            "single_core": {"value": n1 * 32 / dt1, "unit": "games/s", "cores": 1,
-                            "sample": f"shuffles 0..{n1 - 1} ({n1 * 32} games, {dt1:.1f} s)"},
-            "_tally": res["tally"][0], "_n_sh": n_sh}
+    return max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("FK_CPU_THREADS", "16"))))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workloads: every one exposes  local_shape, step(eng, index, rank, world) -> (local tally, games played by THIS rank),
+# games_per_step(world), verify(total, steps, world), sample(eng) -> (rows, k, games) for W, cpu_baseline(eng)
+# ---------------------------------------------------------------------------------------------------------------
+class Tournament:
+    """BASELINE configs[1] / configs[2]: one (grid, k, root) cell, every rank plays its own shuffle range per step."""
+
+    scaling = "weak"
+
+    def __init__(self, config: int, table: np.ndarray, k: int, root: int, shuffles: int, label: str, sample_shuffles: int):
+        self.config, self.table, self.k, self.root, self.shuffles, self.label = config, table, k, root, shuffles, label
+        self.S = len(table)
+        self.gps = self.S // k
+        self.local_shape = (self.S, 26)
+        self.sample_shuffles = min(sample_shuffles, shuffles)
+
+    def games_per_step(self, world: int) -> int:
+        return self.shuffles * self.gps * world
+
+    def step(self, eng, index: int, rank: int, world: int):
+        first = (index * world + rank) * self.shuffles
+        res = eng.tournament(self.table, self.k, self.root, first, first + self.shuffles)
+        return res["tally"][0], self.shuffles * self.gps, add_timing({}, eng.timing())
+
+    def verify(self, tot: np.ndarray, games: int) -> None:
+        assert int(tot[:, 1].sum()) == games * self.k, "exposure conservation failed"
+        assert np.array_equal(tot[:, 1], tot[:, 2] + tot[:, 3]) and int(tot[:, 0].sum()) * self.k == int(tot[:, 2].sum())
+
+    def sample(self, eng):
+        # rows of one launch (of the step's own size when that fits a few GB of rows) -> measured R, T of SURVEY 8d
+        res = eng.tournament(self.table, self.k, self.root, 0, self.sample_shuffles, want_rows=True)
+        return res["rows"], self.k, f"shuffles 0..{self.sample_shuffles - 1} ({self.sample_shuffles * self.gps} games)"
+
+    def hbm_bytes_per_game(self) -> int:
+        # counts-only: seat seeds read once (32 B x k) + 2 B x k permutation entries + 4 B schedule entry per game
+        return 32 * self.k + 2 * self.k + 4
+
+    def cpu_baseline(self, eng, seconds_target: float = 12.0) -> dict:
+        """Time the CPU oracle (checker, never the product) on a bounded sample of the same workload."""
+        po = _oracle()
+        threads = _cpu_threads()
+        t = self.table.view(po.STRATEGY_DTYPE)
+        probe = max(2, 12_800 // self.gps)
+        po.tournament(t, self.k, self.root, 0, max(1, probe // 4), n_threads=threads)  # warm the thread pool
+        t0 = time.perf_counter()
+        po.tournament(t, self.k, self.root, 0, probe, n_threads=threads)
+        rate = probe * self.gps / (time.perf_counter() - t0)
+        n_sh = int(max(probe, min(self.shuffles, rate * seconds_target / self.gps)))
+        t0 = time.perf_counter()
+        res = po.tournament(t, self.k, self.root, 0, n_sh, n_threads=threads)
+        dt = time.perf_counter() - t0
+        # the same oracle on ONE core (SURVEY section 8d asks for both): first shuffles of the workload, about 3 s
+        p1 = max(1, probe // 8)
+        t0 = time.perf_counter()
+        po.tournament(t, self.k, self.root, 0, p1, n_threads=1)
+        n1 = int(max(p1, min(n_sh, p1 * 3.0 / (time.perf_counter() - t0))))
+        t0 = time.perf_counter()
+        po.tournament(t, self.k, self.root, 0, n1, n_threads=1)
+        dt1 = time.perf_counter() - t0
+        # parity on the sample: per-batch tallies of one launch of the step's size
+        if n_sh == self.shuffles or self.config != 2:
+            got = eng.tournament(self.table, self.k, self.root, 0, n_sh)["tally"][0]
+        else:  # config 2: keep every fk_play_kernel launch of this process at the step's size (rocprofv3 per-kernel average)
+            got = eng.tournament(self.table, self.k, self.root, 0, (self.shuffles // n_sh) * n_sh, shuffles_per_batch=n_sh)["tally"][0]
+        assert np.array_equal(got, res["tally"][0]), "GPU tally differs from the CPU oracle on the baseline sample"
+        return {"value": n_sh * self.gps / dt, "unit": "games/s", "cores": threads, "kind": "port",
+                "sample": f"shuffles 0..{n_sh - 1} of the same workload ({n_sh * self.gps} games, {dt:.1f} s, OpenMP over shuffles)",
+                "single_core": {"value": n1 * self.gps / dt1, "unit": "games/s", "cores": 1,
+                                "sample": f"shuffles 0..{n1 - 1} ({n1 * self.gps} games, {dt1:.1f} s)"},
+                "parity": f"GPU tally == oracle tally on the sample ({n_sh * self.gps} games)"}
+
+    def describe(self, world: int) -> dict:
+        return {"workload": self.label, "k": self.k, "n_strategies": self.S, "root_seed": self.root,
+                "games_per_gpu_per_step": self.shuffles * self.gps, "parallelism": f"shuffle-range split x{world}"}
+
+
+class KSweep:
+    """BASELINE configs[3]: k in {2,4,6,8} on the 5 160 grid; each k's shuffle range of the step is split over the ranks."""
+
+    scaling = "strong"
+
+    def __init__(self, table: np.ndarray, games_per_k: int, ks=(2, 4, 6, 8), root: int = 0):
+        self.table, self.ks, self.root = table, tuple(ks), root
+        self.S = len(table)
+        self.n_sh = {k: max(1, games_per_k // (self.S // k)) for k in self.ks}
+        self.local_shape = (len(self.ks), self.S, 26)
+        self.config = 4
+        self.k = self.ks[0]
+
+    def games_per_step(self, world: int) -> int:
+        return sum(self.n_sh[k] * (self.S // k) for k in self.ks)
+
+    def step(self, eng, index: int, rank: int, world: int):
+        from farkle_ii_amd.distributed import shard_shuffle_range
+
+        out = np.zeros(self.local_shape, dtype=np.int64)
+        games, timing = 0, {}
+        for i, k in enumerate(self.ks):
+            lo, hi = shard_shuffle_range(index * self.n_sh[k], (index + 1) * self.n_sh[k], rank, world)
+            if hi > lo:
+                out[i] = eng.tournament(self.table, k, self.root, lo, hi)["tally"][0]
+                games += (hi - lo) * (self.S // k)
+                add_timing(timing, eng.timing())
+        return out, games, timing
+
+    def verify(self, tot: np.ndarray, games: int) -> None:
+        for i, k in enumerate(self.ks):
+            assert np.array_equal(tot[i][:, 1], tot[i][:, 2] + tot[i][:, 3]) and int(tot[i][:, 0].sum()) * k == int(tot[i][:, 2].sum())
+        assert sum(int(tot[i][:, 1].sum()) // k for i, k in enumerate(self.ks)) == games, "exposure conservation failed"
+
+    def sample(self, eng):
+        # W of the sweep = games-weighted mean over k (equal games per k): one small rows launch per k
+        rows = {}
+        for k in self.ks:
+            rows[k] = eng.tournament(self.table, k, self.root, 0, max(1, 500_000 // (self.S // k)), want_rows=True)["rows"]
+        return rows, None, "per k: first ~5*10^5 games of the sweep"
+
+    def hbm_bytes_per_game(self) -> int:
+        return int(np.mean([32 * k + 2 * k + 4 for k in self.ks]))
+
+    def cpu_baseline(self, eng, seconds_target: float = 12.0) -> dict:
+        po = _oracle()
+        threads = _cpu_threads()
+        t = self.table.view(po.STRATEGY_DTYPE)
+        games = 0
+        t0 = time.perf_counter()
+        for k in self.ks:  # ~1/4 of the budget per k: equal GAMES per k as in the sweep
+            n_sh = max(1, int(25_000 * seconds_target / 12.0) // (self.S // k))
+            ref = po.tournament(t, k, self.root, 0, n_sh, n_threads=threads)["tally"][0]
+            got = eng.tournament(self.table, k, self.root, 0, n_sh)["tally"][0]
+            assert np.array_equal(got, ref), f"GPU tally differs from the CPU oracle on the k={k} sample"
+            games += n_sh * (self.S // k)
+        dt = time.perf_counter() - t0
+        return {"value": games / dt, "unit": "games/s", "cores": threads, "kind": "port",
+                "sample": f"first shuffles of every k, {games} games in all, {dt:.1f} s incl. the GPU parity launches",
+                "parity": "GPU tally == oracle tally on every k's sample"}
+
+    def describe(self, world: int) -> dict:
+        return {"workload": "BASELINE configs[3]: k in {2,4,6,8}, 5 160-strategy grid, equal games per k, counts-only tallies",
+                "k": list(self.ks), "n_strategies": self.S, "root_seed": self.root, "shuffles_per_k_per_step": self.n_sh,
+                "parallelism": f"every k's shuffle range split x{world}, one tally reduce per k"}
+
+
+class H2H:
+    """BASELINE configs[4]: all pairs of M candidate strategies x orders, `target` completed games per pair."""
+
+    scaling = "strong"
+
+    def __init__(self, table: np.ndarray, candidates, games_per_pair: int, root: int = 42):
+        self.table, self.root = table, root
+        self.cand = list(candidates)
+        self.per_block = games_per_pair // 2
+        self.blocks = []
+        pair_id = 0
+        for i in range(len(self.cand)):
+            for j in range(i + 1, len(self.cand)):
+                for order in (0, 1):
+                    a, b = (self.cand[i], self.cand[j]) if order == 0 else (self.cand[j], self.cand[i])
+                    self.blocks.append((pair_id, order, a, b))
+                pair_id += 1
+        self.local_shape = (len(self.blocks), 5)
+        self.config = 5
+        self.k = 2
+
+    def games_per_step(self, world: int) -> int:
+        return len(self.blocks) * self.per_block  # completed games required; attempts are reported separately
+
+    def step(self, eng, index: int, rank: int, world: int):
+        out = np.zeros(self.local_shape, dtype=np.int64)
+        timing: dict = {}
+        mine = list(range(rank, len(self.blocks), world))
+        if mine:
+            seats = np.stack([self.table[[self.blocks[b][2], self.blocks[b][3]]] for b in mine])
+            pair = [self.blocks[b][0] + index * 10_000 for b in mine]  # a fresh coordinate range per step
+            order = [self.blocks[b][1] for b in mine]
+            res = eng.h2h_blocks(seats, self.root, pair, order, self.per_block, 2 * self.per_block)
+            out[mine] = res.astype(np.int64)
+            add_timing(timing, eng.timing())
+        return out, int(out[:, 0].sum()), timing
+
+    def verify(self, tot: np.ndarray, games: int) -> None:
+        assert (tot[:, 0] == tot[:, 1] + tot[:, 2]).all() and (tot[:, 1] == tot[:, 3] + tot[:, 4]).all()
+
+    def sample(self, eng):
+        from farkle_ii_amd.backend import make_coords
+
+        n = 200_000
+        b = self.blocks[len(self.blocks) // 2]
+        coords = make_coords(203, self.root, 2, 0, b[0], b[1], np.arange(n, dtype=np.uint64))
+        rows = eng.play_games(coords, self.table[[b[2], b[3]]], np.tile(np.arange(2, dtype=np.int32), (n, 1)), 2)
+        return rows, 2, f"attempts 0..{n - 1} of block (pair {b[0]}, order {b[1]})"
+
+    def hbm_bytes_per_game(self) -> int:
+        return 64
+
+    def cpu_baseline(self, eng, seconds_target: float = 12.0) -> dict:
+        po = _oracle()
+        target = 20_000
+        t0 = time.perf_counter()
+        n = 0
+        for bi in range(0, len(self.blocks), max(1, len(self.blocks) // 12)):
+            b = self.blocks[bi]
+            seats = self.table[[b[2], b[3]]]
+            ref = po.h2h_block(seats.view(po.STRATEGY_DTYPE), self.root, b[0], b[1], target, 2 * target, 10**9)
+            got = eng.h2h_blocks(seats[None], self.root, [b[0]], [b[1]], target, 2 * target)[0]
+            assert np.array_equal(np.asarray(got, dtype=np.uint64), ref), f"H2H block {b[:2]} differs from the CPU oracle"
+            n += int(ref[0])
+            if time.perf_counter() - t0 > seconds_target:
+                break
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "attempts/s", "cores": 1, "kind": "port",
+                "sample": f"{n} attempts of {target}-game blocks spread over the pair list, {dt:.1f} s incl. the GPU parity launches",
+                "parity": "GPU block state == oracle block state on every sampled block"}
+
+    def describe(self, world: int) -> dict:
+        return {"workload": f"BASELINE configs[4]: H2H, {len(self.cand)} candidates of the 5 160 grid -> {len(self.blocks) // 2} pairs x "
+                            f"orders {{0,1}}, {2 * self.per_block} completed games per pair",
+                "k": 2, "n_blocks": len(self.blocks), "root_seed": self.root, "completed_games_per_block": self.per_block,
+                "parallelism": f"blocks dealt round-robin x{world}, one reduce of the block results"}
+
+
+def make_workload(args):
+    if args.config == 2:
+        return Tournament(2, grid64(), K, ROOT_SEED, args.shuffles or SHUFFLES_PER_STEP,
+                          "BASELINE configs[1]: k=2, 64-strategy grid, 10^7 games per GPU per step, root_seed 42, counts-only tallies",
+                          sample_shuffles=args.shuffles or SHUFFLES_PER_STEP)
+    if args.config == 3:
+        return Tournament(3, grid5160(), 4, 0, args.shuffles or 77_520,
+                          "BASELINE configs[2]: k=4, default 5 160-strategy grid, 10^8 games per GPU per step, root_seed 0, counts-only tallies",
+                          sample_shuffles=4_000)
+    if args.config == 4:
+        return KSweep(grid5160(), args.games or 250_000_000)
+    if args.config == 5:
+        table = grid5160()
+        # candidates: twelve ids spread over the grid (a plausible h2h_2p candidate family; SURVEY 8d C5)
+        cand = [int(i) for i in np.linspace(0, len(table) - 1, 12).astype(int)]
+        return H2H(table, cand, args.games or 100_000_000)
+    raise SystemExit(f"unknown --config {args.config}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# launching ranks
+# ---------------------------------------------------------------------------------------------------------------
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """Start n rank processes of this script (one per GPU) and wait.  Runs BEFORE anything in this process touches
+    the GPU; the children are ordinary child processes (no exec of a GPU-initialised process anywhere)."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FK_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *argv], env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:  # one rank failed: the others would wait in a collective until their timeout
+                    rc = rc or code
+                    for o in pending:
+                        procs[o].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def load_engine_factory():
+    """The product engine (HIP through the C-ABI).  FK_BENCH_ENGINE=module:attr swaps in another factory — used by the
+    CPU tests of this file's multi-rank plumbing only; the JSON line then says so and is not a measurement."""
+    spec = os.environ.get("FK_BENCH_ENGINE")
+    if not spec:
+        from farkle_ii_amd.backend import Engine
+
+        return Engine, "farkle_ii_amd.backend.Engine (HIP C-ABI, libfarkle_hip.so)"
+    import importlib
+
+    mod, attr = spec.split(":")
+    return getattr(importlib.import_module(mod), attr), f"{spec} (TEST STUB - not a measurement)"
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--shuffles", type=int, default=SHUFFLES_PER_STEP, help="shuffles per rank per step")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
+    ap.add_argument("--shuffles", type=int, default=0, help="configs 2/3: shuffles per rank per step (default: the BASELINE size)")
+    ap.add_argument("--games", type=int, default=0, help="config 4: games per k per step; config 5: completed games per pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-tally", type=Path, default=None, help="rank 0 saves the reduced tally here (.npy; tests)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {2: 5, 3: 2, 4: 1, 5: 1}[args.config]
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
 
@@ -98,6 +409,7 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    have_gpu = torch.cuda.is_available()
     # FK_DIST_BACKEND=gloo rehearses the multi-rank path on a one-GPU box (ranks share GPU 0, tallies reduced on CPU);
     # the real runs use nccl = RCCL over xGMI with one GPU per rank.
     backend = os.environ.get("FK_DIST_BACKEND", "nccl")
@@ -106,64 +418,58 @@ def main() -> None:
     if distributed:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
+        if have_gpu:
+            torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    n_gpus = world if distributed else 1
+    n_gpus = dist.get_world_size() if distributed else 1
     if args.gpus != n_gpus and rank == 0:
-        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; using {n_gpus}", file=sys.stderr)
+        print(f"note: --gpus {args.gpus} but the process group has {n_gpus} ranks; reporting n_gpus={n_gpus}", file=sys.stderr)
 
-    from farkle_ii_amd.backend import Engine
-
-    table = grid64()
-    S = len(table)
-    eng = Engine(local_rank)
+    make_engine, engine_name = load_engine_factory()
+    wl = make_workload(args)
+    eng = make_engine(local_rank)
     info = eng.device_info()
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if have_gpu else torch.device("cpu")
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the tally reduction runs
 
     def sync() -> None:
         if distributed:
             dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    def step(index: int):
-        first = (index * n_gpus + rank) * args.shuffles
-        res = eng.tournament(table, K, ROOT_SEED, first, first + args.shuffles)
-        return res["tally"][0], eng.timing()
+        if have_gpu:
+            torch.cuda.synchronize(dev)
 
     def reduce_to_rank0(local: np.ndarray):
-        """The path's only exchange: one SUM of the per-strategy int64 tally to rank 0 at the end of the
-        job, the analogue of OutcomeCounter.absorb — RCCL over xGMI when there is more than one rank."""
+        """The path's only exchange: one SUM of the int64 tally to rank 0 at the end of the job, the
+        analogue of OutcomeCounter.absorb — RCCL over xGMI when there is more than one rank."""
         t = torch.from_numpy(local).to(red_dev)
         if distributed:
             dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
         return t
 
     # one-time initialisation outside any step: device workspace, lazily loaded torch kernels, RCCL communicator
-    eng.tournament(table, K, ROOT_SEED, 0, args.shuffles)
-    warm = torch.zeros((S, 26), dtype=torch.int64, device=red_dev)
-    warm += torch.from_numpy(np.zeros((S, 26), dtype=np.int64)).to(red_dev)
+    wl.step(eng, 0, rank, n_gpus)
+    warm = torch.zeros(wl.local_shape, dtype=torch.int64, device=red_dev)
+    warm += torch.from_numpy(np.zeros(wl.local_shape, dtype=np.int64)).to(red_dev)
     if distributed:
         dist.reduce(warm, dst=0, op=dist.ReduceOp.SUM)
-    local = np.zeros((S, 26), dtype=np.int64)
+    local = np.zeros(wl.local_shape, dtype=np.int64)
     for i in range(args.warmup):
-        tally, _ = step(i)
+        tally, _, _ = wl.step(eng, i, rank, n_gpus)
         local += tally
     reduce_to_rank0(local)
     local[:] = 0
-    play_ms, seed_ms, perm_ms, launches = 0.0, 0.0, 0.0, 0
+    my_games = 0
+    t: dict = {}
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        tally, t = step(args.warmup + i)
-        local += tally  # [64][26] int64 host add
-        play_ms += t["play_ms"]
-        seed_ms += t["seed_ms"]
-        perm_ms += t["perm_ms"]
-        launches += t["play_launches"]
+        tally, g, st = wl.step(eng, args.warmup + i, rank, n_gpus)
+        local += tally  # host add of the step's int64 tally
+        my_games += g
+        add_timing(t, st)  # HIP events on the engine's stream, summed over every engine call of the timed steps
     total = reduce_to_rank0(local)  # inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
@@ -171,83 +477,107 @@ def main() -> None:
         e = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = float(e.item())
+        g_all = torch.tensor([my_games], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(g_all, op=dist.ReduceOp.SUM)
+        played = int(g_all.item())
+    else:
+        played = my_games
 
-    games_per_rank_step = args.shuffles * (S // K)
-    total_games = games_per_rank_step * n_gpus * args.steps
+    total_games = wl.games_per_step(n_gpus) * args.steps
     value = total_games / elapsed
 
     if rank == 0:
         tot = total.cpu().numpy()
-        assert int(tot[:, 1].sum()) == total_games * K, "exposure conservation failed"
-        assert np.array_equal(tot[:, 1], tot[:, 2] + tot[:, 3]) and int(tot[:, 0].sum()) * K == int(tot[:, 2].sum())
+        wl.verify(tot, played if wl.config != 5 else total_games)
+        if args.dump_tally is not None:
+            np.save(args.dump_tally, tot)
 
-        # live per-game work (R, T of SURVEY section 8d) from the rows of one launch of the SAME size, so that every
-        # fk_play_kernel launch of this process has the step's shape (the rocprofv3 per-kernel average stays comparable)
-        sample = eng.tournament(table, K, ROOT_SEED, 0, args.shuffles, want_rows=True)
-        wpg = work_per_game(sample["rows"], K)
-        del sample
-        kernel_ms = play_ms / max(launches, 1)
-        kernel_games_per_s = games_per_rank_step / (kernel_ms * 1e-3)
+        # live per-game work (R, T of SURVEY section 8d) from the rows of a launch of the same workload
+        rows, k_s, sample_desc = wl.sample(eng)
+        if isinstance(rows, dict):
+            parts = [work_per_game(r, k) for k, r in rows.items()]
+            wpg = {key: float(np.mean([p[key] for p in parts])) for key in parts[0]}
+        else:
+            wpg = work_per_game(rows, k_s)
+        del rows
+        wpg["sample"] = sample_desc
+        # dominant kernel: average launch duration and games per launch over the last engine call of every timed step
+        launches = max(int(t.get("play_launches", 0)), 1)
+        kernel_ms = t.get("play_ms", 0.0) / launches
+        games_per_launch = t.get("games", 0) / launches
+        kernel_games_per_s = games_per_launch / max(kernel_ms * 1e-3, 1e-12)
         # VALU roof: CUs x 4 SIMD x 32 lanes/clk x clock (MI355X_MICROARCH.md: wave64 issues over 2 cycles on a SIMD-32)
         peak_ops = info["compute_units"] * 4 * 32 * info["clock_mhz"] * 1e6
         achieved_ops = kernel_games_per_s * wpg["ops_per_game"]
-        # algorithmic HBM bytes of the game kernel in counts-only mode: seat seeds read once (32 B x k per game)
-        # + 2 B x k permutation entries; the tally is [S][26] int64 written once per launch
-        hbm_bytes_per_game = 32 * K + 2 * K + 4
-        # HBM bytes per launch from the PMC passes of the same launch (rocprofv3 cannot run inside this process):
-        # profiles/r01_hbm_traffic.json, FETCH_SIZE x2-corrected per MI355X_MICROARCH.md
+        hbm_bpg = wl.hbm_bytes_per_game()
+        # HBM bytes per launch from the PMC passes of the same launch shape (rocprofv3 cannot run inside this process):
+        # profiles/r*_hbm_traffic.json carries the commit it was taken at; dropped when that is not an ancestor's kernel
         traffic = None
-        tpath = ROOT / "profiles" / "r01_hbm_traffic.json"
-        if tpath.exists() and args.shuffles == SHUFFLES_PER_STEP:
-            traffic = json.loads(tpath.read_text())["kernels"]["fk_play_kernel"]["hbm_bytes_corrected"]
+        for tpath in sorted((ROOT / "profiles").glob(f"r*_hbm_traffic_config{wl.config}.json"), reverse=True):
+            rec = json.loads(tpath.read_text())
+            if rec.get("kernel_source_sha256") == kernel_source_sha():
+                traffic = rec["kernels"]["fk_play_kernel"]["hbm_bytes_corrected"]
+            break
         roofline = {
             "bound": "valu", "kernel": "fk_play_kernel",
             "achieved": achieved_ops / 1e12, "peak": peak_ops / 1e12, "unit": "Tlane-op/s (int32)", "frac": achieved_ops / peak_ops,
-            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate pass)",
-            "kernel_ms": kernel_ms, "kernel_games_per_s": kernel_games_per_s, **wpg,
-            "hbm": {"achieved": kernel_games_per_s * hbm_bytes_per_game / 1e9, "peak": 8000.0, "unit": "GB/s",
-                    "frac": kernel_games_per_s * hbm_bytes_per_game / 8e12, "bytes_per_game": hbm_bytes_per_game},
-            "seed_kernel_ms": seed_ms / max(launches, 1), "perm_kernel_ms": perm_ms / max(launches, 1),
-            "launch": {k2: t[k2] for k2 in ("play_block", "play_grid", "play_lds_bytes")},
+            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate pass; null when the kernel sources changed since)",
+            "kernel_ms": kernel_ms, "games_per_launch": games_per_launch, "kernel_games_per_s": kernel_games_per_s, **wpg,
+            "hbm": {"achieved": kernel_games_per_s * hbm_bpg / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": kernel_games_per_s * hbm_bpg / 8e12, "bytes_per_game": hbm_bpg},
+            "seed_kernel_ms": t.get("seed_ms", 0.0) / launches, "perm_kernel_ms": t.get("perm_ms", 0.0) / launches,
+            "launch": {k2: t.get(k2) for k2 in ("play_block", "play_grid", "play_lds_bytes")},
         }
         cpu = None
         if not args.no_cpu_baseline and n_gpus == 1:  # the CPU leg runs on rank 0 of the single-GPU run only
-            cpu = cpu_baseline(table)
-            n_sh = cpu.pop("_n_sh")
-            ref_tally = cpu.pop("_tally")
-            if n_sh == args.shuffles:
-                got = eng.tournament(table, K, ROOT_SEED, 0, n_sh)["tally"][0]
-            else:  # slower host: compare on the sample's shuffles only (per-batch tallies of one same-size launch)
-                spb = n_sh
-                got = eng.tournament(table, K, ROOT_SEED, 0, (args.shuffles // spb) * spb, shuffles_per_batch=spb)["tally"][0]
-            assert np.array_equal(got, ref_tally), "GPU tally differs from the CPU oracle on the baseline sample"
-            cpu["parity"] = f"GPU tally == oracle tally on the sample ({n_sh * 32} games)"
+            cpu = wl.cpu_baseline(eng)
         line = {
-            "metric": "simulated games/sec (whole node) at k=2, fixed strategy-grid size",
+            "metric": METRIC if wl.config in (2,) else f"{METRIC} [variant: BASELINE config {wl.config}]",
             "value": value, "unit": "games/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: k=2, 64-strategy grid, 10^7 games per GPU per step, root_seed 42, counts-only tallies",
-                       "k": K, "n_strategies": S, "games_per_gpu_per_step": games_per_rank_step, "parallelism": f"shuffle-range split x{n_gpus}",
-                       "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"]},
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic", "engine": engine_name,
+            "dist_backend": (f"{dist.get_backend()} (RCCL over xGMI)" if distributed and dist.get_backend() == "nccl"
+                             else (dist.get_backend() if distributed else None)),
+            "launcher": "self (bench.py started the ranks)" if os.environ.get("FK_BENCH_SELF_LAUNCHED") else
+                        ("torch.distributed.run" if distributed else "single process"),
+            "config": {**wl.describe(n_gpus), "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],
+                       "clock_mhz": info["clock_mhz"]},
             "roofline": roofline, "cpu_baseline": cpu,
+        }
+        if wl.config == 5:
+            line["attempts_per_s"] = played / elapsed
+            line["value_note"] = "completed games required by the schedule per second; attempts (incl. safety-limit games) in attempts_per_s"
+        if wl.config == 2:
             # not `vs_baseline` (BASELINE.json publishes nothing for this exact config): the reference's own report of the
             # k=2 tournament path on its 80-strategy grid, Ryzen 7 3700X, 12 workers = 1 142.9 games/s
-            "vs_reference_published_12_workers": value / 1142.9,
-        }
-        # the Python reference itself timed on this same workload in the build container (oracle/time_reference.py; the
-        # reference cannot travel to the GPU box, so this is a committed fixture, not a measurement of this run)
-        fixture = ROOT / "tests" / "golden" / "reference_cpu_timing.json"
-        if fixture.exists():
-            ref = json.loads(fixture.read_text())
-            line["reference_python_fixture"] = {
-                "tournament_loop_games_per_s_1_process": ref["tournament_loop_1_process"]["games_per_s"],
-                "tournament_loop_games_per_s_8_processes": ref["tournament_loop_8_processes"]["games_per_s"],
-                "where": ref["host"]["note"]}
-        print(json.dumps(line))
+            line["vs_reference_published_12_workers"] = value / 1142.9
+            # the Python reference itself timed on this same workload in the build container (oracle/time_reference.py; the
+            # reference cannot travel to the GPU box, so this is a committed fixture, not a measurement of this run)
+            fixture = ROOT / "tests" / "golden" / "reference_cpu_timing.json"
+            if fixture.exists():
+                ref = json.loads(fixture.read_text())
+                line["reference_python_fixture"] = {
+                    "tournament_loop_games_per_s_1_process": ref["tournament_loop_1_process"]["games_per_s"],
+                    "tournament_loop_games_per_s_8_processes": ref["tournament_loop_8_processes"]["games_per_s"],
+                    "where": ref["host"]["note"]}
+            e2e = ROOT / "profiles" / "r02_farkle_run_end_to_end.json"
+            if e2e.exists():  # committed measurement of `farkle run` end to end (rows off / on), not of this run
+                line["farkle_run_end_to_end_fixture"] = json.loads(e2e.read_text())
+        print(json.dumps(line), flush=True)
     eng.close()
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_source_sha() -> str:
+    """sha256 over the kernel sources: profiles carry it so that a stale HBM-traffic figure is never attached."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("farkle_hip.hip", "fk_kernels.h", "fk_device.h"):
+        h.update((ROOT / "farkle_ii_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()
 
 
 if __name__ == "__main__":

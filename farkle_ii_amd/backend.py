@@ -232,6 +232,22 @@ class Engine:
                                          C.c_int32(target_score), C.c_int32(max_rounds), _p(ov), C.c_int32(len(ov)), _p(st)))
         return st
 
+    def h2h_blocks(self, seats: np.ndarray, root_seed: int, pair_ids, orders, target: int, max_attempts: int,
+                   target_score: int = 10_000, max_rounds: int = 200, overrides: np.ndarray | None = None) -> np.ndarray:
+        """Many fresh (pair, order) blocks of one root played to completion: ``seats[b]`` = the two seated strategies of
+        block b -> uint64 ``[n_blocks][5]`` = attempted, completed, safety, wins_seat1, wins_seat2 (each row equals the
+        serial ``h2h`` result of that block)."""
+        seats = np.ascontiguousarray(seats, dtype=STRATEGY_DTYPE).reshape(-1, 2)
+        pair_ids = np.ascontiguousarray(pair_ids, dtype=np.uint64).reshape(-1)
+        orders = np.ascontiguousarray(orders, dtype=np.uint32).reshape(-1)
+        if not (len(seats) == len(pair_ids) == len(orders)):
+            raise ValueError("seats, pair_ids and orders must have one entry per block")
+        out = np.zeros((len(seats), 5), dtype=np.uint64)
+        for b in range(len(seats)):
+            out[b] = self.h2h(seats[b], root_seed, int(pair_ids[b]), int(orders[b]), target, max_attempts, max_attempts,
+                              target_score=target_score, max_rounds=max_rounds, overrides=overrides)
+        return out
+
     def coordinate_seeds(self, coords: np.ndarray, want32: bool = True, want64: bool = False):
         """SeedSequence fingerprints of whole coordinates (``coordinate_seed``, utils/random.py:190-232)."""
         coords = np.ascontiguousarray(coords, dtype=COORD_DTYPE)

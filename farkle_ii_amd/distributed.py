@@ -25,6 +25,19 @@ def shard_shuffle_range(shuffle_begin: int, shuffle_end: int, rank: int, world_s
     return (min(shuffle_begin + lo * batch_size, shuffle_end), min(shuffle_begin + hi * batch_size, shuffle_end))
 
 
+def collective_device(device=None):
+    """Where tensors of a collective must live: the rank's GPU under ``nccl`` (RCCL rejects CPU tensors), the CPU under
+    ``gloo``.  An explicit ``device`` wins."""
+    import torch
+    import torch.distributed as dist
+
+    if device is not None:
+        return torch.device(device)
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def reduce_tally(tally: np.ndarray, dst: int = 0, device=None) -> np.ndarray:
     """SUM-reduce an int64 tally over the default process group; returns the total on ``dst`` (own tally elsewhere)."""
     import torch
@@ -32,11 +45,17 @@ def reduce_tally(tally: np.ndarray, dst: int = 0, device=None) -> np.ndarray:
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return tally
-    t = torch.from_numpy(np.ascontiguousarray(tally, dtype=np.int64))
-    if device is not None:
-        t = t.to(device)
+    t = torch.from_numpy(np.ascontiguousarray(tally, dtype=np.int64)).to(collective_device(device))
     dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+def barrier() -> None:
+    """Process-group barrier (no-op without one)."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
 
 
 def h2h_block_distributed(h2h, seats, root_seed: int, pair_id: int, order: int, target: int, max_attempts: int,
@@ -78,9 +97,7 @@ def h2h_block_distributed(h2h, seats, root_seed: int, pair_id: int, order: int, 
         return out.astype(np.int64) - base.astype(np.int64)
 
     def gather(vec: np.ndarray) -> np.ndarray:
-        t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.int64))
-        if device is not None:
-            t = t.to(device)
+        t = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.int64)).to(collective_device(device))
         parts = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
         return np.stack([p.cpu().numpy() for p in parts])

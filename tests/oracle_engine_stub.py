@@ -1,0 +1,75 @@
+"""TEST INFRASTRUCTURE ONLY — an `Engine`-shaped object backed by the CPU oracle.
+
+It exists so that the multi-rank plumbing of ``bench.py`` / ``farkle run`` (rank launch, shuffle-range shards, the one
+tally reduce, rank-0 artifacts) can be exercised on GPU-less hosts with the gloo backend.  Nothing in the product imports
+it; ``bench.py`` loads it only through the explicit ``FK_BENCH_ENGINE=oracle_engine_stub:Engine`` test hook and then
+labels its output as a stub run."""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (ROOT, ROOT / "oracle"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+import pyoracle as po  # noqa: E402
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self.device = device
+        self._games = 0
+
+    def close(self) -> None:
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        pass
+
+    def set_option(self, name: str, value: int) -> None:
+        pass
+
+    def device_info(self) -> dict:
+        return {"name": "CPU oracle stub", "arch": "host", "compute_units": 1, "clock_mhz": 1, "wavefront_size": 1,
+                "lds_bytes_per_cu": 0, "hbm_bytes": 0}
+
+    def timing(self) -> dict:
+        return {"perm_ms": 0.0, "seed_ms": 0.0, "play_ms": 1.0, "total_ms": 1.0, "play_launches": 1, "play_block": 0,
+                "play_grid": 0, "play_lds_bytes": 0, "games": self._games}
+
+    def tournament(self, table, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=None, target_score=10_000,
+                   max_rounds=200, overrides=None, want_rows=False, want_perms=False) -> dict:
+        t = np.ascontiguousarray(table).view(po.STRATEGY_DTYPE)
+        ov = None if overrides is None or len(overrides) == 0 else np.ascontiguousarray(overrides).view(po.OVERRIDE_DTYPE)
+        res = po.tournament(t, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=shuffles_per_batch,
+                            target_score=target_score, max_rounds=max_rounds, overrides=ov, want_rows=want_rows,
+                            want_perms=want_perms, n_threads=2)
+        self._games = (shuffle_end - shuffle_begin) * (len(t) // k)
+        return {"tally": res["tally"], "rows": res["rows"], "perms": res["perms"]}
+
+    def play_games(self, coords, table, seat_strategy, k, target_score=10_000, max_rounds=200):
+        return po.play_games(np.ascontiguousarray(coords).view(po.COORD_DTYPE), np.ascontiguousarray(table).view(po.STRATEGY_DTYPE),
+                             seat_strategy, k, target_score=target_score, max_rounds=max_rounds, n_threads=2)
+
+    def h2h(self, seats, root_seed, pair_id, order, target, max_attempts, chunk_games, target_score=10_000, max_rounds=200,
+            overrides=None, state=None):
+        ov = None if overrides is None or len(overrides) == 0 else np.ascontiguousarray(overrides).view(po.OVERRIDE_DTYPE)
+        return po.h2h_block(np.ascontiguousarray(seats).view(po.STRATEGY_DTYPE), root_seed, pair_id, order, target, max_attempts,
+                            chunk_games, target_score=target_score, max_rounds=max_rounds, overrides=ov, state=state)
+
+    def h2h_blocks(self, seats, root_seed, pair_ids, orders, target, max_attempts, target_score=10_000, max_rounds=200,
+                   overrides=None):
+        seats = np.ascontiguousarray(seats).reshape(-1, 2)
+        out = np.zeros((len(seats), 5), dtype=np.uint64)
+        for b in range(len(seats)):
+            out[b] = self.h2h(seats[b], root_seed, int(pair_ids[b]), int(orders[b]), target, max_attempts, max_attempts,
+                              target_score=target_score, max_rounds=max_rounds, overrides=overrides)
+            self._games = int(out[b][0])
+        return out
