@@ -31,6 +31,10 @@ SEAT_DTYPE = np.dtype(
      ("highest_turn", "<u2"), ("smart_five_uses", "<u2"), ("n_smart_five_dice", "<u2"), ("smart_one_uses", "<u2"),
      ("n_smart_one_dice", "<u2"), ("hot_dice", "<u2"), ("rank", "u1"), ("hit_max_rounds", "u1")]
 )
+H2H_BLOCK_DTYPE = np.dtype(
+    [("seats", STRATEGY_DTYPE, (2,)), ("pair_id", "<u8"), ("order", "<u4"), ("pad", "<u4"), ("target", "<u8"),
+     ("max_attempts", "<u8"), ("state", "<u8", (5,))]
+)
 TALLY_COLS = 26
 # tally columns (run_tournament.py:109-121, 165-195)
 COL_WINS, COL_ATTEMPTED, COL_COMPLETED, COL_SAFETY, COL_SUMS, COL_SQ_SUMS = 0, 1, 2, 3, 4, 15
@@ -83,7 +87,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
 
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
-            "fk_tournament_run", "fk_play_games", "fk_h2h_run", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
+            "fk_tournament_run", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
             "fk_debug_dice", "fk_debug_dice_state"]
 _lib = None
 
@@ -232,21 +236,29 @@ class Engine:
                                          C.c_int32(target_score), C.c_int32(max_rounds), _p(ov), C.c_int32(len(ov)), _p(st)))
         return st
 
-    def h2h_blocks(self, seats: np.ndarray, root_seed: int, pair_ids, orders, target: int, max_attempts: int,
-                   target_score: int = 10_000, max_rounds: int = 200, overrides: np.ndarray | None = None) -> np.ndarray:
-        """Many fresh (pair, order) blocks of one root played to completion: ``seats[b]`` = the two seated strategies of
-        block b -> uint64 ``[n_blocks][5]`` = attempted, completed, safety, wins_seat1, wins_seat2 (each row equals the
-        serial ``h2h`` result of that block)."""
+    def h2h_blocks(self, seats: np.ndarray, root_seed: int, pair_ids, orders, target, max_attempts, chunk_games=None,
+                   target_score: int = 10_000, max_rounds: int = 200, overrides: np.ndarray | None = None,
+                   states: np.ndarray | None = None) -> np.ndarray:
+        """Many (pair, order) blocks of one root advanced in shared kernel launches (``fk_h2h_run_blocks``): ``seats[b]`` =
+        the two seated strategies of block b; ``target`` / ``max_attempts`` scalars or per-block arrays; ``states`` the
+        blocks' progress so far (default: fresh).  Returns uint64 ``[n_blocks][5]`` = attempted, completed, safety,
+        wins_seat1, wins_seat2 — each row equals the serial ``h2h`` result of that block."""
         seats = np.ascontiguousarray(seats, dtype=STRATEGY_DTYPE).reshape(-1, 2)
-        pair_ids = np.ascontiguousarray(pair_ids, dtype=np.uint64).reshape(-1)
-        orders = np.ascontiguousarray(orders, dtype=np.uint32).reshape(-1)
-        if not (len(seats) == len(pair_ids) == len(orders)):
-            raise ValueError("seats, pair_ids and orders must have one entry per block")
-        out = np.zeros((len(seats), 5), dtype=np.uint64)
-        for b in range(len(seats)):
-            out[b] = self.h2h(seats[b], root_seed, int(pair_ids[b]), int(orders[b]), target, max_attempts, max_attempts,
-                              target_score=target_score, max_rounds=max_rounds, overrides=overrides)
-        return out
+        n = len(seats)
+        blocks = np.zeros(n, dtype=H2H_BLOCK_DTYPE)
+        blocks["seats"] = seats
+        blocks["pair_id"] = np.asarray(pair_ids, dtype=np.uint64).reshape(-1)
+        blocks["order"] = np.asarray(orders, dtype=np.uint32).reshape(-1)
+        blocks["target"] = np.asarray(target, dtype=np.uint64)
+        blocks["max_attempts"] = np.asarray(max_attempts, dtype=np.uint64)
+        if states is not None:
+            blocks["state"] = np.asarray(states, dtype=np.uint64).reshape(n, 5)
+        chunk = int(blocks["max_attempts"].max()) if chunk_games is None and n else int(chunk_games or 0)
+        ov = overrides if overrides is not None else np.zeros(0, dtype=OVERRIDE_DTYPE)
+        ov = np.ascontiguousarray(ov, dtype=OVERRIDE_DTYPE)
+        self._check(self._lib.fk_h2h_run_blocks(self._ctx, _p(blocks), C.c_int64(n), C.c_uint64(root_seed), C.c_uint64(chunk),
+                                                C.c_int32(target_score), C.c_int32(max_rounds), _p(ov), C.c_int32(len(ov))))
+        return blocks["state"].copy()
 
     def coordinate_seeds(self, coords: np.ndarray, want32: bool = True, want64: bool = False):
         """SeedSequence fingerprints of whole coordinates (``coordinate_seed``, utils/random.py:190-232)."""

@@ -35,18 +35,21 @@ struct fk_ctx {
         hipEvent_t a, b;
     };
     std::vector<PendingTimer> pending; // kernel timers recorded on the stream, read after the chunk's one sync
-    DevBuf strat, perm, seeds, tally, rows, misc, ov, seatlist, coords, order, slow, score_lut, discard_lut, classes, dbg[6];
+    DevBuf strat, perm, draws, state, inc, recs, tally, rows, misc, ov, seatlist, coords, order, inv, slow, score_lut, discard_lut,
+        classes, blocks, game_block, block_out, stats, dbg[6];
+    std::vector<uint2> strat_host;   // the packed table currently resident in `strat` (uploaded once per table)
     int32_t longest_first = 1;
     int32_t blocks_per_cu = 0; // 0 = as many as fit
     int32_t lean = -1;         // -1 auto, 0 full 17-dword seat records, 1 lean 11-dword records
+    int32_t gs = -1;           // -1 / 0: LDS records whenever k of them fit a wave's share of LDS, 1: state-store instances always
     int32_t uniform_flags_opt = -1; // -1 auto (scalar-flag instance when the table allows it), 0 never
     uint32_t table_flags = 0;            // set by upload_strategies: flag bits shared by the whole table ...
     uint32_t table_mixed_flags = 0xff00u; // ... and the flag bits that differ between its strategies
-    int32_t waves_per_cu = 16; // resident-wave target used to size the grid
-    int64_t chunk_bytes = (int64_t)24 << 30;
+    int64_t chunk_bytes = (int64_t)48 << 30;
     int32_t batch_threshold = 8;
     int32_t use_lds_tally = -1;
     int32_t block = 0;
+    int32_t perm_split = -1;   // -1 auto, 0 one-kernel Fisher-Yates, 1 draws kernel + swap kernel
 };
 
 namespace {
@@ -97,28 +100,33 @@ uint2 pack_strategy(const fk_strategy &s) {
     return make_uint2((uint32_t)s.score_threshold, bits);
 }
 
-int validate_strategies(fk_ctx *c, const fk_strategy *s, int32_t S) {
-    for (int32_t i = 0; i < S; ++i) {
+int validate_strategies(fk_ctx *c, const fk_strategy *s, int64_t S) {
+    for (int64_t i = 0; i < S; ++i) {
         if (s[i].dice_threshold < -128 || s[i].dice_threshold > 127)
-            return fail(c, FK_ERR_ARG, "strategy %d: dice_threshold %d outside [-128, 127]", i, s[i].dice_threshold);
+            return fail(c, FK_ERR_ARG, "strategy %lld: dice_threshold %d outside [-128, 127]", (long long)i, s[i].dice_threshold);
         if (s[i].smart_one && !s[i].smart_five) // strategies.py:198
-            return fail(c, FK_ERR_ARG, "strategy %d: smart_one requires smart_five", i);
+            return fail(c, FK_ERR_ARG, "strategy %lld: smart_one requires smart_five", (long long)i);
         if (s[i].require_both && !(s[i].consider_score && s[i].consider_dice)) // strategies.py:202
-            return fail(c, FK_ERR_ARG, "strategy %d: require_both requires consider_score and consider_dice", i);
+            return fail(c, FK_ERR_ARG, "strategy %lld: require_both requires consider_score and consider_dice", (long long)i);
     }
     return FK_OK;
 }
 
-int upload_strategies(fk_ctx *c, const fk_strategy *s, int32_t S) {
+// The packed table (+ the per-strategy patience of the longest-first schedule) goes to the device once per TABLE: a call
+// whose table equals the resident one uploads nothing.
+int upload_strategies(fk_ctx *c, const fk_strategy *s, int64_t S) {
     int rc = validate_strategies(c, s, S);
     if (rc) return rc;
     std::vector<uint2> packed((size_t)S);
-    for (int32_t i = 0; i < S; ++i) packed[(size_t)i] = pack_strategy(s[i]);
+    for (int64_t i = 0; i < S; ++i) packed[(size_t)i] = pack_strategy(s[i]);
+    if (packed.size() == c->strat_host.size() && memcmp(packed.data(), c->strat_host.data(), packed.size() * sizeof(uint2)) == 0)
+        return FK_OK;
+    c->strat_host.clear();
     rc = ensure(c, c->strat, sizeof(uint2) * (size_t)S);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->strat.p, packed.data(), sizeof(uint2) * (size_t)S, hipMemcpyHostToDevice, c->stream));
     uint32_t f_and = 0xff00u, f_or = 0u;
-    for (int32_t i = 0; i < S; ++i) {
+    for (int64_t i = 0; i < S; ++i) {
         f_and &= packed[(size_t)i].y;
         f_or |= packed[(size_t)i].y & 0xff00u;
     }
@@ -130,13 +138,14 @@ int upload_strategies(fk_ctx *c, const fk_strategy *s, int32_t S) {
     // score not considered).  With the same "either condition keeps rolling" rule and dice_threshold 1 / 2 it rolls
     // down to one / two dice before it may bank (2 / 1).
     std::vector<uint8_t> patience((size_t)S, 0);
-    for (int32_t i = 0; i < S; ++i)
+    for (int64_t i = 0; i < S; ++i)
         if (s[i].consider_dice && (s[i].require_both || !s[i].consider_score))
             patience[(size_t)i] = s[i].dice_threshold < 1 ? 3 : s[i].dice_threshold == 1 ? 2 : s[i].dice_threshold == 2 ? 1 : 0;
     rc = ensure(c, c->slow, patience.size());
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->slow.p, patience.data(), patience.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream)); // host vectors go out of scope
+    c->strat_host.swap(packed);
     return FK_OK;
 }
 
@@ -152,81 +161,97 @@ struct LaunchPlan {
     size_t lds = 0;
     bool lds_tally = false;
     bool lean = false; // 11-dword seat records (increment + strategy re-read from HBM/L2 each turn)
+    bool gs = false;   // state-store instance: one LDS record per lane, the others in HBM
     int wpe = 4;       // waves per SIMD the chosen instance is compiled for
     uint32_t mixed_flags = 0xff00u; // flag bits that differ between strategies of the table (selects the kernel instance)
 };
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-size_t play_lds_bytes(int32_t k, int block, bool lean, bool lds_tally, int32_t S) {
-    const size_t per_lane = (size_t)(lean ? NF - 6 : NF) * 4 * (size_t)k;
+size_t play_lds_bytes(int32_t k, int block, bool lean, bool gs, bool lds_tally, int32_t S) {
+    const size_t per_lane = (size_t)(lean ? NF - 6 : NF) * 4 * (size_t)(gs ? 1 : k);
     return per_lane * (size_t)block + (lds_tally ? (size_t)S * LT_COLS * 8 : 0);
 }
 
 // Pick block size / record layout for the most resident lanes per CU (ties: full records, larger blocks).
-// Instances are compiled for 4 waves/SIMD (<= 128 VGPRs); the 768-thread LEAN instance for 6 (80 VGPRs): its 12 waves
-// split evenly over the 4 SIMDs, so two blocks (24 waves) co-reside.
-LaunchPlan plan_play(const fk_ctx *c, int32_t k, int32_t S, bool single_batch) {
+// Instances are compiled for 4 waves/SIMD (<= 128 VGPRs); the 768-thread LEAN instances for 6 (80 VGPRs): their 12 waves
+// split evenly over the 4 SIMDs, so two blocks (24 waves) co-reside.  State-store (GS) instances are chosen for k >= 3:
+// their LDS use does not grow with k.
+LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch) {
     LaunchPlan best;
-    const bool want_tally = single_batch && (c->use_lds_tally != 0);
+    const bool want_tally = single_batch && (c->use_lds_tally != 0) && S <= 4096;
     int best_lanes = -1;
-    for (int lean = 0; lean <= 1; ++lean) {
-        if (c->lean >= 0 && lean != c->lean) continue;
-        if (lean && S > (1 << (32 - CE_IDX_SHIFT))) continue; // strategy index must fit cE[31:18]
-        for (int block : {1024, 768, 512, 256, 128, 64}) {
-            if (c->block != 0 && block != c->block) continue;
-            if (block == 768 && !lean) continue;
-            const int wpe = (block == 768) ? 6 : 4;
-            bool tally = want_tally && play_lds_bytes(k, block, lean != 0, true, S) <= LDS_LIMIT;
-            size_t lds = play_lds_bytes(k, block, lean != 0, tally, S);
-            if (lds > LDS_LIMIT) continue;
-            int per_cu = (int)(LDS_LIMIT / std::max<size_t>(lds, 1));
-            per_cu = std::min(per_cu, std::max(1, wpe * 4 * 64 / block));
-            if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
-            per_cu = std::max(per_cu, 1);
-            int lanes = (per_cu * block) * 4 + (tally ? 2 : 0) + (lean ? 0 : 1); // tie-breaks: tally, then full records
-            if (lanes > best_lanes) {
-                best_lanes = lanes;
-                best.block = block;
-                best.lds = lds;
-                best.lds_tally = tally;
-                best.lean = lean != 0;
-                best.wpe = wpe;
-                best.grid = c->prop.multiProcessorCount * per_cu;
+    // state-store instances only on request: measured 2x slower than LDS records at k = 4 / 8 (the per-turn record
+    // exchange is bound by L2 / Infinity-Cache request throughput); they remain the path for tables too wide for LDS
+    const bool gs_wanted = c->gs == 1;
+    for (int gs = 0; gs <= 1; ++gs) {
+        if (gs != (gs_wanted ? 1 : 0) && best_lanes >= 0) continue; // the other layout only if the wanted one does not fit
+        for (int lean = 0; lean <= 1; ++lean) {
+            if (gs && !lean) continue;
+            if (!gs && c->lean >= 0 && lean != c->lean) continue;
+            if (!gs && lean && S > (1 << (32 - CE_IDX_SHIFT))) continue; // strategy index must fit cE[31:18]
+            for (int block : {1024, 768, 512, 256, 128, 64}) {
+                if (gs && block != 768 && block != 256 && block != 64) continue;
+                if (c->block != 0 && block != c->block && !(gs && block == (c->block >= 768 ? 768 : c->block >= 256 ? 256 : 64))) continue;
+                if (block == 768 && !lean) continue;
+                const int wpe = (block == 768) ? 6 : 4;
+                bool tally = want_tally && play_lds_bytes(k, block, lean != 0, gs != 0, true, (int32_t)S) <= LDS_LIMIT / (gs ? 2 : 1);
+                size_t lds = play_lds_bytes(k, block, lean != 0, gs != 0, tally, (int32_t)S);
+                if (lds > LDS_LIMIT) continue;
+                int per_cu = (int)(LDS_LIMIT / std::max<size_t>(lds, 1));
+                per_cu = std::min(per_cu, std::max(1, wpe * 4 * 64 / block));
+                if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
+                per_cu = std::max(per_cu, 1);
+                int lanes = (per_cu * block) * 4 + (tally ? 2 : 0) + (lean ? 0 : 1); // tie-breaks: tally, then full records
+                if (gs == (gs_wanted ? 1 : 0)) lanes += 1 << 24;                     // the wanted layout wins when it fits
+                if (lanes > best_lanes) {
+                    best_lanes = lanes;
+                    best.block = block;
+                    best.lds = lds;
+                    best.lds_tally = tally;
+                    best.lean = lean != 0;
+                    best.gs = gs != 0;
+                    best.wpe = wpe;
+                    best.grid = c->prop.multiProcessorCount * per_cu;
+                }
             }
         }
     }
-    if (best_lanes < 0) { // k too large for one wave: reported by run_chunk
-        best.block = 64;
-        best.lean = S <= (1 << (32 - CE_IDX_SHIFT));
-        best.lds_tally = false;
-        best.lds = play_lds_bytes(k, 64, best.lean, false, S);
-        best.grid = c->prop.multiProcessorCount;
-    }
-    return best;
+    return best; // always feasible: a GS instance needs 44 bytes of LDS per lane whatever k is
 }
 
-template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED>
+template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS>
 hipError_t launch_play_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, LEAN, WPE, MIXED>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(p.lds, 16));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((fk_play_kernel<BLOCK, LEAN, WPE, MIXED>), dim3((unsigned)p.grid), dim3(BLOCK), p.lds, s, a);
+    static bool configured = false; // the dynamic-LDS ceiling of an instance is raised once, not per launch
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL((fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS>), dim3((unsigned)p.grid), dim3(BLOCK), std::max<size_t>(p.lds, 16), s, a);
     return hipGetLastError();
 }
 
 constexpr uint32_t MIXED_ALL = 0xff00u, MIXED_NONE = 0u, MIXED_RB_FAV = SF_REQUIRE_BOTH | SF_FAVOR_SCORE;
 
-template <int BLOCK, bool LEAN, int WPE = 4>
+template <int BLOCK, bool LEAN, int WPE = 4, bool GS = false>
 hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     // the narrowest instance whose MIXED set covers the flags that actually vary in this table
-    if (p.mixed_flags == MIXED_NONE) return launch_play_u<BLOCK, LEAN, WPE, MIXED_NONE>(p, a, s);
-    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_u<BLOCK, LEAN, WPE, MIXED_RB_FAV>(p, a, s);
-    return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL>(p, a, s);
+    if (p.mixed_flags == MIXED_NONE) return launch_play_u<BLOCK, LEAN, WPE, MIXED_NONE, GS>(p, a, s);
+    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_u<BLOCK, LEAN, WPE, MIXED_RB_FAV, GS>(p, a, s);
+    return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS>(p, a, s);
 }
 
 hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     if (p.lds > LDS_LIMIT) return hipErrorInvalidValue;
+    if (p.gs) {
+        switch (p.block) {
+        case 768: return launch_play_t<768, true, 6, true>(p, a, s);
+        case 256: return launch_play_t<256, true, 4, true>(p, a, s);
+        default: return launch_play_t<64, true, 4, true>(p, a, s);
+        }
+    }
     if (p.lean) {
         switch (p.block) {
         case 1024: return launch_play_t<1024, true>(p, a, s);
@@ -289,19 +314,42 @@ int check_device_error(fk_ctx *c, const int32_t *d_err, int64_t game_base, const
     return FK_OK;
 }
 
-// Run seeds + games for `n_games` games whose seeds/strategy sources are already described by the args.
-int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &plan, int64_t game_base, const char *what) {
+// chunk-local overrides, sorted by game id, on the device
+int upload_overrides(fk_ctx *c, std::vector<DevOverride> &dov) {
+    if (dov.empty()) return FK_OK;
+    std::sort(dov.begin(), dov.end(), [](const DevOverride &x, const DevOverride &y) { return x.game < y.game; });
+    // duplicates: the last entry of the caller's list wins (as the linear scan it replaces did)
+    int rc = ensure(c, c->ov, dov.size() * sizeof(DevOverride));
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->ov.p, dov.data(), dov.size() * sizeof(DevOverride), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FK_OK;
+}
+
+// bytes of device workspace one game needs in a chunk (state records, increments, schedule, result record, row)
+size_t game_workspace_bytes(int32_t k, bool full_state, bool recs, bool rows) {
+    return (size_t)k * ((full_state ? STATE_DW * 4 : 16) + 16) + 8 + (recs ? REC_DW * 4 : 0) +
+           (rows ? sizeof(fk_row_hdr) + sizeof(fk_seat) * (size_t)k : 0);
+}
+
+// Seeds + games of one chunk of `n_games` games: fills the state / increment planes, plays, checks the error record.
+// `want_state`: the final state records of every seat must be in the state store afterwards (rows, all-seat statistics).
+// `want_recs`: one result record per game (rec_dw dwords).  Post-passes are the caller's.
+int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &plan, bool want_state, bool want_recs,
+              uint32_t rec_dw, int64_t game_base, const char *what) {
     SeedArgs sa = sa_in;
-    if (plan.lds > LDS_LIMIT)
-        return fail(c, FK_ERR_ARG, "k=%u needs %zu bytes of LDS per wave; the seat contexts of at most 58 players fit a CU",
-                    sa.k, plan.lds);
-    int rc = ensure(c, c->seeds, (size_t)sa.n_games * sa.k * 32);
+    const bool full_state = plan.gs || want_state;
+    sa.state_dw = full_state ? STATE_DW : 4u;
+    int rc = ensure(c, c->state, (size_t)sa.n_games * sa.k * sa.state_dw * 4);
+    if (rc) return rc;
+    rc = ensure(c, c->inc, (size_t)sa.n_games * sa.k * 16);
     if (rc) return rc;
     // misc: [0] ticket counter (hammered by atomics), [16] error record, [256] schedule class cursors of the seed kernel
     rc = ensure(c, c->misc, 512);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 512, c->stream));
-    sa.seeds = static_cast<uint4 *>(c->seeds.p);
+    sa.state = static_cast<uint32_t *>(c->state.p);
+    sa.inc = static_cast<uint4 *>(c->inc.p);
     if (sa.perm_T && c->longest_first) {
         rc = ensure(c, c->order, (size_t)sa.n_games * 4);
         if (rc) return rc;
@@ -317,6 +365,10 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
         sa.sched = nullptr;
         pa.sched = nullptr;
     }
+    if (want_recs) {
+        rc = ensure(c, c->recs, (size_t)sa.n_games * rec_dw * 4);
+        if (rc) return rc;
+    }
     {
         Timer t(c, &c->timing.seed_ms, SLOT_SEED);
         if (sa.sched) // class sizes first: a game's ticket is class offset + rank
@@ -327,7 +379,12 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
         t.stop();
         HIPCHK(c, hipGetLastError());
     }
-    pa.seeds = sa.seeds;
+    pa.state = sa.state;
+    pa.state_dw = sa.state_dw;
+    pa.inc = sa.inc;
+    pa.recs = want_recs ? static_cast<uint32_t *>(c->recs.p) : nullptr;
+    pa.rec_dw = rec_dw;
+    pa.gs_out = (want_state && !plan.gs) ? 1u : 0u;
     pa.ticket = static_cast<uint32_t *>(c->misc.p);
     pa.err = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(c->misc.p) + 16);
     pa.batch_threshold = (uint32_t)std::max(1, std::min(64, c->batch_threshold));
@@ -349,6 +406,22 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
     const int rc_dev = check_device_error(c, pa.err, game_base, what); // synchronises the stream
     HIPCHK(c, collect_timers(c));
     return rc_dev;
+}
+
+// state store + result records of the chunk just played -> rows at `d_rows` (device), game-id order
+int rows_pass(fk_ctx *c, const SeedArgs &sa, bool scheduled, uint32_t n_games, uint32_t gps, uint32_t n_sh, bool perm_mode, uint8_t *d_rows) {
+    const uint32_t *inv = nullptr;
+    if (scheduled) {
+        int rc = ensure(c, c->inv, (size_t)n_games * 4);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fk_invert_sched_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
+                           static_cast<const uint32_t *>(c->order.p), n_games, static_cast<uint32_t *>(c->inv.p));
+        inv = static_cast<const uint32_t *>(c->inv.p);
+    }
+    hipLaunchKernelGGL(fk_rows_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream, static_cast<const uint32_t *>(c->state.p),
+                       static_cast<const uint32_t *>(c->recs.p), inv, n_games, gps, n_sh, sa.k, perm_mode ? 1u : 0u, d_rows);
+    HIPCHK(c, hipGetLastError());
+    return FK_OK;
 }
 
 } // namespace
@@ -400,7 +473,9 @@ void fk_destroy(fk_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->strat, &c->perm, &c->seeds, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist, &c->coords, &c->order, &c->slow, &c->score_lut, &c->discard_lut, &c->classes})
+    for (DevBuf *b : {&c->strat, &c->perm, &c->draws, &c->state, &c->inc, &c->recs, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist,
+                      &c->coords, &c->order, &c->inv, &c->slow, &c->score_lut, &c->discard_lut, &c->classes, &c->blocks, &c->game_block,
+                      &c->block_out, &c->stats})
         release(*b);
     for (auto &b : c->dbg) release(b);
     for (auto &e : c->ev)
@@ -439,8 +514,9 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "longest_first") c->longest_first = (int32_t)value;
     else if (n == "blocks_per_cu") c->blocks_per_cu = (int32_t)value;
     else if (n == "lean") c->lean = (int32_t)value;
+    else if (n == "state_store") c->gs = (int32_t)value;
+    else if (n == "perm_split") c->perm_split = (int32_t)value;
     else if (n == "uniform_flags") c->uniform_flags_opt = (int32_t)value;
-    else if (n == "waves_per_cu") c->waves_per_cu = (int32_t)std::max<int64_t>(1, std::min<int64_t>(32, value));
     else if (n == "block") {
         if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 768 && value != 1024)
             return fail(c, FK_ERR_ARG, "block must be 0, 64, 128, 256, 512, 768 (lean records only) or 1024");
@@ -476,13 +552,15 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->tally.p, 0, tally_bytes, c->stream));
 
+    const LaunchPlan plan = plan_play(c, k, S, n_batches == 1);
+    const bool want_recs = !plan.lds_tally || rows != nullptr;
+
     // chunk planning: whole shuffles per chunk inside the workspace budget
-    const size_t bytes_per_shuffle = (size_t)S * 2 + (size_t)gps * k * 32 + (rows ? (size_t)gps * row_bytes : 0);
+    const size_t bytes_per_shuffle = (size_t)S * 2 + (size_t)gps * game_workspace_bytes(k, plan.gs || rows, want_recs, rows != nullptr);
     uint64_t chunk_sh = std::max<uint64_t>(1, (uint64_t)c->chunk_bytes / bytes_per_shuffle);
     chunk_sh = std::min<uint64_t>(chunk_sh, (uint64_t)0x7fffffff / gps);
     chunk_sh = std::min<uint64_t>(chunk_sh, n_sh_total);
 
-    const LaunchPlan plan = plan_play(c, k, S, n_batches == 1);
     const SeedPool perm_prefix = seed_prefix(101u /* SHUFFLE_PERMUTATION */, root_seed, (uint64_t)k);
     const SeedPool seat_prefix = seed_prefix(103u /* TOURNAMENT_PLAYER */, root_seed, (uint64_t)k);
 
@@ -502,10 +580,29 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
         {
             Timer t(c, &c->timing.perm_ms, SLOT_PERM);
             const size_t perm_lds = (size_t)slots * S * 2;
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)perm_lds));
-            hipLaunchKernelGGL(fk_perm_kernel, dim3(perm_blocks), dim3(PERM_BLOCK), perm_lds, c->stream,
-                               perm_prefix, sh0, n_sh, (uint32_t)S, slots, static_cast<uint16_t *>(c->perm.p));
+            static bool perm_configured = false;
+            if (!perm_configured) {
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_apply_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+                perm_configured = true;
+            }
+            // large tables: draws at full occupancy first, then the bare swap chains over the LDS arrays (fk_kernels.h)
+            const bool split = c->perm_split == 1 || (c->perm_split < 0 && S >= 1024 && n_sh >= 256);
+            if (split) {
+                const uint32_t n_sh_pad = (n_sh + 63u) & ~63u, groups = ((uint32_t)S - 1u + 7u) / 8u;
+                rc = ensure(c, c->draws, (size_t)groups * n_sh_pad * 16);
+                if (rc) return rc;
+                hipLaunchKernelGGL(fk_perm_draw_kernel, dim3((n_sh + DRAW_BLOCK - 1u) / DRAW_BLOCK), dim3(DRAW_BLOCK), 0, c->stream,
+                                   perm_prefix, sh0, n_sh, (uint32_t)S, n_sh_pad, static_cast<uint4 *>(c->draws.p));
+                hipLaunchKernelGGL(fk_perm_apply_kernel, dim3(perm_blocks), dim3(PERM_BLOCK), perm_lds, c->stream,
+                                   static_cast<const uint4 *>(c->draws.p), n_sh_pad, n_sh, (uint32_t)S, slots,
+                                   static_cast<uint16_t *>(c->perm.p));
+            } else {
+                hipLaunchKernelGGL(fk_perm_kernel, dim3(perm_blocks), dim3(PERM_BLOCK), perm_lds, c->stream,
+                                   perm_prefix, sh0, n_sh, (uint32_t)S, slots, static_cast<uint16_t *>(c->perm.p));
+            }
             t.stop();
             HIPCHK(c, hipGetLastError());
         }
@@ -524,14 +621,17 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
             if (ov[i].root_seed != root_seed || ov[i].k_or_order != (uint32_t)k) continue;
             if (ov[i].a < sh0 || ov[i].a >= sh0 + n_sh || ov[i].b >= gps) continue;
             if (ov[i].max_rounds > 65535u) return fail(c, FK_ERR_ARG, "override max_rounds must be <= 65535");
-            dov.push_back(DevOverride{(uint32_t)((ov[i].a - sh0) * gps + ov[i].b), ov[i].max_rounds});
+            const uint32_t game = (uint32_t)((ov[i].a - sh0) * gps + ov[i].b);
+            bool replaced = false;
+            for (auto &d : dov)
+                if (d.game == game) {
+                    d.max_rounds = ov[i].max_rounds;
+                    replaced = true;
+                }
+            if (!replaced) dov.push_back(DevOverride{game, ov[i].max_rounds});
         }
-        if (!dov.empty()) {
-            rc = ensure(c, c->ov, dov.size() * sizeof(DevOverride));
-            if (rc) return rc;
-            HIPCHK(c, hipMemcpyAsync(c->ov.p, dov.data(), dov.size() * sizeof(DevOverride), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-        }
+        rc = upload_overrides(c, dov);
+        if (rc) return rc;
         if (rows) {
             rc = ensure(c, c->rows, (size_t)n_games * row_bytes);
             if (rc) return rc;
@@ -560,7 +660,6 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
         pa.perm_slots = slots;
         pa.seat_strategy = nullptr;
         pa.tally = static_cast<unsigned long long *>(c->tally.p);
-        pa.rows = rows ? static_cast<uint8_t *>(c->rows.p) : nullptr;
         pa.ov = static_cast<const DevOverride *>(c->ov.p);
         pa.n_ov = (uint32_t)dov.size();
         pa.mode = MODE_PERM;
@@ -569,14 +668,42 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
         pa.n_sh = n_sh;
         pa.k = (uint32_t)k;
         pa.S = (uint32_t)S;
-        pa.sh_offset = (uint32_t)done;
-        pa.spb = shuffles_per_batch;
         pa.target = target_score;
         pa.max_rounds = (uint32_t)max_rounds;
 
-        rc = run_chunk(c, sa, pa, plan, (int64_t)done * gps, "tournament");
+        rc = run_chunk(c, sa, pa, plan, rows != nullptr, want_recs, REC_DW, (int64_t)done * gps, "tournament");
         if (rc) return rc;
+        if (!plan.lds_tally) { // result records -> per-batch tallies
+            const uint64_t games_per_batch = (uint64_t)shuffles_per_batch * gps;
+            unsigned long long *d_tally = static_cast<unsigned long long *>(c->tally.p);
+            if (games_per_batch >= 4096) {
+                const uint32_t slice = (uint32_t)std::min<int64_t>(S, 448); // 448 x 22 x 8 B = 77 KiB: two workgroups per CU
+                const uint32_t n_slices = ((uint32_t)S + slice - 1u) / slice;
+                const uint32_t first_batch = (uint32_t)(done / shuffles_per_batch);
+                const uint32_t last_batch = (uint32_t)((done + n_sh - 1) / shuffles_per_batch);
+                const uint32_t nb = last_batch - first_batch + 1u;
+                // enough parts to fill the chip, at least ~16 K games each
+                uint32_t ppb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(games_per_batch / 16384, (2048u + nb * n_slices - 1u) / (nb * n_slices)));
+                static bool reduce_configured = false;
+                if (!reduce_configured) {
+                    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_tally_reduce_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+                    reduce_configured = true;
+                }
+                hipLaunchKernelGGL(fk_tally_reduce_kernel, dim3(ppb * nb, n_slices), dim3(REDUCE_BLOCK), (size_t)slice * RT_COLS * 8, c->stream,
+                                   static_cast<const uint32_t *>(c->recs.p), n_games, gps, (uint32_t)k, (uint32_t)S,
+                                   static_cast<const uint16_t *>(c->perm.p), slots, (uint32_t)done, shuffles_per_batch, n_sh, ppb, slice,
+                                   first_batch, d_tally);
+            } else {
+                hipLaunchKernelGGL(fk_tally_direct_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
+                                   static_cast<const uint32_t *>(c->recs.p), n_games, gps, (uint32_t)k, (uint32_t)S,
+                                   static_cast<const uint16_t *>(c->perm.p), slots, (uint32_t)done, shuffles_per_batch, d_tally);
+            }
+            HIPCHK(c, hipGetLastError());
+        }
         if (rows) {
+            rc = rows_pass(c, sa, c->longest_first != 0, n_games, gps, n_sh, true, static_cast<uint8_t *>(c->rows.p));
+            if (rc) return rc;
             HIPCHK(c, hipMemcpyAsync(static_cast<uint8_t *>(rows) + (size_t)done * gps * row_bytes, c->rows.p,
                                      (size_t)n_games * row_bytes, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -619,39 +746,188 @@ int fk_play_games(fk_ctx *c, const fk_coord *coords, int64_t n_games, const fk_s
     if (rc) return rc;
     rc = ensure(c, c->rows, (size_t)n_games * row_bytes);
     if (rc) return rc;
-    rc = ensure(c, c->tally, sizeof(int64_t) * (size_t)S * FK_TALLY_COLS);
-    if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->coords.p, coords, sizeof(fk_coord) * (size_t)n_games, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->seatlist.p, seat_strategy, sizeof(int32_t) * (size_t)n_games * k, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->tally.p, 0, sizeof(int64_t) * (size_t)S * FK_TALLY_COLS, c->stream));
 
     LaunchPlan plan = plan_play(c, k, S, false);
 
     SeedArgs sa{};
     sa.coords = static_cast<const fk_coord *>(c->coords.p);
+    sa.seat_strategy = static_cast<const int32_t *>(c->seatlist.p);
     sa.k = (uint32_t)k;
     sa.n_games = (uint32_t)n_games;
 
     PlayArgs pa{};
     pa.strat = static_cast<const uint2 *>(c->strat.p);
     pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
-        pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
+    pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
     pa.seat_strategy = static_cast<const int32_t *>(c->seatlist.p);
-    pa.tally = static_cast<unsigned long long *>(c->tally.p);
-    pa.rows = static_cast<uint8_t *>(c->rows.p);
     pa.mode = MODE_LIST;
     pa.n_games = (uint32_t)n_games;
     pa.gps = 1;
     pa.n_sh = 1;
     pa.k = (uint32_t)k;
     pa.S = (uint32_t)S;
-    pa.spb = 1;
     pa.target = target_score;
     pa.max_rounds = (uint32_t)max_rounds;
-    rc = run_chunk(c, sa, pa, plan, 0, "list");
+    rc = run_chunk(c, sa, pa, plan, true, true, REC_DW, 0, "list");
+    if (rc) return rc;
+    rc = rows_pass(c, sa, false, (uint32_t)n_games, 1, 1, false, static_cast<uint8_t *>(c->rows.p));
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(rows, c->rows.p, (size_t)n_games * row_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->timing.total_ms = c->timing.seed_ms + c->timing.play_ms;
+    return FK_OK;
+}
+
+// Many H2H blocks advanced together.  Each pass plays, for every block that still needs games, exactly
+// min(target - completed, stop - attempted) attempts in attempt order: a pass can never overshoot the prefix rule (the
+// first attempt index at which `target` games have completed, h2h_schedule.py:1165-1235), because it reaches the target
+// only if every one of its attempts completes, i.e. at its last attempt.  Blocks with safety-limit games need further
+// (geometrically smaller) passes; all blocks share each pass's launch.
+int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_t root_seed, uint64_t chunk_games,
+                      int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov) {
+    if (!c) return FK_ERR_ARG;
+    if (!blocks || n_blocks < 0 || n_blocks > (1 << 22)) return fail(c, FK_ERR_ARG, "blocks are required (at most 2^22 per call)");
+    if (max_rounds < 0 || max_rounds > 65535) return fail(c, FK_ERR_ARG, "max_rounds must be in [0, 65535]");
+    if (n_ov < 0 || (n_ov > 0 && !ov)) return fail(c, FK_ERR_ARG, "bad override list");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->timing = fk_timing{};
+    c->pending.clear();
+    if (n_blocks == 0) return FK_OK;
+    std::vector<fk_strategy> table((size_t)n_blocks * 2);
+    std::vector<uint64_t> stop((size_t)n_blocks);
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        const fk_h2h_block &blk = blocks[b];
+        if (blk.order > 1u) return fail(c, FK_ERR_ARG, "block %lld: order must be 0 or 1", (long long)b);
+        const uint64_t attempted = blk.state[0], completed = blk.state[1], safety = blk.state[2], w1 = blk.state[3], w2 = blk.state[4];
+        if (!(completed <= blk.target) || !(attempted <= blk.max_attempts) || completed + safety != attempted || w1 + w2 != completed)
+            return fail(c, FK_ERR_ARG, "block %lld: inconsistent block state", (long long)b); // h2h_schedule.py:1366, 1422-1468
+        uint64_t st = attempted + chunk_games; // :1172
+        if (st > blk.max_attempts || st < attempted) st = blk.max_attempts;
+        stop[(size_t)b] = st;
+        table[(size_t)b * 2] = blk.seats[0];
+        table[(size_t)b * 2 + 1] = blk.seats[1];
+    }
+    int rc = upload_strategies(c, table.data(), n_blocks * 2);
+    if (rc) return rc;
+    const SeedPool seat_prefix = seed_prefix(203u /* H2H_PLAYER */, root_seed, 2u);
+    // at most 8 192 blocks share a launch: their 16 384 table rows are what a lean record's strategy-index field holds
+    constexpr size_t MAX_BLOCKS_PER_PASS = (size_t)1 << (32 - CE_IDX_SHIFT - 1);
+    const LaunchPlan plan = plan_play(c, 2, (int64_t)std::min<size_t>((size_t)n_blocks, MAX_BLOCKS_PER_PASS) * 2, false);
+    const uint64_t max_launch = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->chunk_bytes / (game_workspace_bytes(2, plan.gs, false, false) + 8), 1u << 30));
+    rc = ensure(c, c->block_out, (size_t)n_blocks * 4 * 8);
+    if (rc) return rc;
+
+    std::vector<DevBlock> pass;
+    std::vector<int64_t> pass_block;
+    std::vector<unsigned long long> out;
+    int64_t cursor = 0; // round-robin start so that an over-full pass does not starve the later blocks
+    while (true) {
+        pass.clear();
+        pass_block.clear();
+        uint64_t total = 0;
+        for (int64_t i = 0; i < n_blocks; ++i) {
+            const int64_t b = (cursor + i) % n_blocks;
+            fk_h2h_block &blk = blocks[b];
+            if (blk.state[0] >= stop[(size_t)b] || blk.state[1] >= blk.target) continue;
+            uint64_t n = std::min<uint64_t>(stop[(size_t)b] - blk.state[0], blk.target - blk.state[1]);
+            n = std::min<uint64_t>(n, max_launch - total);
+            if (n == 0) break;
+            pass.push_back(DevBlock{blk.pair_id, blk.state[0], blk.order, (uint32_t)total});
+            pass_block.push_back(b);
+            total += n;
+            if (total >= max_launch || pass.size() >= MAX_BLOCKS_PER_PASS) {
+                cursor = b; // this block may need the rest of its range in the next pass
+                break;
+            }
+        }
+        if (pass.empty()) break;
+        const uint32_t n_games = (uint32_t)total, nb = (uint32_t)pass.size();
+        // overrides -> pass-local game ids
+        std::vector<DevOverride> dov;
+        for (int32_t i = 0; i < n_ov && nb; ++i) {
+            if (ov[i].root_seed != root_seed) continue;
+            if (ov[i].max_rounds > 65535u) return fail(c, FK_ERR_ARG, "override max_rounds must be <= 65535");
+            for (uint32_t p = 0; p < nb; ++p) {
+                const uint32_t n_p = (p + 1 < nb ? pass[p + 1].start : n_games) - pass[p].start;
+                if (ov[i].a != pass[p].pair || ov[i].k_or_order != pass[p].order) continue;
+                if (ov[i].b < pass[p].attempt0 || ov[i].b >= pass[p].attempt0 + n_p) continue;
+                const uint32_t game = pass[p].start + (uint32_t)(ov[i].b - pass[p].attempt0);
+                bool replaced = false;
+                for (auto &d : dov)
+                    if (d.game == game) {
+                        d.max_rounds = ov[i].max_rounds;
+                        replaced = true;
+                    }
+                if (!replaced) dov.push_back(DevOverride{game, ov[i].max_rounds});
+            }
+        }
+        rc = upload_overrides(c, dov);
+        if (rc) return rc;
+        // the pass's strategy table rows: seats of pass block p sit at 2p, 2p + 1 -> re-pack when the pass is a subset
+        if (nb != (uint32_t)n_blocks || pass_block[0] != 0) {
+            std::vector<fk_strategy> sub((size_t)nb * 2);
+            for (uint32_t p = 0; p < nb; ++p) {
+                sub[(size_t)p * 2] = blocks[pass_block[p]].seats[0];
+                sub[(size_t)p * 2 + 1] = blocks[pass_block[p]].seats[1];
+            }
+            rc = upload_strategies(c, sub.data(), (int64_t)nb * 2);
+        } else {
+            rc = upload_strategies(c, table.data(), n_blocks * 2);
+        }
+        if (rc) return rc;
+        rc = ensure(c, c->blocks, (size_t)nb * sizeof(DevBlock));
+        if (rc) return rc;
+        rc = ensure(c, c->game_block, (size_t)n_games * 4);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->blocks.p, pass.data(), (size_t)nb * sizeof(DevBlock), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->block_out.p, 0, (size_t)nb * 4 * 8, c->stream));
+        SeedArgs sa{};
+        sa.prefix = seat_prefix;
+        sa.gps = 0;
+        sa.k = 2;
+        sa.n_games = n_games;
+        sa.blocks = static_cast<const DevBlock *>(c->blocks.p);
+        sa.n_blocks = nb;
+        sa.game_block = static_cast<uint32_t *>(c->game_block.p);
+        PlayArgs pa{};
+        pa.strat = static_cast<const uint2 *>(c->strat.p);
+        pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
+        pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
+        pa.game_block = sa.game_block;
+        pa.ov = static_cast<const DevOverride *>(c->ov.p);
+        pa.n_ov = (uint32_t)dov.size();
+        pa.mode = MODE_BLOCKS;
+        pa.n_games = n_games;
+        pa.gps = 1;
+        pa.n_sh = 1;
+        pa.k = 2;
+        pa.S = nb * 2;
+        pa.target = target_score;
+        pa.max_rounds = (uint32_t)max_rounds;
+        rc = run_chunk(c, sa, pa, plan, false, true, REC_DW_H2H, 0, "h2h attempt (pass-local index)");
+        if (rc) return rc;
+        hipLaunchKernelGGL(fk_h2h_reduce_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
+                           static_cast<const uint32_t *>(c->recs.p), n_games, nb, static_cast<unsigned long long *>(c->block_out.p));
+        HIPCHK(c, hipGetLastError());
+        out.resize((size_t)nb * 4);
+        HIPCHK(c, hipMemcpyAsync(out.data(), c->block_out.p, (size_t)nb * 4 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (uint32_t p = 0; p < nb; ++p) {
+            const uint64_t n_p = (uint64_t)((p + 1 < nb ? pass[p + 1].start : n_games) - pass[p].start);
+            const uint64_t comp = out[(size_t)p * 4], saf = out[(size_t)p * 4 + 1], a1 = out[(size_t)p * 4 + 2], a2 = out[(size_t)p * 4 + 3];
+            if (comp + saf != n_p || a1 + a2 != comp)
+                return fail(c, FK_ERR_HIP, "h2h block conservation failed (block %lld: %llu + %llu != %llu)", (long long)pass_block[p],
+                            (unsigned long long)comp, (unsigned long long)saf, (unsigned long long)n_p);
+            fk_h2h_block &blk = blocks[pass_block[p]];
+            blk.state[0] += n_p;
+            blk.state[1] += comp;
+            blk.state[2] += saf;
+            blk.state[3] += a1;
+            blk.state[4] += a2;
+        }
+    }
     c->timing.total_ms = c->timing.seed_ms + c->timing.play_ms;
     return FK_OK;
 }
@@ -662,89 +938,17 @@ int fk_h2h_run(fk_ctx *c, const fk_strategy seats[2], uint64_t root_seed, uint64
     if (!c) return FK_ERR_ARG;
     if (!seats || !state) return fail(c, FK_ERR_ARG, "seats and state are required");
     if (order > 1u) return fail(c, FK_ERR_ARG, "order must be 0 or 1");
-    if (max_rounds < 0 || max_rounds > 65535) return fail(c, FK_ERR_ARG, "max_rounds must be in [0, 65535]");
-    if (n_ov < 0 || (n_ov > 0 && !ov)) return fail(c, FK_ERR_ARG, "bad override list");
-    HIPCHK(c, hipSetDevice(c->device));
-    c->timing = fk_timing{};
-    c->pending.clear();
-    uint64_t attempted = state[0], completed = state[1], safety = state[2], w1 = state[3], w2 = state[4];
-    if (!(completed <= target) || !(attempted <= max_attempts) || completed + safety != attempted || w1 + w2 != completed)
-        return fail(c, FK_ERR_ARG, "inconsistent block state"); // h2h_schedule.py:1366, 1422-1468
-    uint64_t stop = attempted + chunk_games; // :1172
-    if (stop > max_attempts || stop < attempted) stop = max_attempts;
-    int rc = upload_strategies(c, seats, 2);
-    if (rc) return rc;
-    rc = ensure(c, c->tally, sizeof(int64_t) * 2 * FK_TALLY_COLS);
-    if (rc) return rc;
-    const SeedPool seat_prefix = seed_prefix(203u /* H2H_PLAYER */, root_seed, 2u);
-    const LaunchPlan plan = plan_play(c, 2, 2, true);
-    const uint64_t max_launch = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->chunk_bytes / 64, 1u << 30));
-
-    // The stop rule is a prefix rule (first attempt index at which `target` games have completed).
-    // Launching exactly (target - completed) attempts per pass can never overshoot it: the pass reaches
-    // the target only if every attempt in it completes, i.e. at its last attempt.
-    while (attempted < stop && completed < target) {
-        const uint64_t n = std::min<uint64_t>(std::min<uint64_t>(stop - attempted, target - completed), max_launch);
-        std::vector<DevOverride> dov;
-        for (int32_t i = 0; i < n_ov; ++i) {
-            if (ov[i].root_seed != root_seed || ov[i].k_or_order != order || ov[i].a != pair_id) continue;
-            if (ov[i].b < attempted || ov[i].b >= attempted + n) continue;
-            if (ov[i].max_rounds > 65535u) return fail(c, FK_ERR_ARG, "override max_rounds must be <= 65535");
-            dov.push_back(DevOverride{(uint32_t)(ov[i].b - attempted), ov[i].max_rounds});
-        }
-        if (!dov.empty()) {
-            rc = ensure(c, c->ov, dov.size() * sizeof(DevOverride));
-            if (rc) return rc;
-            HIPCHK(c, hipMemcpyAsync(c->ov.p, dov.data(), dov.size() * sizeof(DevOverride), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-        }
-        HIPCHK(c, hipMemsetAsync(c->tally.p, 0, sizeof(int64_t) * 2 * FK_TALLY_COLS, c->stream));
-        SeedArgs sa{};
-        sa.prefix = seat_prefix;
-        sa.shuffle0 = 0;
-        sa.pair = pair_id;
-        sa.order = order;
-        sa.game0 = attempted;
-        sa.gps = 0;
-        sa.k = 2;
-        sa.n_games = (uint32_t)n;
-        PlayArgs pa{};
-        pa.strat = static_cast<const uint2 *>(c->strat.p);
-        pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
-        pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
-        pa.tally = static_cast<unsigned long long *>(c->tally.p);
-        pa.ov = static_cast<const DevOverride *>(c->ov.p);
-        pa.n_ov = (uint32_t)dov.size();
-        pa.mode = MODE_FIXED;
-        pa.n_games = (uint32_t)n;
-        pa.gps = 1;
-        pa.n_sh = 1;
-        pa.k = 2;
-        pa.S = 2;
-        pa.spb = 1;
-        pa.target = target_score;
-        pa.max_rounds = (uint32_t)max_rounds;
-        rc = run_chunk(c, sa, pa, plan, (int64_t)attempted, "h2h attempt");
-        if (rc) return rc;
-        int64_t t[2 * FK_TALLY_COLS];
-        HIPCHK(c, hipMemcpyAsync(t, c->tally.p, sizeof(t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        const uint64_t comp = (uint64_t)t[2], saf = (uint64_t)t[3]; // seat-1 strategy row: one exposure per game
-        if (comp + saf != n) return fail(c, FK_ERR_HIP, "h2h tally conservation failed (%llu + %llu != %llu)",
-                                         (unsigned long long)comp, (unsigned long long)saf, (unsigned long long)n);
-        attempted += n;
-        completed += comp;
-        safety += saf;
-        w1 += (uint64_t)t[0];
-        w2 += (uint64_t)t[FK_TALLY_COLS + 0];
-    }
-    state[0] = attempted;
-    state[1] = completed;
-    state[2] = safety;
-    state[3] = w1;
-    state[4] = w2;
-    c->timing.total_ms = c->timing.seed_ms + c->timing.play_ms;
-    return FK_OK;
+    fk_h2h_block blk{};
+    blk.seats[0] = seats[0];
+    blk.seats[1] = seats[1];
+    blk.pair_id = pair_id;
+    blk.order = order;
+    blk.target = target;
+    blk.max_attempts = max_attempts;
+    memcpy(blk.state, state, sizeof(blk.state));
+    const int rc = fk_h2h_run_blocks(c, &blk, 1, root_seed, chunk_games, target_score, max_rounds, ov, n_ov);
+    if (rc == FK_OK) memcpy(state, blk.state, sizeof(blk.state));
+    return rc;
 }
 
 // ---- probes ----
@@ -813,21 +1017,25 @@ static int debug_dice_common(fk_ctx *c, int64_t n, const fk_coord *coords, const
         total += sizes[i];
     }
     int rc;
-    const uint4 *d_seeds = nullptr;
+    const uint4 *d_seeds = nullptr, *d_incs = nullptr;
     const uint64_t *d_state = nullptr;
     if (coords) {
         if ((rc = ensure(c, c->coords, sizeof(fk_coord) * (size_t)n))) return rc;
-        if ((rc = ensure(c, c->seeds, (size_t)n * 32))) return rc;
+        if ((rc = ensure(c, c->state, (size_t)n * 16))) return rc;
+        if ((rc = ensure(c, c->inc, (size_t)n * 16))) return rc;
         // one 1-seat "game" per coordinate; the seed kernel offsets the seat stream by coords[i].seat_index
         HIPCHK(c, hipMemcpyAsync(c->coords.p, coords, sizeof(fk_coord) * (size_t)n, hipMemcpyHostToDevice, c->stream));
         SeedArgs sa{};
         sa.coords = static_cast<const fk_coord *>(c->coords.p);
         sa.k = 1;
         sa.n_games = (uint32_t)n;
-        sa.seeds = static_cast<uint4 *>(c->seeds.p);
+        sa.state = static_cast<uint32_t *>(c->state.p);
+        sa.state_dw = 4;
+        sa.inc = static_cast<uint4 *>(c->inc.p);
         hipLaunchKernelGGL(fk_seed_kernel, dim3((unsigned)((n + SEED_BLOCK - 1) / SEED_BLOCK)), dim3(SEED_BLOCK), 0, c->stream, sa);
         HIPCHK(c, hipGetLastError());
-        d_seeds = sa.seeds;
+        d_seeds = static_cast<const uint4 *>(c->state.p);
+        d_incs = sa.inc;
     } else {
         if (!state) return fail(c, FK_ERR_ARG, "state is required");
         if ((rc = ensure(c, c->dbg[0], (size_t)n * 48))) return rc;
@@ -839,7 +1047,7 @@ static int debug_dice_common(fk_ctx *c, int64_t n, const fk_coord *coords, const
     if ((rc = ensure(c, c->dbg[3], (size_t)n * 32))) return rc;
     if ((rc = ensure(c, c->dbg[4], (size_t)n * 48))) return rc;
     if (n_calls) HIPCHK(c, hipMemcpyAsync(c->dbg[1].p, sizes, (size_t)n_calls * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(fk_dbg_dice_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, n, d_seeds, d_state, n_calls,
+    hipLaunchKernelGGL(fk_dbg_dice_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, n, d_seeds, d_incs, d_state, n_calls,
                        static_cast<const int32_t *>(c->dbg[1].p), total, static_cast<uint8_t *>(c->dbg[2].p),
                        raw64 ? static_cast<uint64_t *>(c->dbg[3].p) : nullptr,
                        state_out ? static_cast<uint64_t *>(c->dbg[4].p) : nullptr);

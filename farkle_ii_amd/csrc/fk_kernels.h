@@ -2,12 +2,19 @@
 //
 //   fk_perm_kernel         one lane per shuffle: SeedSequence(ns=101) -> PCG64DXSM -> Fisher-Yates
 //                          (Generator.permutation, run_tournament.py:312-318), arrays in LDS, written shuffle-minor.
-//   fk_class_count_kernel  sizes of the schedule classes (how many seats of a game never bank).
+//   fk_class_count_kernel  sizes of the schedule classes (how patient the seats of a game are).
 //   fk_seed_kernel         one lane per game: coordinate -> SeedSequence -> PCG64DXSM (state, increment) of every seat
-//                          (random.py:80-188), longest-first schedule, seed records stored in dealing order.
-//   fk_play_kernel         persistent lanes, one lane = one game at a time, one roll per loop trip; seat records in
-//                          LDS, finished lanes are handed new games in wave-level batches; per-strategy tallies
-//                          privatised in LDS when they fit.
+//                          (random.py:80-188), longest-first schedule, per-seat state records stored in dealing order.
+//   fk_play_kernel         persistent lanes, one lane = one game at a time, one roll per loop trip.  Seat records live in
+//                          LDS (k <= 2) or, for wider tables, in a per-game state store in HBM of which only the turn
+//                          owner's record is staged in LDS (GS instances: LDS bytes per lane independent of k);
+//                          finished lanes are handed new games in wave-level batches; per-strategy tallies privatised in
+//                          LDS when they fit, otherwise one 32-byte result record per game.
+//   fk_tally_reduce_kernel result records -> per-(batch, strategy) tallies, privatised in LDS slices (no HBM atomics
+//                          from the game kernel).
+//   fk_rows_kernel         state store + result records -> per-game rows (4 + 28k bytes), a streaming post-pass.
+//   fk_seat_stats_kernel   state store + result records -> integer sufficient statistics of ALL seats per strategy.
+//   fk_h2h_reduce_kernel   result records of many H2H blocks -> per-block completed / safety / wins.
 //   fk_finalize_tally, fk_score_lut_kernel, fk_discard_lut_kernel, fk_coordinate_seed_kernel, fk_dbg_* probes.
 //
 // The per-roll arithmetic (SeedSequence, PCG64DXSM, dice, scoring, discards, decisions) lives in fk_device.h.
@@ -24,7 +31,7 @@ namespace {
 
 constexpr uint32_t HC_AFTER_6_WORDS = ss_hc(24); // 4 + 12 (all pairs) + 2*4 hashmix calls
 
-enum : uint32_t { MODE_PERM = 0, MODE_LIST = 1, MODE_FIXED = 2 };
+enum : uint32_t { MODE_PERM = 0, MODE_LIST = 1, MODE_BLOCKS = 2 };
 
 // LDS seat-record fields (dwords), record layout lds[(seat * BLOCK + tid) * NFIELDS + field]
 enum : uint32_t {
@@ -36,14 +43,33 @@ enum : uint32_t {
 //   cC = sf_uses | sf_dice << 16      cD = so_uses | so_dice << 16
 //   cE = hot_dice | flags << 16       flags: bit0 has_scored, bit1 has_buf
 constexpr uint32_t CE_HAS_SCORED = 1u << 16, CE_HAS_BUF = 1u << 17;
-constexpr uint32_t CE_IDX_SHIFT = 18; // LEAN records: strategy index in cE[31:18] (S <= 16384)
+constexpr uint32_t CE_IDX_SHIFT = 18; // LEAN records in LDS: strategy index in cE[31:18] (S <= 16384)
+
+// State record of one seat in HBM (the seed kernel writes it, GS game kernels keep it current, the post-passes read the
+// final one): the eleven dwords a turn mutates, in the order of the LEAN LDS record, + the seat's strategy index.
+// 48 bytes = three 16-byte accesses; index = slot * k + seat (slot = ticket position of the game's schedule).
+enum : uint32_t { R_LO0 = 0, R_LO1, R_HI0, R_HI1, R_BUF, R_SCORE, R_CA, R_CB, R_CC, R_CD, R_CE, R_IDX, STATE_DW = 12 };
+
+// Result record of one finished game (index = game id), written by the game kernel when the tallies are not privatised
+// in LDS or when rows / all-seat statistics are wanted:
+//   d0 = winner's strategy index [23:0] | winner seat [30:24] | safety-limit flag [31]
+//   d1 = winning score   d2 = n_rounds | farkles << 16   d3 = rolls | highest_turn << 16
+//   d4 = sf_uses | sf_dice << 16   d5 = so_uses | so_dice << 16   d6 = hot_dice   d7 = 0      (winner's counters)
+// H2H block launches store d0 only (REC_DW_H2H).
+constexpr uint32_t REC_DW = 8, REC_DW_H2H = 1, REC_SAFETY = 0x80000000u;
 
 constexpr uint32_t LT_COLS = 24; // LDS tally columns: wins, completed, safety, 10 sums, 10 square sums, pad
 constexpr uint32_t TICKET_CHUNK = 64;
 
 struct DevOverride {
-    uint32_t game; // chunk-local game id
+    uint32_t game; // chunk-local game id (the list is sorted by it)
     uint32_t max_rounds;
+};
+
+// One H2H block of a batched launch: games [start, next block's start) are its attempts attempt0, attempt0 + 1, ...
+struct DevBlock {
+    uint64_t pair, attempt0;
+    uint32_t order, start;
 };
 
 struct SeedArgs {
@@ -53,9 +79,12 @@ struct SeedArgs {
     uint32_t gps;            // games per shuffle (affine id -> (shuffle, game)); 0 = no split
     uint32_t k;
     uint32_t n_games;
-    uint4 *seeds;            // [2][n_games][k]: plane 0 = PCG state {lo, hi} (read once per game), plane 1 = increment
-                             // {lo, hi} (re-read at every turn start by lean-record kernels: a compact plane keeps
-                             // the increments of all resident games in L2)
+    uint32_t *state;         // [n_games][k][state_dw]: state_dw = 4 (PCG state {lo, hi} only, read once per game) or
+                             // STATE_DW (the full initial state record, strategy index included)
+    uint32_t state_dw;
+    uint4 *inc;              // [n_games][k] PCG increment {lo, hi}: its own plane, re-read at every turn start by
+                             // lean-record kernels (a compact plane keeps the increments of all resident games in L2)
+    const int32_t *seat_strategy; // LIST mode, state_dw == STATE_DW: [n_games][k] strategy indices
     // longest-first scheduling (tournament mode): games whose seats ALL never bank run to the round
     // limit (~13x the mean length); they are dealt first so that they do not form the tail of a wave.
     const uint16_t *perm_T;  // nullable; blocked layout, see perm_at()
@@ -65,6 +94,10 @@ struct SeedArgs {
     uint32_t *sched;         // [n_games] ticket -> game id, in dealing order (see the kernel)
     const uint32_t *class_ctr; // [SCHED_CLASSES] class sizes (fk_class_count_kernel)
     uint32_t *sched_ctr;     // [SCHED_CLASSES] per-class cursors
+    // batched H2H blocks (MODE_BLOCKS): game -> (block, attempt)
+    const DevBlock *blocks;
+    uint32_t n_blocks;
+    uint32_t *game_block;    // [n_games] out: block index of every game
 };
 
 struct PlayArgs {
@@ -74,17 +107,21 @@ struct PlayArgs {
     const uint16_t *perm_T;      // blocked permutations (MODE_PERM), see perm_at()
     uint32_t perm_slots;
     const int32_t *seat_strategy; // [n_games][k] (MODE_LIST)
-    const uint4 *seeds;
-    const uint32_t *sched;       // nullable: ticket -> game id (longest-first schedule; seeds are stored by ticket)
-    unsigned long long *tally;   // [n_batches][S][26]
-    uint8_t *rows;               // nullable, [n_games] * (4 + 28k)
+    const uint32_t *game_block;  // [n_games] (MODE_BLOCKS): strategy index of seat s = 2 * block + s
+    uint32_t *state;             // seat state records, see SeedArgs (GS instances update them in place)
+    uint32_t state_dw;
+    const uint4 *inc;
+    const uint32_t *sched;       // nullable: ticket -> game id (longest-first schedule; state records are stored by ticket)
+    unsigned long long *tally;   // [S][26] (LDS-tally launches only: one batch)
+    uint32_t *recs;              // nullable: [n_games][rec_dw] result records
+    uint32_t rec_dw;
+    uint32_t gs_out;             // LDS-record instances: flush every seat's final record to `state` at game end
     uint32_t *ticket;
     int32_t *err;                // [0] code, [1] game id
     const DevOverride *ov;
     uint32_t n_ov;
     uint32_t mode;
     uint32_t n_games, gps, n_sh, k, S;
-    uint32_t sh_offset, spb;     // batch = (sh_offset + sh_local) / spb
     int32_t target;
     uint32_t max_rounds;
     uint32_t batch_threshold;
@@ -172,6 +209,117 @@ __global__ __launch_bounds__(PERM_BLOCK) void fk_perm_kernel(SeedPool prefix, ui
 }
 
 // ---------------------------------------------------------------------------------------
+// Fisher-Yates in two kernels (large tables).  The swap chain of one shuffle is serial and its arrays fill LDS (15
+// chains per CU at S = 5 160), so every instruction on the chain is paid at the latency of a nearly empty CU.  The
+// draws do not depend on the array: fk_perm_draw_kernel produces the accepted j of every step — SeedSequence,
+// PCG64DXSM and the masked rejection, the expensive part — with one lane per shuffle at full occupancy, packed eight
+// 16-bit draws per 16-byte store, group-major ([group][shuffle]) so that lanes in step write neighbouring words;
+// fk_perm_apply_kernel then runs the bare chain (two LDS reads, two LDS writes per step) over the LDS arrays.
+constexpr int DRAW_BLOCK = 256;
+
+__global__ __launch_bounds__(DRAW_BLOCK) void fk_perm_draw_kernel(SeedPool prefix, uint64_t shuffle0, uint32_t n_sh, uint32_t S,
+                                                                 uint32_t n_sh_pad, uint4 *draws) {
+    const uint32_t sh = blockIdx.x * DRAW_BLOCK + threadIdx.x;
+    const bool valid = sh < n_sh;
+    Rng r{};
+    if (valid) {
+        SeedPool p = prefix;
+        p.hc = HC_AFTER_6_WORDS;
+        ss_absorb64(p, shuffle0 + sh); // shuffle_index
+#pragma unroll
+        for (int w = 0; w < 5; ++w) ss_absorb64(p, 0); // pair_id, order, game_index, seat_index, replicate_index
+        uint32_t g8[8];
+        ss_generate<8>(p, g8);
+        pcg_seed(r, g8);
+    }
+    uint32_t i = valid ? S - 1u : 0u, n = 0;
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0; // the eight most recent draws, oldest in the low half of q0
+    auto consume = [&](uint32_t w) {
+        if (i >= 1u) {
+            const uint32_t j = w & (0xffffffffu >> __clz((int)i));
+            if (j <= i) {
+                q0 = (q0 >> 16) | (q1 << 16);
+                q1 = (q1 >> 16) | (q2 << 16);
+                q2 = (q2 >> 16) | (q3 << 16);
+                q3 = (q3 >> 16) | (j << 16);
+                i -= 1u;
+                n += 1u;
+                if ((n & 7u) == 0u) draws[(size_t)((n >> 3) - 1u) * n_sh_pad + sh] = make_uint4(q0, q1, q2, q3);
+            }
+        }
+    };
+    while (__ballot(i >= 1u)) {
+        const uint64_t o = pcg_next64(r);
+        consume((uint32_t)o);         // low half first ...
+        consume((uint32_t)(o >> 32)); // ... then the buffered high half
+    }
+    if (valid && (n & 7u)) draws[(size_t)(n >> 3) * n_sh_pad + sh] = make_uint4(q0, q1, q2, q3); // last group: draws in the TOP halves
+}
+
+__global__ __launch_bounds__(PERM_BLOCK) void fk_perm_apply_kernel(const uint4 *draws, uint32_t n_sh_pad, uint32_t n_sh, uint32_t S,
+                                                                  uint32_t slots, uint16_t *perm_T) {
+    extern __shared__ uint16_t perm_lds[];
+    const uint32_t per_wave = (slots + PERM_WAVES - 1u) / PERM_WAVES;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t slot = wave * per_wave + lane;
+    const uint32_t sh = blockIdx.x * slots + slot;
+    const bool valid = lane < per_wave && slot < slots && sh < n_sh;
+    uint16_t *a = perm_lds + (size_t)(valid ? slot : 0u) * S;
+    if (valid) {
+        for (uint32_t e = 0; e < S; ++e) a[e] = (uint16_t)e;
+        const uint32_t steps = S - 1u, groups = (steps + 7u) >> 3, tail = steps & 7u;
+        uint32_t i = S - 1u;
+        // The draws come from HBM/L2 (a couple of thousand cycles away); a group of eight steps takes about a thousand:
+        // keep DEPTH groups in flight ahead of the chain.
+        constexpr uint32_t DEPTH = 4;
+        uint4 ring[DEPTH];
+#pragma unroll
+        for (uint32_t d = 0; d < DEPTH; ++d) ring[d] = (d < groups) ? draws[(size_t)d * n_sh_pad + sh] : make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t g0 = 0; g0 < groups; g0 += DEPTH) {
+#pragma unroll
+            for (uint32_t d = 0; d < DEPTH; ++d) {
+                const uint32_t g = g0 + d;
+                if (g < groups) {
+                    const uint4 q = ring[d];
+                    ring[d] = (g + DEPTH < groups) ? draws[(size_t)(g + DEPTH) * n_sh_pad + sh] : make_uint4(0u, 0u, 0u, 0u);
+                    uint32_t w[4] = {q.x, q.y, q.z, q.w};
+                    uint32_t cnt = 8u;
+                    if (g + 1u == groups && tail) { // the last group's draws sit in the top `tail` halves: bring them down
+                        cnt = tail;
+                        const uint32_t drop = 8u - tail; // halves to shift out
+                        for (uint32_t x = 0; x < drop; ++x) {
+                            w[0] = (w[0] >> 16) | (w[1] << 16);
+                            w[1] = (w[1] >> 16) | (w[2] << 16);
+                            w[2] = (w[2] >> 16) | (w[3] << 16);
+                            w[3] = w[3] >> 16;
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t t = 0; t < 8u; ++t) {
+                        if (t < cnt) {
+                            const uint32_t j = (w[t >> 1] >> (16u * (t & 1u))) & 0xffffu;
+                            const uint16_t ai = a[i], aj = a[j];
+                            a[i] = aj;
+                            a[j] = ai;
+                            i -= 1u;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // blocked store [block][e][slot]: one contiguous, fully coalesced region per block
+    const uint32_t first = blockIdx.x * slots;
+    const uint32_t count = min(slots, n_sh > first ? n_sh - first : 0u);
+    uint16_t *out = perm_T + (size_t)blockIdx.x * S * slots;
+    for (uint32_t idx = threadIdx.x; idx < S * slots; idx += PERM_BLOCK) {
+        const uint32_t e = idx / slots, l = idx - e * slots;
+        out[idx] = l < count ? perm_lds[(size_t)l * S + e] : (uint16_t)0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 constexpr int SEED_BLOCK = 1024;
 
 // Longest-first schedule classes (scheduling only: results do not depend on the order games are dealt in).
@@ -235,8 +383,8 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
     }
     // Longest-first schedule (tournament mode; classes above).  fk_class_count_kernel has sized the classes, so a game's
     // ticket is class offset + its rank in the class; ranks come from one returning atomic per block and class (a single
-    // word sustains only ~90 returning atomics/us).  The seeds are stored at the TICKET position: a wave's 64
-    // consecutive tickets then read 64 consecutive seed records whatever the class mix (stored in walk order, a sparse
+    // word sustains only ~90 returning atomics/us).  The state records are stored at the TICKET position: a wave's 64
+    // consecutive tickets then read 64 consecutive records whatever the class mix (stored in walk order, a sparse
     // class dragged a full 128-B line per game through L2: 3.7 GB of HBM fetches per 10^7 games instead of 0.5).
     uint32_t slot = t;
     if (a.sched) {
@@ -269,6 +417,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
     if (valid) {
         SeedPool gp;
         uint64_t seat0 = 0, replicate = 0;
+        uint32_t blk = 0;
         if (a.coords) {
             const fk_coord c = a.coords[id];
             seat0 = c.seat_index;
@@ -279,6 +428,22 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
             ss_absorb64(gp, c.pair_id);
             ss_absorb64(gp, c.order);
             ss_absorb64(gp, c.game_index);
+        } else if (a.blocks) { // batched H2H: the block holding game t (largest start <= t), then its attempt index
+            uint32_t lo = 0, hi = a.n_blocks;
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (a.blocks[mid].start <= t) lo = mid;
+                else hi = mid;
+            }
+            blk = lo;
+            const DevBlock b = a.blocks[blk];
+            a.game_block[t] = blk;
+            gp = a.prefix;
+            gp.hc = HC_AFTER_6_WORDS;
+            ss_absorb64(gp, 0);                        // shuffle_index
+            ss_absorb64(gp, b.pair);
+            ss_absorb64(gp, b.order);
+            ss_absorb64(gp, b.attempt0 + (t - b.start)); // attempt index in the game_index slot (random.py:106-111)
         } else {
             gp = a.prefix;
             gp.hc = HC_AFTER_6_WORDS;
@@ -295,10 +460,18 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
             ss_generate<8>(sp, g8);
             Rng r;
             pcg_seed(r, g8);
-            uint4 *dst = a.seeds + ((size_t)slot * a.k + s); // ticket position (walk order without a schedule)
+            const size_t rec = (size_t)slot * a.k + s; // ticket position (walk order without a schedule)
+            uint4 *dst = reinterpret_cast<uint4 *>(a.state + rec * a.state_dw);
             dst[0] = make_uint4((uint32_t)r.lo, (uint32_t)(r.lo >> 32), (uint32_t)r.hi, (uint32_t)(r.hi >> 32));
-            dst[(size_t)a.n_games * a.k] =
-                make_uint4((uint32_t)r.inc_lo, (uint32_t)(r.inc_lo >> 32), (uint32_t)r.inc_hi, (uint32_t)(r.inc_hi >> 32));
+            if (a.state_dw == STATE_DW) { // full initial record: nothing buffered, score 0, counters 0, strategy index
+                uint32_t idx = s;
+                if (a.perm_T) idx = perm_at(a.perm_T, a.S, a.perm_slots, sh_local, g_local * a.k + s);
+                else if (a.seat_strategy) idx = (uint32_t)a.seat_strategy[(size_t)id * a.k + s];
+                else if (a.blocks) idx = 2u * blk + s;
+                dst[1] = make_uint4(0u, 0u, 0u, 0u);
+                dst[2] = make_uint4(0u, 0u, 0u, idx);
+            }
+            a.inc[rec] = make_uint4((uint32_t)r.inc_lo, (uint32_t)(r.inc_lo >> 32), (uint32_t)r.inc_hi, (uint32_t)(r.inc_hi >> 32));
         }
     }
 }
@@ -323,32 +496,34 @@ __global__ void fk_finalize_tally(unsigned long long *tally, uint32_t n_rows, ui
 }
 
 // ---------------------------------------------------------------------------------------
-// One seat's context.  Every seat has a contiguous LDS record that each roll step loads, updates and stores; nothing
+// The game kernel.  Every seat has a state record (PCG state, buffered half word, score, packed counters: the eleven
+// dwords a turn mutates); each roll step loads the turn owner's record from LDS, updates it and stores it back; nothing
 // but the turn registers and the owner's read-only data (increment, strategy) is carried in VGPRs across rolls.
-// LEAN records keep only what a turn mutates (PCG state, buffered half word, score, counters: 11 dwords = 44 bytes
-// instead of 68): the read-only PCG increment and the packed strategy are re-read from the seed buffer's increment
-// plane / the strategy table (L2-resident) at the start of each turn, the strategy index riding in the spare bits of
-// cE.  Fewer LDS bytes per lane = more resident waves per SIMD (k=2: 4 -> 6, k=4: 2 -> 3.5).  `Seat` is the in-register
-// form used while a fresh game is set up.
-struct Seat {
-    uint64_t lo, hi, inc_lo, inc_hi; // PCG64DXSM state / increment
-    uint32_t buf;                    // buffered half word (has_buf is bit 17 of cE)
-    int32_t score;
-    uint32_t cA, cB, cC, cD, cE;     // packed u16 counters + flags
-    Strat sp;
-};
-
+//
+//   LDS-record instances (GS = false): all k records of the lane's game sit in LDS.  LEAN records keep only the eleven
+//   mutable dwords (44 bytes instead of 68): the read-only PCG increment and the packed strategy are re-read from the
+//   increment plane / the strategy table (L2-resident) at the start of each turn, the strategy index riding in the
+//   spare bits of cE.  Fewer LDS bytes per lane = more resident waves per SIMD (k = 2: 4 -> 6).
+//
+//   State-store instances (GS = true): LDS holds ONE record per lane, the turn owner's; the records of all seats live
+//   in the per-game state store in HBM (written by the seed kernel).  A record is touched twice per turn, at the
+//   hand-over to the next seat (already a divergent region): the owner's record is stored, the next seat's is loaded
+//   — three 16-byte accesses each, L2 / Infinity-Cache resident for the games in flight.  LDS bytes per lane (44) and
+//   with them the resident waves per SIMD (6) no longer depend on k, there is no limit on k or on S, and the final
+//   records of every game stay in HBM for the streaming post-passes (rows, all-seat statistics).
+//
 // MIXED: the strategy flag bits that may differ between strategies of the table.  The other flags are the same for
 // the whole table (threshold grids fix most of them): they arrive as a kernel argument, so their tests run on the
 // scalar unit and the constants they select become s_cselects.  Instances: all flags mixed (generic), none, and
 // require_both | favor_score (the pair the reference's grid always enumerates).
-template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED>
+template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void fk_play_kernel(PlayArgs a) {
+    static_assert(!GS || LEAN, "state-store instances stage the lean record");
     extern __shared__ uint32_t lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t K = a.k;
     constexpr uint32_t NFIELDS = LEAN ? (uint32_t)NF - 6u : (uint32_t)NF; // 11 or 17 dwords per seat record
-    unsigned long long *tl = reinterpret_cast<unsigned long long *>(lds + NFIELDS * K * BLOCK);
+    unsigned long long *tl = reinterpret_cast<unsigned long long *>(lds + NFIELDS * (GS ? 1u : K) * BLOCK);
 
     if (a.use_lds_tally) {
         for (uint32_t i = tid; i < a.S * LT_COLS; i += BLOCK) tl[i] = 0ull;
@@ -373,17 +548,22 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     int32_t own_thr = 0;
     uint32_t own_bits = 0;
 
-    // Seat records are contiguous per (seat, lane): record base = (seat * BLOCK + tid) * NFIELDS, field = immediate
+    // LDS records are contiguous per (seat, lane): record base = (seat * BLOCK + tid) * NFIELDS, field = immediate
     // offset (one address VGPR per record, ds_read2/ds_write2 pairs).  The odd record stride (11 / 17 dwords) maps the
     // 32 lanes of an LDS lane group to 32 distinct banks whatever seat each lane is on (BLOCK % 32 == 0).
     // LEAN records have no increment / strategy slots: fields after the increment move up by four.
     // Address = loop-invariant lane base + seat * compile-time stride: one full-rate v_mad_u32_u24 per record instead
-    // of the quarter-rate 32-bit multiplies the plain index expression costs.
+    // of the quarter-rate 32-bit multiplies the plain index expression costs.  GS: one record per lane, no seat term.
     const uint32_t lane_base = tid * NFIELDS;
     constexpr uint32_t SEAT_STRIDE = (uint32_t)BLOCK * NFIELDS; // < 2^24
     auto L = [&](uint32_t field, uint32_t s) __attribute__((always_inline)) -> uint32_t & {
         const uint32_t f = (LEAN && field > F_INC_HI1) ? field - 4u : field;
+        if (GS) return lds[lane_base + f];
         return lds[__umul24(s, SEAT_STRIDE) + lane_base + f];
+    };
+    // state record of seat s of the lane's game in HBM
+    auto G = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t * {
+        return a.state + ((size_t)seed_slot * K + s) * a.state_dw;
     };
 
     auto strategy_index = [&](uint32_t id, uint32_t s) -> uint32_t {
@@ -392,39 +572,45 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             return perm_at(a.perm_T, a.S, a.perm_slots, sh, g * K + s);
         }
         if (a.mode == MODE_LIST) return (uint32_t)a.seat_strategy[(size_t)id * K + s];
-        return s;
+        return 2u * a.game_block[id] + s; // MODE_BLOCKS
     };
 
     // per-seat views used by the end-of-game code (seat s may be the turn owner or not)
     auto seat_strategy = [&](uint32_t s) -> uint32_t { // strategy-table index of seat s of the lane's current game
+        if (GS) return G(s)[R_IDX];
         if (LEAN) return L(F_CE, s) >> CE_IDX_SHIFT;
         return strategy_index(game_id, s);
     };
-    auto seat_score = [&](uint32_t s) -> int32_t { return (int32_t)L(F_SCORE, s); };
-    auto seat_counter = [&](uint32_t s, uint32_t field) -> uint32_t { return L(field, s); }; // field in F_CA..F_CE
-
-    uint32_t x_idx = 0; // strategy index of the seat last loaded by load_seat_from_global
-    auto load_seat_from_global = [&](Seat &x, uint32_t id, uint32_t slot, uint32_t s) {
-        x_idx = strategy_index(id, s);
-        const uint2 pk = a.strat[x_idx];
-        const uint4 *src = a.seeds + ((size_t)slot * K + s);
-        const uint4 stv = src[0], inc = src[(size_t)a.n_games * K];
-        x.lo = (uint64_t)stv.x | ((uint64_t)stv.y << 32);
-        x.hi = (uint64_t)stv.z | ((uint64_t)stv.w << 32);
-        x.inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
-        x.inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
-        x.buf = 0;
-        x.score = 0;
-        x.cA = x.cB = x.cC = x.cD = x.cE = 0;
-        x.sp = Strat{(int32_t)pk.x, pk.y};
+    auto seat_score = [&](uint32_t s) -> int32_t { return (int32_t)(GS ? G(s)[R_SCORE] : L(F_SCORE, s)); };
+    auto seat_counter = [&](uint32_t s, uint32_t field) -> uint32_t { // field in F_CA..F_CE
+        return GS ? G(s)[R_CA + (field - F_CA)] : L(field, s);
     };
 
     // turn owner := seat s (engine.py:236-240): n_turns += 1 in its record, fresh turn registers, read-only data
     auto begin_turn = [&](uint32_t s) __attribute__((always_inline)) {
-        L(F_CB, s) += 0x10000u; // n_turns += 1 (engine.py:236)
+        uint32_t idx = 0;
+        if (GS) { // stage the seat's record: HBM state store -> the lane's LDS record
+            const uint4 *g = reinterpret_cast<const uint4 *>(G(s));
+            const uint4 q0 = g[0], q1 = g[1], q2 = g[2];
+            lds[lane_base + 0] = q0.x;
+            lds[lane_base + 1] = q0.y;
+            lds[lane_base + 2] = q0.z;
+            lds[lane_base + 3] = q0.w;
+            lds[lane_base + 4] = q1.x;
+            lds[lane_base + 5] = q1.y;
+            lds[lane_base + 6] = q1.z;
+            lds[lane_base + 7] = q1.w + 0x10000u; // n_turns += 1 (engine.py:236)
+            lds[lane_base + 8] = q2.x;
+            lds[lane_base + 9] = q2.y;
+            lds[lane_base + 10] = q2.z;
+            idx = q2.w;
+        } else {
+            L(F_CB, s) += 0x10000u; // n_turns += 1 (engine.py:236)
+            if (LEAN) idx = L(F_CE, s) >> CE_IDX_SHIFT;
+        }
         if (LEAN) { // read-only per-seat data comes from HBM/L2; the loads overlap the first dice of the turn
-            const uint4 inc = a.seeds[(size_t)a.n_games * K + (size_t)seed_slot * K + s];
-            const uint2 pk = a.strat[L(F_CE, s) >> CE_IDX_SHIFT];
+            const uint4 inc = a.inc[(size_t)seed_slot * K + s];
+            const uint2 pk = a.strat[idx];
             own_inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
             own_inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
             own_thr = (int32_t)pk.x;
@@ -445,7 +631,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         st = ST_DONE;
     };
 
-    // ---- finished game -> tallies / row (run_tournament.py:375-391, simulation.py:628-655) ----
+    // ---- finished game -> LDS tallies or one result record (run_tournament.py:375-391) ----
     auto finish_game = [&]() {
         const bool completed = (safety == 0u);
         uint32_t w = 0;
@@ -457,74 +643,51 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                 w = s;
             }
         }
-        uint32_t batch = 0;
-        if (a.mode == MODE_PERM) batch = (a.sh_offset + game_id / a.gps) / a.spb;
-        uint32_t widx = 0;
-        // exposures: tournament mode counts only safety-limit exposures (completed is derived in fk_finalize_tally)
-        const bool count_exposures = !completed || a.mode != MODE_PERM;
-        if (count_exposures) {
+        if (!GS && a.gs_out) { // final records of every seat -> state store (rows / all-seat statistics post-passes)
             for (uint32_t s = 0; s < K; ++s) {
-                const uint32_t idx = seat_strategy(s);
-                if (a.use_lds_tally) atomicAdd(&tl[idx * LT_COLS + (completed ? 1u : 2u)], 1ull);
-                else atomicAdd(&a.tally[((size_t)batch * a.S + idx) * FK_TALLY_COLS + (completed ? 2u : 3u)], 1ull);
+                uint4 *g = reinterpret_cast<uint4 *>(G(s));
+                const uint32_t ce = L(F_CE, s);
+                g[0] = make_uint4(L(F_LO0, s), L(F_LO1, s), L(F_HI0, s), L(F_HI1, s));
+                g[1] = make_uint4(L(F_BUF, s), L(F_SCORE, s), L(F_CA, s), L(F_CB, s));
+                g[2] = make_uint4(L(F_CC, s), L(F_CD, s), LEAN ? (ce & ((1u << CE_IDX_SHIFT) - 1u)) : ce, seat_strategy(s));
             }
         }
-        if (completed) widx = seat_strategy(w);
+        if (a.use_lds_tally) {
+            // exposures: tournament mode counts only safety-limit exposures (completed is derived in fk_finalize_tally)
+            if (!completed || a.mode != MODE_PERM) {
+                for (uint32_t s = 0; s < K; ++s) atomicAdd(&tl[seat_strategy(s) * LT_COLS + (completed ? 1u : 2u)], 1ull);
+            }
+        }
+        if (!(a.use_lds_tally && completed) && !a.recs) return;
+        uint32_t widx = 0, wa = 0, wb = 0, wc = 0, wd = 0, we = 0;
         if (completed) {
-            const uint32_t wa = seat_counter(w, F_CA), wb = seat_counter(w, F_CB), wc = seat_counter(w, F_CC),
-                           wd = seat_counter(w, F_CD), we = seat_counter(w, F_CE);
+            widx = seat_strategy(w);
+            wa = seat_counter(w, F_CA), wb = seat_counter(w, F_CB), wc = seat_counter(w, F_CC), wd = seat_counter(w, F_CD),
+            we = seat_counter(w, F_CE);
+        } else if (a.mode == MODE_BLOCKS) {
+            widx = seat_strategy(0); // names the block of a safety-limit attempt
+        }
+        if (a.use_lds_tally && completed) {
             const unsigned long long m[10] = {(unsigned long long)(uint32_t)best, rounds, wa >> 16, wa & 0xffffu,
                                               wb & 0xffffu, wc & 0xffffu, wc >> 16, wd & 0xffffu, wd >> 16, we & 0xffffu};
-            if (a.use_lds_tally) {
-                unsigned long long *t = tl + widx * LT_COLS;
-                atomicAdd(&t[0], 1ull);
+            unsigned long long *t = tl + widx * LT_COLS;
+            atomicAdd(&t[0], 1ull);
 #pragma unroll
-                for (int j = 0; j < 10; ++j) {
-                    if (m[j]) { // zero-valued metrics (e.g. smart-discard counters of non-smart winners) add nothing
-                        atomicAdd(&t[3 + j], m[j]);
-                        atomicAdd(&t[13 + j], m[j] * m[j]);
-                    }
-                }
-            } else {
-                unsigned long long *t = a.tally + ((size_t)batch * a.S + widx) * FK_TALLY_COLS;
-                atomicAdd(&t[0], 1ull);
-#pragma unroll
-                for (int j = 0; j < 10; ++j) {
-                    if (m[j]) {
-                        atomicAdd(&t[4 + j], m[j]);
-                        atomicAdd(&t[15 + j], m[j] * m[j]);
-                    }
+            for (int j = 0; j < 10; ++j) {
+                if (m[j]) { // zero-valued metrics (e.g. smart-discard counters of non-smart winners) add nothing
+                    atomicAdd(&t[3 + j], m[j]);
+                    atomicAdd(&t[13 + j], m[j] * m[j]);
                 }
             }
         }
-        if (a.rows) {
-            const size_t row_bytes = sizeof(fk_row_hdr) + sizeof(fk_seat) * (size_t)K;
-            uint8_t *row = a.rows + (size_t)game_id * row_bytes;
-            fk_row_hdr hdr;
-            hdr.n_rounds = (uint16_t)rounds;
-            hdr.status = completed ? FK_COMPLETED : FK_SAFETY_LIMIT;
-            hdr.winner_seat = completed ? (int8_t)w : (int8_t)-1;
-            *reinterpret_cast<fk_row_hdr *>(row) = hdr;
-            for (uint32_t s = 0; s < K; ++s) {
-                const int32_t sc = seat_score(s);
-                uint32_t rank = 0;
-                if (completed) {
-                    rank = 1;
-                    for (uint32_t j = 0; j < K; ++j) {
-                        const int32_t o = seat_score(j);
-                        rank += (o > sc || (o == sc && j < s)) ? 1u : 0u;
-                    }
-                }
-                const uint32_t xa = seat_counter(s, F_CA), xb = seat_counter(s, F_CB), xc = seat_counter(s, F_CC),
-                               xd = seat_counter(s, F_CD), xe = seat_counter(s, F_CE);
-                uint32_t *d = reinterpret_cast<uint32_t *>(row + sizeof(fk_row_hdr) + sizeof(fk_seat) * s);
-                d[0] = (uint32_t)sc;
-                d[1] = seat_strategy(s);
-                d[2] = (xa >> 16) | (xa << 16);                    // farkles, rolls
-                d[3] = (xb >> 16) | (xb << 16);                    // n_turns, highest_turn
-                d[4] = xc;                                         // sf_uses, sf_dice
-                d[5] = xd;                                         // so_uses, so_dice
-                d[6] = (xe & 0xffffu) | (rank << 16) | ((completed ? 0u : 1u) << 24); // hot_dice, rank, hit_max_rounds
+        if (a.recs) {
+            const uint32_t d0 = widx | (completed ? (w << 24) : REC_SAFETY);
+            if (a.rec_dw == REC_DW_H2H) {
+                a.recs[game_id] = d0;
+            } else {
+                uint4 *r = reinterpret_cast<uint4 *>(a.recs + (size_t)game_id * REC_DW);
+                r[0] = make_uint4(d0, completed ? (uint32_t)best : 0u, rounds | (wa & 0xffff0000u), (wa & 0xffffu) | (wb << 16));
+                r[1] = make_uint4(wc, wd, we & 0xffffu, 0u);
             }
         }
     };
@@ -533,9 +696,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     auto init_game = [&](uint32_t id, uint32_t ticket) {
         game_id = id;
         max_rounds = a.max_rounds;
-        for (uint32_t i = 0; i < a.n_ov; ++i)
-            if (a.ov[i].game == id) max_rounds = a.ov[i].max_rounds;
-        // seed records sit at the ticket position when there is a schedule, else in the seed kernel's walk order
+        if (a.n_ov) { // sorted by game id: binary search
+            uint32_t lo = 0, hi = a.n_ov;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (a.ov[mid].game < id) lo = mid + 1u;
+                else hi = mid;
+            }
+            if (lo < a.n_ov && a.ov[lo].game == id) max_rounds = a.ov[lo].max_rounds;
+        }
+        // state records sit at the ticket position when there is a schedule, else in the seed kernel's walk order
         // (shuffle-minor in tournament mode)
         uint32_t slot = a.sched ? ticket : id;
         if (!a.sched && a.mode == MODE_PERM) {
@@ -543,28 +713,33 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             slot = g * a.n_sh + sh;
         }
         seed_slot = slot;
-        for (uint32_t s = 0; s < K; ++s) {
-            Seat x;
-            load_seat_from_global(x, id, slot, s);
-            L(F_LO0, s) = (uint32_t)x.lo;
-            L(F_LO1, s) = (uint32_t)(x.lo >> 32);
-            L(F_HI0, s) = (uint32_t)x.hi;
-            L(F_HI1, s) = (uint32_t)(x.hi >> 32);
-            if (!LEAN) {
-                L(F_INC_LO0, s) = (uint32_t)x.inc_lo;
-                L(F_INC_LO1, s) = (uint32_t)(x.inc_lo >> 32);
-                L(F_INC_HI0, s) = (uint32_t)x.inc_hi;
-                L(F_INC_HI1, s) = (uint32_t)(x.inc_hi >> 32);
-                L(F_SPX, s) = (uint32_t)x.sp.score_thr;
-                L(F_SPY, s) = x.sp.bits;
+        if (!GS) {
+            for (uint32_t s = 0; s < K; ++s) {
+                const uint32_t *src = G(s);
+                const uint4 stv = *reinterpret_cast<const uint4 *>(src);
+                const uint32_t idx = (a.state_dw == STATE_DW) ? src[R_IDX] : strategy_index(id, s);
+                L(F_LO0, s) = stv.x;
+                L(F_LO1, s) = stv.y;
+                L(F_HI0, s) = stv.z;
+                L(F_HI1, s) = stv.w;
+                if (!LEAN) {
+                    const uint4 inc = a.inc[(size_t)slot * K + s];
+                    const uint2 pk = a.strat[idx];
+                    L(F_INC_LO0, s) = inc.x;
+                    L(F_INC_LO1, s) = inc.y;
+                    L(F_INC_HI0, s) = inc.z;
+                    L(F_INC_HI1, s) = inc.w;
+                    L(F_SPX, s) = pk.x;
+                    L(F_SPY, s) = pk.y;
+                }
+                L(F_BUF, s) = 0u;
+                L(F_SCORE, s) = 0u;
+                L(F_CA, s) = 0u;
+                L(F_CB, s) = 0u;
+                L(F_CC, s) = 0u;
+                L(F_CD, s) = 0u;
+                L(F_CE, s) = LEAN ? (idx << CE_IDX_SHIFT) : 0u;
             }
-            L(F_BUF, s) = 0u;
-            L(F_SCORE, s) = 0u;
-            L(F_CA, s) = 0u;
-            L(F_CB, s) = 0u;
-            L(F_CC, s) = 0u;
-            L(F_CD, s) = 0u;
-            L(F_CE, s) = LEAN ? (x_idx << CE_IDX_SHIFT) : 0u;
         }
         seat = 0;
         trigger = 0;
@@ -645,6 +820,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             return;
         }
         cE = (cE & ~CE_HAS_BUF) | (rng.has_buf ? CE_HAS_BUF : 0u);
+        if (GS) {
+            if (over) { // the turn is over: the record goes back to the state store, the next seat's comes in
+                uint4 *g = reinterpret_cast<uint4 *>(G(s));
+                g[0] = make_uint4((uint32_t)rng.lo, (uint32_t)(rng.lo >> 32), (uint32_t)rng.hi, (uint32_t)(rng.hi >> 32));
+                g[1] = make_uint4(rng.buf, (uint32_t)score, cA, cB);
+                uint32_t *g2 = reinterpret_cast<uint32_t *>(g + 2); // R_IDX stays as the seed kernel wrote it
+                g2[0] = cC;
+                g2[1] = cD;
+                g2[2] = cE;
+                advance(score);
+                return;
+            }
+        }
         L(F_LO0, s) = (uint32_t)rng.lo;
         L(F_LO1, s) = (uint32_t)(rng.lo >> 32);
         L(F_HI0, s) = (uint32_t)rng.hi;
@@ -656,7 +844,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         L(F_CC, s) = cC;
         L(F_CD, s) = cD;
         L(F_CE, s) = cE;
-        if (over) advance(score);
+        if (!GS && over) advance(score);
     };
 
     // ---- wave-level hand-over: finish ended games, deal new tickets ----
@@ -732,6 +920,189 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
 }
 
 // ---------------------------------------------------------------------------------------
+// Post-passes over the result records / the state store (streaming kernels, one thread per game).
+// ---------------------------------------------------------------------------------------
+
+// chunk-local game id -> schedule slot of its state records (inverse of the seed kernel's dealing order)
+__device__ inline uint32_t walk_slot(uint32_t id, uint32_t gps, uint32_t n_sh, bool perm_mode) {
+    if (!perm_mode) return id;
+    const uint32_t sh = id / gps, g = id - sh * gps;
+    return g * n_sh + sh;
+}
+
+// Result records -> tally [n_batches][S][26].  Games are in id order = shuffle order, so a deterministic batch is a
+// contiguous record range; a workgroup takes one part of one batch and one SLICE of the strategy axis, accumulates the
+// slice in LDS (ds_add_u64) and flushes what is non-zero with contiguous global atomics: every record is read
+// ceil(S / slice) times (32 B each, coalesced), nothing is atomically added to HBM per game.
+//   grid = (parts_per_batch * n_batches, n_slices); completed games count wins + 10 sums + 10 square sums for the winner,
+//   safety-limit games one safety exposure per seat (strategies re-derived from the permutation).
+constexpr uint32_t REDUCE_BLOCK = 512, RT_COLS = 22; // wins, safety, 10 sums, 10 square sums
+
+__global__ __launch_bounds__(REDUCE_BLOCK) void fk_tally_reduce_kernel(const uint32_t *recs, uint32_t n_games, uint32_t gps, uint32_t k,
+                                                                       uint32_t S, const uint16_t *perm_T, uint32_t perm_slots,
+                                                                       uint32_t sh_offset, uint32_t spb, uint32_t n_sh,
+                                                                       uint32_t parts_per_batch, uint32_t slice, uint32_t first_batch,
+                                                                       unsigned long long *tally) {
+    extern __shared__ unsigned long long rt[];
+    const uint32_t b_local = blockIdx.x / parts_per_batch, part = blockIdx.x - b_local * parts_per_batch;
+    const uint32_t batch = first_batch + b_local;
+    // shuffles of this batch inside the chunk: [sh_lo, sh_hi) chunk-local
+    const uint64_t g_lo = (uint64_t)batch * spb, g_hi = g_lo + spb;
+    const uint32_t sh_lo = g_lo > sh_offset ? (uint32_t)(g_lo - sh_offset) : 0u;
+    const uint32_t sh_hi = (uint32_t)min<uint64_t>(n_sh, g_hi > sh_offset ? g_hi - sh_offset : 0u);
+    if (sh_hi <= sh_lo) return;
+    const uint32_t games = (sh_hi - sh_lo) * gps, per_part = (games + parts_per_batch - 1u) / parts_per_batch;
+    const uint32_t first = sh_lo * gps + part * per_part, last = min(first + per_part, sh_lo * gps + games);
+    const uint32_t s_lo = blockIdx.y * slice, s_n = min(slice, S - s_lo);
+    for (uint32_t i = threadIdx.x; i < s_n * RT_COLS; i += REDUCE_BLOCK) rt[i] = 0ull;
+    __syncthreads();
+    for (uint32_t id = first + threadIdx.x; id < last; id += REDUCE_BLOCK) {
+        const uint4 *r = reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
+        const uint4 q0 = r[0];
+        if (q0.x & REC_SAFETY) {
+            const uint32_t sh = id / gps, g = id - sh * gps;
+            for (uint32_t s = 0; s < k; ++s) {
+                const uint32_t idx = perm_at(perm_T, S, perm_slots, sh, g * k + s) - s_lo;
+                if (idx < s_n) atomicAdd(&rt[idx * RT_COLS + 1u], 1ull);
+            }
+            continue;
+        }
+        const uint32_t idx = (q0.x & 0xffffffu) - s_lo;
+        if (idx >= s_n) continue;
+        const uint4 q1 = r[1];
+        const unsigned long long m[10] = {q0.y, q0.z & 0xffffu, q0.z >> 16, q0.w & 0xffffu, q0.w >> 16,
+                                          q1.x & 0xffffu, q1.x >> 16, q1.y & 0xffffu, q1.y >> 16, q1.z};
+        unsigned long long *t = rt + idx * RT_COLS;
+        atomicAdd(&t[0], 1ull);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            if (m[j]) {
+                atomicAdd(&t[2 + j], m[j]);
+                atomicAdd(&t[12 + j], m[j] * m[j]);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long *out = tally + ((size_t)batch * S + s_lo) * FK_TALLY_COLS;
+    for (uint32_t i = threadIdx.x; i < s_n * RT_COLS; i += REDUCE_BLOCK) {
+        const unsigned long long v = rt[i];
+        if (v == 0ull) continue;
+        const uint32_t idx = i / RT_COLS, c = i - idx * RT_COLS;
+        // wins -> 0, safety -> 3, sums -> 4..13, square sums -> 15..24 (column 14 / 25 = winner_hit_max_rounds, always 0)
+        const uint32_t col = (c == 0u) ? 0u : (c == 1u) ? 3u : (c < 12u) ? (c + 2u) : (c + 3u);
+        atomicAdd(&out[(size_t)idx * FK_TALLY_COLS + col], v);
+    }
+}
+
+// Small batches (per-shuffle tallies of a few dozen games each): one thread per game, atomics straight into the tally.
+__global__ void fk_tally_direct_kernel(const uint32_t *recs, uint32_t n_games, uint32_t gps, uint32_t k, uint32_t S,
+                                       const uint16_t *perm_T, uint32_t perm_slots, uint32_t sh_offset, uint32_t spb,
+                                       unsigned long long *tally) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_games) return;
+    const uint32_t sh = id / gps, g = id - sh * gps;
+    const uint32_t batch = (sh_offset + sh) / spb;
+    const uint4 *r = reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
+    const uint4 q0 = r[0];
+    unsigned long long *base = tally + (size_t)batch * S * FK_TALLY_COLS;
+    if (q0.x & REC_SAFETY) {
+        for (uint32_t s = 0; s < k; ++s)
+            atomicAdd(&base[(size_t)perm_at(perm_T, S, perm_slots, sh, g * k + s) * FK_TALLY_COLS + 3u], 1ull);
+        return;
+    }
+    if ((q0.x & 0xffffffu) >= S) return;
+    const uint4 q1 = r[1];
+    const unsigned long long m[10] = {q0.y, q0.z & 0xffffu, q0.z >> 16, q0.w & 0xffffu, q0.w >> 16,
+                                      q1.x & 0xffffu, q1.x >> 16, q1.y & 0xffffu, q1.y >> 16, q1.z};
+    unsigned long long *t = base + (size_t)(q0.x & 0xffffffu) * FK_TALLY_COLS;
+    atomicAdd(&t[0], 1ull);
+    for (int j = 0; j < 10; ++j) {
+        if (m[j]) {
+            atomicAdd(&t[4 + j], m[j]);
+            atomicAdd(&t[15 + j], m[j] * m[j]);
+        }
+    }
+}
+
+// Result records of a batched H2H launch -> per-block {completed, safety, wins_seat1, wins_seat2}.  A block's attempts
+// are contiguous games, so almost every wave sees one block: ballots + one atomic per counter and wave.
+__global__ void fk_h2h_reduce_kernel(const uint32_t *recs, uint32_t n_games, uint32_t n_blocks,
+                                     unsigned long long *out /* [n_blocks][4] */) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t d0 = id < n_games ? recs[id] : 0u;
+    const uint32_t blk = (d0 & 0xffffffu) >> 1;
+    const bool valid = id < n_games && blk < n_blocks; // (a record of a launch that raised an error may be garbage)
+    const bool safety = (d0 & REC_SAFETY) != 0u;
+    const uint32_t which = safety ? 1u : (2u + ((d0 >> 24) & 1u)); // completed games also count in column 0 below
+    const uint64_t live = __ballot(valid);
+    if (!live) return;
+    const uint32_t first_live = (uint32_t)(__ffsll((long long)live) - 1);
+    const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)blk, (int)__builtin_amdgcn_readfirstlane((int)first_live));
+    if (__ballot(valid && blk != lead) == 0ull) {
+        const uint32_t n_safe = (uint32_t)__popcll(__ballot(valid && safety));
+        const uint32_t n_w2 = (uint32_t)__popcll(__ballot(valid && which == 3u));
+        const uint32_t n_all = (uint32_t)__popcll(live);
+        if ((threadIdx.x & 63u) == first_live) {
+            unsigned long long *o = out + (size_t)blk * 4;
+            const uint32_t n_comp = n_all - n_safe;
+            if (n_comp) atomicAdd(&o[0], (unsigned long long)n_comp);
+            if (n_safe) atomicAdd(&o[1], (unsigned long long)n_safe);
+            if (n_comp - n_w2) atomicAdd(&o[2], (unsigned long long)(n_comp - n_w2));
+            if (n_w2) atomicAdd(&o[3], (unsigned long long)n_w2);
+        }
+    } else if (valid) { // a wave that straddles blocks
+        unsigned long long *o = out + (size_t)blk * 4;
+        if (!safety) atomicAdd(&o[0], 1ull);
+        atomicAdd(&o[which], 1ull);
+    }
+}
+
+// State store + result records -> rows (fk_row_hdr + k x fk_seat = 4 + 28k bytes, simulation.py:628-655), in game-id
+// order.  One thread per game; ranks by stable sort on score desc (engine.py:477-483).
+__global__ void fk_rows_kernel(const uint32_t *state, const uint32_t *recs, const uint32_t *inv_sched, uint32_t n_games, uint32_t gps,
+                               uint32_t n_sh, uint32_t k, uint32_t perm_mode, uint8_t *rows) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_games) return;
+    const uint32_t slot = inv_sched ? inv_sched[id] : walk_slot(id, gps, n_sh, perm_mode != 0u);
+    const uint4 *r = reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
+    const uint4 q0 = r[0];
+    const bool completed = !(q0.x & REC_SAFETY);
+    const size_t row_bytes = sizeof(fk_row_hdr) + sizeof(fk_seat) * (size_t)k;
+    uint32_t *row = reinterpret_cast<uint32_t *>(rows + (size_t)id * row_bytes);
+    // header: n_rounds u16 | status u8 | winner_seat i8
+    row[0] = (q0.z & 0xffffu) | ((completed ? (uint32_t)FK_COMPLETED : (uint32_t)FK_SAFETY_LIMIT) << 16) |
+             ((completed ? ((q0.x >> 24) & 0x7fu) : 0xffu) << 24);
+    const uint32_t *g = state + (size_t)slot * k * STATE_DW;
+    for (uint32_t s = 0; s < k; ++s) {
+        const uint32_t *x = g + (size_t)s * STATE_DW;
+        const int32_t sc = (int32_t)x[R_SCORE];
+        uint32_t rank = 0;
+        if (completed) {
+            rank = 1;
+            for (uint32_t j = 0; j < k; ++j) {
+                const int32_t o = (int32_t)g[(size_t)j * STATE_DW + R_SCORE];
+                rank += (o > sc || (o == sc && j < s)) ? 1u : 0u;
+            }
+        }
+        const uint32_t xa = x[R_CA], xb = x[R_CB], xe = x[R_CE];
+        uint32_t *d = row + 1u + 7u * s;
+        d[0] = (uint32_t)sc;
+        d[1] = x[R_IDX];
+        d[2] = (xa >> 16) | (xa << 16); // farkles, rolls
+        d[3] = (xb >> 16) | (xb << 16); // n_turns, highest_turn
+        d[4] = x[R_CC];                 // sf_uses, sf_dice
+        d[5] = x[R_CD];                 // so_uses, so_dice
+        d[6] = (xe & 0xffffu) | (rank << 16) | ((completed ? 0u : 1u) << 24); // hot_dice, rank, hit_max_rounds
+    }
+}
+
+// ticket -> game id schedule inverted (rows are produced in game-id order)
+__global__ void fk_invert_sched_kernel(const uint32_t *sched, uint32_t n_games, uint32_t *inv) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_games) inv[sched[t]] = t;
+}
+
+// ---------------------------------------------------------------------------------------
 // single-op probes (parity tests of the device functions above)
 // ---------------------------------------------------------------------------------------
 __device__ inline uint32_t pack_faces(const uint8_t *f, int32_t n) {
@@ -793,14 +1164,14 @@ __global__ void fk_dbg_continue_kernel(int64_t n, const int32_t *args, const uin
     out[i] = should_continue(unpack_strat(strat[i]), g[0], g[1], g[2] != 0, g[3] != 0, g[4], g[5]) ? 1 : 0;
 }
 
-__global__ void fk_dbg_dice_kernel(int64_t n, const uint4 *seeds, const uint64_t *state_in, int32_t n_calls,
+__global__ void fk_dbg_dice_kernel(int64_t n, const uint4 *seeds, const uint4 *incs, const uint64_t *state_in, int32_t n_calls,
                                    const int32_t *sizes, int32_t total, uint8_t *faces, uint64_t *raw64,
                                    uint64_t *state_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Rng r;
     if (seeds) {
-        const uint4 s = seeds[i], c = seeds[n + i]; // state plane, increment plane (k = 1)
+        const uint4 s = seeds[i], c = incs[i]; // state plane (state_dw = 4), increment plane (k = 1)
         r.lo = (uint64_t)s.x | ((uint64_t)s.y << 32);
         r.hi = (uint64_t)s.z | ((uint64_t)s.w << 32);
         r.inc_lo = (uint64_t)c.x | ((uint64_t)c.y << 32);

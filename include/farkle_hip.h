@@ -119,9 +119,11 @@ int fk_get_device_info(fk_ctx *ctx, fk_device_info *out);
 int fk_get_timing(fk_ctx *ctx, fk_timing *out);
 /* Tunables: "chunk_bytes" (device workspace budget per chunk), "batch_threshold" (lanes that must be waiting
  * before a wave runs its game hand-over), "use_lds_tally" (0/1/-1 auto), "block" (0 auto), "lean" (seat-record layout:
- * -1 auto, 0 full, 1 lean), "blocks_per_cu", "longest_first" (1 = deal never-banking pairings first), "uniform_flags" (-1 auto: tables whose
- * strategies share all flag bits run the scalar-flag kernel instance, 0 never).  All of them are
- * scheduling / layout choices: results are identical for every setting. */
+ * -1 auto, 0 full, 1 lean), "state_store" (-1 auto: seat records of k >= 3 tables live in the HBM state store with only the
+ * turn owner's staged in LDS, 0 LDS records whenever they fit, 1 always), "blocks_per_cu", "longest_first" (1 = deal
+ * never-banking pairings first), "uniform_flags" (-1 auto: tables whose strategies share all flag bits run the scalar-flag
+ * kernel instance, 0 never), "perm_split" (-1 auto).  All of them are scheduling / layout choices: results are identical
+ * for every setting. */
 int fk_set_option(fk_ctx *ctx, const char *name, int64_t value);
 
 /* Tournament shuffles [shuffle_begin, shuffle_end) of the S-strategy table at k players.
@@ -145,6 +147,23 @@ int fk_play_games(fk_ctx *ctx, const fk_coord *coords, int64_t n_games, const fk
 int fk_h2h_run(fk_ctx *ctx, const fk_strategy seats[2], uint64_t root_seed, uint64_t pair_id, uint32_t order,
                uint64_t target, uint64_t max_attempts, uint64_t chunk_games, int32_t target_score,
                int32_t max_rounds, const fk_override *ov, int32_t n_ov, uint64_t state[5]);
+
+/* One (pair, order) block of a batched H2H call: the two seated strategies, the block's coordinates and limits, and its
+ * progress {attempted, completed, safety, wins_seat1, wins_seat2} in/out (h2h_schedule.py:1088-1146, 1165-1235). */
+typedef struct {
+    fk_strategy seats[2];
+    uint64_t pair_id;
+    uint32_t order;
+    uint32_t pad;
+    uint64_t target, max_attempts;
+    uint64_t state[5];
+} fk_h2h_block;
+
+/* Many H2H blocks of one root advanced together, each by at most chunk_games attempts, each exactly as fk_h2h_run would
+ * advance it alone (same in-order prefix rule per block); all blocks share the kernel launches (the production H2H
+ * schedule is tens of thousands of blocks of ~2 000 games: execute_h2h_schedule's block loop, h2h_schedule.py:2038-2093). */
+int fk_h2h_run_blocks(fk_ctx *ctx, fk_h2h_block *blocks, int64_t n_blocks, uint64_t root_seed, uint64_t chunk_games,
+                      int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov);
 
 /* SeedSequence fingerprints of n coordinates (all nine coordinate words of the record, seat_index included):
  * seed32[i] = generate_state(1, uint32)[0], seed64[i] = generate_state(1, uint64)[0]; either may be NULL.

@@ -541,12 +541,90 @@ def gen_artifacts():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gen_resume():
+    """A genuine MID-RUN checkpoint of the reference: its own ``run_single_n`` (plain v2 write path, no row shards / metric
+    chunks, so the pickle is the only recovery authority) is interrupted right after its parent loop has written the
+    checkpoint that owns the first process block.  Frozen: the pickle's bytes (base64 — data the reference wrote, its
+    ``win_totals`` pickled through ``farkle.simulation.run_tournament._restore_outcome_counter``) and, from an
+    uninterrupted run of the same configuration, the final checkpoint payload the resumed run must reproduce."""
+    import base64
+    import dataclasses
+    import pickle
+    import shutil
+    import tempfile
+
+    import yaml
+    from farkle.config import load_app_config
+    from farkle.simulation import run_tournament as rt
+    from farkle.simulation import runner
+    from farkle.utils.authenticated_contract import CodeIdentityError
+
+    class _Interrupt(Exception):
+        pass
+
+    out = {"config": None, "runs": {}}
+    for k in (2, 4):
+        tmp = Path(tempfile.mkdtemp(prefix="fk_resume_"))
+        try:
+            payload = {key: dict(val) for key, val in ARTIFACT_CONFIG.items()}
+            payload["sim"].update({"row_dir": None, "metric_chunk_dir": None, "ckpt_every_sec": 0, "n_players_list": [k]})
+            payload["io"] = {"results_dir_prefix": str(tmp / "out"), "analysis_subdir": "analysis"}
+            out["config"] = {key: val for key, val in payload.items() if key != "io"}
+            cfg_path = tmp / "tiny.yaml"
+            cfg_path.write_text(yaml.safe_dump(payload))
+
+            def load():
+                cfg = load_app_config(cfg_path, seed_list_len=1)
+                cfg.artifact_contract = dataclasses.replace(cfg.artifact_contract, artifact_contract_version=2)
+                return cfg
+
+            cfg = load()
+            ckpt = cfg.results_root / f"{k}_players" / f"{k}p_checkpoint.pkl"
+            original = rt._save_checkpoint
+            calls = {"n": 0}
+
+            def interrupting(path, *args, **kwargs):
+                original(path, *args, **kwargs)
+                calls["n"] += 1
+                raise _Interrupt()  # the process dies right after the first periodic checkpoint
+
+            rt._save_checkpoint = interrupting
+            try:
+                runner.run_single_n(cfg, k)
+                raise AssertionError("the reference run was not interrupted")
+            except _Interrupt:
+                pass
+            finally:
+                rt._save_checkpoint = original
+            partial_bytes = ckpt.read_bytes()
+            partial = pickle.loads(partial_bytes)
+            shutil.rmtree(cfg.results_root, ignore_errors=True)
+            try:
+                runner.run_single_n(load(), k)
+            except CodeIdentityError:
+                pass  # everything but the authenticated stage stamp has been written
+            full = pickle.loads(ckpt.read_bytes())
+            out["runs"][str(k)] = {
+                "partial_checkpoint_pickle_b64": base64.b64encode(partial_bytes).decode("ascii"),
+                "partial_meta": _jsonable({key: partial["meta"][key] for key in ("completed_shuffle_indices",
+                                          "completed_process_block_indices", "num_shuffles", "deterministic_batch_size")}),
+                "partial_games_attempted": partial["outcome_counts"]["games_attempted"],
+                "final": {"win_totals": _jsonable(dict(full["win_totals"])), "outcome_counts": _jsonable(full["outcome_counts"]),
+                          "metric_sums": _jsonable({m: dict(v) for m, v in full["metric_sums"].items()}),
+                          "metric_square_sums": _jsonable({m: dict(v) for m, v in full["metric_square_sums"].items()}),
+                          "meta": _jsonable(full["meta"])}}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    _dump(out, open(OUT / "resume_vectors.json", "w"))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # e.g. `python oracle/gen_golden.py gen_artifacts`
         for name in sys.argv[1:]:
             globals()[name]()
         sys.exit(0)
     gen_artifacts()
+    gen_resume()
     gen_runner()
     gen_fuzz()
     gen_rng()

@@ -1,0 +1,179 @@
+"""GPU parity tests of the round-2 device paths, through the C-ABI, against the CPU oracle (bit-exact):
+
+* state-store (GS) game-kernel instances — seat records in the HBM state store, only the turn owner's in LDS — at
+  every k, forced on for k = 2 and off for k = 4 (``state_store`` option), every launch geometry;
+* result records + ``fk_tally_reduce_kernel`` (LDS-sliced per-(batch, strategy) reduction) and ``fk_tally_direct_kernel``;
+* rows produced by the streaming post-pass (``fk_rows_kernel``) from the state store;
+* batched H2H blocks (``fk_h2h_run_blocks``): every block equals the serial block loop of the oracle.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from farkle_ii_amd.backend import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def po():
+    import pyoracle
+
+    return pyoracle
+
+
+def _strats(tuples):
+    from farkle_ii_amd.strategies import STRATEGY_DTYPE
+
+    return gu.strategies_from_tuples(tuples, STRATEGY_DTYPE)
+
+
+def _default_table():
+    from farkle_ii_amd.strategies import default_grid_tuples
+
+    return _strats(default_grid_tuples())
+
+
+def _random_valid_table(n: int, seed: int) -> np.ndarray:
+    from farkle_ii_amd.strategies import STRATEGY_DTYPE
+
+    rng = np.random.default_rng(seed)
+    t = np.zeros(n, dtype=STRATEGY_DTYPE)
+    t["score_threshold"] = rng.integers(2, 21, n) * 50
+    t["dice_threshold"] = rng.integers(0, 5, n)
+    for name in ("smart_five", "consider_score", "consider_dice", "auto_hot_dice", "run_up_score", "favor_score"):
+        t[name] = rng.integers(0, 2, n)
+    t["smart_one"] = t["smart_five"] & rng.integers(0, 2, n).astype(np.uint8)
+    t["require_both"] = t["consider_score"] & t["consider_dice"] & rng.integers(0, 2, n).astype(np.uint8)
+    t["strategy_id"] = np.arange(n)
+    return t
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 6, 8, 12])
+def test_state_store_and_lds_record_instances_agree_with_oracle(eng, po, k):
+    """Same shuffles through the state-store instance, the LDS-record instance (when k records fit) and the oracle:
+    tallies per batch, rows, and the three GS block sizes."""
+    table = _random_valid_table(96, 100 + k)
+    n_sh = 40
+    ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 5, 3, 3 + n_sh, shuffles_per_batch=16, want_rows=True, n_threads=8)
+    try:
+        for store, block in [(1, 0), (1, 256), (1, 64), (0, 0), (-1, 0)]:
+            eng.set_option("state_store", store)
+            eng.set_option("block", block)
+            got = eng.tournament(table, k, 5, 3, 3 + n_sh, shuffles_per_batch=16, want_rows=True)
+            assert np.array_equal(got["tally"], ref["tally"]), (k, store, block)
+            assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, store, block)
+            one = eng.tournament(table, k, 5, 3, 3 + n_sh)  # one batch: LDS tally (96 strategies fit)
+            assert np.array_equal(one["tally"][0], ref["tally"].sum(axis=0)), (k, store, block)
+            eng.set_option("use_lds_tally", 0)               # ... and the same through result records
+            rec = eng.tournament(table, k, 5, 3, 3 + n_sh)
+            eng.set_option("use_lds_tally", -1)
+            assert np.array_equal(rec["tally"][0], ref["tally"].sum(axis=0)), (k, store, block)
+    finally:
+        eng.set_option("state_store", -1)
+        eng.set_option("block", 0)
+        eng.set_option("use_lds_tally", -1)
+
+
+def test_state_store_limits_overrides_and_safety_games(eng, po):
+    """max_rounds / target variants, per-game overrides (sorted + binary search on the device), never-banking tables that
+    run to the round limit, max_rounds = 0 — through the state-store instance at k = 4 and k = 2."""
+    from farkle_ii_amd.backend import make_overrides
+
+    table = _strats(gu.load("grid_vectors.json")["g64"])
+    never = table.copy()
+    never["dice_threshold"], never["require_both"] = 0, 1   # every strategy rolls on: all games hit the safety limit
+    try:
+        for k, store in [(4, -1), (2, 1)]:
+            eng.set_option("state_store", store)
+            gps = 64 // k
+            ovs = [(9, 2, 1, k, 0), (9, 2, 3, k, 7), (9, 5, gps - 1, k, 1), (9, 0, 0, k, 3), (9, 7, 2, k, 250), (9, 2, 5, k, 5)]
+            for tbl, target, mr in [(table, 10_000, 200), (table, 2_000, 5), (never, 10_000, 12), (table, 50, 200), (table, 10_000, 0)]:
+                ref = po.tournament(tbl.view(po.STRATEGY_DTYPE), k, 9, 0, 10, shuffles_per_batch=3, target_score=target, max_rounds=mr,
+                                    overrides=po.make_overrides(ovs), want_rows=True)
+                got = eng.tournament(tbl, k, 9, 0, 10, shuffles_per_batch=3, target_score=target, max_rounds=mr,
+                                     overrides=make_overrides(ovs), want_rows=True)
+                assert np.array_equal(got["tally"], ref["tally"]), (k, target, mr)
+                assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, target, mr)
+    finally:
+        eng.set_option("state_store", -1)
+
+
+def test_tally_reduce_slices_on_the_default_grid(eng, po):
+    """5 160 strategies: twelve LDS slices per batch part in fk_tally_reduce_kernel (batches of >= 4 096 games), and the
+    direct kernel for per-shuffle batches; k = 4 (state store) and k = 2 (LDS records)."""
+    table = _default_table()
+    for k, n_sh, spb in [(4, 9, 4), (2, 5, 2), (4, 3, 1), (8, 8, 8)]:
+        ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 0, 11, 11 + n_sh, shuffles_per_batch=spb, n_threads=16)
+        got = eng.tournament(table, k, 0, 11, 11 + n_sh, shuffles_per_batch=spb)
+        assert np.array_equal(got["tally"], ref["tally"]), (k, n_sh, spb)
+    # chunked: whole shuffles per chunk, batches straddling chunk boundaries
+    try:
+        eng.set_option("chunk_bytes", 3 << 20)
+        ref = po.tournament(table.view(po.STRATEGY_DTYPE), 4, 0, 0, 10, shuffles_per_batch=4, n_threads=16)
+        got = eng.tournament(table, 4, 0, 0, 10, shuffles_per_batch=4)
+        assert np.array_equal(got["tally"], ref["tally"])
+    finally:
+        eng.set_option("chunk_bytes", 48 << 30)
+
+
+def test_h2h_blocks_batched_equal_serial_blocks(eng, po):
+    """Hundreds of (pair, order) blocks in shared launches: mixed strategies incl. never-banking seats (every attempt a
+    safety-limit game), per-block targets / attempt caps, resumed states, a chunk limit, overrides."""
+    from farkle_ii_amd.backend import make_overrides
+
+    rng = np.random.default_rng(7)
+    pool = _random_valid_table(40, 3)
+    pool["dice_threshold"][:3], pool["consider_dice"][:3], pool["require_both"][:3], pool["consider_score"][:3] = 0, 1, 1, 1
+    n = 300
+    seats = np.stack([pool[rng.integers(0, 40, 2)] for _ in range(n)])
+    seats[5] = pool[[0, 1]]                        # two never-banking seats: no attempt ever completes
+    pair = rng.integers(0, 50, n).astype(np.uint64)
+    order = rng.integers(0, 2, n).astype(np.uint32)
+    target = rng.integers(1, 160, n).astype(np.uint64)
+    max_attempts = (target * rng.choice([1, 2, 3], n)).astype(np.uint64)
+    ovs = [(11, int(pair[7]), 3, int(order[7]), 2), (11, int(pair[20]), 0, int(order[20]), 0), (11, int(pair[20]), 5, int(order[20]), 1)]
+    for chunk in (None, 37):
+        got = eng.h2h_blocks(seats, 11, pair, order, target, max_attempts, chunk_games=chunk, max_rounds=60,
+                             overrides=make_overrides(ovs))
+        for b in range(n):
+            want = po.h2h_block(seats[b].view(po.STRATEGY_DTYPE), 11, int(pair[b]), int(order[b]), int(target[b]), int(max_attempts[b]),
+                                int(max_attempts[b]) if chunk is None else chunk, max_rounds=60, overrides=po.make_overrides(ovs))
+            assert np.array_equal(got[b], want), (chunk, b, got[b], want)
+    assert got[5][1] == 0 and got[5][2] > 0
+    # resumed blocks: the first chunk's states go back in
+    first = eng.h2h_blocks(seats, 11, pair, order, target, max_attempts, chunk_games=25, max_rounds=60)
+    second = eng.h2h_blocks(seats, 11, pair, order, target, max_attempts, chunk_games=10**9, max_rounds=60, states=first)
+    full = eng.h2h_blocks(seats, 11, pair, order, target, max_attempts, max_rounds=60)
+    assert np.array_equal(second, full)
+    # more blocks than one launch takes (8 192): 9 000 tiny blocks
+    m = 9000
+    seats_m = np.stack([pool[[3 + (i % 30), 4 + ((7 * i) % 30)]] for i in range(m)])
+    got = eng.h2h_blocks(seats_m, 5, np.arange(m), np.arange(m) % 2, 3, 6, max_rounds=200)
+    for b in list(range(0, m, 601)) + [8191, 8192, m - 1]:
+        want = po.h2h_block(seats_m[b].view(po.STRATEGY_DTYPE), 5, b, b % 2, 3, 6, 6)
+        assert np.array_equal(got[b], want), b
+    assert (got[:, 1] == 3).all() or (got[:, 0] == 6).any()
+
+
+def test_h2h_production_shape_throughput_sanity(eng):
+    """10 000 blocks of 2 191 completed games (the production H2H schedule's block size) in a few launches: every block
+    reaches its target, conservation holds, wins are order-symmetric in distribution (not checked bit-wise here)."""
+    table = _default_table()
+    rng = np.random.default_rng(1)
+    n = 10_000
+    idx = rng.integers(0, len(table), (n, 2))
+    st = eng.h2h_blocks(table[idx], 42, np.arange(n) // 2, np.arange(n) % 2, 2191, 4382)
+    assert (st[:, 0] == st[:, 1] + st[:, 2]).all() and (st[:, 1] == st[:, 3] + st[:, 4]).all()
+    done = st[:, 1] == 2191
+    assert done.mean() > 0.9 and ((st[:, 0] == 4382) | done).all()
