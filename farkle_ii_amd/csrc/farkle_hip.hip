@@ -350,7 +350,12 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
     HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 512, c->stream));
     sa.state = static_cast<uint32_t *>(c->state.p);
     sa.inc = static_cast<uint4 *>(c->inc.p);
-    if (sa.perm_T && c->longest_first) {
+    if (sa.blocks) { // batched H2H: game -> block map first (the schedule classes and the seed kernel read it)
+        hipLaunchKernelGGL(fk_block_map_kernel, dim3((sa.n_games + 255u) / 256u), dim3(256), 0, c->stream, sa.blocks, sa.n_blocks,
+                           sa.n_games, const_cast<uint32_t *>(sa.game_block));
+        HIPCHK(c, hipGetLastError());
+    }
+    if ((sa.perm_T || sa.blocks) && c->longest_first) {
         rc = ensure(c, c->order, (size_t)sa.n_games * 4);
         if (rc) return rc;
         sa.sched = static_cast<uint32_t *>(c->order.p);
@@ -374,7 +379,7 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
         if (sa.sched) // class sizes first: a game's ticket is class offset + rank
             hipLaunchKernelGGL(fk_class_count_kernel, dim3(std::min<uint32_t>((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK, 1024u)), dim3(SEED_BLOCK), 0,
                                c->stream, sa.perm_T, sa.perm_slots, sa.S, sa.k, sa.n_sh, sa.n_games, sa.patience,
-                               static_cast<uint32_t *>(c->classes.p));
+                               sa.blocks ? sa.game_block : nullptr, static_cast<uint32_t *>(c->classes.p));
         hipLaunchKernelGGL(fk_seed_kernel, dim3((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK), dim3(SEED_BLOCK), 0, c->stream, sa);
         t.stop();
         HIPCHK(c, hipGetLastError());
@@ -890,7 +895,7 @@ int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_
         sa.n_games = n_games;
         sa.blocks = static_cast<const DevBlock *>(c->blocks.p);
         sa.n_blocks = nb;
-        sa.game_block = static_cast<uint32_t *>(c->game_block.p);
+        sa.game_block = static_cast<const uint32_t *>(c->game_block.p);
         PlayArgs pa{};
         pa.strat = static_cast<const uint2 *>(c->strat.p);
         pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);

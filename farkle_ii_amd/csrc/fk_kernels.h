@@ -97,7 +97,7 @@ struct SeedArgs {
     // batched H2H blocks (MODE_BLOCKS): game -> (block, attempt)
     const DevBlock *blocks;
     uint32_t n_blocks;
-    uint32_t *game_block;    // [n_games] out: block index of every game
+    const uint32_t *game_block; // [n_games] block index of every game (fk_block_map_kernel)
 };
 
 struct PlayArgs {
@@ -330,6 +330,10 @@ constexpr int SEED_BLOCK = 1024;
 // launch drains on the games that are shortest in expectation.
 constexpr uint32_t SCHED_CLASSES = 16;
 
+__device__ inline uint32_t class_of(uint32_t sum, uint32_t n_never, uint32_t k) {
+    return n_never == k ? 0u : (SCHED_CLASSES - 1u) - min(sum, SCHED_CLASSES - 2u);
+}
+
 __device__ inline uint32_t schedule_class(const uint16_t *perm_T, uint32_t perm_slots, uint32_t S, uint32_t k,
                                           const uint8_t *patience, uint32_t sh_local, uint32_t g_local) {
     uint32_t sum = 0, n_never = 0;
@@ -338,14 +342,34 @@ __device__ inline uint32_t schedule_class(const uint16_t *perm_T, uint32_t perm_
         sum += p;
         n_never += (p == 3u) ? 1u : 0u;
     }
-    return n_never == k ? 0u : (SCHED_CLASSES - 1u) - min(sum, SCHED_CLASSES - 2u);
+    return class_of(sum, n_never, k);
+}
+
+// batched H2H: the two seats of block b are table rows 2b, 2b + 1
+__device__ inline uint32_t schedule_class_block(const uint8_t *patience, uint32_t blk) {
+    const uint32_t p0 = patience[2u * blk], p1 = patience[2u * blk + 1u];
+    return class_of(p0 + p1, (p0 == 3u ? 1u : 0u) + (p1 == 3u ? 1u : 0u), 2u);
+}
+
+// batched H2H: game -> block (the block with the largest start <= game), one lane per game
+__global__ void fk_block_map_kernel(const DevBlock *blocks, uint32_t n_blocks, uint32_t n_games, uint32_t *game_block) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_games) return;
+    uint32_t lo = 0, hi = n_blocks;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (blocks[mid].start <= t) lo = mid;
+        else hi = mid;
+    }
+    game_block[t] = lo;
 }
 
 // Class sizes: one lane per game in the seed kernel's walk order (coalesced permutation reads), grid-stride so that few
 // blocks add to the same global words at the end.
 __global__ __launch_bounds__(SEED_BLOCK) void fk_class_count_kernel(const uint16_t *perm_T, uint32_t perm_slots, uint32_t S,
                                                                     uint32_t k, uint32_t n_sh, uint32_t n_games,
-                                                                    const uint8_t *patience, uint32_t *class_ctr) {
+                                                                    const uint8_t *patience, const uint32_t *game_block,
+                                                                    uint32_t *class_ctr) {
     __shared__ uint32_t cnt[SCHED_CLASSES];
     if (threadIdx.x < SCHED_CLASSES) cnt[threadIdx.x] = 0u;
     __syncthreads();
@@ -353,8 +377,12 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_class_count_kernel(const uint16
         const uint32_t t = base + threadIdx.x;
         uint32_t cls = SCHED_CLASSES;
         if (t < n_games) {
-            const uint32_t g_local = t / n_sh, sh_local = t - g_local * n_sh;
-            cls = schedule_class(perm_T, perm_slots, S, k, patience, sh_local, g_local);
+            if (game_block) {
+                cls = schedule_class_block(patience, game_block[t]);
+            } else {
+                const uint32_t g_local = t / n_sh, sh_local = t - g_local * n_sh;
+                cls = schedule_class(perm_T, perm_slots, S, k, patience, sh_local, g_local);
+            }
         }
         for (uint32_t cidx = 0; cidx < SCHED_CLASSES; ++cidx) {
             const uint64_t m = __ballot(cls == cidx);
@@ -388,7 +416,9 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
     // class dragged a full 128-B line per game through L2: 3.7 GB of HBM fetches per 10^7 games instead of 0.5).
     uint32_t slot = t;
     if (a.sched) {
-        const uint32_t cls = valid ? schedule_class(a.perm_T, a.perm_slots, a.S, a.k, a.patience, sh_local, g_local) : SCHED_CLASSES;
+        uint32_t cls = SCHED_CLASSES;
+        if (valid) cls = a.blocks ? schedule_class_block(a.patience, a.game_block[t])
+                                  : schedule_class(a.perm_T, a.perm_slots, a.S, a.k, a.patience, sh_local, g_local);
         const uint32_t wave = threadIdx.x >> 6;
         uint64_t mine_m = 0;
         for (uint32_t cidx = 0; cidx < SCHED_CLASSES; ++cidx) {
@@ -428,16 +458,9 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
             ss_absorb64(gp, c.pair_id);
             ss_absorb64(gp, c.order);
             ss_absorb64(gp, c.game_index);
-        } else if (a.blocks) { // batched H2H: the block holding game t (largest start <= t), then its attempt index
-            uint32_t lo = 0, hi = a.n_blocks;
-            while (hi - lo > 1u) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (a.blocks[mid].start <= t) lo = mid;
-                else hi = mid;
-            }
-            blk = lo;
+        } else if (a.blocks) { // batched H2H: the block holding game t (fk_block_map_kernel), then its attempt index
+            blk = a.game_block[t];
             const DevBlock b = a.blocks[blk];
-            a.game_block[t] = blk;
             gp = a.prefix;
             gp.hc = HC_AFTER_6_WORDS;
             ss_absorb64(gp, 0);                        // shuffle_index

@@ -50,6 +50,26 @@ def reduce_tally(tally: np.ndarray, dst: int = 0, device=None) -> np.ndarray:
     return t.cpu().numpy()
 
 
+def gather_objects(obj, dst: int | None = None, broadcast_from: int | None = None):
+    """Small picklable objects across ranks (manifest records, recovered batch sets).  ``dst``: list of every rank's
+    object on ``dst`` (None elsewhere); ``broadcast_from``: that rank's object on every rank.  Single process: identity."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [obj] if dst is not None else obj
+    if dist.get_backend() == "nccl":
+        import torch
+
+        torch.cuda.set_device(collective_device())
+    if broadcast_from is not None:
+        box = [obj]
+        dist.broadcast_object_list(box, src=broadcast_from)
+        return box[0]
+    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(obj, out, dst=dst)
+    return out
+
+
 def barrier() -> None:
     """Process-group barrier (no-op without one)."""
     import torch.distributed as dist

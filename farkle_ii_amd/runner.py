@@ -21,18 +21,17 @@ from __future__ import annotations
 import json
 import logging
 import os
-import pickle
 import time
-from collections import Counter
 from pathlib import Path
 from typing import Any, Mapping, Sequence
 
 import numpy as np
 
+from . import checkpoint as ckpt
 from . import random as urandom
 from . import tournament as rt
 from .config import AppConfig
-from .distributed import reduce_tally, shard_shuffle_range
+from .distributed import barrier, gather_objects, reduce_tally, shard_shuffle_range
 from .engine import get_engine
 from .game_profile import GameProfile
 from .rows import OUTCOME_SCHEMA_VERSION, TOURNAMENT_METHOD_VERSION
@@ -155,6 +154,71 @@ def _metric_chunk_table(batch_tally: np.ndarray, ids: Sequence[int], k: int):
     return pa.Table.from_pylist(rows)
 
 
+def _read_manifest(path: Path) -> list[dict]:
+    if not path.exists():
+        return []
+    out = []
+    for line in path.read_text(encoding="utf-8").splitlines():
+        line = line.strip()
+        if line:
+            try:
+                out.append(json.loads(line))
+            except json.JSONDecodeError:
+                continue  # a torn last line of an interrupted append
+    return out
+
+
+def _rewrite_manifest(path: Path, records: Sequence[Mapping[str, Any]]) -> None:
+    _atomic_write_bytes(path, "".join(json.dumps(r, sort_keys=True) + "\n" for r in records).encode("utf-8"))
+
+
+def _prune_manifest(path: Path, owned: set[int], batch_of) -> int:
+    """Keep one record per unit, and only units whose deterministic batch the checkpoint owns: a run that died between
+    appending manifest lines and writing the checkpoint that owns them replays that launch group, and its records must
+    not be there twice (the reference replays every manifest record on recovery, run_tournament.py:820-941)."""
+    records = _read_manifest(path)
+    kept, seen = [], set()
+    for r in records:
+        unit, batch = batch_of(r)
+        if batch in owned and unit not in seen:
+            seen.add(unit)
+            kept.append(r)
+    if path.exists() and len(kept) != len(records):
+        _rewrite_manifest(path, kept)
+    return len(records) - len(kept)
+
+
+def _recover_from_metric_chunks(metric_chunk_dir: Path, ids: Sequence[int]) -> tuple[np.ndarray, set[int]]:
+    """Aggregates and completed batches rebuilt from the metric chunk files a manifest lists — the reference's recovery
+    authority when the periodic checkpoint is missing or behind (``_load_metric_chunk_aggregates``,
+    run_tournament.py:871-941)."""
+    import pyarrow.parquet as pq
+
+    index = {int(sid): i for i, sid in enumerate(ids)}
+    label_col = {label: j for j, label in enumerate(rt.METRIC_LABELS)}
+    tally = np.zeros((len(ids), 26), dtype=np.int64)
+    done: set[int] = set()
+    for rec in _read_manifest(metric_chunk_dir / "metrics_manifest.jsonl"):
+        batch = int(rec["chunk_index"]) - 1
+        path = metric_chunk_dir / str(rec["path"])
+        if batch in done or not path.exists():
+            continue
+        t = pq.read_table(path).to_pydict()
+        for metric, strat, total, sq, wins, att, comp, saf in zip(t["metric"], t["strategy"], t["sum"], t["square_sum"], t["wins"],
+                                                                   t["attempted_exposures"], t["completed_exposures"],
+                                                                   t["safety_limit_exposures"]):
+            i, j = index[int(strat)], label_col[metric]
+            tally[i, 4 + j] += int(total)
+            tally[i, 15 + j] += int(sq)
+            if j == 0:  # the outcome columns repeat on every metric's row: count them once (run_tournament.py:905-922)
+                tally[i, 0] += int(wins)
+                tally[i, 1] += int(att)
+                tally[i, 2] += int(comp)
+                tally[i, 3] += int(saf)
+        done.add(batch)
+    return tally, done
+
+
 def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[ThresholdStrategy], plan: TournamentWorkloadPlan,
                    checkpoint_path: Path, collect_metrics: bool, row_dir: Path | None, metric_chunk_dir: Path | None,
                    resume: bool, checkpoint_metadata: Mapping[str, Any], oracle_game_profile: GameProfile | None = None) -> dict:
@@ -178,21 +242,42 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         **dict(checkpoint_metadata),
         "workload_plan_version": plan.plan_version, "screening_resolution_delta": plan.resolution_delta,
         "screening_interval_confidence": plan.confidence, "batch_count": plan.batch_count, "shuffles_per_batch": spb,
-        "batch_construction": plan.batch_construction, "backend": "farkle_ii_amd/hip-gfx950",
+        "batch_construction": plan.batch_construction,
     }
     total = np.zeros((S, 26), dtype=np.int64)
     done_batches: set[int] = set()
-    if resume and checkpoint_path.exists():
-        payload = pickle.loads(checkpoint_path.read_bytes())
-        old = payload.get("meta", {})
-        stale = [key for key in ("n_players", "num_shuffles", "global_seed", "n_strategies", "deterministic_batch_size",
-                                 "strategy_manifest_sha", "rng_scheme_version")
-                 if key in old and old.get(key) != meta.get(key)]
-        if stale:
-            raise ValueError(f"checkpoint {checkpoint_path} was written under a different contract: {stale}; use --force")
-        total = np.asarray(payload["tally_int64"], dtype=np.int64)
-        done_batches = set(int(b) - 1 for b in old.get("completed_process_block_indices", []))  # recorded 1-based
+    row_manifest = (row_dir / "manifest.jsonl") if row_dir is not None else None
+    metrics_manifest = (metric_chunk_dir / "metrics_manifest.jsonl") if metric_chunk_dir is not None else None
+    if resume and rank == 0:
+        if checkpoint_path.exists():
+            payload = ckpt.load_checkpoint(checkpoint_path)  # written by this engine or by the reference
+            old = payload.get("meta", {})
+            stale = [key for key in ("n_players", "num_shuffles", "global_seed", "n_strategies", "deterministic_batch_size",
+                                     "strategy_manifest_sha", "rng_scheme_version")
+                     if key in old and old.get(key) != meta.get(key)]
+            if stale:
+                raise ValueError(f"checkpoint {checkpoint_path} was written under a different contract: {stale}; use --force")
+            done_batches = set(int(b) - 1 for b in old.get("completed_process_block_indices", []))  # recorded 1-based
+            shuffles_done = set(int(i) for i in old.get("completed_shuffle_indices", []))
+            if shuffles_done:  # a batch the shuffle list does not fully cover is not owned
+                done_batches = {b for b in done_batches if all(i in shuffles_done for i in range(b * spb, min((b + 1) * spb, plan.required_shuffles)))}
+            if done_batches:
+                total = ckpt.payload_to_tally(payload, ids, rt.METRIC_LABELS)
+                if collect_metrics and not payload.get("metric_sums"):
+                    raise ValueError(f"checkpoint {checkpoint_path} holds no metric sums but this run collects metrics; use --force")
+        if metric_chunk_dir is not None:
+            chunk_tally, chunk_done = _recover_from_metric_chunks(metric_chunk_dir, ids)
+            if chunk_done - done_batches:  # the chunk files are ahead of the pickle: they are the recovery authority
+                LOGGER.info("Recovered %d batches from metric chunks (checkpoint owned %d)", len(chunk_done), len(done_batches))
+                total, done_batches = chunk_tally, chunk_done
+        # manifests hold exactly what the recovered state owns (no record of a replayed group survives twice)
+        if metrics_manifest is not None:
+            _prune_manifest(metrics_manifest, done_batches, lambda r: (int(r["chunk_index"]), int(r["chunk_index"]) - 1))
+        if row_manifest is not None:
+            _prune_manifest(row_manifest, done_batches, lambda r: (int(r["shuffle_index"]), int(r["shuffle_index"]) // spb))
         LOGGER.info("Resuming: %d of %d batches already complete", len(done_batches), n_batches)
+    if world > 1:  # every rank plans against rank 0's recovered state
+        done_batches = set(gather_objects(sorted(done_batches), broadcast_from=0))
     pending = [b for b in range(n_batches) if b not in done_batches]
     target = oracle_game_profile.default_target_score if oracle_game_profile else 10_000
     max_rounds = oracle_game_profile.default_max_rounds if oracle_game_profile else 200
@@ -206,17 +291,12 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
 
     def save(final: bool) -> None:
         wins, sums, sqs = rt.tally_to_counters(total, ids, k, dense=metric_chunk_dir is not None)
-        # the OutcomeCounter itself is pickled, exposures included (run_tournament.py:622-651)
-        payload: dict[str, Any] = {"win_totals": wins, "outcome_counts": wins.outcome_payload(),
-                                   "tally_int64": total.copy()}
-        if collect_metrics:
-            payload["metric_sums"] = {m: dict(v) for m, v in sums.items()}
-            payload["metric_square_sums"] = {m: dict(v) for m, v in sqs.items()}
         completed = sorted(done_batches)
         # process blocks are numbered from 1 (run_tournament.py:1576-1586); one block = one deterministic batch here
-        payload["meta"] = {**meta, "completed_shuffle_indices": [s for b in completed for s in range(b * spb, (b + 1) * spb)],
-                           "completed_process_block_indices": [b + 1 for b in completed], "complete": final}
-        _atomic_write_bytes(checkpoint_path, pickle.dumps(payload, protocol=pickle.HIGHEST_PROTOCOL))
+        ck_meta = {**meta, "completed_shuffle_indices": [s for b in completed for s in range(b * spb, min((b + 1) * spb, plan.required_shuffles))],
+                   "completed_process_block_indices": [b + 1 for b in completed], "complete": final}
+        _atomic_write_bytes(checkpoint_path, ckpt.dump_checkpoint(wins, sums if collect_metrics else None,
+                                                                  sqs if collect_metrics else None, ck_meta))
 
     i = 0
     while i < len(pending):
@@ -225,32 +305,42 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         while j + 1 < len(pending) and pending[j + 1] == pending[j] + 1 and (j + 1 - i) < group_batches:
             j += 1
         b0, b1 = pending[i], pending[j] + 1
-        lo, hi = shard_shuffle_range(b0 * spb, b1 * spb, rank, world, batch_size=spb)
+        lo, hi = shard_shuffle_range(b0 * spb, min(b1 * spb, plan.required_shuffles), rank, world, batch_size=spb)
         # Per-batch tallies are only needed for the metric chunk files; without them the group is one tally, which the
-        # engine keeps in LDS (per-batch tallies use global int64 atomics: +23 % kernel time on a 64-strategy grid).
+        # engine keeps in LDS when the table is small.
         per_batch = metric_chunk_dir is not None
         local = np.zeros((b1 - b0 if per_batch else 1, S, 26), dtype=np.int64)
+        row_records: list[dict] = []
         if hi > lo:
             res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=spb if per_batch else hi - lo,
                                  target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows)
             first = lo // spb - b0 if per_batch else 0
             local[first:first + len(res["tally"])] = res["tally"]
-            if want_rows:  # every rank writes the shards of its own shuffles
+            if want_rows:  # every rank writes the shards of its own shuffles; rank 0 appends the manifest lines
                 tasks = rt.shuffle_tasks(cfg.sim.seed, k, lo, hi, spb)
                 for n, task in enumerate(tasks):
-                    rt.write_row_shard(row_dir, None, task, res["rows"][n * gps:(n + 1) * gps], ids,
-                                       game_profile_sha256=oracle_game_profile.sha256 if oracle_game_profile else None)
+                    _, record = rt.write_row_shard(row_dir, None, task, res["rows"][n * gps:(n + 1) * gps], ids,
+                                                   game_profile_sha256=oracle_game_profile.sha256 if oracle_game_profile else None,
+                                                   append_manifest=False, return_record=True)
+                    row_records.append(record)
         group = reduce_tally(local, dst=0)
+        if want_rows and world > 1:
+            gathered = gather_objects(row_records, dst=0)
+            row_records = [r for part in (gathered or []) for r in part]
         if rank == 0:
+            if want_rows:
+                rt.append_manifest_records(row_manifest, sorted(row_records, key=lambda r: r["shuffle_index"]))
+            chunk_records = []
             for n, b in enumerate(range(b0, b1)):
                 if metric_chunk_dir is not None:
                     chunk = _metric_chunk_table(group[n], ids, k)
                     name = f"metrics_{b + 1:06d}.parquet"  # chunk / process-block indices count from 1 (run_tournament.py:1603-1642)
                     _write_parquet_atomic(chunk, metric_chunk_dir / name)
-                    tasks = rt.shuffle_tasks(cfg.sim.seed, k, b * spb, (b + 1) * spb, spb)
+                    first_sh, last_sh = b * spb, min((b + 1) * spb, plan.required_shuffles)
+                    tasks = rt.shuffle_tasks(cfg.sim.seed, k, first_sh, last_sh, spb)
                     record = {"path": name, "rows": chunk.num_rows, "chunk_index": b + 1, "process_block_index": b + 1,
                               "root_seed": cfg.sim.seed, "n_players": k, "deterministic_batch_id": b,
-                              "shuffle_index_start": b * spb, "shuffle_index_end": (b + 1) * spb - 1, "shuffle_count": spb,
+                              "shuffle_index_start": first_sh, "shuffle_index_end": last_sh - 1, "shuffle_count": last_sh - first_sh,
                               "shuffle_indices": [t.shuffle_index for t in tasks], "shuffle_seeds": [t.shuffle_seed for t in tasks],
                               "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
                               "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
@@ -258,20 +348,22 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                               "tournament_method_version": TOURNAMENT_METHOD_VERSION}
                     if oracle_game_profile is not None:  # run_tournament.py:1668
                         record["game_profile_sha256"] = oracle_game_profile.sha256
-                    with open(metric_chunk_dir / "metrics_manifest.jsonl", "a", encoding="utf-8") as fh:
-                        fh.write(json.dumps(record, sort_keys=True) + "\n")
+                    chunk_records.append(record)
                 if per_batch:
                     total += group[n]
                 done_batches.add(b)
+            if chunk_records:
+                rt.append_manifest_records(metrics_manifest, chunk_records)
             if not per_batch:
                 total += group[0]
-            games_done += (b1 - b0) * spb * gps
-            save(final=False)
+            games_done += (min(b1 * spb, plan.required_shuffles) - b0 * spb) * gps
+            save(final=False)  # the checkpoint that owns the manifest lines just appended
             LOGGER.info("Batches %d..%d done: %.3g games/s so far", b0, b1 - 1,
                         games_done / max(time.perf_counter() - t_start, 1e-9))
         i = j + 1
     if rank == 0:
         save(final=True)
+    barrier()
     return {"tally": total, "games": games_done, "seconds": time.perf_counter() - t_start}
 
 
@@ -322,6 +414,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
     for d in (row_dir, metric_chunk_dir):
         if d is not None:
             d.mkdir(parents=True, exist_ok=True)
+    barrier()  # rank 0's --force cleanup and manifest write are complete before any rank plays or writes a shard
     result = run_tournament(cfg=cfg, n_players=n, strategies=strategies, plan=plan, checkpoint_path=ckpt_path,
                             collect_metrics=cfg.sim.expanded_metrics, row_dir=row_dir, metric_chunk_dir=metric_chunk_dir,
                             resume=not force, checkpoint_metadata={"strategy_manifest_sha": manifest_sha},
@@ -366,7 +459,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         _write_parquet_atomic(pa.Table.from_pylist(summary), n_dir / f"{n}p_checkpoint.parquet")
     if metrics_rows:
         _write_parquet_atomic(pa.Table.from_pylist(metrics_rows), cfg.metrics_path(n))
-    done = {"stage": "simulation", "status": "success", "backend": "farkle_ii_amd/hip-gfx950",
+    done = {"stage": "simulation", "status": "success", "engine": "farkle_ii_amd/hip-gfx950",
             "metadata": {"n_players": n, "seed": cfg.sim.seed, "root_seed": cfg.sim.seed, "k": n,
                          "num_shuffles": plan.required_shuffles, "shuffle_index_start": 0,
                          "shuffle_index_end": plan.required_shuffles - 1, "deterministic_batch_count": plan.batch_count,

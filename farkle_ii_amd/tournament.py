@@ -59,28 +59,30 @@ class ShuffleTask:
     deterministic_batch_id: int
 
 
+_EXPOSURE_COUNTERS = ("attempted_exposures", "completed_exposures", "safety_limit_exposures")
+_GAME_TOTALS = ("games_attempted", "games_completed", "games_safety_limit")
+
+
 class OutcomeCounter(Counter):
-    """Win counter carrying additive attempted/completed exposure conservation."""
+    """Win counter that also carries the per-strategy exposure counters and the three game totals
+    (the pickled interface type of run_tournament.py:165-245; ``absorb`` merges, ``outcome_payload`` serialises)."""
 
     def __init__(self, *args: Any, **kwargs: Any) -> None:
-        self.attempted_exposures: Counter = Counter()
-        self.completed_exposures: Counter = Counter()
-        self.safety_limit_exposures: Counter = Counter()
-        self.games_attempted = 0
-        self.games_completed = 0
-        self.games_safety_limit = 0
+        for name in _EXPOSURE_COUNTERS:
+            setattr(self, name, Counter())
+        for name in _GAME_TOTALS:
+            setattr(self, name, 0)
         super().__init__(*args, **kwargs)
 
     def absorb(self, other: Counter) -> None:
         super().update(other)
         if isinstance(other, OutcomeCounter):
-            self.attempted_exposures.update(other.attempted_exposures)
-            self.completed_exposures.update(other.completed_exposures)
-            self.safety_limit_exposures.update(other.safety_limit_exposures)
-            self.games_attempted += other.games_attempted
-            self.games_completed += other.games_completed
-            self.games_safety_limit += other.games_safety_limit
+            for name in _EXPOSURE_COUNTERS:
+                getattr(self, name).update(getattr(other, name))
+            for name in _GAME_TOTALS:
+                setattr(self, name, getattr(self, name) + getattr(other, name))
             return
+        # a plain win counter: every win is one completed game, every winner one completed exposure
         completed = int(sum(other.values()))
         self.attempted_exposures.update(other)
         self.completed_exposures.update(other)
@@ -88,10 +90,8 @@ class OutcomeCounter(Counter):
         self.games_completed += completed
 
     def outcome_payload(self) -> dict[str, Any]:
-        return {"games_attempted": self.games_attempted, "games_completed": self.games_completed,
-                "games_safety_limit": self.games_safety_limit, "attempted_exposures": dict(self.attempted_exposures),
-                "completed_exposures": dict(self.completed_exposures),
-                "safety_limit_exposures": dict(self.safety_limit_exposures)}
+        return {**{name: getattr(self, name) for name in _GAME_TOTALS},
+                **{name: dict(getattr(self, name)) for name in _EXPOSURE_COUNTERS}}
 
     def __reduce__(self):
         return (_restore_outcome_counter, (dict(self), self.outcome_payload()))
@@ -99,12 +99,10 @@ class OutcomeCounter(Counter):
 
 def _restore_outcome_counter(counts: dict, outcome_counts: dict) -> OutcomeCounter:
     restored = OutcomeCounter(counts)
-    restored.attempted_exposures.update(outcome_counts.get("attempted_exposures", {}))
-    restored.completed_exposures.update(outcome_counts.get("completed_exposures", {}))
-    restored.safety_limit_exposures.update(outcome_counts.get("safety_limit_exposures", {}))
-    restored.games_attempted = int(outcome_counts.get("games_attempted", 0))
-    restored.games_completed = int(outcome_counts.get("games_completed", 0))
-    restored.games_safety_limit = int(outcome_counts.get("games_safety_limit", 0))
+    for name in _EXPOSURE_COUNTERS:
+        getattr(restored, name).update(outcome_counts.get(name, {}))
+    for name in _GAME_TOTALS:
+        setattr(restored, name, int(outcome_counts.get(name, 0)))
     return restored
 
 
@@ -271,13 +269,27 @@ def _run_chunk_metrics(shuffle_tasks: Sequence[ShuffleTask | int], *, collect_ro
         if row_dir is not None and collect_rows:
             gps = len(res["rows"]) // len(group)
             for n, task in enumerate(group):
-                write_row_shard(Path(row_dir), manifest_path, task, res["rows"][n * gps:(n + 1) * gps], ids)
+                write_row_shard(Path(row_dir), manifest_path, task, res["rows"][n * gps:(n + 1) * gps], ids,
+                                game_profile_sha256=state.game_profile.sha256 if state.game_profile else None)  # :549-553
     return wins_total, sums_total, sq_total
 
 
+def append_manifest_records(manifest: Path, records: Sequence[Mapping[str, Any]]) -> None:
+    """Append JSON lines to a manifest (one write call, flushed)."""
+    import json
+
+    if not records:
+        return
+    manifest.parent.mkdir(parents=True, exist_ok=True)
+    with open(manifest, "a", encoding="utf-8") as fh:
+        fh.write("".join(json.dumps(r, sort_keys=True) + "\n" for r in records))
+        fh.flush()
+
+
 def write_row_shard(row_dir: Path, manifest_path: Path | None, task: ShuffleTask, rows: np.ndarray, ids: Sequence[int],
-                    game_profile_sha256: str | None = None) -> Path:
-    """One shuffle's rows -> parquet shard + manifest record (run_tournament.py:530-558)."""
+                    game_profile_sha256: str | None = None, *, append_manifest: bool = True, return_record: bool = False):
+    """One shuffle's rows -> parquet shard + manifest record (run_tournament.py:530-558).  With ``append_manifest=False``
+    the record is only returned (multi-rank runs gather the records and let rank 0 append them)."""
     import json
     import os
 
@@ -305,9 +317,9 @@ def write_row_shard(row_dir: Path, manifest_path: Path | None, task: ShuffleTask
               "pid": os.getpid()}
     if game_profile_sha256 is not None:  # run_tournament.py:549-553
         record["game_profile_sha256"] = game_profile_sha256
-    with open(manifest, "a", encoding="utf-8") as fh:
-        fh.write(json.dumps(record, sort_keys=True) + "\n")
-    return out
+    if append_manifest:
+        append_manifest_records(manifest, [record])
+    return (out, record) if return_record else out
 
 
 def shuffle_tasks(root_seed: int, k: int, shuffle_begin: int, shuffle_end: int, deterministic_batch_size: int) -> list[ShuffleTask]:

@@ -1,0 +1,522 @@
+"""`farkle run` (AppConfig front-end -> batches -> artifacts -> checkpoint / resume) on BOTH engines:
+
+* ``hip`` — the product: every game runs in the HIP kernels (``-m gpu``);
+* ``oracle-stub`` — tests/oracle_engine_stub.py, the CPU oracle behind the Engine interface: the same host logic on a GPU-less
+  host, so artifact fidelity against the reference's frozen run, checkpoint interoperability, crash recovery and the
+  multi-rank file protocol are checked in the CPU suite as well.
+"""
+from __future__ import annotations
+
+import json
+import os
+import pickle
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(params=["oracle-stub", pytest.param("hip", marks=pytest.mark.gpu)])
+def engine(request):
+    from farkle_ii_amd import engine as eng_mod
+
+    if request.param == "hip":
+        eng_mod.set_engine(None)
+        yield eng_mod.get_engine()
+    else:
+        import oracle_engine_stub
+
+        stub = oracle_engine_stub.Engine(0)
+        eng_mod.set_engine(stub)
+        yield stub
+    eng_mod.set_engine(None)
+
+
+def _write_partial_checkpoint(path: Path, tally: np.ndarray, ids, k: int, meta: dict, done_blocks: list[int], spb: int) -> None:
+    """An interrupted run's checkpoint: totals of the batches in `done_blocks` (1-based) only."""
+    from farkle_ii_amd import checkpoint as ckpt
+    from farkle_ii_amd import tournament as rt
+
+    wins, sums, sqs = rt.tally_to_counters(tally, ids, k)
+    meta = {**meta, "completed_process_block_indices": list(done_blocks), "complete": False,
+            "completed_shuffle_indices": [s for b in done_blocks for s in range((b - 1) * spb, b * spb)]}
+    path.write_bytes(ckpt.dump_checkpoint(wins, sums, sqs, meta))
+
+
+def _tally(payload, n_strategies: int) -> np.ndarray:
+    from farkle_ii_amd import checkpoint as ckpt
+    from farkle_ii_amd import tournament as rt
+
+    return ckpt.payload_to_tally(payload, list(range(n_strategies)), rt.METRIC_LABELS)
+
+
+def test_farkle_run_end_to_end_artifacts_resume_and_force(engine, tmp_path):
+    """`farkle run` on a tiny grid: artifacts, checkpoint payload, per-batch metric chunks, row shards, resume, --force;
+    aggregates cross-checked against the CPU oracle."""
+    import pyarrow.parquet as pq
+    import pyoracle as po
+
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.cli import main
+    from farkle_ii_amd.strategies import pack_strategies
+
+    cfg_path = tmp_path / "tiny.yaml"
+    cfg_path.write_text(f"""
+io:
+  results_dir_prefix: "{tmp_path / 'out'}"
+sim:
+  n_players_list: [2, 4]
+  seed_list: [11]
+  expanded_metrics: true
+  row_dir: "rows"
+  metric_chunk_dir: "metric_chunks"
+  score_thresholds: [300, 500]
+  dice_thresholds: [2]
+  smart_five_opts: [false]
+  smart_one_opts: [false]
+  consider_score_opts: [true]
+  consider_dice_opts: [true]
+  auto_hot_dice_opts: [false, true]
+  run_up_score_opts: [false]
+screening:
+  resolution_delta: 0.5
+batching:
+  target_batches: 3
+  min_shuffles_per_batch: 2
+""")
+    main(["--config", str(cfg_path), "run"])
+    root = tmp_path / "out_seed_11"
+    assert (root / "strategy_manifest.parquet").exists() and (root / "active_config.yaml").exists()
+    manifest = pq.read_table(root / "strategy_manifest.parquet").to_pandas()
+    assert list(manifest["strategy_id"]) == list(range(8)) and manifest["strategy_str"][0].startswith("Strat(300,2)")
+    for k in (2, 4):
+        n_dir = root / f"{k}_players"
+        plan = json.loads((n_dir / "simulation_workload_plan.json").read_text())
+        assert plan["k"] == k and plan["batch_count"] == 3 and plan["required_shuffles"] == 3 * plan["shuffles_per_batch"]
+        payload = pickle.loads((n_dir / f"{k}p_checkpoint.pkl").read_bytes())
+        assert set(payload) >= {"win_totals", "outcome_counts", "metric_sums", "metric_square_sums", "meta"}
+        assert payload["meta"]["completed_process_block_indices"] == [1, 2, 3] and payload["meta"]["complete"]
+        n_sh = plan["required_shuffles"]
+        from farkle_ii_amd.config import load_app_config
+
+        strategies, _ = runner._resolve_strategies(load_app_config(cfg_path, seed_list_len=1), None)
+        ref = po.tournament(pack_strategies(strategies).view(po.STRATEGY_DTYPE), k, 11, 0, n_sh)["tally"][0]
+        # totals are rebuilt from the metric chunks: every seated strategy is present, zeros included
+        assert {int(s): int(v) for s, v in payload["win_totals"].items()} == {i: int(ref[i, 0]) for i in range(8)}
+        assert payload["outcome_counts"]["games_attempted"] == n_sh * (8 // k)
+        assert payload["metric_sums"]["winner_rolls"] == {i: float(ref[i, 7]) for i in range(8)}
+        summary = pq.read_table(n_dir / f"{k}p_checkpoint.parquet").to_pandas()
+        assert list(summary["attempted_exposures"]) == [n_sh] * 8 and summary["wins"].sum() == ref[:, 0].sum()
+        metrics = pq.read_table(n_dir / f"{k}p_metrics.parquet")
+        assert "var_winning_score" in metrics.column_names and "expected_score" in metrics.column_names
+        chunks = sorted((n_dir / f"{k}p_metric_chunks").glob("metrics_*.parquet"))
+        assert [c.name for c in chunks] == ["metrics_000001.parquet", "metrics_000002.parquet", "metrics_000003.parquet"]
+        chunk_wins = sum(pq.read_table(c).to_pandas().query("metric == 'n_rounds'")["wins"].sum() for c in chunks)
+        assert chunk_wins == ref[:, 0].sum()
+        rows = sorted((n_dir / f"{k}p_rows").glob("rows_*.parquet"))
+        assert len(rows) == n_sh and sum(pq.read_table(r).num_rows for r in rows) == n_sh * (8 // k)
+        done = json.loads((n_dir / "simulation.done.json").read_text())
+        assert done["metadata"]["num_shuffles"] == n_sh and done["status"] == "success"
+    # second invocation: complete -> preserved untouched
+    before = (root / "2_players" / "2p_checkpoint.pkl").stat().st_mtime_ns
+    main(["--config", str(cfg_path), "run"])
+    assert (root / "2_players" / "2p_checkpoint.pkl").stat().st_mtime_ns == before
+    # interrupted run: drop the done marker and one batch from the checkpoint -> resume replays only that batch
+    n_dir = root / "2_players"
+    payload = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    full = _tally(payload, 8)
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    strategies, _ = runner._resolve_strategies(cfg, None)
+    spb = payload["meta"]["shuffles_per_batch"]
+    last = po.tournament(pack_strategies(strategies).view(po.STRATEGY_DTYPE), 2, 11, 2 * spb, 3 * spb)["tally"][0]
+    _write_partial_checkpoint(n_dir / "2p_checkpoint.pkl", full - last, list(range(8)), 2, payload["meta"], [1, 2], spb)
+    (n_dir / "simulation.done.json").unlink()
+    main(["--config", str(cfg_path), "--set", "sim.n_players_list=[2]", "run"])
+    again = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    assert np.array_equal(_tally(again, 8), full) and again["meta"]["completed_process_block_indices"] == [1, 2, 3]
+    # the manifests of the resumed run list every unit exactly once (the third batch's stale records were pruned first)
+    recs = [json.loads(x) for x in (n_dir / "2p_rows" / "manifest.jsonl").read_text().splitlines()]
+    assert sorted(r["shuffle_index"] for r in recs) == list(range(3 * spb))
+    chunks = [json.loads(x) for x in (n_dir / "2p_metric_chunks" / "metrics_manifest.jsonl").read_text().splitlines()]
+    assert sorted(r["chunk_index"] for r in chunks) == [1, 2, 3]
+    # --force recomputes from scratch to the same totals
+    main(["--config", str(cfg_path), "--set", "sim.n_players_list=[2]", "run", "--force"])
+    forced = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    assert np.array_equal(_tally(forced, 8), full)
+    assert len(list((n_dir / "2p_rows").glob("rows_*.parquet"))) == 3 * spb
+
+
+def test_farkle_run_artifacts_match_reference_run(engine, tmp_path):
+    """Every artifact `run_single_n` writes, against the same run of the reference's own runner (runner.py:1326)
+    frozen in tests/golden/artifact_vectors.json (oracle/gen_golden.py:gen_artifacts): file set, parquet schemas and
+    records, manifest records, workload plan, checkpoint payload."""
+    import math
+
+    import pyarrow.parquet as pq
+    import yaml
+
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.config import load_app_config
+    from farkle_ii_amd.game_profile import GameProfile, TournamentMaxRoundsOverride
+
+    gold = gu.load("artifact_vectors.json")
+    payload = dict(gold["config"])
+    payload["io"] = {"results_dir_prefix": str(tmp_path / "out"), "analysis_subdir": "analysis"}
+    cfg_path = tmp_path / "tiny.yaml"
+    cfg_path.write_text(yaml.safe_dump(payload))
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    gpd = gold["game_profile"]
+    gp = GameProfile(default_target_score=gpd["target"], default_max_rounds=gpd["max_rounds"],
+                     tournament_max_rounds_overrides=tuple(TournamentMaxRoundsOverride(*o) for o in gpd["overrides"]))
+    diffs: list[str] = []
+
+    def same(a, b) -> bool:
+        if isinstance(a, float) and isinstance(b, float):
+            return (math.isnan(a) and math.isnan(b)) or a == b
+        if isinstance(a, dict) and isinstance(b, dict):
+            return a.keys() == b.keys() and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, (list, tuple)) and isinstance(b, (list, tuple)):
+            return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        return type(a) == type(b) and a == b or (isinstance(a, (int, float)) and isinstance(b, (int, float))
+                                                 and not isinstance(a, bool) and not isinstance(b, bool) and a == b)
+
+    def jsonable(obj):
+        if isinstance(obj, dict):
+            return {str(k): jsonable(v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return [jsonable(v) for v in obj]
+        if isinstance(obj, (np.integer,)):
+            return int(obj)
+        if isinstance(obj, (np.floating,)):
+            return float(obj)
+        return obj
+
+    ours_extra_ok = {"active_config.yaml"}  # the reference's orchestrator writes it next to the results too
+    for k in (2, 4):
+        ref = gold["runs"][str(k)]
+        runner.run_single_n(cfg, k, oracle_game_profile=gp)
+        root = cfg.results_root
+        n_dir = root / f"{k}_players"
+        files = sorted(str(f.relative_to(root)) for f in root.rglob("*") if f.is_file() and (f.parent == root or n_dir in f.parents))
+        # the reference's stage-done stamp needs its Git identity and is absent from the frozen run
+        mine = [f for f in files if f not in ours_extra_ok and not f.endswith("simulation.done.json")]
+        if mine != ref["files"]:
+            diffs.append(f"k={k} file set: only ours {sorted(set(mine) - set(ref['files']))} only reference {sorted(set(ref['files']) - set(mine))}")
+        for name, want in ref["parquet"].items():
+            path = root / name
+            if not path.exists():
+                continue
+            t = pq.read_table(path)
+            schema = [[f.name, str(f.type)] for f in t.schema]
+            if schema != want["schema"]:
+                diffs.append(f"k={k} {name} schema: ours {[s for s in schema if s not in want['schema']]} reference {[s for s in want['schema'] if s not in schema]}")
+            recs = t.to_pylist()
+            if len(recs) != len(want["records"]):
+                diffs.append(f"k={k} {name}: {len(recs)} records, reference {len(want['records'])}")
+            for i, (a, b) in enumerate(zip(recs, want["records"])):
+                if not same(a, b):
+                    bad = {c: (a.get(c), b.get(c)) for c in set(a) | set(b) if not same(a.get(c), b.get(c))}
+                    diffs.append(f"k={k} {name} record {i}: {bad}")
+                    break
+        for name, want in ref["jsonl"].items():
+            path = root / name
+            if not path.exists():
+                continue
+            recs = [{kk: vv for kk, vv in json.loads(line).items() if kk not in ("ts", "pid")} for line in path.read_text().splitlines()]
+            recs.sort(key=lambda r: r["path"])
+            want = sorted(want, key=lambda r: r["path"])
+            if len(recs) != len(want):
+                diffs.append(f"k={k} {name}: {len(recs)} records, reference {len(want)}")
+            for a, b in zip(recs, want):
+                if not same(a, b):
+                    diffs.append(f"k={k} {name} {b['path']}: {({c: (a.get(c), b.get(c)) for c in set(a) | set(b) if not same(a.get(c), b.get(c))})}")
+                    break
+        plan = json.loads((n_dir / "simulation_workload_plan.json").read_text())
+        for key, val in ref["workload_plan"].items():
+            if key in ("projected_games_per_second", "projected_runtime_seconds"):  # throughput of the backend, not of the plan
+                continue
+            if key not in plan or not same(plan[key], val):
+                diffs.append(f"k={k} workload plan {key}: ours {plan.get(key)!r} reference {val!r}")
+        ck = pickle.loads((n_dir / f"{k}p_checkpoint.pkl").read_bytes())
+        ours = {"win_totals": jsonable(dict(ck["win_totals"])), "outcome_counts": jsonable(ck["outcome_counts"]),
+                "metric_sums": jsonable({m: dict(v) for m, v in ck["metric_sums"].items()}),
+                "metric_square_sums": jsonable({m: dict(v) for m, v in ck["metric_square_sums"].items()})}
+        for part, val in ours.items():
+            if not same(val, ref["checkpoint"][part]):
+                diffs.append(f"k={k} checkpoint {part}: ours {val} reference {ref['checkpoint'][part]}")
+        meta = jsonable(ck["meta"])
+        for key, val in ref["checkpoint"]["meta"].items():
+            if key not in meta or not same(meta[key], val):
+                diffs.append(f"k={k} checkpoint meta {key}: ours {meta.get(key)!r} reference {val!r}")
+        # plain containers only (the reference's _coerce_counter restores the exposures from outcome_counts,
+        # run_tournament.py:654-744), the reference's payload keys and no others
+        if type(ck["win_totals"]).__module__ != "collections" or set(ck) != {"win_totals", "outcome_counts", "metric_sums", "metric_square_sums", "meta"}:
+            diffs.append(f"k={k} checkpoint payload: win_totals {type(ck['win_totals'])}, keys {sorted(ck)}")
+        extra_meta = set(meta) - set(ref["checkpoint"]["meta"])
+        if extra_meta - {"complete"}:
+            diffs.append(f"k={k} checkpoint meta carries keys the reference does not write: {sorted(extra_meta)}")
+    assert not diffs, "\n".join(diffs)
+
+
+def test_farkle_run_without_metric_chunks_uses_one_tally_per_group(engine, tmp_path):
+    """No metric chunk directory -> the runner asks the engine for one tally per launch group (LDS tally path); totals,
+    checkpoint ownership and resume are the same as with per-batch tallies."""
+    import pyoracle as po
+
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.cli import main
+    from farkle_ii_amd.config import load_app_config
+    from farkle_ii_amd.strategies import pack_strategies
+
+    cfg_path = tmp_path / "tiny.yaml"
+    cfg_path.write_text(f"""
+io:
+  results_dir_prefix: "{tmp_path / 'out'}"
+sim:
+  n_players_list: [2]
+  seed_list: [7]
+  expanded_metrics: true
+  row_dir: null
+  metric_chunk_dir: null
+  score_thresholds: [300, 500]
+  dice_thresholds: [1, 2]
+  smart_five_opts: [true]
+  smart_one_opts: [true, false]
+  consider_score_opts: [true]
+  consider_dice_opts: [true]
+  auto_hot_dice_opts: [true]
+  run_up_score_opts: [false]
+screening:
+  resolution_delta: 0.3
+batching:
+  target_batches: 4
+  min_shuffles_per_batch: 2
+""")
+    main(["--config", str(cfg_path), "run"])
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    n_dir = cfg.n_dir(2)
+    assert not (n_dir / "2p_metric_chunks").exists() and not (n_dir / "2p_rows").exists()
+    payload = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    strategies, _ = runner._resolve_strategies(cfg, None)
+    n_sh = payload["meta"]["num_shuffles"]
+    ref = po.tournament(pack_strategies(strategies).view(po.STRATEGY_DTYPE), 2, 7, 0, n_sh)["tally"][0]
+    assert np.array_equal(_tally(payload, len(ref)), ref)
+    assert payload["meta"]["completed_process_block_indices"] == [1, 2, 3, 4] and payload["meta"]["complete"]
+    # worker-style counters (no chunk files to rebuild from): only what was incremented is present
+    assert {int(s): int(v) for s, v in payload["win_totals"].items()} == {i: int(ref[i, 0]) for i in range(len(ref)) if ref[i, 0]}
+    # resume after losing the last batch
+    spb = payload["meta"]["shuffles_per_batch"]
+    last = po.tournament(pack_strategies(strategies).view(po.STRATEGY_DTYPE), 2, 7, 3 * spb, 4 * spb)["tally"][0]
+    _write_partial_checkpoint(n_dir / "2p_checkpoint.pkl", ref - last, list(range(len(ref))), 2, payload["meta"], [1, 2, 3], spb)
+    (n_dir / "simulation.done.json").unlink()
+    main(["--config", str(cfg_path), "run"])
+    again = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    assert np.array_equal(_tally(again, len(ref)), ref) and again["meta"]["completed_process_block_indices"] == [1, 2, 3, 4]
+
+
+def test_checkpoint_unpickles_without_this_package_or_the_reference(engine, tmp_path):
+    """`{k}p_checkpoint.pkl` holds plain containers: a bare interpreter (isolated mode: no PYTHONPATH, cwd elsewhere) loads
+    it, and its payload is what the reference's `_coerce_counter` accepts (Counter + outcome_counts mapping)."""
+    import yaml
+
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.config import load_app_config
+
+    cfg_payload = dict(gu.load("resume_vectors.json")["config"])
+    cfg_payload["io"] = {"results_dir_prefix": str(tmp_path / "out"), "analysis_subdir": "analysis"}
+    cfg_path = tmp_path / "tiny.yaml"
+    cfg_path.write_text(yaml.safe_dump(cfg_payload))
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    runner.run_single_n(cfg, 2)
+    path = cfg.checkpoint_path(2)
+    code = ("import pickle, sys, collections\n"
+            "assert not any('farkle' in m for m in sys.modules)\n"
+            f"p = pickle.load(open({str(path)!r}, 'rb'))\n"
+            "assert type(p['win_totals']) is collections.Counter, type(p['win_totals'])\n"
+            "assert not any('farkle' in m for m in sys.modules)\n"
+            "oc = p['outcome_counts']\n"
+            "assert oc['games_attempted'] == oc['games_completed'] + oc['games_safety_limit'] == 42\n"
+            "assert sum(p['win_totals'].values()) == oc['games_completed']\n"
+            "print(sorted(p))\n")
+    res = subprocess.run([sys.executable, "-I", "-c", code], capture_output=True, text=True, cwd="/tmp")
+    assert res.returncode == 0, res.stderr
+    assert res.stdout.strip() == "['meta', 'metric_square_sums', 'metric_sums', 'outcome_counts', 'win_totals']"
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_resume_from_a_checkpoint_the_reference_wrote_mid_run(engine, tmp_path, k):
+    """tests/golden/resume_vectors.json holds the bytes of a checkpoint the reference's own runner wrote before it was
+    interrupted (its OutcomeCounter pickled through farkle.simulation.run_tournament._restore_outcome_counter; that
+    package is NOT importable here) and the final payload of its uninterrupted run.  Resuming from those bytes plays the
+    remaining batches only and reproduces the reference's final totals."""
+    import base64
+
+    import yaml
+
+    from farkle_ii_amd import checkpoint as ckpt
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.config import load_app_config
+
+    gold = gu.load("resume_vectors.json")
+    run = gold["runs"][str(k)]
+    cfg_payload = dict(gold["config"])
+    cfg_payload["sim"] = {**cfg_payload["sim"], "n_players_list": [k]}
+    cfg_payload["io"] = {"results_dir_prefix": str(tmp_path / "out"), "analysis_subdir": "analysis"}
+    cfg_path = tmp_path / "tiny.yaml"
+    cfg_path.write_text(yaml.safe_dump(cfg_payload))
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    path = cfg.checkpoint_path(k)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    path.write_bytes(base64.b64decode(run["partial_checkpoint_pickle_b64"]))
+    assert "farkle.simulation" not in sys.modules
+    partial = ckpt.load_checkpoint(path)
+    assert type(partial["win_totals"]).__name__ == "OutcomeCounter" and partial["meta"]["completed_process_block_indices"] == [1]
+    with pytest.raises(Exception):
+        pickle.loads(path.read_bytes())  # the plain unpickler wants the reference package
+    played = []
+    real = engine.tournament
+
+    def spy(table, kk, seed, lo, hi, **kw):
+        played.append((lo, hi))
+        return real(table, kk, seed, lo, hi, **kw)
+
+    engine.tournament = spy
+    try:
+        runner.run_single_n(cfg, k)
+    finally:
+        engine.tournament = real
+    spb = run["partial_meta"]["deterministic_batch_size"]
+    assert played and min(lo for lo, _ in played) == spb and max(hi for _, hi in played) == run["partial_meta"]["num_shuffles"]
+    final = pickle.loads(path.read_bytes())
+    want = run["final"]
+    assert {str(s): v for s, v in final["win_totals"].items() if v} == {s: v for s, v in want["win_totals"].items() if v}
+    for name in ("games_attempted", "games_completed", "games_safety_limit"):
+        assert final["outcome_counts"][name] == want["outcome_counts"][name]
+    for name in ("attempted_exposures", "completed_exposures", "safety_limit_exposures"):
+        assert {str(s): v for s, v in final["outcome_counts"][name].items() if v} == {s: v for s, v in want["outcome_counts"][name].items() if v}
+    for part in ("metric_sums", "metric_square_sums"):
+        for label, vals in want[part].items():
+            assert {str(s): v for s, v in final[part][label].items() if v} == {s: v for s, v in vals.items() if v}, (part, label)
+    assert final["meta"]["completed_process_block_indices"] == want["meta"]["completed_process_block_indices"]
+    assert final["meta"]["completed_shuffle_indices"] == want["meta"]["completed_shuffle_indices"]
+
+
+def test_crash_between_manifest_append_and_checkpoint_leaves_no_duplicate_records(engine, tmp_path, monkeypatch):
+    """The run dies after a launch group's row / metric-chunk manifest lines are on disk but before the checkpoint that
+    owns them is written.  The resumed run replays that group; the manifests then list every shuffle / chunk exactly once
+    and the totals equal an uninterrupted run's."""
+    import yaml
+
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.config import load_app_config
+
+    gold = gu.load("artifact_vectors.json")
+    cfg_payload = dict(gold["config"])
+    cfg_payload["sim"] = {**cfg_payload["sim"], "n_players_list": [2]}
+    cfg_payload["io"] = {"results_dir_prefix": str(tmp_path / "out"), "analysis_subdir": "analysis"}
+    cfg_path = tmp_path / "tiny.yaml"
+    cfg_path.write_text(yaml.safe_dump(cfg_payload))
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    monkeypatch.setattr(runner, "MAX_GAMES_PER_LAUNCH", 1)  # one deterministic batch per launch group
+    real_write = runner._atomic_write_bytes
+    saves = {"n": 0}
+
+    def dying_write(path, content):
+        if path.name.endswith("checkpoint.pkl"):
+            saves["n"] += 1
+            if saves["n"] == 2:
+                raise KeyboardInterrupt("power cut before the second checkpoint")
+        real_write(path, content)
+
+    monkeypatch.setattr(runner, "_atomic_write_bytes", dying_write)
+    with pytest.raises(KeyboardInterrupt):
+        runner.run_single_n(cfg, 2)
+    n_dir = cfg.n_dir(2)
+    row_manifest, chunk_manifest = n_dir / "2p_rows" / "manifest.jsonl", n_dir / "2p_metric_chunks" / "metrics_manifest.jsonl"
+    spb = json.loads((n_dir / "simulation_workload_plan.json").read_text())["shuffles_per_batch"]
+    assert len(row_manifest.read_text().splitlines()) == 2 * spb and len(chunk_manifest.read_text().splitlines()) == 2
+    assert pickle.loads(cfg.checkpoint_path(2).read_bytes())["meta"]["completed_process_block_indices"] == [1]
+    monkeypatch.setattr(runner, "_atomic_write_bytes", real_write)
+    # (the metric chunk files are a recovery authority: batch 2 is recovered from its chunk, not replayed)
+    runner.run_single_n(cfg, 2)
+    rows = [json.loads(x) for x in row_manifest.read_text().splitlines()]
+    chunks = [json.loads(x) for x in chunk_manifest.read_text().splitlines()]
+    assert sorted(r["shuffle_index"] for r in rows) == list(range(3 * spb))
+    assert sorted(r["chunk_index"] for r in chunks) == [1, 2, 3]
+    final = pickle.loads(cfg.checkpoint_path(2).read_bytes())
+    ref = gold["runs"]["2"]["checkpoint"]
+    # the frozen reference run used a game profile; compare with a clean run of this configuration instead
+    cfg2_payload = dict(cfg_payload)
+    cfg2_payload["io"] = {"results_dir_prefix": str(tmp_path / "clean"), "analysis_subdir": "analysis"}
+    (tmp_path / "clean.yaml").write_text(yaml.safe_dump(cfg2_payload))
+    cfg2 = load_app_config(tmp_path / "clean.yaml", seed_list_len=1)
+    runner.run_single_n(cfg2, 2)
+    clean = pickle.loads(cfg2.checkpoint_path(2).read_bytes())
+    for part in ("win_totals", "outcome_counts", "metric_sums", "metric_square_sums"):
+        assert final[part] == clean[part], part
+    assert final["meta"]["completed_process_block_indices"] == [1, 2, 3] and ref["meta"]["completed_process_block_indices"] == [1, 2, 3]
+
+
+def _run_rank(rank: int, world: int, port: int, cfg_path: str, k: int) -> None:
+    for p in (ROOT, ROOT / "oracle", ROOT / "tests"):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    import oracle_engine_stub
+    from farkle_ii_amd import engine as eng_mod
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.config import load_app_config
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng_mod.set_engine(oracle_engine_stub.Engine(0))
+    runner.run_single_n(load_app_config(Path(cfg_path), seed_list_len=1), k)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_gloo_ranks_write_the_same_artifacts_as_one_process(tmp_path):
+    """`farkle run` with two ranks (whole batches per rank, one tally reduce per launch group, row shards written by the
+    rank that played them, manifest lines gathered to rank 0) against the single-process run of the same configuration."""
+    import pyarrow.parquet as pq
+    import torch.multiprocessing as mp
+    import yaml
+
+    import oracle_engine_stub
+    from farkle_ii_amd import engine as eng_mod
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.config import load_app_config
+
+    gold = gu.load("artifact_vectors.json")
+    roots = {}
+    for name in ("one", "two"):
+        cfg_payload = dict(gold["config"])
+        cfg_payload["sim"] = {**cfg_payload["sim"], "n_players_list": [2]}
+        cfg_payload["io"] = {"results_dir_prefix": str(tmp_path / name), "analysis_subdir": "analysis"}
+        (tmp_path / f"{name}.yaml").write_text(yaml.safe_dump(cfg_payload))
+        roots[name] = load_app_config(tmp_path / f"{name}.yaml", seed_list_len=1)
+    eng_mod.set_engine(oracle_engine_stub.Engine(0))
+    try:
+        runner.run_single_n(roots["one"], 2)
+    finally:
+        eng_mod.set_engine(None)
+    mp.spawn(_run_rank, args=(2, 33500 + os.getpid() % 2000, str(tmp_path / "two.yaml"), 2), nprocs=2, join=True)
+    a, b = roots["one"].results_root, roots["two"].results_root
+    files_a = sorted(str(f.relative_to(a)) for f in a.rglob("*") if f.is_file())
+    files_b = sorted(str(f.relative_to(b)) for f in b.rglob("*") if f.is_file())
+    assert files_a == files_b
+    for rel in files_a:
+        if rel.endswith(".parquet"):
+            assert pq.read_table(a / rel).equals(pq.read_table(b / rel)), rel
+        elif rel.endswith(".jsonl"):
+            strip = lambda text: sorted(json.dumps({k: v for k, v in json.loads(x).items() if k not in ("pid", "ts")}, sort_keys=True)
+                                        for x in text.splitlines())
+            assert strip((a / rel).read_text()) == strip((b / rel).read_text()), rel
+        elif rel.endswith("checkpoint.pkl"):
+            assert pickle.loads((a / rel).read_bytes()) == pickle.loads((b / rel).read_bytes())
