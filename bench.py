@@ -441,9 +441,24 @@ def main() -> None:
         if have_gpu:
             torch.cuda.synchronize(dev)
 
+    # FK_TALLY_REDUCE=rccl: the tally reduction runs as fk_reduce_tally (ncclReduce on the engine's stream through the
+    # C-ABI, no PyTorch in the data path) instead of torch.distributed's reduce; both are RCCL over xGMI under `nccl`.
+    tally_reduce = "single process"
+    use_fk_comm = False
+    if distributed:
+        tally_reduce = f"torch.distributed.reduce ({backend})"
+        if os.environ.get("FK_TALLY_REDUCE", "") == "rccl":
+            from farkle_ii_amd.distributed import init_engine_comm
+
+            use_fk_comm = init_engine_comm(eng)
+            if use_fk_comm:
+                tally_reduce = "fk_reduce_tally (ncclReduce int64 sum through the C-ABI)"
+
     def reduce_to_rank0(local: np.ndarray):
         """The path's only exchange: one SUM of the int64 tally to rank 0 at the end of the job, the
         analogue of OutcomeCounter.absorb — RCCL over xGMI when there is more than one rank."""
+        if use_fk_comm:
+            return torch.from_numpy(eng.reduce_tally(local, 0))
         t = torch.from_numpy(local).to(red_dev)
         if distributed:
             dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
@@ -535,7 +550,7 @@ def main() -> None:
             "metric": METRIC if wl.config in (2,) else f"{METRIC} [variant: BASELINE config {wl.config}]",
             "value": value, "unit": "games/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic", "engine": engine_name,
+            "dtype": "int32", "data": "synthetic", "engine": engine_name, "tally_reduce": tally_reduce,
             "dist_backend": (f"{dist.get_backend()} (RCCL over xGMI)" if distributed and dist.get_backend() == "nccl"
                              else (dist.get_backend() if distributed else None)),
             "launcher": "self (bench.py started the ranks)" if os.environ.get("FK_BENCH_SELF_LAUNCHED") else

@@ -36,10 +36,17 @@ H2H_BLOCK_DTYPE = np.dtype(
      ("max_attempts", "<u8"), ("state", "<u8", (5,))]
 )
 TALLY_COLS = 26
+SEAT_STAT_COLS = 31
+SEAT_STAT_NAMES = ("exposures", "completed_exposures", "safety_limit_exposures", "wins", "final_score_sum", "final_score_square_sum",
+                   "n_turns_sum", "n_turns_square_sum", "turn_round_mismatch_count", "turn_minus_rounds_sum",
+                   "turn_minus_rounds_square_sum") + tuple(
+    f"{name}_{kind}" for name in ("rank", "loss_margin", "rolls", "farkles", "highest_turn", "hot_dice", "smart_five_uses",
+                                   "n_smart_five_dice", "smart_one_uses", "n_smart_one_dice") for kind in ("sum", "square_sum"))
 # tally columns (run_tournament.py:109-121, 165-195)
 COL_WINS, COL_ATTEMPTED, COL_COMPLETED, COL_SAFETY, COL_SUMS, COL_SQ_SUMS = 0, 1, 2, 3, 4, 15
 
-FK_ERR_ROLL_LIMIT, FK_ERR_ARG, FK_ERR_COUNTER_OVERFLOW, FK_ERR_HIP, FK_ERR_NO_DEVICE = -1, -2, -3, -4, -5
+FK_ERR_ROLL_LIMIT, FK_ERR_ARG, FK_ERR_COUNTER_OVERFLOW, FK_ERR_HIP, FK_ERR_NO_DEVICE, FK_ERR_COMM = -1, -2, -3, -4, -5, -6
+COMM_ID_BYTES = 128
 
 
 def row_dtype(k: int) -> np.dtype:
@@ -87,8 +94,8 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
 
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
-            "fk_tournament_run", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
-            "fk_debug_dice", "fk_debug_dice_state"]
+            "fk_tournament_run", "fk_tournament_run_stats", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
+            "fk_debug_dice", "fk_debug_dice_state", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy"]
 _lib = None
 
 
@@ -147,6 +154,7 @@ class Engine:
                      FK_ERR_HIP: "HIP runtime failure during fk_init"}
             raise FarkleHipError(rc, f"fk_init({device}) failed: {names.get(rc, rc)}")
         self.device = device
+        self.comm_world = 1
 
     # -- plumbing -------------------------------------------------------------------------
     def close(self) -> None:
@@ -189,8 +197,10 @@ class Engine:
     # -- hot path ------------------------------------------------------------------------
     def tournament(self, table: np.ndarray, k: int, root_seed: int, shuffle_begin: int, shuffle_end: int,
                    shuffles_per_batch: int | None = None, target_score: int = 10_000, max_rounds: int = 200,
-                   overrides: np.ndarray | None = None, want_rows: bool = False, want_perms: bool = False) -> dict:
-        """All games of shuffles ``[shuffle_begin, shuffle_end)``: per-batch tallies (+ rows / permutations)."""
+                   overrides: np.ndarray | None = None, want_rows: bool = False, want_perms: bool = False,
+                   want_seat_stats: bool = False) -> dict:
+        """All games of shuffles ``[shuffle_begin, shuffle_end)``: per-batch tallies (+ rows / permutations / the all-seat
+        integer statistics ``[n_batches][S][SEAT_STAT_COLS]``, columns ``SEAT_STAT_NAMES``)."""
         table = np.ascontiguousarray(table, dtype=STRATEGY_DTYPE)
         S = len(table)
         n_sh = int(shuffle_end) - int(shuffle_begin)
@@ -203,11 +213,13 @@ class Engine:
         perms = np.zeros((max(n_sh, 0), S), dtype=np.int32) if want_perms else None
         ov = overrides if overrides is not None else np.zeros(0, dtype=OVERRIDE_DTYPE)
         ov = np.ascontiguousarray(ov, dtype=OVERRIDE_DTYPE)
-        self._check(self._lib.fk_tournament_run(
+        stats = np.zeros((max(n_batches, 1), S, SEAT_STAT_COLS), dtype=np.int64) if want_seat_stats else None
+        self._check(self._lib.fk_tournament_run_stats(
             self._ctx, _p(table), C.c_int32(S), C.c_int32(k), C.c_uint64(root_seed), C.c_uint64(shuffle_begin),
             C.c_uint64(shuffle_end), C.c_uint32(spb), C.c_int32(target_score), C.c_int32(max_rounds), _p(ov),
-            C.c_int32(len(ov)), _p(tally), _p(rows), _p(perms)))
-        return {"tally": tally[:n_batches], "rows": rows, "perms": perms}
+            C.c_int32(len(ov)), _p(tally), _p(rows), _p(perms), _p(stats)))
+        return {"tally": tally[:n_batches], "rows": rows, "perms": perms,
+                "seat_stats": None if stats is None else stats[:n_batches]}
 
     def play_games(self, coords: np.ndarray, table: np.ndarray, seat_strategy, k: int, target_score: int = 10_000,
                    max_rounds: int = 200) -> np.ndarray:
@@ -259,6 +271,32 @@ class Engine:
         self._check(self._lib.fk_h2h_run_blocks(self._ctx, _p(blocks), C.c_int64(n), C.c_uint64(root_seed), C.c_uint64(chunk),
                                                 C.c_int32(target_score), C.c_int32(max_rounds), _p(ov), C.c_int32(len(ov))))
         return blocks["state"].copy()
+
+    # -- multi-GPU: the one exchange of the path, RCCL through the C-ABI ---------------------
+    def comm_unique_id(self) -> bytes:
+        """Rank 0: a fresh RCCL communicator id (128 bytes) to ship to every rank."""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = self._lib.fk_comm_unique_id(buf)
+        if rc != 0:
+            raise FarkleHipError(rc, "fk_comm_unique_id failed: librccl.so.1 could not be loaded or ncclGetUniqueId failed")
+        return buf.raw
+
+    def comm_init(self, comm_id: bytes, rank: int, world_size: int) -> None:
+        """Collective: every rank joins the communicator on its own GPU."""
+        if len(comm_id) != COMM_ID_BYTES:
+            raise ValueError("communicator id must be 128 bytes")
+        self._check(self._lib.fk_comm_init(self._ctx, C.create_string_buffer(comm_id, COMM_ID_BYTES), C.c_int32(rank), C.c_int32(world_size)))
+        self.comm_world = world_size
+
+    def reduce_tally(self, tally: np.ndarray, root: int = 0) -> np.ndarray:
+        """Collective: int64 SUM over the communicator; the total on ``root`` (the rank's own tally elsewhere)."""
+        t = np.ascontiguousarray(tally, dtype=np.int64).copy()
+        self._check(self._lib.fk_reduce_tally(self._ctx, _p(t), C.c_int64(t.size), C.c_int32(root)))
+        return t
+
+    def comm_destroy(self) -> None:
+        self._check(self._lib.fk_comm_destroy(self._ctx))
+        self.comm_world = 1
 
     def coordinate_seeds(self, coords: np.ndarray, want32: bool = True, want64: bool = False):
         """SeedSequence fingerprints of whole coordinates (``coordinate_seed``, utils/random.py:190-232)."""

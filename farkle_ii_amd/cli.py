@@ -80,6 +80,12 @@ def main(argv: Sequence[str] | None = None) -> None:
     if args.row_dir is not None:
         cfg.sim.row_dir = args.row_dir
     _maybe_init_distributed()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("FK_TALLY_REDUCE", "") == "rccl":
+        # the per-group tally reduction through the C-ABI's own RCCL communicator (fk_comm_init / fk_reduce_tally)
+        from .distributed import init_engine_comm
+        from .engine import get_engine
+
+        init_engine_comm(get_engine())
     rank = int(os.environ.get("RANK", "0"))
     if rank == 0:
         runner.write_active_config(cfg, cfg.results_root)

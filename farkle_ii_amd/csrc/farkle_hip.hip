@@ -6,6 +6,8 @@
 // No MFMA (integer/table work), no CPU fallback.
 #include "fk_kernels.h" // device side: every kernel of the engine (pulls in farkle_hip.h, fk_device.h, hip_runtime.h)
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -50,6 +52,9 @@ struct fk_ctx {
     int32_t use_lds_tally = -1;
     int32_t block = 0;
     int32_t perm_split = -1;   // -1 auto, 0 one-kernel Fisher-Yates, 1 draws kernel + swap kernel
+    void *comm = nullptr;      // RCCL communicator (fk_comm_init), one per context / GPU
+    int comm_rank = 0, comm_world = 1;
+    DevBuf comm_buf;
 };
 
 namespace {
@@ -415,18 +420,54 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
 
 // state store + result records of the chunk just played -> rows at `d_rows` (device), game-id order
 int rows_pass(fk_ctx *c, const SeedArgs &sa, bool scheduled, uint32_t n_games, uint32_t gps, uint32_t n_sh, bool perm_mode, uint8_t *d_rows) {
-    const uint32_t *inv = nullptr;
-    if (scheduled) {
-        int rc = ensure(c, c->inv, (size_t)n_games * 4);
-        if (rc) return rc;
-        hipLaunchKernelGGL(fk_invert_sched_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
-                           static_cast<const uint32_t *>(c->order.p), n_games, static_cast<uint32_t *>(c->inv.p));
-        inv = static_cast<const uint32_t *>(c->inv.p);
-    }
+    // `scheduled`: the caller has inverted the schedule into c->inv (fk_invert_sched_kernel)
+    const uint32_t *inv = scheduled ? static_cast<const uint32_t *>(c->inv.p) : nullptr;
     hipLaunchKernelGGL(fk_rows_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream, static_cast<const uint32_t *>(c->state.p),
                        static_cast<const uint32_t *>(c->recs.p), inv, n_games, gps, n_sh, sa.k, perm_mode ? 1u : 0u, d_rows);
     HIPCHK(c, hipGetLastError());
     return FK_OK;
+}
+
+// ---- RCCL, bound at run time ----
+// The tally reduction is the path's only exchange: one ncclReduce(sum, int64) over xGMI.  librccl is
+// dlopen'ed on first use, so the library loads (and every single-GPU entry point works) on hosts without RCCL.
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, fk_comm_id, int) = nullptr; // ncclUniqueId is a 128-byte struct passed by value
+    int (*Reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    if (r.lib || !r.why.empty()) return r;
+    for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) {
+        r.why = std::string("librccl.so.1 could not be loaded: ") + (dlerror() ? dlerror() : "not found");
+        return r;
+    }
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+    r.Reduce = reinterpret_cast<decltype(r.Reduce)>(dlsym(r.lib, "ncclReduce"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.Reduce || !r.CommDestroy) {
+        r.why = "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclReduce / ncclCommDestroy";
+        dlclose(r.lib);
+        r.lib = nullptr;
+    }
+    return r;
+}
+
+int rccl_fail(fk_ctx *c, const char *what, int code) {
+    Rccl &r = rccl();
+    return fail(c, FK_ERR_COMM, "%s failed: %s", what, r.GetErrorString ? r.GetErrorString(code) : "RCCL error");
 }
 
 } // namespace
@@ -478,6 +519,9 @@ void fk_destroy(fk_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    c->comm = nullptr;
+    release(c->comm_buf);
     for (DevBuf *b : {&c->strat, &c->perm, &c->draws, &c->state, &c->inc, &c->recs, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist,
                       &c->coords, &c->order, &c->inv, &c->slow, &c->score_lut, &c->discard_lut, &c->classes, &c->blocks, &c->game_block,
                       &c->block_out, &c->stats})
@@ -533,6 +577,14 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
 int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
                       uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
                       int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms) {
+    return fk_tournament_run_stats(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score,
+                                   max_rounds, ov, n_ov, tally, rows, perms, nullptr);
+}
+
+int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                            uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
+                            int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
+                            int64_t *seat_stats) {
     if (!c) return FK_ERR_ARG;
     if (!strategies || !tally) return fail(c, FK_ERR_ARG, "strategies and tally are required");
     if (k < 1 || S < k || S % k != 0) return fail(c, FK_ERR_ARG, "n_players must divide %d", S); // run_tournament.py:274
@@ -558,10 +610,17 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
     HIPCHK(c, hipMemsetAsync(c->tally.p, 0, tally_bytes, c->stream));
 
     const LaunchPlan plan = plan_play(c, k, S, n_batches == 1);
-    const bool want_recs = !plan.lds_tally || rows != nullptr;
+    const bool want_state = rows != nullptr || seat_stats != nullptr;
+    const bool want_recs = !plan.lds_tally || want_state;
+    const size_t stats_bytes = sizeof(int64_t) * (size_t)n_batches * (size_t)S * FK_SEAT_STAT_COLS;
+    if (seat_stats) {
+        rc = ensure(c, c->stats, stats_bytes);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(c->stats.p, 0, stats_bytes, c->stream));
+    }
 
     // chunk planning: whole shuffles per chunk inside the workspace budget
-    const size_t bytes_per_shuffle = (size_t)S * 2 + (size_t)gps * game_workspace_bytes(k, plan.gs || rows, want_recs, rows != nullptr);
+    const size_t bytes_per_shuffle = (size_t)S * 2 + (size_t)gps * game_workspace_bytes(k, plan.gs || want_state, want_recs, rows != nullptr);
     uint64_t chunk_sh = std::max<uint64_t>(1, (uint64_t)c->chunk_bytes / bytes_per_shuffle);
     chunk_sh = std::min<uint64_t>(chunk_sh, (uint64_t)0x7fffffff / gps);
     chunk_sh = std::min<uint64_t>(chunk_sh, n_sh_total);
@@ -676,8 +735,33 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
         pa.target = target_score;
         pa.max_rounds = (uint32_t)max_rounds;
 
-        rc = run_chunk(c, sa, pa, plan, rows != nullptr, want_recs, REC_DW, (int64_t)done * gps, "tournament");
+        rc = run_chunk(c, sa, pa, plan, want_state, want_recs, REC_DW, (int64_t)done * gps, "tournament");
         if (rc) return rc;
+        const bool scheduled = c->longest_first != 0;
+        if (want_state && scheduled) { // game id -> slot of its state records
+            rc = ensure(c, c->inv, (size_t)n_games * 4);
+            if (rc) return rc;
+            hipLaunchKernelGGL(fk_invert_sched_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
+                               static_cast<const uint32_t *>(c->order.p), n_games, static_cast<uint32_t *>(c->inv.p));
+        }
+        if (seat_stats) {
+            rc = ensure(c, c->draws, (size_t)perm_blocks * S * slots * 2); // the draws buffer is free again: inverse permutations
+            if (rc) return rc;
+            const uint32_t cells = perm_blocks * (uint32_t)S * slots;
+            hipLaunchKernelGGL(fk_invert_perm_kernel, dim3((cells + 255u) / 256u), dim3(256), 0, c->stream,
+                               static_cast<const uint16_t *>(c->perm.p), (uint32_t)S, slots, n_sh, static_cast<uint16_t *>(c->draws.p));
+            const uint32_t first_batch = (uint32_t)(done / shuffles_per_batch);
+            const uint32_t nb = (uint32_t)((done + n_sh - 1) / shuffles_per_batch) - first_batch + 1u;
+            const uint32_t s_blocks = ((uint32_t)S + 255u) / 256u;
+            // enough (strategy block, batch, part) workgroups to fill the chip; a part is at least 8 shuffles
+            const uint32_t ppb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(shuffles_per_batch, n_sh) / 8, (4096u + nb * s_blocks - 1u) / (nb * s_blocks)));
+            hipLaunchKernelGGL(fk_seat_stats_kernel, dim3(s_blocks, nb * ppb), dim3(256), 0, c->stream,
+                               static_cast<const uint32_t *>(c->state.p), static_cast<const uint32_t *>(c->recs.p),
+                               scheduled ? static_cast<const uint32_t *>(c->inv.p) : nullptr, static_cast<const uint16_t *>(c->draws.p),
+                               slots, (uint32_t)S, (uint32_t)k, gps, n_sh, (uint32_t)done, shuffles_per_batch, ppb, first_batch,
+                               static_cast<long long *>(c->stats.p));
+            HIPCHK(c, hipGetLastError());
+        }
         if (!plan.lds_tally) { // result records -> per-batch tallies
             const uint64_t games_per_batch = (uint64_t)shuffles_per_batch * gps;
             unsigned long long *d_tally = static_cast<unsigned long long *>(c->tally.p);
@@ -707,7 +791,7 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
             HIPCHK(c, hipGetLastError());
         }
         if (rows) {
-            rc = rows_pass(c, sa, c->longest_first != 0, n_games, gps, n_sh, true, static_cast<uint8_t *>(c->rows.p));
+            rc = rows_pass(c, sa, scheduled, n_games, gps, n_sh, true, static_cast<uint8_t *>(c->rows.p));
             if (rc) return rc;
             HIPCHK(c, hipMemcpyAsync(static_cast<uint8_t *>(rows) + (size_t)done * gps * row_bytes, c->rows.p,
                                      (size_t)n_games * row_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -720,6 +804,7 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(t1, c->stream));
     HIPCHK(c, hipMemcpyAsync(tally, c->tally.p, tally_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (seat_stats) HIPCHK(c, hipMemcpyAsync(seat_stats, c->stats.p, stats_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipEventElapsedTime(&c->timing.total_ms, t0, t1));
     return FK_OK;
@@ -954,6 +1039,64 @@ int fk_h2h_run(fk_ctx *c, const fk_strategy seats[2], uint64_t root_seed, uint64
     const int rc = fk_h2h_run_blocks(c, &blk, 1, root_seed, chunk_games, target_score, max_rounds, ov, n_ov);
     if (rc == FK_OK) memcpy(state, blk.state, sizeof(blk.state));
     return rc;
+}
+
+// ---- multi-GPU: one RCCL sum of the tally (the analogue of OutcomeCounter.absorb, run_tournament.py:197-213) ----
+int fk_comm_unique_id(fk_comm_id *out) {
+    if (!out) return FK_ERR_ARG;
+    Rccl &r = rccl();
+    if (!r.lib) return FK_ERR_COMM;
+    return r.GetUniqueId(out) == 0 ? FK_OK : FK_ERR_COMM;
+}
+
+int fk_comm_init(fk_ctx *c, const fk_comm_id *id, int32_t rank, int32_t world_size) {
+    if (!c) return FK_ERR_ARG;
+    if (!id || world_size < 1 || rank < 0 || rank >= world_size) return fail(c, FK_ERR_ARG, "bad communicator id / rank / world size");
+    Rccl &r = rccl();
+    if (!r.lib) return fail(c, FK_ERR_COMM, "%s", r.why.c_str());
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm) {
+        (void)r.CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    const int rc = r.CommInitRank(&c->comm, world_size, *id, rank);
+    if (rc != 0) {
+        c->comm = nullptr;
+        return rccl_fail(c, "ncclCommInitRank", rc);
+    }
+    c->comm_rank = rank;
+    c->comm_world = world_size;
+    return FK_OK;
+}
+
+int fk_reduce_tally(fk_ctx *c, int64_t *tally, int64_t n, int32_t root_rank) {
+    if (!c) return FK_ERR_ARG;
+    if (!tally || n < 0) return fail(c, FK_ERR_ARG, "tally is required");
+    if (!c->comm) return fail(c, FK_ERR_COMM, "no communicator: call fk_comm_init first");
+    if (root_rank < 0 || root_rank >= c->comm_world) return fail(c, FK_ERR_ARG, "root rank outside the communicator");
+    if (n == 0) return FK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * sizeof(int64_t);
+    int rc = ensure(c, c->comm_buf, bytes);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->comm_buf.p, tally, bytes, hipMemcpyHostToDevice, c->stream));
+    const int nrc = rccl().Reduce(c->comm_buf.p, c->comm_buf.p, (size_t)n, 4 /* ncclInt64 */, 0 /* ncclSum */, root_rank, c->comm, c->stream);
+    if (nrc != 0) return rccl_fail(c, "ncclReduce", nrc);
+    if (c->comm_rank == root_rank) HIPCHK(c, hipMemcpyAsync(tally, c->comm_buf.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FK_OK;
+}
+
+int fk_comm_destroy(fk_ctx *c) {
+    if (!c) return FK_ERR_ARG;
+    if (c->comm) {
+        HIPCHK(c, hipSetDevice(c->device));
+        (void)rccl().CommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->comm_world = 1;
+    c->comm_rank = 0;
+    return FK_OK;
 }
 
 // ---- probes ----

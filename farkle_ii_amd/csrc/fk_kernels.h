@@ -1119,6 +1119,87 @@ __global__ void fk_rows_kernel(const uint32_t *state, const uint32_t *recs, cons
     }
 }
 
+// Integer sufficient statistics of ALL seats per (batch, strategy) — what the reference's unconditional all-player
+// metrics are sums of (analysis/all_player_metrics.py:257-340): exposures, completed / safety / wins, sums and square
+// sums of final score, n_turns, turns - rounds, rank, loss margin and the eight behaviour counters.  Exact in int64; the
+// two ratio statistics of that module (score / n_turns, score / n_rounds) are float64 sums in row order and stay on the host.
+// A strategy is seated exactly once per shuffle, so the kernel GATHERS: thread = (strategy, part of a batch's shuffles);
+// for every shuffle it finds the strategy's seat through the inverse permutation, reads that game's result record and state
+// records, and accumulates in registers — no atomics per exposure, nothing read twice.
+//   columns: 0 exposures 1 completed 2 safety 3 wins 4 score 5 score^2 6 turns 7 turns^2 8 [turns != rounds]
+//            9 (turns - rounds) 10 (turns - rounds)^2, then (sum, sum of squares) of rank, loss_margin [completed games
+//            only], rolls, farkles, highest_turn, hot_dice, smart_five_uses, n_smart_five_dice, smart_one_uses, n_smart_one_dice
+__global__ void fk_invert_perm_kernel(const uint16_t *perm_T, uint32_t S, uint32_t slots, uint32_t n_sh, uint16_t *inv_T) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; // walks the blocked layout: coalesced reads
+    const uint32_t per_block = S * slots, blocks = (n_sh + slots - 1u) / slots;
+    if (t >= per_block * blocks) return;
+    const uint32_t b = t / per_block, r = t - b * per_block, e = r / slots, l = r - e * slots;
+    if (b * slots + l >= n_sh) return;
+    inv_T[((size_t)b * S + perm_T[t]) * slots + l] = (uint16_t)e;
+}
+
+__global__ __launch_bounds__(256) void fk_seat_stats_kernel(const uint32_t *state, const uint32_t *recs, const uint32_t *inv_sched,
+                                                            const uint16_t *inv_T, uint32_t perm_slots, uint32_t S, uint32_t k,
+                                                            uint32_t gps, uint32_t n_sh, uint32_t sh_offset, uint32_t spb,
+                                                            uint32_t parts_per_batch, uint32_t first_batch, long long *stats) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b_local = blockIdx.y / parts_per_batch, part = blockIdx.y - b_local * parts_per_batch;
+    const uint32_t batch = first_batch + b_local;
+    const uint64_t g_lo = (uint64_t)batch * spb, g_hi = g_lo + spb;
+    const uint32_t sh_lo = g_lo > sh_offset ? (uint32_t)(g_lo - sh_offset) : 0u;
+    const uint32_t sh_hi = (uint32_t)min<uint64_t>(n_sh, g_hi > sh_offset ? g_hi - sh_offset : 0u);
+    if (s >= S || sh_hi <= sh_lo) return;
+    const uint32_t per_part = (sh_hi - sh_lo + parts_per_batch - 1u) / parts_per_batch;
+    const uint32_t first = sh_lo + part * per_part, last = min(first + per_part, sh_hi);
+    long long acc[FK_SEAT_STAT_COLS];
+#pragma unroll
+    for (int c = 0; c < FK_SEAT_STAT_COLS; ++c) acc[c] = 0;
+    for (uint32_t sh = first; sh < last; ++sh) {
+        const uint32_t p = perm_at(inv_T, S, perm_slots, sh, s), g = p / k, seat = p - g * k;
+        const uint32_t id = sh * gps + g;
+        const uint32_t slot = inv_sched ? inv_sched[id] : walk_slot(id, gps, n_sh, true);
+        const uint4 *r = reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
+        const uint4 q0 = r[0];
+        const bool completed = !(q0.x & REC_SAFETY);
+        const uint32_t *gs = state + (size_t)slot * k * STATE_DW, *x = gs + (size_t)seat * STATE_DW;
+        const long long score = (int32_t)x[R_SCORE], rounds = q0.z & 0xffffu;
+        const uint32_t xa = x[R_CA], xb = x[R_CB], xc = x[R_CC], xd = x[R_CD], xe = x[R_CE];
+        const long long turns = xb >> 16, tmr = turns - rounds;
+        acc[0] += 1;
+        acc[completed ? 1 : 2] += 1;
+        acc[4] += score;
+        acc[5] += score * score;
+        acc[6] += turns;
+        acc[7] += turns * turns;
+        acc[8] += tmr != 0 ? 1 : 0;
+        acc[9] += tmr;
+        acc[10] += tmr * tmr;
+        if (completed) {
+            long long rank = 1;
+            for (uint32_t j = 0; j < k; ++j) {
+                const long long o = (int32_t)gs[(size_t)j * STATE_DW + R_SCORE];
+                rank += (o > score || (o == score && j < seat)) ? 1 : 0;
+            }
+            const long long margin = (long long)q0.y - score; // winning score - own score
+            acc[3] += (((q0.x >> 24) & 0x7fu) == seat) ? 1 : 0;
+            acc[11] += rank;
+            acc[12] += rank * rank;
+            acc[13] += margin;
+            acc[14] += margin * margin;
+        }
+        const long long v[8] = {xa & 0xffffu, xa >> 16, xb & 0xffffu, xe & 0xffffu, xc & 0xffffu, xc >> 16, xd & 0xffffu, xd >> 16};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[15 + 2 * j] += v[j];
+            acc[16 + 2 * j] += v[j] * v[j];
+        }
+    }
+    long long *out = stats + ((size_t)batch * S + s) * FK_SEAT_STAT_COLS;
+#pragma unroll
+    for (int c = 0; c < FK_SEAT_STAT_COLS; ++c)
+        if (acc[c]) atomicAdd(reinterpret_cast<unsigned long long *>(&out[c]), (unsigned long long)acc[c]);
+}
+
 // ticket -> game id schedule inverted (rows are produced in game-id order)
 __global__ void fk_invert_sched_kernel(const uint32_t *sched, uint32_t n_games, uint32_t *inv) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

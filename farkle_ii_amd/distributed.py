@@ -38,8 +38,92 @@ def collective_device(device=None):
     return torch.device("cpu")
 
 
+_ENGINE_COMM = None  # the engine whose RCCL communicator (fk_comm_init) carries the tally reduction
+
+
+def tcp_broadcast(payload: bytes | None, rank: int, world: int, addr: str, port: int, timeout: float = 300.0) -> bytes:
+    """Rank 0's bytes to every rank over plain TCP (stdlib only): the rendezvous of the RCCL communicator id when no
+    torch.distributed process group exists."""
+    import socket
+    import struct
+    import time
+
+    if world == 1:
+        return payload or b""
+    if rank == 0:
+        assert payload is not None
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _ = srv.accept()
+                with conn:
+                    conn.sendall(struct.pack("<I", len(payload)) + payload)
+        return payload
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as conn:
+                head = b""
+                while len(head) < 4:
+                    head += conn.recv(4 - len(head))
+                n, = struct.unpack("<I", head)
+                data = b""
+                while len(data) < n:
+                    chunk = conn.recv(n - len(data))
+                    if not chunk:
+                        raise ConnectionError("rendezvous closed early")
+                    data += chunk
+                return data
+        except (ConnectionError, OSError):
+            if time.monotonic() > deadline:
+                raise
+            time.sleep(0.05)
+
+
+def init_engine_comm(engine, rank: int | None = None, world: int | None = None) -> bool:
+    """Give ``engine`` an RCCL communicator over all ranks (``fk_comm_init``) so that :func:`reduce_tally` runs as one
+    ``ncclReduce`` on the engine's stream, through the C-ABI, with no PyTorch in the data path.  The 128-byte
+    communicator id travels over the torch.distributed process group when one exists (launched by torchrun), otherwise
+    over a stdlib TCP rendezvous on ``MASTER_ADDR``:``FK_COMM_PORT`` (default ``MASTER_PORT`` + 17).  Collective: every
+    rank calls it.  Returns False (and leaves the torch path in place) when the engine has no communicator support."""
+    import os
+
+    global _ENGINE_COMM
+    if not hasattr(engine, "comm_init"):
+        return False
+    try:
+        import torch.distributed as dist
+
+        group = dist.is_available() and dist.is_initialized()
+    except ImportError:
+        group = False
+    if group:
+        rank, world = dist.get_rank(), dist.get_world_size()
+    else:
+        rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    if world == 1:
+        return False
+    comm_id = engine.comm_unique_id() if rank == 0 else None
+    if group:
+        comm_id = gather_objects(comm_id, broadcast_from=0)
+    else:
+        port = int(os.environ.get("FK_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 17))
+        comm_id = tcp_broadcast(comm_id, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port)
+    engine.comm_init(comm_id, rank, world)
+    _ENGINE_COMM = engine
+    return True
+
+
 def reduce_tally(tally: np.ndarray, dst: int = 0, device=None) -> np.ndarray:
-    """SUM-reduce an int64 tally over the default process group; returns the total on ``dst`` (own tally elsewhere)."""
+    """SUM-reduce an int64 tally over all ranks; returns the total on ``dst`` (own tally elsewhere).  With an engine
+    communicator (:func:`init_engine_comm`) this is ``fk_reduce_tally`` — RCCL through the C-ABI; otherwise the default
+    torch.distributed process group (``nccl`` = RCCL on GPU tensors, ``gloo`` on the CPU in tests)."""
+    if _ENGINE_COMM is not None and getattr(_ENGINE_COMM, "comm_world", 1) > 1:
+        return _ENGINE_COMM.reduce_tally(tally, dst)
     import torch
     import torch.distributed as dist
 

@@ -39,7 +39,8 @@ enum {
     FK_ERR_ARG = -2,              /* invalid argument */
     FK_ERR_COUNTER_OVERFLOW = -3, /* a per-seat u16 counter left its guarded range */
     FK_ERR_HIP = -4,              /* HIP runtime failure */
-    FK_ERR_NO_DEVICE = -5
+    FK_ERR_NO_DEVICE = -5,
+    FK_ERR_COMM = -6              /* RCCL not loadable / communicator failure */
 };
 
 enum { FK_COMPLETED = 0, FK_SAFETY_LIMIT = 1 };
@@ -86,6 +87,7 @@ typedef struct {
     uint64_t root_seed, k, shuffle_index, pair_id, order, game_index, seat_index, replicate_index;
 } fk_coord;
 
+#define FK_SEAT_STAT_COLS 31 /* all-seat integer statistics per strategy, see fk_tournament_run_stats */
 #define FK_TALLY_COLS 26 /* wins, attempted, completed, safety, 11 metric sums, 11 square sums (run_tournament.py:109-121) */
 
 typedef struct {
@@ -136,6 +138,22 @@ int fk_tournament_run(fk_ctx *ctx, const fk_strategy *strategies, int32_t S, int
                       int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov,
                       int64_t *tally, void *rows, int32_t *perms);
 
+/* fk_tournament_run plus the integer sufficient statistics of ALL seats (not winners only), per batch and strategy:
+ *   seat_stats  nullable; int64 [n_batches][S][FK_SEAT_STAT_COLS]; overwritten.  Columns:
+ *     0 exposures, 1 completed exposures, 2 safety-limit exposures (= max-round aborts), 3 wins,
+ *     4/5 sum / sum of squares of the final score, 6/7 of n_turns, 8 exposures with n_turns != n_rounds,
+ *     9/10 sum / sum of squares of (n_turns - n_rounds), then (sum, sum of squares) pairs of: rank, loss_margin (both over
+ *     completed exposures only), rolls, farkles, highest_turn, hot_dice, smart_five_uses, n_smart_five_dice,
+ *     smart_one_uses, n_smart_one_dice.
+ * These are the integer accumulators of the reference's unconditional all-player batch metrics
+ * (src/farkle/analysis/all_player_metrics.py:257-340), produced on the device from the state store without
+ * materialising rows; its two ratio statistics (score / n_turns, score / n_rounds) are float64 sums in row order and are
+ * not produced here. */
+int fk_tournament_run_stats(fk_ctx *ctx, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                            uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch,
+                            int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov,
+                            int64_t *tally, void *rows, int32_t *perms, int64_t *seat_stats);
+
 /* Explicit game list: game g seats strategies table[seat_strategy[g*k+i]] with streams coords[g](seat i).
  * rows: n_games * (4+28k) bytes (required). */
 int fk_play_games(fk_ctx *ctx, const fk_coord *coords, int64_t n_games, const fk_strategy *table, int32_t S,
@@ -164,6 +182,22 @@ typedef struct {
  * schedule is tens of thousands of blocks of ~2 000 games: execute_h2h_schedule's block loop, h2h_schedule.py:2038-2093). */
 int fk_h2h_run_blocks(fk_ctx *ctx, fk_h2h_block *blocks, int64_t n_blocks, uint64_t root_seed, uint64_t chunk_games,
                       int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov);
+
+/* ---- multi-GPU: one process per GPU, one context per process, ONE exchange ----
+ * The (seed x shuffle x game) space partitions with no data dependency; the only collective of the path is the integer
+ * SUM of the per-strategy tally to one rank — the analogue of OutcomeCounter.absorb + _reduce_metric_chunk_payloads
+ * (src/farkle/simulation/run_tournament.py:197-213, 1023-1042).  It runs as ncclReduce(sum, int64) on the context's
+ * stream over RCCL/xGMI; librccl is loaded on first use.
+ *   rank 0:     fk_comm_unique_id(&id); ship the 128 bytes to every rank (any channel: env, file, socket)
+ *   every rank: fk_comm_init(ctx, &id, rank, world)           (collective: all ranks call it)
+ *               fk_reduce_tally(ctx, tally, n, root)          (collective; `tally` is overwritten with the sum on root) */
+typedef struct {
+    char bytes[128];
+} fk_comm_id;
+int fk_comm_unique_id(fk_comm_id *out);
+int fk_comm_init(fk_ctx *ctx, const fk_comm_id *id, int32_t rank, int32_t world_size);
+int fk_reduce_tally(fk_ctx *ctx, int64_t *tally, int64_t n, int32_t root_rank);
+int fk_comm_destroy(fk_ctx *ctx);
 
 /* SeedSequence fingerprints of n coordinates (all nine coordinate words of the record, seat_index included):
  * seed32[i] = generate_state(1, uint32)[0], seed64[i] = generate_state(1, uint64)[0]; either may be NULL.

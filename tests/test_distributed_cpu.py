@@ -96,3 +96,36 @@ def test_two_rank_h2h_prefix_cut_matches_serial_block(tmp_path):
     got = np.load(out)
     assert np.array_equal(got, np.stack(want)), (got, want)
     assert (np.stack(want)[:, 2] > 0).any()  # the cases include safety-limit games (attempted != completed)
+
+
+def test_tcp_rendezvous_ships_the_communicator_id_to_every_rank():
+    """The stdlib rendezvous of the 128-byte RCCL communicator id (no torch.distributed group): rank 0 serves, the other
+    ranks connect (also when they arrive first)."""
+    import threading
+    import time
+
+    from farkle_ii_amd.distributed import tcp_broadcast
+
+    port = 36500 + os.getpid() % 2000
+    payload = bytes(range(128))
+    got: dict[int, bytes] = {}
+
+    def run(rank: int, delay: float) -> None:
+        time.sleep(delay)
+        got[rank] = tcp_broadcast(payload if rank == 0 else None, rank, 4, "127.0.0.1", port, timeout=30)
+
+    threads = [threading.Thread(target=run, args=(r, 0.3 if r == 0 else 0.0)) for r in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert got == {r: payload for r in range(4)}
+
+
+def test_engine_comm_is_skipped_for_engines_without_it_and_single_rank():
+    from farkle_ii_amd.distributed import init_engine_comm
+
+    class NoComm:
+        pass
+
+    assert init_engine_comm(NoComm()) is False

@@ -177,3 +177,84 @@ def test_h2h_production_shape_throughput_sanity(eng):
     assert (st[:, 0] == st[:, 1] + st[:, 2]).all() and (st[:, 1] == st[:, 3] + st[:, 4]).all()
     done = st[:, 1] == 2191
     assert done.mean() > 0.9 and ((st[:, 0] == 4382) | done).all()
+
+
+def _seat_stats_from_rows(rows: np.ndarray, k: int, S: int, gps: int, spb: int) -> np.ndarray:
+    """The same integer accumulators computed from the oracle's rows the way the reference's all_player_metrics.py does
+    (one exposure per seat; rank / loss_margin over completed games only)."""
+    from farkle_ii_amd.backend import SEAT_STAT_COLS
+
+    n = len(rows)
+    batch = (np.arange(n) // gps) // spb
+    out = np.zeros((int(batch.max()) + 1, S, SEAT_STAT_COLS), dtype=np.int64)
+    completed = rows["status"] == 0
+    scores = rows["seats"]["score"].astype(np.int64)
+    winning = scores.max(axis=1)
+    rounds = rows["n_rounds"].astype(np.int64)
+    for seat in range(k):
+        x = rows["seats"][:, seat]
+        strat = x["strategy"].astype(np.int64)
+        score, turns = x["score"].astype(np.int64), x["n_turns"].astype(np.int64)
+        tmr = turns - rounds
+        cols = {0: np.ones(n, dtype=np.int64), 1: completed.astype(np.int64), 2: (~completed).astype(np.int64),
+                3: (completed & (rows["winner_seat"] == seat)).astype(np.int64), 4: score, 5: score * score, 6: turns, 7: turns * turns,
+                8: (tmr != 0).astype(np.int64), 9: tmr, 10: tmr * tmr}
+        rank = x["rank"].astype(np.int64)
+        margin = np.where(completed, winning - score, 0)
+        cols[11], cols[12] = np.where(completed, rank, 0), np.where(completed, rank * rank, 0)
+        cols[13], cols[14] = margin, margin * margin
+        for j, name in enumerate(("rolls", "farkles", "highest_turn", "hot_dice", "smart_five_uses", "n_smart_five_dice",
+                                  "smart_one_uses", "n_smart_one_dice")):
+            v = x[name].astype(np.int64)
+            cols[15 + 2 * j], cols[16 + 2 * j] = v, v * v
+        for c, v in cols.items():
+            np.add.at(out[:, :, c], (batch, strat), v)
+    return out
+
+
+@pytest.mark.parametrize("k,table_kind", [(2, "g64"), (4, "g64"), (4, "default"), (3, "random")])
+def test_all_seat_integer_statistics_match_the_rows(eng, po, k, table_kind):
+    """fk_tournament_run_stats: per-(batch, strategy) integer sufficient statistics of all seats, gathered on the device
+    from the state store, against the same sums taken over the oracle's rows (incl. safety-limit games and chunking)."""
+    table = {"g64": lambda: _strats(gu.load("grid_vectors.json")["g64"]), "default": _default_table,
+             "random": lambda: _random_valid_table(96, 5)}[table_kind]()
+    S = len(table)
+    gps = S // k
+    n_sh, spb = (6, 4) if table_kind == "default" else (60, 16)
+    ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 3, 5, 5 + n_sh, shuffles_per_batch=spb, want_rows=True, max_rounds=40, n_threads=16)
+    # the oracle numbers batches from the first shuffle of the call; shuffle 5 is local shuffle 0
+    want = _seat_stats_from_rows(ref["rows"], k, S, gps, spb)
+    for chunk in (48 << 30, 2 << 20):
+        try:
+            eng.set_option("chunk_bytes", chunk)
+            got = eng.tournament(table, k, 3, 5, 5 + n_sh, shuffles_per_batch=spb, max_rounds=40, want_seat_stats=True, want_rows=True)
+        finally:
+            eng.set_option("chunk_bytes", 48 << 30)
+        assert np.array_equal(got["tally"], ref["tally"])
+        assert got["rows"].tobytes() == ref["rows"].tobytes()
+        assert got["seat_stats"].shape == want.shape
+        assert np.array_equal(got["seat_stats"], want), (k, table_kind, chunk, np.argwhere(got["seat_stats"] != want)[:5])
+    assert want[:, :, 2].sum() > 0 or (k, table_kind) != (2, "g64")  # the 64-grid's never-banking pairings hit the 40-round limit
+    only = eng.tournament(table, k, 3, 5, 5 + n_sh, shuffles_per_batch=spb, max_rounds=40, want_seat_stats=True)
+    assert np.array_equal(only["seat_stats"], want)
+
+
+def test_rccl_tally_reduce_through_the_c_abi_single_rank(eng):
+    """fk_comm_unique_id / fk_comm_init / fk_reduce_tally / fk_comm_destroy on a one-rank communicator (the box has one
+    GPU): librccl is loaded at run time, ncclReduce(sum, int64) runs on the engine's stream, and the tally comes back
+    unchanged; the engine keeps working afterwards.  Multi-rank use is the same calls with world > 1."""
+    from farkle_ii_amd.backend import FarkleHipError
+
+    rng = np.random.default_rng(0)
+    tally = rng.integers(0, 2**40, (3, 64, 26), dtype=np.int64)
+    with pytest.raises(FarkleHipError, match="no communicator"):
+        eng.reduce_tally(tally)
+    eng.comm_init(eng.comm_unique_id(), 0, 1)
+    try:
+        assert np.array_equal(eng.reduce_tally(tally, 0), tally)
+        big = rng.integers(0, 2**50, (5160, 26), dtype=np.int64)
+        assert np.array_equal(eng.reduce_tally(big, 0), big)
+    finally:
+        eng.comm_destroy()
+    table = _strats(gu.load("grid_vectors.json")["g64"])
+    assert eng.tournament(table, 2, 42, 0, 4)["tally"].sum() > 0
