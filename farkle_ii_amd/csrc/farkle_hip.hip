@@ -444,8 +444,23 @@ struct Rccl {
 Rccl &rccl() {
     static Rccl r;
     if (r.lib || !r.why.empty()) return r;
-    for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
-        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    // The RCCL that belongs to the HIP runtime this process actually runs on: the one next to the loaded libamdhip64
+    // (a process that imported PyTorch first runs on the runtime bundled with it, and so must the communicator), then
+    // the system one.
+    std::vector<std::string> names;
+    Dl_info info{};
+    if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash);
+            names.push_back(dir + "/librccl.so.1");
+            names.push_back(dir + "/librccl.so");
+        }
+    }
+    for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) names.emplace_back(name);
+    for (const auto &name : names) {
+        r.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (r.lib) break;
     }
     if (!r.lib) {
