@@ -41,6 +41,7 @@ from .workload_planner import TournamentWorkloadPlan, WorkloadCapExceeded, plan_
 
 LOGGER = logging.getLogger(__name__)
 MAX_GAMES_PER_LAUNCH = 200_000_000  # checkpoint cadence on the GPU: a launch group is at most this many games
+ROW_WRITER_THREADS = max(1, min(16, (os.cpu_count() or 1)))  # row-shard writers (rows mode)
 
 
 def _rank_world() -> tuple[int, int]:
@@ -318,11 +319,23 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             local[first:first + len(res["tally"])] = res["tally"]
             if want_rows:  # every rank writes the shards of its own shuffles; rank 0 appends the manifest lines
                 tasks = rt.shuffle_tasks(cfg.sim.seed, k, lo, hi, spb)
-                for n, task in enumerate(tasks):
-                    _, record = rt.write_row_shard(row_dir, None, task, res["rows"][n * gps:(n + 1) * gps], ids,
-                                                   game_profile_sha256=oracle_game_profile.sha256 if oracle_game_profile else None,
-                                                   append_manifest=False, return_record=True)
-                    row_records.append(record)
+                sha = oracle_game_profile.sha256 if oracle_game_profile else None
+
+                def write(item):
+                    n, task = item
+                    return rt.write_row_shard(row_dir, None, task, res["rows"][n * gps:(n + 1) * gps], ids, game_profile_sha256=sha,
+                                              append_manifest=False, return_record=True)[1]
+
+                # one parquet file per shuffle is the reference's format: the host side of rows mode is file creation and
+                # Arrow encoding, which pyarrow does outside the GIL — a small thread pool keeps several shards in flight
+                workers = max(1, min(ROW_WRITER_THREADS, len(tasks)))
+                if workers > 1:
+                    from concurrent.futures import ThreadPoolExecutor
+
+                    with ThreadPoolExecutor(max_workers=workers) as pool:
+                        row_records.extend(pool.map(write, enumerate(tasks), chunksize=16))
+                else:
+                    row_records.extend(write(item) for item in enumerate(tasks))
         group = reduce_tally(local, dst=0)
         if want_rows and world > 1:
             gathered = gather_objects(row_records, dst=0)
