@@ -37,7 +37,7 @@ struct fk_ctx {
         hipEvent_t a, b;
     };
     std::vector<PendingTimer> pending; // kernel timers recorded on the stream, read after the chunk's one sync
-    DevBuf strat, perm, draws, state, inc, recs, tally, rows, misc, ov, seatlist, coords, order, inv, slow, score_lut, discard_lut,
+    DevBuf strat, perm, draws, state, inc, recs, rec0, tally, rows, misc, ov, seatlist, coords, order, inv, slow, score_lut, discard_lut,
         classes, blocks, game_block, block_out, stats, dbg[6];
     std::vector<uint2> strat_host;   // the packed table currently resident in `strat` (uploaded once per table)
     int32_t longest_first = 1;
@@ -51,7 +51,7 @@ struct fk_ctx {
     int32_t batch_threshold = 8;
     int32_t use_lds_tally = -1;
     int32_t block = 0;
-    int32_t perm_split = -1;   // -1 auto, 0 one-kernel Fisher-Yates, 1 draws kernel + swap kernel
+    int32_t perm_split = -1;   // -1 auto, 0 one-kernel Fisher-Yates, 1 draws + serial swap chains, 2 draws + chain-free kernel
     void *comm = nullptr;      // RCCL communicator (fk_comm_init), one per context / GPU
     int comm_rank = 0, comm_world = 1;
     DevBuf comm_buf;
@@ -173,8 +173,8 @@ struct LaunchPlan {
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
-size_t play_lds_bytes(int32_t k, int block, bool lean, bool gs, bool lds_tally, int32_t S) {
-    const size_t per_lane = (size_t)(lean ? NF - 6 : NF) * 4 * (size_t)(gs ? 1 : k);
+size_t play_lds_bytes(int32_t k, int block, bool lean, bool gs, bool lds_tally, int32_t S, bool blocks_mode = false) {
+    const size_t per_lane = (size_t)(lean ? NF - 6 : NF) * 4 * (size_t)(gs ? 1 : k) + (blocks_mode ? 4 : 0);
     return per_lane * (size_t)block + (lds_tally ? (size_t)S * LT_COLS * 8 : 0);
 }
 
@@ -182,9 +182,9 @@ size_t play_lds_bytes(int32_t k, int block, bool lean, bool gs, bool lds_tally, 
 // Instances are compiled for 4 waves/SIMD (<= 128 VGPRs); the 768-thread LEAN instances for 6 (80 VGPRs): their 12 waves
 // split evenly over the 4 SIMDs, so two blocks (24 waves) co-reside.  State-store (GS) instances are chosen for k >= 3:
 // their LDS use does not grow with k.
-LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch) {
+LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, bool blocks_mode = false) {
     LaunchPlan best;
-    const bool want_tally = single_batch && (c->use_lds_tally != 0) && S <= 4096;
+    const bool want_tally = single_batch && !blocks_mode && (c->use_lds_tally != 0) && S <= 4096;
     int best_lanes = -1;
     // state-store instances only on request: measured 2x slower than LDS records at k = 4 / 8 (the per-turn record
     // exchange is bound by L2 / Infinity-Cache request throughput); they remain the path for tables too wide for LDS
@@ -194,14 +194,14 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch) {
         for (int lean = 0; lean <= 1; ++lean) {
             if (gs && !lean) continue;
             if (!gs && c->lean >= 0 && lean != c->lean) continue;
-            if (!gs && lean && S > (1 << (32 - CE_IDX_SHIFT))) continue; // strategy index must fit cE[31:18]
+            if (!gs && lean && !blocks_mode && S > (1 << (32 - CE_IDX_SHIFT))) continue; // strategy index must fit cE[31:18]
             for (int block : {1024, 768, 512, 256, 128, 64}) {
                 if (gs && block != 768 && block != 256 && block != 64) continue;
                 if (c->block != 0 && block != c->block && !(gs && block == (c->block >= 768 ? 768 : c->block >= 256 ? 256 : 64))) continue;
                 if (block == 768 && !lean) continue;
                 const int wpe = (block == 768) ? 6 : 4;
                 bool tally = want_tally && play_lds_bytes(k, block, lean != 0, gs != 0, true, (int32_t)S) <= LDS_LIMIT / (gs ? 2 : 1);
-                size_t lds = play_lds_bytes(k, block, lean != 0, gs != 0, tally, (int32_t)S);
+                size_t lds = play_lds_bytes(k, block, lean != 0, gs != 0, tally, (int32_t)S, blocks_mode);
                 if (lds > LDS_LIMIT) continue;
                 int per_cu = (int)(LDS_LIMIT / std::max<size_t>(lds, 1));
                 per_cu = std::min(per_cu, std::max(1, wpe * 4 * 64 / block));
@@ -333,15 +333,15 @@ int upload_overrides(fk_ctx *c, std::vector<DevOverride> &dov) {
 
 // bytes of device workspace one game needs in a chunk (state records, increments, schedule, result record, row)
 size_t game_workspace_bytes(int32_t k, bool full_state, bool recs, bool rows) {
-    return (size_t)k * ((full_state ? STATE_DW * 4 : 16) + 16) + 8 + (recs ? REC_DW * 4 : 0) +
+    return (size_t)k * ((full_state ? STATE_DW * 4 : 16) + 16) + 8 + (recs ? REC_DW * 4 + 4 : 0) +
            (rows ? sizeof(fk_row_hdr) + sizeof(fk_seat) * (size_t)k : 0);
 }
 
 // Seeds + games of one chunk of `n_games` games: fills the state / increment planes, plays, checks the error record.
 // `want_state`: the final state records of every seat must be in the state store afterwards (rows, all-seat statistics).
-// `want_recs`: one result record per game (rec_dw dwords).  Post-passes are the caller's.
-int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &plan, bool want_state, bool want_recs,
-              uint32_t rec_dw, int64_t game_base, const char *what) {
+// `want_rec0` / `want_recs`: the rec0 word / the full result record of every game.  Post-passes are the caller's.
+int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &plan, bool want_state, bool want_rec0, bool want_recs,
+              int64_t game_base, const char *what) {
     SeedArgs sa = sa_in;
     const bool full_state = plan.gs || want_state;
     sa.state_dw = full_state ? STATE_DW : 4u;
@@ -375,8 +375,12 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
         sa.sched = nullptr;
         pa.sched = nullptr;
     }
+    if (want_rec0) {
+        rc = ensure(c, c->rec0, (size_t)sa.n_games * 4);
+        if (rc) return rc;
+    }
     if (want_recs) {
-        rc = ensure(c, c->recs, (size_t)sa.n_games * rec_dw * 4);
+        rc = ensure(c, c->recs, (size_t)sa.n_games * REC_DW * 4);
         if (rc) return rc;
     }
     {
@@ -392,8 +396,8 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
     pa.state = sa.state;
     pa.state_dw = sa.state_dw;
     pa.inc = sa.inc;
+    pa.rec0 = want_rec0 ? static_cast<uint32_t *>(c->rec0.p) : nullptr;
     pa.recs = want_recs ? static_cast<uint32_t *>(c->recs.p) : nullptr;
-    pa.rec_dw = rec_dw;
     pa.gs_out = (want_state && !plan.gs) ? 1u : 0u;
     pa.ticket = static_cast<uint32_t *>(c->misc.p);
     pa.err = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(c->misc.p) + 16);
@@ -537,7 +541,7 @@ void fk_destroy(fk_ctx *c) {
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     c->comm = nullptr;
     release(c->comm_buf);
-    for (DevBuf *b : {&c->strat, &c->perm, &c->draws, &c->state, &c->inc, &c->recs, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist,
+    for (DevBuf *b : {&c->strat, &c->perm, &c->draws, &c->state, &c->inc, &c->recs, &c->rec0, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist,
                       &c->coords, &c->order, &c->inv, &c->slow, &c->score_lut, &c->discard_lut, &c->classes, &c->blocks, &c->game_block,
                       &c->block_out, &c->stats})
         release(*b);
@@ -667,14 +671,35 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
                 perm_configured = true;
             }
-            // large tables: draws at full occupancy first, then the bare swap chains over the LDS arrays (fk_kernels.h)
-            const bool split = c->perm_split == 1 || (c->perm_split < 0 && S >= 1024 && n_sh >= 256);
-            if (split) {
+            // large tables: the draws at full occupancy first (fk_perm_draw_kernel); then either the chain-free
+            // permutation (fk_perm_parallel_kernel, one workgroup per shuffle, 14 B of LDS per strategy) or, for tables
+            // beyond its LDS reach, the bare swap chains over LDS arrays (fk_perm_apply_kernel)
+            const bool split = c->perm_split >= 1 || (c->perm_split < 0 && S >= 1024 && n_sh >= 256);
+            const size_t pp_lds = (size_t)S * 14;
+            const bool parallel = split && c->perm_split != 1 && pp_lds <= LDS_LIMIT - 1024;
+            if (parallel) {
+                const uint32_t groups = ((uint32_t)S - 1u + 7u) / 8u, row_u4 = groups + 1u; // a row also holds the S results
+                rc = ensure(c, c->draws, (size_t)n_sh * row_u4 * 16);
+                if (rc) return rc;
+                static bool pp_configured = false;
+                if (!pp_configured) {
+                    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_parallel_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+                    pp_configured = true;
+                }
+                hipLaunchKernelGGL(fk_perm_draw_kernel, dim3((n_sh + DRAW_BLOCK - 1u) / DRAW_BLOCK), dim3(DRAW_BLOCK), 0, c->stream,
+                                   perm_prefix, sh0, n_sh, (uint32_t)S, 1u, row_u4, static_cast<uint4 *>(c->draws.p));
+                hipLaunchKernelGGL(fk_perm_parallel_kernel, dim3(n_sh), dim3(PP_BLOCK), pp_lds, c->stream,
+                                   static_cast<uint4 *>(c->draws.p), row_u4, n_sh, (uint32_t)S);
+                hipLaunchKernelGGL(fk_perm_block_kernel, dim3(((uint32_t)S + 255u) / 256u, perm_blocks), dim3(256), (size_t)slots * 512, c->stream,
+                                   static_cast<const uint16_t *>(c->draws.p), row_u4 * 8u, n_sh, (uint32_t)S, slots,
+                                   static_cast<uint16_t *>(c->perm.p));
+            } else if (split) {
                 const uint32_t n_sh_pad = (n_sh + 63u) & ~63u, groups = ((uint32_t)S - 1u + 7u) / 8u;
                 rc = ensure(c, c->draws, (size_t)groups * n_sh_pad * 16);
                 if (rc) return rc;
                 hipLaunchKernelGGL(fk_perm_draw_kernel, dim3((n_sh + DRAW_BLOCK - 1u) / DRAW_BLOCK), dim3(DRAW_BLOCK), 0, c->stream,
-                                   perm_prefix, sh0, n_sh, (uint32_t)S, n_sh_pad, static_cast<uint4 *>(c->draws.p));
+                                   perm_prefix, sh0, n_sh, (uint32_t)S, n_sh_pad, 1u, static_cast<uint4 *>(c->draws.p));
                 hipLaunchKernelGGL(fk_perm_apply_kernel, dim3(perm_blocks), dim3(PERM_BLOCK), perm_lds, c->stream,
                                    static_cast<const uint4 *>(c->draws.p), n_sh_pad, n_sh, (uint32_t)S, slots,
                                    static_cast<uint16_t *>(c->perm.p));
@@ -750,7 +775,7 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
         pa.target = target_score;
         pa.max_rounds = (uint32_t)max_rounds;
 
-        rc = run_chunk(c, sa, pa, plan, want_state, want_recs, REC_DW, (int64_t)done * gps, "tournament");
+        rc = run_chunk(c, sa, pa, plan, want_state, want_recs, want_recs, (int64_t)done * gps, "tournament");
         if (rc) return rc;
         const bool scheduled = c->longest_first != 0;
         if (want_state && scheduled) { // game id -> slot of its state records
@@ -781,7 +806,9 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
             const uint64_t games_per_batch = (uint64_t)shuffles_per_batch * gps;
             unsigned long long *d_tally = static_cast<unsigned long long *>(c->tally.p);
             if (games_per_batch >= 4096) {
-                const uint32_t slice = (uint32_t)std::min<int64_t>(S, 448); // 448 x 22 x 8 B = 77 KiB: two workgroups per CU
+                // 896 x 22 x 8 B = 154 KiB of LDS: one 1024-thread workgroup per CU, half as many passes over rec0 as two
+                // smaller ones would need
+                const uint32_t slice = (uint32_t)std::min<int64_t>(S, 896);
                 const uint32_t n_slices = ((uint32_t)S + slice - 1u) / slice;
                 const uint32_t first_batch = (uint32_t)(done / shuffles_per_batch);
                 const uint32_t last_batch = (uint32_t)((done + n_sh - 1) / shuffles_per_batch);
@@ -795,9 +822,9 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
                     reduce_configured = true;
                 }
                 hipLaunchKernelGGL(fk_tally_reduce_kernel, dim3(ppb * nb, n_slices), dim3(REDUCE_BLOCK), (size_t)slice * RT_COLS * 8, c->stream,
-                                   static_cast<const uint32_t *>(c->recs.p), n_games, gps, (uint32_t)k, (uint32_t)S,
-                                   static_cast<const uint16_t *>(c->perm.p), slots, (uint32_t)done, shuffles_per_batch, n_sh, ppb, slice,
-                                   first_batch, d_tally);
+                                   static_cast<const uint32_t *>(c->rec0.p), static_cast<const uint32_t *>(c->recs.p), n_games, gps,
+                                   (uint32_t)k, (uint32_t)S, static_cast<const uint16_t *>(c->perm.p), slots, (uint32_t)done,
+                                   shuffles_per_batch, n_sh, ppb, slice, first_batch, d_tally);
             } else {
                 hipLaunchKernelGGL(fk_tally_direct_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
                                    static_cast<const uint32_t *>(c->recs.p), n_games, gps, (uint32_t)k, (uint32_t)S,
@@ -875,7 +902,7 @@ int fk_play_games(fk_ctx *c, const fk_coord *coords, int64_t n_games, const fk_s
     pa.S = (uint32_t)S;
     pa.target = target_score;
     pa.max_rounds = (uint32_t)max_rounds;
-    rc = run_chunk(c, sa, pa, plan, true, true, REC_DW, 0, "list");
+    rc = run_chunk(c, sa, pa, plan, true, true, true, 0, "list");
     if (rc) return rc;
     rc = rows_pass(c, sa, false, (uint32_t)n_games, 1, 1, false, static_cast<uint8_t *>(c->rows.p));
     if (rc) return rc;
@@ -917,9 +944,8 @@ int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_
     int rc = upload_strategies(c, table.data(), n_blocks * 2);
     if (rc) return rc;
     const SeedPool seat_prefix = seed_prefix(203u /* H2H_PLAYER */, root_seed, 2u);
-    // at most 8 192 blocks share a launch: their 16 384 table rows are what a lean record's strategy-index field holds
-    constexpr size_t MAX_BLOCKS_PER_PASS = (size_t)1 << (32 - CE_IDX_SHIFT - 1);
-    const LaunchPlan plan = plan_play(c, 2, (int64_t)std::min<size_t>((size_t)n_blocks, MAX_BLOCKS_PER_PASS) * 2, false);
+    constexpr size_t MAX_BLOCKS_PER_PASS = (size_t)1 << 22; // rec0 holds the winner's table row in 24 bits
+    const LaunchPlan plan = plan_play(c, 2, n_blocks * 2, false, true);
     const uint64_t max_launch = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->chunk_bytes / (game_workspace_bytes(2, plan.gs, false, false) + 8), 1u << 30));
     rc = ensure(c, c->block_out, (size_t)n_blocks * 4 * 8);
     if (rc) return rc;
@@ -1011,10 +1037,10 @@ int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_
         pa.S = nb * 2;
         pa.target = target_score;
         pa.max_rounds = (uint32_t)max_rounds;
-        rc = run_chunk(c, sa, pa, plan, false, true, REC_DW_H2H, 0, "h2h attempt (pass-local index)");
+        rc = run_chunk(c, sa, pa, plan, false, true, false, 0, "h2h attempt (pass-local index)");
         if (rc) return rc;
         hipLaunchKernelGGL(fk_h2h_reduce_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
-                           static_cast<const uint32_t *>(c->recs.p), n_games, nb, static_cast<unsigned long long *>(c->block_out.p));
+                           static_cast<const uint32_t *>(c->rec0.p), n_games, nb, static_cast<unsigned long long *>(c->block_out.p));
         HIPCHK(c, hipGetLastError());
         out.resize((size_t)nb * 4);
         HIPCHK(c, hipMemcpyAsync(out.data(), c->block_out.p, (size_t)nb * 4 * 8, hipMemcpyDeviceToHost, c->stream));

@@ -55,8 +55,9 @@ enum : uint32_t { R_LO0 = 0, R_LO1, R_HI0, R_HI1, R_BUF, R_SCORE, R_CA, R_CB, R_
 //   d0 = winner's strategy index [23:0] | winner seat [30:24] | safety-limit flag [31]
 //   d1 = winning score   d2 = n_rounds | farkles << 16   d3 = rolls | highest_turn << 16
 //   d4 = sf_uses | sf_dice << 16   d5 = so_uses | so_dice << 16   d6 = hot_dice   d7 = 0      (winner's counters)
-// H2H block launches store d0 only (REC_DW_H2H).
-constexpr uint32_t REC_DW = 8, REC_DW_H2H = 1, REC_SAFETY = 0x80000000u;
+// d0 is also stored in a dense array of its own (rec0[id]): the reducing post-passes filter on it at 4 bytes per game and
+// touch the 32-byte record of the games they keep only; H2H block launches store rec0 alone.
+constexpr uint32_t REC_DW = 8, REC_SAFETY = 0x80000000u;
 
 constexpr uint32_t LT_COLS = 24; // LDS tally columns: wins, completed, safety, 10 sums, 10 square sums, pad
 constexpr uint32_t TICKET_CHUNK = 64;
@@ -113,8 +114,8 @@ struct PlayArgs {
     const uint4 *inc;
     const uint32_t *sched;       // nullable: ticket -> game id (longest-first schedule; state records are stored by ticket)
     unsigned long long *tally;   // [S][26] (LDS-tally launches only: one batch)
-    uint32_t *recs;              // nullable: [n_games][rec_dw] result records
-    uint32_t rec_dw;
+    uint32_t *rec0;              // nullable: [n_games] d0 of the result records
+    uint32_t *recs;              // nullable: [n_games][REC_DW] result records (tournament / list launches)
     uint32_t gs_out;             // LDS-record instances: flush every seat's final record to `state` at game end
     uint32_t *ticket;
     int32_t *err;                // [0] code, [1] game id
@@ -218,7 +219,9 @@ __global__ __launch_bounds__(PERM_BLOCK) void fk_perm_kernel(SeedPool prefix, ui
 constexpr int DRAW_BLOCK = 256;
 
 __global__ __launch_bounds__(DRAW_BLOCK) void fk_perm_draw_kernel(SeedPool prefix, uint64_t shuffle0, uint32_t n_sh, uint32_t S,
-                                                                 uint32_t n_sh_pad, uint4 *draws) {
+                                                                 uint32_t g_stride, uint32_t sh_stride, uint4 *draws) {
+    // group g of shuffle sh sits at draws[g * g_stride + sh * sh_stride]: group-major (n_sh_pad, 1) for the serial swap
+    // chains, one row per shuffle (1, row length) for fk_perm_parallel_kernel
     const uint32_t sh = blockIdx.x * DRAW_BLOCK + threadIdx.x;
     const bool valid = sh < n_sh;
     Rng r{};
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(DRAW_BLOCK) void fk_perm_draw_kernel(SeedPool prefi
                 q3 = (q3 >> 16) | (j << 16);
                 i -= 1u;
                 n += 1u;
-                if ((n & 7u) == 0u) draws[(size_t)((n >> 3) - 1u) * n_sh_pad + sh] = make_uint4(q0, q1, q2, q3);
+                if ((n & 7u) == 0u) draws[(size_t)((n >> 3) - 1u) * g_stride + (size_t)sh * sh_stride] = make_uint4(q0, q1, q2, q3);
             }
         }
     };
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(DRAW_BLOCK) void fk_perm_draw_kernel(SeedPool prefi
         consume((uint32_t)o);         // low half first ...
         consume((uint32_t)(o >> 32)); // ... then the buffered high half
     }
-    if (valid && (n & 7u)) draws[(size_t)(n >> 3) * n_sh_pad + sh] = make_uint4(q0, q1, q2, q3); // last group: draws in the TOP halves
+    if (valid && (n & 7u)) draws[(size_t)(n >> 3) * g_stride + (size_t)sh * sh_stride] = make_uint4(q0, q1, q2, q3); // last group: draws in the TOP halves
 }
 
 __global__ __launch_bounds__(PERM_BLOCK) void fk_perm_apply_kernel(const uint4 *draws, uint32_t n_sh_pad, uint32_t n_sh, uint32_t S,
@@ -316,6 +319,134 @@ __global__ __launch_bounds__(PERM_BLOCK) void fk_perm_apply_kernel(const uint4 *
     for (uint32_t idx = threadIdx.x; idx < S * slots; idx += PERM_BLOCK) {
         const uint32_t e = idx / slots, l = idx - e * slots;
         out[idx] = l < count ? perm_lds[(size_t)l * S + e] : (uint16_t)0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fisher-Yates WITHOUT the serial chain: one workgroup per shuffle, everything in LDS.
+// numpy runs  for i = S-1 .. 1: swap(a[i], a[j_i])  on a = arange(S).  Position i is final after step i, and
+//     final[i] = what position j_i held just before step i.
+// A position p <= i changes before step i only as the TARGET of an earlier step i' > i with j_i' = p, which leaves
+// there what position i' held just before step i'.  With f(i) = content of position i just before step i:
+//     f(i)     = f(n(i)) if n(i) exists, else i,          n(i) = min{ i' > i : j_i' = i }     (a pointer chain, ascending)
+//     final[i] = f(u(i)) if u(i) exists, else j_i,        u(i) = min{ i' > i : j_i' = j_i }
+//     final[0] = f(0).
+// n and u are "next step with the same target": the steps are bucketed by target with a counting sort (LDS atomics + one
+// scan), each (tiny) bucket is sorted, and the chains are resolved by pointer jumping — O(S log S) fully parallel work
+// instead of S dependent LDS round trips per shuffle.  14 bytes of LDS per strategy: two shuffles per CU at S = 5 160.
+constexpr int PP_BLOCK = 512;
+constexpr uint32_t PP_NONE = 0xffffu;
+
+__global__ __launch_bounds__(PP_BLOCK) void fk_perm_parallel_kernel(uint4 *draws_rows, uint32_t row_u4, uint32_t n_sh, uint32_t S) {
+    extern __shared__ uint32_t pp_lds[];
+    __shared__ uint32_t wave_sum[PP_BLOCK / 64];
+    __shared__ uint32_t changed;
+    uint32_t *cnt = pp_lds;                                              // [S] bucket sizes, then fill cursors
+    uint16_t *J = reinterpret_cast<uint16_t *>(cnt + S);                 // [S] draw of step i (J[0] unused)
+    uint16_t *order = J + S, *U = order + S, *F = U + S, *start = F + S; // [S] each
+    const uint32_t sh = blockIdx.x, tid = threadIdx.x;
+    if (sh >= n_sh) return;
+    uint4 *row = draws_rows + (size_t)sh * row_u4;
+    const uint32_t steps = S - 1u, groups = (steps + 7u) >> 3, tail = steps & 7u;
+    for (uint32_t i = tid; i < S; i += PP_BLOCK) {
+        cnt[i] = 0u;
+        U[i] = (uint16_t)PP_NONE;
+    }
+    if (tid == 0) J[0] = 0;
+    for (uint32_t g = tid; g < groups; g += PP_BLOCK) { // draw number n = 8g + e is the draw of step i = S - 1 - n
+        const uint4 q = row[g];
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        const bool last = (g + 1u == groups) && tail;
+        const uint32_t n_in = last ? tail : 8u, shift = last ? 8u - tail : 0u; // the last group's draws sit in the TOP halves
+        for (uint32_t e = 0; e < n_in; ++e) {
+            const uint32_t h = e + shift;
+            J[S - 1u - (8u * g + e)] = (uint16_t)((w[h >> 1] >> (16u * (h & 1u))) & 0xffffu);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = 1u + tid; i < S; i += PP_BLOCK) atomicAdd(&cnt[J[i]], 1u);
+    __syncthreads();
+    // exclusive scan of cnt: a contiguous chunk per thread, wave scan of the chunk sums, block scan of the wave sums
+    const uint32_t chunk = (S + PP_BLOCK - 1u) / PP_BLOCK, c0 = min(tid * chunk, S), c1 = min(c0 + chunk, S);
+    uint32_t mine = 0;
+    for (uint32_t i = c0; i < c1; ++i) mine += cnt[i];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)(tid & 63u) >= d) incl += up;
+    }
+    if ((tid & 63u) == 63u) wave_sum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - mine;
+    for (uint32_t w = 0; w < (tid >> 6); ++w) base += wave_sum[w];
+    for (uint32_t i = c0; i < c1; ++i) {
+        const uint32_t c = cnt[i];
+        cnt[i] = base;
+        start[i] = (uint16_t)base;
+        base += c;
+    }
+    __syncthreads();
+    for (uint32_t i = 1u + tid; i < S; i += PP_BLOCK) order[atomicAdd(&cnt[J[i]], 1u)] = (uint16_t)i;
+    __syncthreads();
+    for (uint32_t p = tid; p < S; p += PP_BLOCK) { // bucket p = the steps that target position p, ascending
+        const uint32_t lo = start[p], hi = cnt[p];
+        for (uint32_t a = lo + 1u; a < hi; ++a) { // insertion sort (buckets hold one or two steps on average)
+            const uint16_t v = order[a];
+            uint32_t b = a;
+            while (b > lo && order[b - 1u] > v) {
+                order[b] = order[b - 1u];
+                --b;
+            }
+            order[b] = v;
+        }
+        uint32_t nxt = PP_NONE;
+        for (uint32_t a = lo; a < hi; ++a) {
+            const uint32_t i = order[a];
+            if (a + 1u < hi) U[i] = order[a + 1u];
+            if (nxt == PP_NONE && i > p) nxt = i; // n(p): the first step of the bucket beyond p itself (a self-swap is step p)
+        }
+        F[p] = (uint16_t)(nxt == PP_NONE ? p : nxt);
+    }
+    __syncthreads();
+    for (int round = 0; round < 17; ++round) { // pointer jumping: chains ascend, terminals are fixed points
+        if (tid == 0) changed = 0u;
+        __syncthreads();
+        uint32_t any = 0;
+        for (uint32_t i = tid; i < S; i += PP_BLOCK) {
+            const uint32_t f = F[i], ff = F[f];
+            if (ff != f) {
+                F[i] = (uint16_t)ff;
+                any = 1u;
+            }
+        }
+        if (any) changed = 1u;
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+    // the finished permutation goes back over the shuffle's own draws row (read completely in the first phase)
+    uint16_t *out = reinterpret_cast<uint16_t *>(row);
+    for (uint32_t i = tid; i < S; i += PP_BLOCK) {
+        const uint32_t u = U[i];
+        out[i] = (i == 0u) ? F[0] : (u != PP_NONE ? F[u] : J[i]);
+    }
+}
+
+// rows [n_sh][row_u16] (one permutation per row) -> the blocked layout [n_sh / slots][S][slots] the game kernels read
+__global__ __launch_bounds__(256) void fk_perm_block_kernel(const uint16_t *rows, uint32_t row_u16, uint32_t n_sh, uint32_t S, uint32_t slots,
+                                                           uint16_t *perm_T) {
+    extern __shared__ uint16_t tile[]; // [slots][256]
+    const uint32_t b = blockIdx.y, e0 = blockIdx.x * 256u, ne = min(256u, S - e0);
+    for (uint32_t l = 0; l < slots; ++l) {
+        const uint32_t sh = b * slots + l;
+        if (threadIdx.x < ne) tile[l * 256u + threadIdx.x] = sh < n_sh ? rows[(size_t)sh * row_u16 + e0 + threadIdx.x] : (uint16_t)0;
+    }
+    __syncthreads();
+    uint16_t *out = perm_T + ((size_t)b * S + e0) * slots;
+    for (uint32_t j = threadIdx.x; j < ne * slots; j += 256u) {
+        const uint32_t e = j / slots, l = j - e * slots;
+        out[j] = tile[l * 256u + e];
     }
 }
 
@@ -547,6 +678,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     const uint32_t K = a.k;
     constexpr uint32_t NFIELDS = LEAN ? (uint32_t)NF - 6u : (uint32_t)NF; // 11 or 17 dwords per seat record
     unsigned long long *tl = reinterpret_cast<unsigned long long *>(lds + NFIELDS * (GS ? 1u : K) * BLOCK);
+    // batched H2H launches (no LDS tally): one dword per lane behind the records holds the lane's block index — the strategy
+    // index of seat s is 2 * block + s, whatever the number of blocks (the 14-bit index field of cE would cap it at 8 192)
+    uint32_t *lane_block = lds + NFIELDS * (GS ? 1u : K) * BLOCK + tid;
 
     if (a.use_lds_tally) {
         for (uint32_t i = tid; i < a.S * LT_COLS; i += BLOCK) tl[i] = 0ull;
@@ -601,7 +735,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     // per-seat views used by the end-of-game code (seat s may be the turn owner or not)
     auto seat_strategy = [&](uint32_t s) -> uint32_t { // strategy-table index of seat s of the lane's current game
         if (GS) return G(s)[R_IDX];
-        if (LEAN) return L(F_CE, s) >> CE_IDX_SHIFT;
+        if (LEAN) return a.mode == MODE_BLOCKS ? 2u * *lane_block + s : L(F_CE, s) >> CE_IDX_SHIFT;
         return strategy_index(game_id, s);
     };
     auto seat_score = [&](uint32_t s) -> int32_t { return (int32_t)(GS ? G(s)[R_SCORE] : L(F_SCORE, s)); };
@@ -629,7 +763,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             idx = q2.w;
         } else {
             L(F_CB, s) += 0x10000u; // n_turns += 1 (engine.py:236)
-            if (LEAN) idx = L(F_CE, s) >> CE_IDX_SHIFT;
+            if (LEAN) idx = a.mode == MODE_BLOCKS ? 2u * *lane_block + s : L(F_CE, s) >> CE_IDX_SHIFT;
         }
         if (LEAN) { // read-only per-seat data comes from HBM/L2; the loads overlap the first dice of the turn
             const uint4 inc = a.inc[(size_t)seed_slot * K + s];
@@ -681,7 +815,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                 for (uint32_t s = 0; s < K; ++s) atomicAdd(&tl[seat_strategy(s) * LT_COLS + (completed ? 1u : 2u)], 1ull);
             }
         }
-        if (!(a.use_lds_tally && completed) && !a.recs) return;
+        if (!(a.use_lds_tally && completed) && !a.rec0) return;
         uint32_t widx = 0, wa = 0, wb = 0, wc = 0, wd = 0, we = 0;
         if (completed) {
             widx = seat_strategy(w);
@@ -703,11 +837,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                 }
             }
         }
-        if (a.recs) {
+        if (a.rec0) {
             const uint32_t d0 = widx | (completed ? (w << 24) : REC_SAFETY);
-            if (a.rec_dw == REC_DW_H2H) {
-                a.recs[game_id] = d0;
-            } else {
+            a.rec0[game_id] = d0;
+            if (a.recs) {
                 uint4 *r = reinterpret_cast<uint4 *>(a.recs + (size_t)game_id * REC_DW);
                 r[0] = make_uint4(d0, completed ? (uint32_t)best : 0u, rounds | (wa & 0xffff0000u), (wa & 0xffffu) | (wb << 16));
                 r[1] = make_uint4(wc, wd, we & 0xffffu, 0u);
@@ -737,6 +870,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         }
         seed_slot = slot;
         if (!GS) {
+            if (LEAN && a.mode == MODE_BLOCKS) *lane_block = a.game_block[id];
             for (uint32_t s = 0; s < K; ++s) {
                 const uint32_t *src = G(s);
                 const uint4 stv = *reinterpret_cast<const uint4 *>(src);
@@ -761,7 +895,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                 L(F_CB, s) = 0u;
                 L(F_CC, s) = 0u;
                 L(F_CD, s) = 0u;
-                L(F_CE, s) = LEAN ? (idx << CE_IDX_SHIFT) : 0u;
+                L(F_CE, s) = (LEAN && a.mode != MODE_BLOCKS) ? (idx << CE_IDX_SHIFT) : 0u;
             }
         }
         seat = 0;
@@ -955,13 +1089,14 @@ __device__ inline uint32_t walk_slot(uint32_t id, uint32_t gps, uint32_t n_sh, b
 
 // Result records -> tally [n_batches][S][26].  Games are in id order = shuffle order, so a deterministic batch is a
 // contiguous record range; a workgroup takes one part of one batch and one SLICE of the strategy axis, accumulates the
-// slice in LDS (ds_add_u64) and flushes what is non-zero with contiguous global atomics: every record is read
-// ceil(S / slice) times (32 B each, coalesced), nothing is atomically added to HBM per game.
+// slice in LDS (ds_add_u64) and flushes what is non-zero with contiguous global atomics: the 4-byte rec0 word of every game
+// is read ceil(S / slice) times (coalesced), its 32-byte record once — by the slice that holds the winner; nothing is
+// atomically added to HBM per game.
 //   grid = (parts_per_batch * n_batches, n_slices); completed games count wins + 10 sums + 10 square sums for the winner,
 //   safety-limit games one safety exposure per seat (strategies re-derived from the permutation).
-constexpr uint32_t REDUCE_BLOCK = 512, RT_COLS = 22; // wins, safety, 10 sums, 10 square sums
+constexpr uint32_t REDUCE_BLOCK = 1024, RT_COLS = 22; // wins, safety, 10 sums, 10 square sums
 
-__global__ __launch_bounds__(REDUCE_BLOCK) void fk_tally_reduce_kernel(const uint32_t *recs, uint32_t n_games, uint32_t gps, uint32_t k,
+__global__ __launch_bounds__(REDUCE_BLOCK) void fk_tally_reduce_kernel(const uint32_t *rec0, const uint32_t *recs, uint32_t n_games, uint32_t gps, uint32_t k,
                                                                        uint32_t S, const uint16_t *perm_T, uint32_t perm_slots,
                                                                        uint32_t sh_offset, uint32_t spb, uint32_t n_sh,
                                                                        uint32_t parts_per_batch, uint32_t slice, uint32_t first_batch,
@@ -980,9 +1115,8 @@ __global__ __launch_bounds__(REDUCE_BLOCK) void fk_tally_reduce_kernel(const uin
     for (uint32_t i = threadIdx.x; i < s_n * RT_COLS; i += REDUCE_BLOCK) rt[i] = 0ull;
     __syncthreads();
     for (uint32_t id = first + threadIdx.x; id < last; id += REDUCE_BLOCK) {
-        const uint4 *r = reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
-        const uint4 q0 = r[0];
-        if (q0.x & REC_SAFETY) {
+        const uint32_t d0 = rec0[id];
+        if (d0 & REC_SAFETY) {
             const uint32_t sh = id / gps, g = id - sh * gps;
             for (uint32_t s = 0; s < k; ++s) {
                 const uint32_t idx = perm_at(perm_T, S, perm_slots, sh, g * k + s) - s_lo;
@@ -990,9 +1124,10 @@ __global__ __launch_bounds__(REDUCE_BLOCK) void fk_tally_reduce_kernel(const uin
             }
             continue;
         }
-        const uint32_t idx = (q0.x & 0xffffffu) - s_lo;
+        const uint32_t idx = (d0 & 0xffffffu) - s_lo;
         if (idx >= s_n) continue;
-        const uint4 q1 = r[1];
+        const uint4 *r = reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
+        const uint4 q0 = r[0], q1 = r[1];
         const unsigned long long m[10] = {q0.y, q0.z & 0xffffu, q0.z >> 16, q0.w & 0xffffu, q0.w >> 16,
                                           q1.x & 0xffffu, q1.x >> 16, q1.y & 0xffffu, q1.y >> 16, q1.z};
         unsigned long long *t = rt + idx * RT_COLS;
