@@ -167,6 +167,7 @@ struct LaunchPlan {
     bool lds_tally = false;
     bool lean = false; // 11-dword seat records (increment + strategy re-read from HBM/L2 each turn)
     bool gs = false;   // state-store instance: one LDS record per lane, the others in HBM
+    bool blk = false;  // batched-H2H instance (strategy index from the lane's block index)
     int wpe = 4;       // waves per SIMD the chosen instance is compiled for
     uint32_t mixed_flags = 0xff00u; // flag bits that differ between strategies of the table (selects the kernel instance)
 };
@@ -184,6 +185,16 @@ size_t play_lds_bytes(int32_t k, int block, bool lean, bool gs, bool lds_tally, 
 // their LDS use does not grow with k.
 LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, bool blocks_mode = false) {
     LaunchPlan best;
+    if (blocks_mode) { // batched H2H: the one instance built for it (768 threads, lean LDS records of both seats + block index)
+        best.block = 768;
+        best.lean = true;
+        best.blk = true;
+        best.wpe = 6;
+        best.lds = play_lds_bytes(2, 768, true, false, false, 0, true);
+        const int per_cu = c->blocks_per_cu > 0 ? std::min(2, c->blocks_per_cu) : 2;
+        best.grid = c->prop.multiProcessorCount * per_cu;
+        return best;
+    }
     const bool want_tally = single_batch && !blocks_mode && (c->use_lds_tally != 0) && S <= 4096;
     int best_lanes = -1;
     // state-store instances only on request: measured 2x slower than LDS records at k = 4 / 8 (the per-turn record
@@ -225,31 +236,32 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, b
     return best; // always feasible: a GS instance needs 44 bytes of LDS per lane whatever k is
 }
 
-template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS>
+template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS, bool BLK = false>
 hipError_t launch_play_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     static bool configured = false; // the dynamic-LDS ceiling of an instance is raised once, not per launch
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS, BLK>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL((fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS>), dim3((unsigned)p.grid), dim3(BLOCK), std::max<size_t>(p.lds, 16), s, a);
+    hipLaunchKernelGGL((fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS, BLK>), dim3((unsigned)p.grid), dim3(BLOCK), std::max<size_t>(p.lds, 16), s, a);
     return hipGetLastError();
 }
 
 constexpr uint32_t MIXED_ALL = 0xff00u, MIXED_NONE = 0u, MIXED_RB_FAV = SF_REQUIRE_BOTH | SF_FAVOR_SCORE;
 
-template <int BLOCK, bool LEAN, int WPE = 4, bool GS = false>
+template <int BLOCK, bool LEAN, int WPE = 4, bool GS = false, bool BLK = false>
 hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     // the narrowest instance whose MIXED set covers the flags that actually vary in this table
-    if (p.mixed_flags == MIXED_NONE) return launch_play_u<BLOCK, LEAN, WPE, MIXED_NONE, GS>(p, a, s);
-    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_u<BLOCK, LEAN, WPE, MIXED_RB_FAV, GS>(p, a, s);
-    return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS>(p, a, s);
+    if (p.mixed_flags == MIXED_NONE) return launch_play_u<BLOCK, LEAN, WPE, MIXED_NONE, GS, BLK>(p, a, s);
+    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_u<BLOCK, LEAN, WPE, MIXED_RB_FAV, GS, BLK>(p, a, s);
+    return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS, BLK>(p, a, s);
 }
 
 hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     if (p.lds > LDS_LIMIT) return hipErrorInvalidValue;
+    if (p.blk) return launch_play_t<768, true, 6, false, true>(p, a, s); // batched H2H: k = 2, lean LDS records
     if (p.gs) {
         switch (p.block) {
         case 768: return launch_play_t<768, true, 6, true>(p, a, s);
@@ -684,7 +696,7 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
                 static bool pp_configured = false;
                 if (!pp_configured) {
                     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_parallel_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_LIMIT - 1024))); // + its static words
                     pp_configured = true;
                 }
                 hipLaunchKernelGGL(fk_perm_draw_kernel, dim3((n_sh + DRAW_BLOCK - 1u) / DRAW_BLOCK), dim3(DRAW_BLOCK), 0, c->stream,

@@ -670,9 +670,11 @@ __global__ void fk_finalize_tally(unsigned long long *tally, uint32_t n_rows, ui
 // the whole table (threshold grids fix most of them): they arrive as a kernel argument, so their tests run on the
 // scalar unit and the constants they select become s_cselects.  Instances: all flags mixed (generic), none, and
 // require_both | favor_score (the pair the reference's grid always enumerates).
-template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS>
+// BLK: batched-H2H instance (MODE_BLOCKS with lean LDS records): the strategy index comes from the lane's block index.
+template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS, bool BLK = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void fk_play_kernel(PlayArgs a) {
     static_assert(!GS || LEAN, "state-store instances stage the lean record");
+    static_assert(!BLK || (LEAN && !GS), "block-index instances use lean LDS records");
     extern __shared__ uint32_t lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t K = a.k;
@@ -735,7 +737,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     // per-seat views used by the end-of-game code (seat s may be the turn owner or not)
     auto seat_strategy = [&](uint32_t s) -> uint32_t { // strategy-table index of seat s of the lane's current game
         if (GS) return G(s)[R_IDX];
-        if (LEAN) return a.mode == MODE_BLOCKS ? 2u * *lane_block + s : L(F_CE, s) >> CE_IDX_SHIFT;
+        if (BLK) return 2u * *lane_block + s;
+        if (LEAN) return L(F_CE, s) >> CE_IDX_SHIFT;
         return strategy_index(game_id, s);
     };
     auto seat_score = [&](uint32_t s) -> int32_t { return (int32_t)(GS ? G(s)[R_SCORE] : L(F_SCORE, s)); };
@@ -763,7 +766,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             idx = q2.w;
         } else {
             L(F_CB, s) += 0x10000u; // n_turns += 1 (engine.py:236)
-            if (LEAN) idx = a.mode == MODE_BLOCKS ? 2u * *lane_block + s : L(F_CE, s) >> CE_IDX_SHIFT;
+            if (BLK) idx = 2u * *lane_block + s;
+            else if (LEAN) idx = L(F_CE, s) >> CE_IDX_SHIFT;
         }
         if (LEAN) { // read-only per-seat data comes from HBM/L2; the loads overlap the first dice of the turn
             const uint4 inc = a.inc[(size_t)seed_slot * K + s];
@@ -870,7 +874,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         }
         seed_slot = slot;
         if (!GS) {
-            if (LEAN && a.mode == MODE_BLOCKS) *lane_block = a.game_block[id];
+            if (BLK) *lane_block = a.game_block[id];
             for (uint32_t s = 0; s < K; ++s) {
                 const uint32_t *src = G(s);
                 const uint4 stv = *reinterpret_cast<const uint4 *>(src);
@@ -895,7 +899,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                 L(F_CB, s) = 0u;
                 L(F_CC, s) = 0u;
                 L(F_CD, s) = 0u;
-                L(F_CE, s) = (LEAN && a.mode != MODE_BLOCKS) ? (idx << CE_IDX_SHIFT) : 0u;
+                L(F_CE, s) = (LEAN && !BLK) ? (idx << CE_IDX_SHIFT) : 0u;
             }
         }
         seat = 0;

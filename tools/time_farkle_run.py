@@ -52,8 +52,8 @@ with tempfile.TemporaryDirectory(prefix="fk_e2e_") as tmp:
         plan = json.loads(next((Path(tmp)).glob(f"{name}_seed_42/2_players/simulation_workload_plan.json")).read_text())
         games = plan["required_games"]
         out["runs"][name] = {"games": games, "shuffles": plan["required_shuffles"], "wall_s": wall, "games_per_s": games / wall,
-                             "engine_s": acc["engine_s"], "engine_calls": acc["calls"], "row_shard_write_s": acc["shard_s"],
-                             "other_host_s": wall - acc["engine_s"] - acc["shard_s"]}
+                             "engine_s": acc["engine_s"], "engine_calls": acc["calls"], "host_s": wall - acc["engine_s"],
+                             "row_shard_writer_thread_s": acc["shard_s"], "row_writer_threads": runner.ROW_WRITER_THREADS}
         print(name, json.dumps(out["runs"][name]), flush=True)
     run("warm", {}, {"target_batches": 4, "min_shuffles_per_batch": 8}, {"resolution_delta": 0.3})  # import / first-launch costs out of the way
     del out["runs"]["warm"]
@@ -63,8 +63,11 @@ with tempfile.TemporaryDirectory(prefix="fk_e2e_") as tmp:
     run("rows_on", {"row_dir": "rows", "metric_chunk_dir": "metric_chunks"}, {"target_batches": 100, "min_shuffles_per_batch": per_batch}, {"resolution_delta": 0.5})
 r = out["runs"]
 out["host_bottleneck"] = ("rows on: one parquet file + one manifest line per shuffle of 32 games (the reference's row-shard format, "
-                          "run_tournament.py:530-558): %.1f ms per shard in pyarrow/Python against %.3f ms of engine time per shuffle"
-                          % (1e3 * r["rows_on"]["row_shard_write_s"] / r["rows_on"]["shuffles"], 1e3 * r["rows_on"]["engine_s"] / r["rows_on"]["shuffles"]))
+                          "run_tournament.py:530-558): %.2f ms of host wall time per shard (pyarrow + Python on %d writer threads, "
+                          "%.1f ms of thread time each) against %.4f ms of engine time per shuffle"
+                          % (1e3 * r["rows_on"]["host_s"] / r["rows_on"]["shuffles"], runner.ROW_WRITER_THREADS,
+                             1e3 * r["rows_on"]["row_shard_writer_thread_s"] / r["rows_on"]["shuffles"],
+                             1e3 * r["rows_on"]["engine_s"] / r["rows_on"]["shuffles"]))
 out["reference_published"] = {"games_per_s_1_worker": 279.0, "games_per_s_12_workers": 1142.9,
                               "where": "docs/remediation/task4c_simulation_execution_report.md:109-116 (Ryzen 7 3700X, rows + metrics)"}
 print(json.dumps(out, indent=1))
