@@ -703,7 +703,7 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
                                    perm_prefix, sh0, n_sh, (uint32_t)S, 1u, row_u4, static_cast<uint4 *>(c->draws.p));
                 hipLaunchKernelGGL(fk_perm_parallel_kernel, dim3(n_sh), dim3(PP_BLOCK), pp_lds, c->stream,
                                    static_cast<uint4 *>(c->draws.p), row_u4, n_sh, (uint32_t)S);
-                hipLaunchKernelGGL(fk_perm_block_kernel, dim3(((uint32_t)S + 255u) / 256u, perm_blocks), dim3(256), (size_t)slots * 512, c->stream,
+                hipLaunchKernelGGL(fk_perm_block_kernel, dim3(((uint32_t)S + 255u) / 256u, perm_blocks), dim3(256), 0, c->stream,
                                    static_cast<const uint16_t *>(c->draws.p), row_u4 * 8u, n_sh, (uint32_t)S, slots,
                                    static_cast<uint16_t *>(c->perm.p));
             } else if (split) {

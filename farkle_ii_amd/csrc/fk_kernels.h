@@ -334,7 +334,7 @@ __global__ __launch_bounds__(PERM_BLOCK) void fk_perm_apply_kernel(const uint4 *
 // n and u are "next step with the same target": the steps are bucketed by target with a counting sort (LDS atomics + one
 // scan), each (tiny) bucket is sorted, and the chains are resolved by pointer jumping — O(S log S) fully parallel work
 // instead of S dependent LDS round trips per shuffle.  14 bytes of LDS per strategy: two shuffles per CU at S = 5 160.
-constexpr int PP_BLOCK = 512;
+constexpr int PP_BLOCK = 1024;
 constexpr uint32_t PP_NONE = 0xffffu;
 
 __global__ __launch_bounds__(PP_BLOCK) void fk_perm_parallel_kernel(uint4 *draws_rows, uint32_t row_u4, uint32_t n_sh, uint32_t S) {
@@ -433,20 +433,27 @@ __global__ __launch_bounds__(PP_BLOCK) void fk_perm_parallel_kernel(uint4 *draws
     }
 }
 
-// rows [n_sh][row_u16] (one permutation per row) -> the blocked layout [n_sh / slots][S][slots] the game kernels read
+// rows [n_sh][row_u16] (one permutation per row) -> the blocked layout [n_sh / slots][S][slots] the game kernels read;
+// a workgroup moves 256 entries of up to 64 shuffles of one block through an LDS tile (coalesced on both sides)
+constexpr uint32_t PB_ROWS = 64;
+
 __global__ __launch_bounds__(256) void fk_perm_block_kernel(const uint16_t *rows, uint32_t row_u16, uint32_t n_sh, uint32_t S, uint32_t slots,
                                                            uint16_t *perm_T) {
-    extern __shared__ uint16_t tile[]; // [slots][256]
+    __shared__ uint16_t tile[PB_ROWS * 256];
     const uint32_t b = blockIdx.y, e0 = blockIdx.x * 256u, ne = min(256u, S - e0);
-    for (uint32_t l = 0; l < slots; ++l) {
-        const uint32_t sh = b * slots + l;
-        if (threadIdx.x < ne) tile[l * 256u + threadIdx.x] = sh < n_sh ? rows[(size_t)sh * row_u16 + e0 + threadIdx.x] : (uint16_t)0;
-    }
-    __syncthreads();
     uint16_t *out = perm_T + ((size_t)b * S + e0) * slots;
-    for (uint32_t j = threadIdx.x; j < ne * slots; j += 256u) {
-        const uint32_t e = j / slots, l = j - e * slots;
-        out[j] = tile[l * 256u + e];
+    for (uint32_t l0 = 0; l0 < slots; l0 += PB_ROWS) {
+        const uint32_t lc = min(PB_ROWS, slots - l0);
+        for (uint32_t l = 0; l < lc; ++l) {
+            const uint32_t sh = b * slots + l0 + l;
+            if (threadIdx.x < ne) tile[l * 256u + threadIdx.x] = sh < n_sh ? rows[(size_t)sh * row_u16 + e0 + threadIdx.x] : (uint16_t)0;
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < ne * lc; j += 256u) {
+            const uint32_t e = j / lc, l = j - e * lc;
+            out[(size_t)e * slots + l0 + l] = tile[l * 256u + e];
+        }
+        __syncthreads();
     }
 }
 

@@ -271,7 +271,10 @@ def test_permutation_kernels_agree_with_numpy_semantics(eng, po, S, k):
     try:
         for mode in (0, 1, 2, -1):
             eng.set_option("perm_split", mode)
-            got = eng.tournament(table, k, 21, 1000, 1000 + n_sh, want_perms=True, max_rounds=3)
+            try:
+                got = eng.tournament(table, k, 21, 1000, 1000 + n_sh, want_perms=True, max_rounds=3)
+            except Exception as exc:
+                raise AssertionError(f"perm_split={mode} S={S}: {exc}") from exc
             assert np.array_equal(got["perms"], ref["perms"]), (S, mode, np.argwhere(got["perms"] != ref["perms"])[:4])
             assert np.array_equal(got["tally"], ref["tally"]), (S, mode)
     finally:
