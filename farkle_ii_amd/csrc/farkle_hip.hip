@@ -236,32 +236,32 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, b
     return best; // always feasible: a GS instance needs 44 bytes of LDS per lane whatever k is
 }
 
-template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS, bool BLK = false>
+template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS, bool BLK = false, int KC = 0>
 hipError_t launch_play_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     static bool configured = false; // the dynamic-LDS ceiling of an instance is raised once, not per launch
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS, BLK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS, BLK, KC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL((fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS, BLK>), dim3((unsigned)p.grid), dim3(BLOCK), std::max<size_t>(p.lds, 16), s, a);
+    hipLaunchKernelGGL((fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS, BLK, KC>), dim3((unsigned)p.grid), dim3(BLOCK), std::max<size_t>(p.lds, 16), s, a);
     return hipGetLastError();
 }
 
 constexpr uint32_t MIXED_ALL = 0xff00u, MIXED_NONE = 0u, MIXED_RB_FAV = SF_REQUIRE_BOTH | SF_FAVOR_SCORE;
 
-template <int BLOCK, bool LEAN, int WPE = 4, bool GS = false, bool BLK = false>
+template <int BLOCK, bool LEAN, int WPE = 4, bool GS = false, bool BLK = false, int KC = 0>
 hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     // the narrowest instance whose MIXED set covers the flags that actually vary in this table
-    if (p.mixed_flags == MIXED_NONE) return launch_play_u<BLOCK, LEAN, WPE, MIXED_NONE, GS, BLK>(p, a, s);
-    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_u<BLOCK, LEAN, WPE, MIXED_RB_FAV, GS, BLK>(p, a, s);
-    return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS, BLK>(p, a, s);
+    if (p.mixed_flags == MIXED_NONE) return launch_play_u<BLOCK, LEAN, WPE, MIXED_NONE, GS, BLK, KC>(p, a, s);
+    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_u<BLOCK, LEAN, WPE, MIXED_RB_FAV, GS, BLK, KC>(p, a, s);
+    return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS, BLK, KC>(p, a, s);
 }
 
 hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     if (p.lds > LDS_LIMIT) return hipErrorInvalidValue;
-    if (p.blk) return launch_play_t<768, true, 6, false, true>(p, a, s); // batched H2H: k = 2, lean LDS records
+    if (p.blk) return launch_play_t<768, true, 6, false, true, 2>(p, a, s); // batched H2H: k = 2, lean LDS records
     if (p.gs) {
         switch (p.block) {
         case 768: return launch_play_t<768, true, 6, true>(p, a, s);
@@ -272,7 +272,7 @@ hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     if (p.lean) {
         switch (p.block) {
         case 1024: return launch_play_t<1024, true>(p, a, s);
-        case 768: return launch_play_t<768, true, 6>(p, a, s);
+        case 768: return a.k == 2u ? launch_play_t<768, true, 6, false, false, 2>(p, a, s) : launch_play_t<768, true, 6>(p, a, s);
         case 512: return launch_play_t<512, true>(p, a, s);
         case 256: return launch_play_t<256, true>(p, a, s);
         case 128: return launch_play_t<128, true>(p, a, s);

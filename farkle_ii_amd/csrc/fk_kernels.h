@@ -678,13 +678,15 @@ __global__ void fk_finalize_tally(unsigned long long *tally, uint32_t n_rows, ui
 // scalar unit and the constants they select become s_cselects.  Instances: all flags mixed (generic), none, and
 // require_both | favor_score (the pair the reference's grid always enumerates).
 // BLK: batched-H2H instance (MODE_BLOCKS with lean LDS records): the strategy index comes from the lane's block index.
-template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS, bool BLK = false>
+// KC: compile-time player count (0 = run-time a.k).  The two-player instances (BASELINE config 2, every H2H launch) fold
+// the seat arithmetic of the table advance and the record addressing.
+template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS, bool BLK = false, int KC = 0>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void fk_play_kernel(PlayArgs a) {
     static_assert(!GS || LEAN, "state-store instances stage the lean record");
     static_assert(!BLK || (LEAN && !GS), "block-index instances use lean LDS records");
     extern __shared__ uint32_t lds[];
     const uint32_t tid = threadIdx.x;
-    const uint32_t K = a.k;
+    const uint32_t K = KC ? (uint32_t)KC : a.k;
     constexpr uint32_t NFIELDS = LEAN ? (uint32_t)NF - 6u : (uint32_t)NF; // 11 or 17 dwords per seat record
     unsigned long long *tl = reinterpret_cast<unsigned long long *>(lds + NFIELDS * (GS ? 1u : K) * BLOCK);
     // batched H2H launches (no LDS tally): one dword per lane behind the records holds the lane's block index — the strategy
