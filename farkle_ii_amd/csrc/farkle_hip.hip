@@ -37,7 +37,7 @@ struct fk_ctx {
         hipEvent_t a, b;
     };
     std::vector<PendingTimer> pending; // kernel timers recorded on the stream, read after the chunk's one sync
-    DevBuf strat, perm, draws, state, inc, recs, rec0, tally, rows, misc, ov, seatlist, coords, order, inv, slow, score_lut, discard_lut,
+    DevBuf strat, perm, draws, state, inc, seat_idx, recs, rec0, tally, rows, misc, ov, seatlist, coords, order, inv, slow, score_lut, discard_lut,
         classes, blocks, game_block, block_out, stats, dbg[6];
     std::vector<uint2> strat_host;   // the packed table currently resident in `strat` (uploaded once per table)
     int32_t longest_first = 1;
@@ -345,7 +345,7 @@ int upload_overrides(fk_ctx *c, std::vector<DevOverride> &dov) {
 
 // bytes of device workspace one game needs in a chunk (state records, increments, schedule, result record, row)
 size_t game_workspace_bytes(int32_t k, bool full_state, bool recs, bool rows) {
-    return (size_t)k * ((full_state ? STATE_DW * 4 : 16) + 16) + 8 + (recs ? REC_DW * 4 + 4 : 0) +
+    return (size_t)k * ((full_state ? STATE_DW * 4 : 18) + 16) + 8 + (recs ? REC_DW * 4 + 4 : 0) +
            (rows ? sizeof(fk_row_hdr) + sizeof(fk_seat) * (size_t)k : 0);
 }
 
@@ -367,6 +367,13 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
     HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 512, c->stream));
     sa.state = static_cast<uint32_t *>(c->state.p);
     sa.inc = static_cast<uint4 *>(c->inc.p);
+    sa.seat_idx = nullptr;
+    if (sa.perm_T && !full_state) { // the seats' strategy indices, resolved once by the seed kernel
+        rc = ensure(c, c->seat_idx, (size_t)sa.n_games * sa.k * 2);
+        if (rc) return rc;
+        sa.seat_idx = static_cast<uint16_t *>(c->seat_idx.p);
+    }
+    pa.seat_idx = sa.seat_idx;
     if (sa.blocks) { // batched H2H: game -> block map first (the schedule classes and the seed kernel read it)
         hipLaunchKernelGGL(fk_block_map_kernel, dim3((sa.n_games + 255u) / 256u), dim3(256), 0, c->stream, sa.blocks, sa.n_blocks,
                            sa.n_games, const_cast<uint32_t *>(sa.game_block));
@@ -553,7 +560,7 @@ void fk_destroy(fk_ctx *c) {
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     c->comm = nullptr;
     release(c->comm_buf);
-    for (DevBuf *b : {&c->strat, &c->perm, &c->draws, &c->state, &c->inc, &c->recs, &c->rec0, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist,
+    for (DevBuf *b : {&c->strat, &c->perm, &c->draws, &c->state, &c->inc, &c->seat_idx, &c->recs, &c->rec0, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist,
                       &c->coords, &c->order, &c->inv, &c->slow, &c->score_lut, &c->discard_lut, &c->classes, &c->blocks, &c->game_block,
                       &c->block_out, &c->stats})
         release(*b);

@@ -83,6 +83,9 @@ struct SeedArgs {
     uint32_t *state;         // [n_games][k][state_dw]: state_dw = 4 (PCG state {lo, hi} only, read once per game) or
                              // STATE_DW (the full initial state record, strategy index included)
     uint32_t state_dw;
+    uint16_t *seat_idx;      // nullable, [n_games][k]: strategy index of every seat at the game's slot (tournament launches with
+                             // state_dw == 4): the game kernel's hand-over reads it instead of redoing three integer
+                             // divisions and a permutation gather per seat
     uint4 *inc;              // [n_games][k] PCG increment {lo, hi}: its own plane, re-read at every turn start by
                              // lean-record kernels (a compact plane keeps the increments of all resident games in L2)
     const int32_t *seat_strategy; // LIST mode, state_dw == STATE_DW: [n_games][k] strategy indices
@@ -112,6 +115,7 @@ struct PlayArgs {
     uint32_t *state;             // seat state records, see SeedArgs (GS instances update them in place)
     uint32_t state_dw;
     const uint4 *inc;
+    const uint16_t *seat_idx;    // nullable, see SeedArgs
     const uint32_t *sched;       // nullable: ticket -> game id (longest-first schedule; state records are stored by ticket)
     unsigned long long *tally;   // [S][26] (LDS-tally launches only: one batch)
     uint32_t *rec0;              // nullable: [n_games] d0 of the result records
@@ -631,6 +635,8 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
                 else if (a.blocks) idx = 2u * blk + s;
                 dst[1] = make_uint4(0u, 0u, 0u, 0u);
                 dst[2] = make_uint4(0u, 0u, 0u, idx);
+            } else if (a.seat_idx && a.perm_T) {
+                a.seat_idx[rec] = (uint16_t)perm_at(a.perm_T, a.S, a.perm_slots, sh_local, g_local * a.k + s);
             }
             a.inc[rec] = make_uint4((uint32_t)r.inc_lo, (uint32_t)(r.inc_lo >> 32), (uint32_t)r.inc_hi, (uint32_t)(r.inc_hi >> 32));
         }
@@ -887,7 +893,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             for (uint32_t s = 0; s < K; ++s) {
                 const uint32_t *src = G(s);
                 const uint4 stv = *reinterpret_cast<const uint4 *>(src);
-                const uint32_t idx = (a.state_dw == STATE_DW) ? src[R_IDX] : strategy_index(id, s);
+                const uint32_t idx = (a.state_dw == STATE_DW) ? src[R_IDX]
+                                     : a.seat_idx            ? (uint32_t)a.seat_idx[(size_t)slot * K + s]
+                                                             : strategy_index(id, s);
                 L(F_LO0, s) = stv.x;
                 L(F_LO1, s) = stv.y;
                 L(F_HI0, s) = stv.z;
