@@ -617,6 +617,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
             ss_absorb64(gp, a.order);
             ss_absorb64(gp, a.game0 + g_local);
         }
+        uint64_t idx_pack = 0;
         for (uint32_t s = 0; s < a.k; ++s) {
             SeedPool sp = gp;
             ss_absorb64(sp, seat0 + s); // seat_index
@@ -635,8 +636,15 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
                 else if (a.blocks) idx = 2u * blk + s;
                 dst[1] = make_uint4(0u, 0u, 0u, 0u);
                 dst[2] = make_uint4(0u, 0u, 0u, idx);
-            } else if (a.seat_idx && a.perm_T) {
-                a.seat_idx[rec] = (uint16_t)perm_at(a.perm_T, a.S, a.perm_slots, sh_local, g_local * a.k + s);
+            } else if (a.seat_idx && a.perm_T) { // packed: one 8-byte store per four seats, 4-byte per two (fewer partial lines)
+                const uint64_t idx = perm_at(a.perm_T, a.S, a.perm_slots, sh_local, g_local * a.k + s);
+                const uint32_t group = (a.k % 4u == 0u) ? 4u : (a.k % 2u == 0u) ? 2u : 1u, pos = s % group;
+                idx_pack = (pos == 0u ? 0ull : idx_pack) | (idx << (16u * pos));
+                if (pos + 1u == group) {
+                    if (group == 4u) *reinterpret_cast<uint64_t *>(a.seat_idx + rec - 3u) = idx_pack;
+                    else if (group == 2u) *reinterpret_cast<uint32_t *>(a.seat_idx + rec - 1u) = (uint32_t)idx_pack;
+                    else a.seat_idx[rec] = (uint16_t)idx_pack;
+                }
             }
             a.inc[rec] = make_uint4((uint32_t)r.inc_lo, (uint32_t)(r.inc_lo >> 32), (uint32_t)r.inc_hi, (uint32_t)(r.inc_hi >> 32));
         }
