@@ -75,6 +75,14 @@ def work_per_game(rows: np.ndarray, k: int) -> dict:
     return {"rolls_per_game": float(R.mean()), "turns_per_game": float(T.mean()), "ops_per_game": float(W.mean())}
 
 
+def work_from_seat_stats(stats: np.ndarray, games: int, k: int) -> dict:
+    """The same R, T, W from the all-seat integer statistics of a launch (fk_tournament_run_stats: column 15 = sum of seat
+    rolls, column 6 = sum of seat turns) — exact over ALL games of a full-size launch, no rows materialised."""
+    R = float(stats[..., 15].sum()) / games
+    T = float(stats[..., 6].sum()) / games
+    return {"rolls_per_game": R, "turns_per_game": T, "ops_per_game": 229.0 * R + 30.0 * T + 850.0 * k}
+
+
 def add_timing(acc: dict, t: dict) -> dict:
     """Accumulate fk_timing records (HIP events on the engine's stream) over the engine calls of a step."""
     for key in ("play_ms", "seed_ms", "perm_ms", "play_launches", "games"):
@@ -125,9 +133,11 @@ class Tournament:
         assert np.array_equal(tot[:, 1], tot[:, 2] + tot[:, 3]) and int(tot[:, 0].sum()) * self.k == int(tot[:, 2].sum())
 
     def sample(self, eng):
-        # rows of one launch (of the step's own size when that fits a few GB of rows) -> measured R, T of SURVEY 8d
-        res = eng.tournament(self.table, self.k, self.root, 0, self.sample_shuffles, want_rows=True)
-        return res["rows"], self.k, f"shuffles 0..{self.sample_shuffles - 1} ({self.sample_shuffles * self.gps} games)"
+        # measured R, T of SURVEY 8d over ALL games of one launch of the step's own size (every fk_play_kernel launch of the
+        # process has the step's shape, so the rocprofv3 per-kernel average stays comparable): the all-seat statistics
+        res = eng.tournament(self.table, self.k, self.root, 0, self.shuffles, want_seat_stats=True)
+        games = self.shuffles * self.gps
+        return work_from_seat_stats(res["seat_stats"], games, self.k), None, f"all {games} games of shuffles 0..{self.shuffles - 1} (all-seat statistics of one launch)"
 
     def hbm_bytes_per_game(self) -> int:
         # counts-only: seat seeds read once (32 B x k) + 2 B x k permutation entries + 4 B schedule entry per game
@@ -207,11 +217,12 @@ class KSweep:
         assert sum(int(tot[i][:, 1].sum()) // k for i, k in enumerate(self.ks)) == games, "exposure conservation failed"
 
     def sample(self, eng):
-        # W of the sweep = games-weighted mean over k (equal games per k): one small rows launch per k
-        rows = {}
+        # W of the sweep = games-weighted mean over k (equal games per k): all-seat statistics of one full-size launch per k
+        parts = []
         for k in self.ks:
-            rows[k] = eng.tournament(self.table, k, self.root, 0, max(1, 500_000 // (self.S // k)), want_rows=True)["rows"]
-        return rows, None, "per k: first ~5*10^5 games of the sweep"
+            res = eng.tournament(self.table, k, self.root, 0, self.n_sh[k], want_seat_stats=True)
+            parts.append(work_from_seat_stats(res["seat_stats"], self.n_sh[k] * (self.S // k), k))
+        return {key: float(np.mean([p[key] for p in parts])) for key in parts[0]}, None, "per k: all games of one full-size launch (all-seat statistics)"
 
     def hbm_bytes_per_game(self) -> int:
         return int(np.mean([32 * k + 2 * k + 4 for k in self.ks]))
@@ -509,11 +520,7 @@ def main() -> None:
 
         # live per-game work (R, T of SURVEY section 8d) from the rows of a launch of the same workload
         rows, k_s, sample_desc = wl.sample(eng)
-        if isinstance(rows, dict):
-            parts = [work_per_game(r, k) for k, r in rows.items()]
-            wpg = {key: float(np.mean([p[key] for p in parts])) for key in parts[0]}
-        else:
-            wpg = work_per_game(rows, k_s)
+        wpg = dict(rows) if isinstance(rows, dict) else work_per_game(rows, k_s)
         del rows
         wpg["sample"] = sample_desc
         # dominant kernel: average launch duration and games per launch over the last engine call of every timed step

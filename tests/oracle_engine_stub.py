@@ -19,6 +19,35 @@ for p in (ROOT, ROOT / "oracle"):
 import pyoracle as po  # noqa: E402
 
 
+def seat_stats_from_rows(rows: np.ndarray, k: int, S: int, gps: int, spb: int) -> np.ndarray:
+    """The integer accumulators of fk_tournament_run_stats computed from rows, the way the reference's
+    analysis/all_player_metrics.py:257-340 sums them (one exposure per seat; rank / loss_margin over completed games)."""
+    n = len(rows)
+    batch = (np.arange(n) // gps) // max(spb, 1)
+    out = np.zeros((int(batch.max()) + 1 if n else 1, S, 31), dtype=np.int64)
+    completed = rows["status"] == 0
+    winning = rows["seats"]["score"].astype(np.int64).max(axis=1)
+    rounds = rows["n_rounds"].astype(np.int64)
+    for seat in range(k):
+        x = rows["seats"][:, seat]
+        strat = x["strategy"].astype(np.int64)
+        score, turns = x["score"].astype(np.int64), x["n_turns"].astype(np.int64)
+        tmr = turns - rounds
+        rank = x["rank"].astype(np.int64)
+        margin = np.where(completed, winning - score, 0)
+        cols = {0: np.ones(n, dtype=np.int64), 1: completed.astype(np.int64), 2: (~completed).astype(np.int64),
+                3: (completed & (rows["winner_seat"] == seat)).astype(np.int64), 4: score, 5: score * score, 6: turns, 7: turns * turns,
+                8: (tmr != 0).astype(np.int64), 9: tmr, 10: tmr * tmr, 11: np.where(completed, rank, 0),
+                12: np.where(completed, rank * rank, 0), 13: margin, 14: margin * margin}
+        for j, name in enumerate(("rolls", "farkles", "highest_turn", "hot_dice", "smart_five_uses", "n_smart_five_dice",
+                                  "smart_one_uses", "n_smart_one_dice")):
+            v = x[name].astype(np.int64)
+            cols[15 + 2 * j], cols[16 + 2 * j] = v, v * v
+        for c, v in cols.items():
+            np.add.at(out[:, :, c], (batch, strat), v)
+    return out
+
+
 class Engine:
     def __init__(self, device: int = 0):
         self.device = device
@@ -45,14 +74,18 @@ class Engine:
                 "play_grid": 0, "play_lds_bytes": 0, "games": self._games}
 
     def tournament(self, table, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=None, target_score=10_000,
-                   max_rounds=200, overrides=None, want_rows=False, want_perms=False) -> dict:
+                   max_rounds=200, overrides=None, want_rows=False, want_perms=False, want_seat_stats=False) -> dict:
         t = np.ascontiguousarray(table).view(po.STRATEGY_DTYPE)
         ov = None if overrides is None or len(overrides) == 0 else np.ascontiguousarray(overrides).view(po.OVERRIDE_DTYPE)
         res = po.tournament(t, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=shuffles_per_batch,
-                            target_score=target_score, max_rounds=max_rounds, overrides=ov, want_rows=want_rows,
+                            target_score=target_score, max_rounds=max_rounds, overrides=ov, want_rows=want_rows or want_seat_stats,
                             want_perms=want_perms, n_threads=2)
         self._games = (shuffle_end - shuffle_begin) * (len(t) // k)
-        return {"tally": res["tally"], "rows": res["rows"], "perms": res["perms"]}
+        stats = None
+        if want_seat_stats:
+            spb = (shuffle_end - shuffle_begin) if not shuffles_per_batch else shuffles_per_batch
+            stats = seat_stats_from_rows(res["rows"], k, len(t), len(t) // k, spb)
+        return {"tally": res["tally"], "rows": res["rows"] if want_rows else None, "perms": res["perms"], "seat_stats": stats}
 
     def play_games(self, coords, table, seat_strategy, k, target_score=10_000, max_rounds=200):
         return po.play_games(np.ascontiguousarray(coords).view(po.COORD_DTYPE), np.ascontiguousarray(table).view(po.STRATEGY_DTYPE),

@@ -180,36 +180,9 @@ def test_h2h_production_shape_throughput_sanity(eng):
 
 
 def _seat_stats_from_rows(rows: np.ndarray, k: int, S: int, gps: int, spb: int) -> np.ndarray:
-    """The same integer accumulators computed from the oracle's rows the way the reference's all_player_metrics.py does
-    (one exposure per seat; rank / loss_margin over completed games only)."""
-    from farkle_ii_amd.backend import SEAT_STAT_COLS
+    from oracle_engine_stub import seat_stats_from_rows
 
-    n = len(rows)
-    batch = (np.arange(n) // gps) // spb
-    out = np.zeros((int(batch.max()) + 1, S, SEAT_STAT_COLS), dtype=np.int64)
-    completed = rows["status"] == 0
-    scores = rows["seats"]["score"].astype(np.int64)
-    winning = scores.max(axis=1)
-    rounds = rows["n_rounds"].astype(np.int64)
-    for seat in range(k):
-        x = rows["seats"][:, seat]
-        strat = x["strategy"].astype(np.int64)
-        score, turns = x["score"].astype(np.int64), x["n_turns"].astype(np.int64)
-        tmr = turns - rounds
-        cols = {0: np.ones(n, dtype=np.int64), 1: completed.astype(np.int64), 2: (~completed).astype(np.int64),
-                3: (completed & (rows["winner_seat"] == seat)).astype(np.int64), 4: score, 5: score * score, 6: turns, 7: turns * turns,
-                8: (tmr != 0).astype(np.int64), 9: tmr, 10: tmr * tmr}
-        rank = x["rank"].astype(np.int64)
-        margin = np.where(completed, winning - score, 0)
-        cols[11], cols[12] = np.where(completed, rank, 0), np.where(completed, rank * rank, 0)
-        cols[13], cols[14] = margin, margin * margin
-        for j, name in enumerate(("rolls", "farkles", "highest_turn", "hot_dice", "smart_five_uses", "n_smart_five_dice",
-                                  "smart_one_uses", "n_smart_one_dice")):
-            v = x[name].astype(np.int64)
-            cols[15 + 2 * j], cols[16 + 2 * j] = v, v * v
-        for c, v in cols.items():
-            np.add.at(out[:, :, c], (batch, strat), v)
-    return out
+    return seat_stats_from_rows(rows, k, S, gps, spb)
 
 
 @pytest.mark.parametrize("k,table_kind", [(2, "g64"), (4, "g64"), (4, "default"), (3, "random")])

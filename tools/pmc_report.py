@@ -1,19 +1,29 @@
 """Summarise the passes of tools/pmc_cfg.sh for the game kernel.
 usage: python tools/pmc_report.py <tag> <rolls_per_launch> [kernel-substring]
 Counters are averaged over the dispatches of the kernel (one launch each)."""
-import collections, csv, glob, sys
+import collections, csv, glob, os, sys
 
 tag, rolls = sys.argv[1], float(sys.argv[2])
 sub = sys.argv[3] if len(sys.argv) > 3 else "fk_play"
 agg: dict[str, float] = {}
-for f in sorted(glob.glob(f"gpurun_out/{tag}_pmc*/**/*_counter_collection.csv", recursive=True)):
+def newest(paths):
+    """one file per directory: the most recent run (gpurun merges every run's files into the same directory)"""
+    best = {}
+    for q in paths:
+        d = os.path.dirname(q)
+        if d not in best or os.path.getmtime(q) > os.path.getmtime(best[d]):
+            best[d] = q
+    return sorted(best.values())
+
+
+for f in newest(glob.glob(f"gpurun_out/{tag}_pmc*/**/*_counter_collection.csv", recursive=True)):
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if sub in r["Kernel_Name"]:
             per[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in per.items():
         agg[k] = sum(v) / len(v)
-for f in sorted(glob.glob(f"gpurun_out/{tag}_stats/**/*_kernel_stats.csv", recursive=True)):
+for f in newest(glob.glob(f"gpurun_out/{tag}_stats/**/*_kernel_stats.csv", recursive=True)):
     print("kernel stats:", f)
     for r in csv.DictReader(open(f)):
         print(f"  {r['Name'][:70]:70s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e6:9.3f} ms min {float(r['MinNs'])/1e6:9.3f} pct {r['Percentage']}")
