@@ -173,21 +173,27 @@ def rows_to_table(rows: np.ndarray, k: int, strategy_ids: Sequence[int], *, root
     def nullable(values, dtype):
         return pa.array(values, type=dtype, mask=mask)
 
+    # string columns without per-row Python objects: seat names are taken from a k-entry dictionary
     rank_order = np.argsort(seats["rank"].astype(np.int64), axis=1, kind="stable")
-    names = np.array([f"P{i + 1}" for i in range(k)], dtype=object)
-    seat_ranks = [list(names[rank_order[i]]) if completed[i] else [None] * k for i in range(n)]
+    names = pa.array([f"P{i + 1}" for i in range(k)], type=pa.string())
+    flat_mask = np.repeat(mask, k)  # a safety-limit game lists k nulls (engine.py:485-489)
+    ranked = names.take(pa.array(rank_order.ravel().astype(np.int32), mask=flat_mask))
+    seat_ranks = pa.ListArray.from_arrays(pa.array(np.arange(0, n * k + 1, k, dtype=np.int32)), ranked,
+                                          type=pa.list_(pa.field("item", pa.string(), nullable=True)))
+    winner_seat = names.take(pa.array(w.astype(np.int32), mask=mask))
+    status = pa.array(["completed", "safety_limit"], type=pa.string()).take(pa.array(mask.astype(np.int32)))
     cols: dict[str, Any] = {
         "root_seed": pa.array(full(root_seed, np.int64)), "k": pa.array(full(k, np.int16)),
         "shuffle_index": pa.array(full(shuffle_index, np.int64)), "game_index": pa.array(full(game_index, np.int32)),
         "deterministic_batch_id": pa.array(full(deterministic_batch_id, np.int32)),
         "shuffle_seed": pa.array(full(shuffle_seed, np.int64)),
-        "termination_status": pa.array(np.where(completed, "completed", "safety_limit").tolist(), type=pa.string()),
+        "termination_status": status,
         "hit_safety_limit": pa.array(mask), "outcome_schema_version": pa.array(full(OUTCOME_SCHEMA_VERSION, np.int16)),
-        "winner_seat": pa.array([f"P{int(x) + 1}" if c else None for x, c in zip(w, completed)], type=pa.string()),
+        "winner_seat": winner_seat,
         "winner_strategy": nullable(ids[seats["strategy"][ar, w]], pa.int32()),
         "game_seed": pa.array(full(game_seed, np.int64)), "rng_scheme_version": pa.array(full(2, np.int16)),
         "rng_purpose_namespace": pa.array(full(rng_purpose_namespace, np.int32)),
-        "seat_ranks": pa.array(seat_ranks, type=pa.list_(pa.field("item", pa.string(), nullable=True))),
+        "seat_ranks": seat_ranks,
         "winning_score": nullable(win_score.astype(np.int32), pa.int32()),
         "victory_margin": nullable((win_score - (second if k > 1 else 0)).astype(np.int32), pa.int32()),
         "n_rounds": pa.array(rows["n_rounds"].astype(np.int16)),

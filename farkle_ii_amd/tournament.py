@@ -322,6 +322,78 @@ def write_row_shard(row_dir: Path, manifest_path: Path | None, task: ShuffleTask
     return (out, record) if return_record else out
 
 
+def write_row_shards(row_dir: Path, tasks: Sequence[ShuffleTask], rows: np.ndarray, ids: Sequence[int],
+                     game_profile_sha256: str | None = None, *, threads: int = 1, group: int = 1024) -> list[dict]:
+    """Row shards of many shuffles of one (root, k) cell: the same files and manifest records as ``write_row_shard`` per
+    shuffle (run_tournament.py:530-558), but the Arrow conversion runs once per ``group`` shuffles (vectorised over all their
+    rows) and every shard is a zero-copy slice of that table, written by a small thread pool (pyarrow encodes and writes
+    outside the GIL).  Returns the manifest records in task order; the caller appends them."""
+    import os
+
+    import pyarrow.parquet as pq
+
+    if not tasks:
+        return []
+    k = tasks[0].k
+    gps = len(rows) // len(tasks)
+    row_dir.mkdir(parents=True, exist_ok=True)
+    pid = os.getpid()
+    records: list[dict] = []
+
+    def write_one(item):
+        table, task = item
+        out = row_dir / f"rows_{task.root_seed}_{task.k}p_{task.shuffle_index:012d}.parquet"
+        tmp = out.with_suffix(".parquet.tmp")
+        pq.write_table(table, tmp)
+        os.replace(tmp, out)
+        record = {"path": out.name, "rows": gps, "root_seed": task.root_seed, "n_players": task.k,
+                  "shuffle_index": task.shuffle_index, "shuffle_seed": task.shuffle_seed,
+                  "deterministic_batch_id": task.deterministic_batch_id, "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
+                  "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
+                  "outcome_schema_version": OUTCOME_SCHEMA_VERSION, "tournament_method_version": TOURNAMENT_METHOD_VERSION,
+                  "pid": pid}
+        if game_profile_sha256 is not None:  # run_tournament.py:549-553
+            record["game_profile_sha256"] = game_profile_sha256
+        return record
+
+    pool = None
+    arrow_threads = None
+    if threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        import pyarrow as pa
+
+        pool = ThreadPoolExecutor(max_workers=threads)
+        # 32-row files: Arrow's own per-column thread pool only adds contention under several writer threads
+        # (measured: 3.1 ms per shard with it, 0.9 ms without, 8 writers)
+        arrow_threads = pa.cpu_count()
+        pa.set_cpu_count(1)
+    try:
+        for g0 in range(0, len(tasks), group):
+            part = tasks[g0:g0 + group]
+            n = len(part) * gps
+            sh = np.repeat(np.array([t.shuffle_index for t in part], dtype=np.uint64), gps)
+            gi = np.tile(np.arange(gps, dtype=np.uint64), len(part))
+            game_seeds = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=part[0].root_seed, k=k,
+                                                  shuffle_index=sh, game_index=gi, dtype=np.uint32)
+            table = rows_to_table(rows[g0 * gps:g0 * gps + n], k, ids, root_seed=part[0].root_seed, shuffle_index=sh.astype(np.int64),
+                                  game_index=gi.astype(np.int32),
+                                  deterministic_batch_id=np.repeat(np.array([t.deterministic_batch_id for t in part], dtype=np.int32), gps),
+                                  shuffle_seed=np.repeat(np.array([t.shuffle_seed for t in part], dtype=np.int64), gps),
+                                  game_seed=game_seeds.astype(np.int64),
+                                  rng_purpose_namespace=int(urandom.RandomPurpose.TOURNAMENT_GAME))
+            items = [(table.slice(i * gps, gps), t) for i, t in enumerate(part)]
+            records.extend(pool.map(write_one, items) if pool else map(write_one, items))
+    finally:
+        if pool:
+            pool.shutdown()
+        if arrow_threads is not None:
+            import pyarrow as pa
+
+            pa.set_cpu_count(arrow_threads)
+    return records
+
+
 def shuffle_tasks(root_seed: int, k: int, shuffle_begin: int, shuffle_end: int, deterministic_batch_size: int) -> list[ShuffleTask]:
     """Stable ShuffleTask identities of a shuffle range (shuffle_seed = ns-100 uint32 fingerprint)."""
     idx = np.arange(shuffle_begin, shuffle_end, dtype=np.uint64)

@@ -16,7 +16,7 @@ rows_shuffles = int(sys.argv[1]) if len(sys.argv) > 1 else 6400
 base = yaml.safe_load((ROOT / "configs" / "bench_config2.yaml").read_text())
 eng = get_engine()
 acc = {"engine_s": 0.0, "shard_s": 0.0, "calls": 0}
-real_t, real_w = eng.tournament, rt.write_row_shard
+real_t, real_w = eng.tournament, rt.write_row_shards
 
 def timed_tournament(*a, **kw):
     t0 = time.perf_counter()
@@ -34,7 +34,7 @@ def timed_shard(*a, **kw):
         acc["shard_s"] += time.perf_counter() - t0
 
 eng.tournament = timed_tournament
-rt.write_row_shard = timed_shard
+rt.write_row_shards = timed_shard
 out = {"config": "configs/bench_config2.yaml (k=2, 64-strategy grid, root seed 42), `farkle run --metrics`", "runs": {}}
 with tempfile.TemporaryDirectory(prefix="fk_e2e_") as tmp:
     def run(name, sim_extra, batching=None, screening=None):
@@ -53,7 +53,7 @@ with tempfile.TemporaryDirectory(prefix="fk_e2e_") as tmp:
         games = plan["required_games"]
         out["runs"][name] = {"games": games, "shuffles": plan["required_shuffles"], "wall_s": wall, "games_per_s": games / wall,
                              "engine_s": acc["engine_s"], "engine_calls": acc["calls"], "host_s": wall - acc["engine_s"],
-                             "row_shard_writer_thread_s": acc["shard_s"], "row_writer_threads": runner.ROW_WRITER_THREADS}
+                             "row_shard_write_s": acc["shard_s"], "row_writer_threads": runner.ROW_WRITER_THREADS}
         print(name, json.dumps(out["runs"][name]), flush=True)
     run("warm", {}, {"target_batches": 4, "min_shuffles_per_batch": 8}, {"resolution_delta": 0.3})  # import / first-launch costs out of the way
     del out["runs"]["warm"]
@@ -63,10 +63,10 @@ with tempfile.TemporaryDirectory(prefix="fk_e2e_") as tmp:
     run("rows_on", {"row_dir": "rows", "metric_chunk_dir": "metric_chunks"}, {"target_batches": 100, "min_shuffles_per_batch": per_batch}, {"resolution_delta": 0.5})
 r = out["runs"]
 out["host_bottleneck"] = ("rows on: one parquet file + one manifest line per shuffle of 32 games (the reference's row-shard format, "
-                          "run_tournament.py:530-558): %.2f ms of host wall time per shard (pyarrow + Python on %d writer threads, "
-                          "%.1f ms of thread time each) against %.4f ms of engine time per shuffle"
-                          % (1e3 * r["rows_on"]["host_s"] / r["rows_on"]["shuffles"], runner.ROW_WRITER_THREADS,
-                             1e3 * r["rows_on"]["row_shard_writer_thread_s"] / r["rows_on"]["shuffles"],
+                          "run_tournament.py:530-558): %.2f ms of host wall time per shard, %.2f ms of it Arrow conversion (one per 1 024 "
+                          "shuffles) + parquet encoding + file creation on %d writer threads, against %.4f ms of engine time per shuffle"
+                          % (1e3 * r["rows_on"]["host_s"] / r["rows_on"]["shuffles"],
+                             1e3 * r["rows_on"]["row_shard_write_s"] / r["rows_on"]["shuffles"], runner.ROW_WRITER_THREADS,
                              1e3 * r["rows_on"]["engine_s"] / r["rows_on"]["shuffles"]))
 out["reference_published"] = {"games_per_s_1_worker": 279.0, "games_per_s_12_workers": 1142.9,
                               "where": "docs/remediation/task4c_simulation_execution_report.md:109-116 (Ryzen 7 3700X, rows + metrics)"}
