@@ -123,8 +123,13 @@ class Tournament:
     def games_per_step(self, world: int) -> int:
         return self.shuffles * self.gps * world
 
-    def step(self, eng, index: int, rank: int, world: int):
+    def step(self, eng, index: int, rank: int, world: int, next_index: int | None = None):
         first = (index * world + rank) * self.shuffles
+        if next_index is not None and hasattr(eng, "hint_next"):
+            # the step after this one: its permutations and seat seeding are prepared in the drain tail of this step's game
+            # kernel (both steps are inside the timed region; the last timed step hints nothing)
+            nxt = (next_index * world + rank) * self.shuffles
+            eng.hint_next(nxt, nxt + self.shuffles)
         res = eng.tournament(self.table, self.k, self.root, first, first + self.shuffles)
         return res["tally"][0], self.shuffles * self.gps, add_timing({}, eng.timing())
 
@@ -198,7 +203,7 @@ class KSweep:
     def games_per_step(self, world: int) -> int:
         return sum(self.n_sh[k] * (self.S // k) for k in self.ks)
 
-    def step(self, eng, index: int, rank: int, world: int):
+    def step(self, eng, index: int, rank: int, world: int, next_index: int | None = None):
         from farkle_ii_amd.distributed import shard_shuffle_range
 
         out = np.zeros(self.local_shape, dtype=np.int64)
@@ -274,7 +279,7 @@ class H2H:
     def games_per_step(self, world: int) -> int:
         return len(self.blocks) * self.per_block  # completed games required; attempts are reported separately
 
-    def step(self, eng, index: int, rank: int, world: int):
+    def step(self, eng, index: int, rank: int, world: int, next_index: int | None = None):
         out = np.zeros(self.local_shape, dtype=np.int64)
         timing: dict = {}
         mine = list(range(rank, len(self.blocks), world))
@@ -482,8 +487,8 @@ def main() -> None:
     if distributed:
         dist.reduce(warm, dst=0, op=dist.ReduceOp.SUM)
     local = np.zeros(wl.local_shape, dtype=np.int64)
-    for i in range(args.warmup):
-        tally, _, _ = wl.step(eng, i, rank, n_gpus)
+    for i in range(args.warmup):  # (the last warm-up step does not prepare the first timed step)
+        tally, _, _ = wl.step(eng, i, rank, n_gpus, next_index=i + 1 if i + 1 < args.warmup else None)
         local += tally
     reduce_to_rank0(local)
     local[:] = 0
@@ -492,7 +497,7 @@ def main() -> None:
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        tally, g, st = wl.step(eng, args.warmup + i, rank, n_gpus)
+        tally, g, st = wl.step(eng, args.warmup + i, rank, n_gpus, next_index=args.warmup + i + 1 if i + 1 < args.steps else None)
         local += tally  # host add of the step's int64 tally
         my_games += g
         add_timing(t, st)  # HIP events on the engine's stream, summed over every engine call of the timed steps

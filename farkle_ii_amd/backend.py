@@ -94,7 +94,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
 
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
-            "fk_tournament_run", "fk_tournament_run_stats", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
+            "fk_tournament_run", "fk_tournament_run_stats", "fk_tournament_hint_next", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
             "fk_debug_dice", "fk_debug_dice_state", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy"]
 _lib = None
 
@@ -220,6 +220,12 @@ class Engine:
             C.c_int32(len(ov)), _p(tally), _p(rows), _p(perms), _p(stats)))
         return {"tally": tally[:n_batches], "rows": rows, "perms": perms,
                 "seat_stats": None if stats is None else stats[:n_batches]}
+
+    def hint_next(self, shuffle_begin: int, shuffle_end: int, need_state: bool = False) -> None:
+        """The call after the next ``tournament`` call will play this shuffle range of the same table, k and root: its
+        permutations and seat seeding are then prepared in the drain tail of the next call's game kernel."""
+        self._check(self._lib.fk_tournament_hint_next(self._ctx, C.c_uint64(shuffle_begin), C.c_uint64(shuffle_end),
+                                                      C.c_int32(1 if need_state else 0)))
 
     def play_games(self, coords: np.ndarray, table: np.ndarray, seat_strategy, k: int, target_score: int = 10_000,
                    max_rounds: int = 200) -> np.ndarray:

@@ -25,20 +25,50 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// Everything a chunk's preparation (permutations, schedule, seat seeding) writes and its game kernel reads.  There are two
+// sets: while the game kernel of one chunk runs, the preparation of the next chunk (of this call, or — after
+// fk_tournament_hint_next — of the next call) is enqueued on a low-priority stream into the other set; its kernels
+// find free CUs only as the persistent game kernel's blocks retire, i.e. they fill its drain tail.
+struct ChunkDesc {
+    uint64_t epoch = 0, root = 0, sh0 = 0; // strategy-table upload epoch, root seed, first shuffle
+    uint32_t n_sh = 0, S = 0, k = 0, state_dw = 0, sched = 0, slots = 0;
+    bool operator==(const ChunkDesc &o) const {
+        return epoch == o.epoch && root == o.root && sh0 == o.sh0 && n_sh == o.n_sh && S == o.S && k == o.k && state_dw == o.state_dw &&
+               sched == o.sched && slots == o.slots;
+    }
+};
+
+struct ChunkSet {
+    DevBuf perm, draws, state, inc, seat_idx, order, classes, misc;
+    hipEvent_t ready = nullptr;                       // recorded behind the preparation kernels
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // permutation begin / end, seeding begin / end (timing)
+    bool prepared = false;
+    ChunkDesc desc;
+    SeedArgs sa{}; // the prepared chunk's buffers as the kernels see them
+};
+
 struct fk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t prep_stream = nullptr; // low priority: preparation of the next chunk
+    ChunkSet sets[2];
+    int cur = 0;
+    uint64_t table_epoch = 0;
+    bool hint_valid = false;           // fk_tournament_hint_next
+    uint64_t hint_begin = 0, hint_end = 0;
+    int32_t hint_state = 0, pipeline = 1;
     hipDeviceProp_t prop{};
     std::string err;
     fk_timing timing{};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // see TimerSlot
+    hipEvent_t main_idle = nullptr; // recorded on the main stream in front of a game kernel: what a side-stream preparation waits for
     struct PendingTimer {
         float *acc;
         hipEvent_t a, b;
     };
     std::vector<PendingTimer> pending; // kernel timers recorded on the stream, read after the chunk's one sync
-    DevBuf strat, perm, draws, state, inc, seat_idx, recs, rec0, tally, rows, misc, ov, seatlist, coords, order, inv, slow, score_lut, discard_lut,
-        classes, blocks, game_block, block_out, stats, dbg[6];
+    DevBuf strat, recs, rec0, tally, rows, ov, seatlist, coords, inv, slow, score_lut, discard_lut, blocks, game_block, block_out, stats,
+        dbg[6];
     std::vector<uint2> strat_host;   // the packed table currently resident in `strat` (uploaded once per table)
     int32_t longest_first = 1;
     int32_t blocks_per_cu = 0; // 0 = as many as fit
@@ -56,6 +86,8 @@ struct fk_ctx {
     int comm_rank = 0, comm_world = 1;
     DevBuf comm_buf;
 };
+
+#define CSET(c) ((c)->sets[(c)->cur])
 
 namespace {
 
@@ -127,6 +159,9 @@ int upload_strategies(fk_ctx *c, const fk_strategy *s, int64_t S) {
     if (packed.size() == c->strat_host.size() && memcmp(packed.data(), c->strat_host.data(), packed.size() * sizeof(uint2)) == 0)
         return FK_OK;
     c->strat_host.clear();
+    c->table_epoch += 1; // anything prepared for the previous table is void
+    for (auto &cs : c->sets) cs.prepared = false;
+    if (c->prep_stream) HIPCHK(c, hipStreamSynchronize(c->prep_stream));
     rc = ensure(c, c->strat, sizeof(uint2) * (size_t)S);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->strat.p, packed.data(), sizeof(uint2) * (size_t)S, hipMemcpyHostToDevice, c->stream));
@@ -343,57 +378,69 @@ int upload_overrides(fk_ctx *c, std::vector<DevOverride> &dov) {
     return FK_OK;
 }
 
+
+// Preparation of one chunk into chunk set `si` on `st`: (batched H2H) game -> block map, schedule class sizes, seat seeding.
+// Fills the pointers of `sa`.  `full_state`: 48-byte state records (state-store instances, rows, all-seat statistics).
+int seed_stage(fk_ctx *c, int si, hipStream_t st, SeedArgs &sa, bool full_state, bool timed) {
+    ChunkSet &cs = c->sets[si];
+    sa.state_dw = full_state ? STATE_DW : 4u;
+    int rc = ensure(c, cs.state, (size_t)sa.n_games * sa.k * sa.state_dw * 4);
+    if (rc) return rc;
+    rc = ensure(c, cs.inc, (size_t)sa.n_games * sa.k * 16);
+    if (rc) return rc;
+    // misc: [0] ticket counter (hammered by atomics), [16] error record, [256] schedule class cursors of the seed kernel
+    rc = ensure(c, cs.misc, 512);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(cs.misc.p, 0, 512, st));
+    sa.state = static_cast<uint32_t *>(cs.state.p);
+    sa.inc = static_cast<uint4 *>(cs.inc.p);
+    sa.seat_idx = nullptr;
+    if (sa.perm_T && !full_state) { // the seats' strategy indices, resolved once by the seed kernel
+        rc = ensure(c, cs.seat_idx, (size_t)sa.n_games * sa.k * 2);
+        if (rc) return rc;
+        sa.seat_idx = static_cast<uint16_t *>(cs.seat_idx.p);
+    }
+    if (sa.blocks) { // batched H2H: game -> block map first (the schedule classes and the seed kernel read it)
+        hipLaunchKernelGGL(fk_block_map_kernel, dim3((sa.n_games + 255u) / 256u), dim3(256), 0, st, sa.blocks, sa.n_blocks,
+                           sa.n_games, const_cast<uint32_t *>(sa.game_block));
+        HIPCHK(c, hipGetLastError());
+    }
+    if ((sa.perm_T || sa.blocks) && c->longest_first) {
+        rc = ensure(c, cs.order, (size_t)sa.n_games * 4);
+        if (rc) return rc;
+        sa.sched = static_cast<uint32_t *>(cs.order.p);
+        sa.sched_ctr = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(cs.misc.p) + 256);
+        rc = ensure(c, cs.classes, 64);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(cs.classes.p, 0, 64, st));
+        sa.class_ctr = static_cast<const uint32_t *>(cs.classes.p);
+        sa.patience = static_cast<const uint8_t *>(c->slow.p);
+    } else {
+        sa.sched = nullptr;
+    }
+    if (timed) (void)hipEventRecord(cs.ev[2], st);
+    if (sa.sched) // class sizes first: a game's ticket is class offset + rank
+        hipLaunchKernelGGL(fk_class_count_kernel, dim3(std::min<uint32_t>((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK, 1024u)), dim3(SEED_BLOCK), 0,
+                           st, sa.perm_T, sa.perm_slots, sa.S, sa.k, sa.n_sh, sa.n_games, sa.patience,
+                           sa.blocks ? sa.game_block : nullptr, static_cast<uint32_t *>(cs.classes.p));
+    hipLaunchKernelGGL(fk_seed_kernel, dim3((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK), dim3(SEED_BLOCK), 0, st, sa);
+    if (timed) (void)hipEventRecord(cs.ev[3], st);
+    HIPCHK(c, hipGetLastError());
+    return FK_OK;
+}
+
 // bytes of device workspace one game needs in a chunk (state records, increments, schedule, result record, row)
 size_t game_workspace_bytes(int32_t k, bool full_state, bool recs, bool rows) {
     return (size_t)k * ((full_state ? STATE_DW * 4 : 18) + 16) + 8 + (recs ? REC_DW * 4 + 4 : 0) +
            (rows ? sizeof(fk_row_hdr) + sizeof(fk_seat) * (size_t)k : 0);
 }
 
-// Seeds + games of one chunk of `n_games` games: fills the state / increment planes, plays, checks the error record.
-// `want_state`: the final state records of every seat must be in the state store afterwards (rows, all-seat statistics).
-// `want_rec0` / `want_recs`: the rec0 word / the full result record of every game.  Post-passes are the caller's.
-int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &plan, bool want_state, bool want_rec0, bool want_recs,
-              int64_t game_base, const char *what) {
-    SeedArgs sa = sa_in;
-    const bool full_state = plan.gs || want_state;
-    sa.state_dw = full_state ? STATE_DW : 4u;
-    int rc = ensure(c, c->state, (size_t)sa.n_games * sa.k * sa.state_dw * 4);
-    if (rc) return rc;
-    rc = ensure(c, c->inc, (size_t)sa.n_games * sa.k * 16);
-    if (rc) return rc;
-    // misc: [0] ticket counter (hammered by atomics), [16] error record, [256] schedule class cursors of the seed kernel
-    rc = ensure(c, c->misc, 512);
-    if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->misc.p, 0, 512, c->stream));
-    sa.state = static_cast<uint32_t *>(c->state.p);
-    sa.inc = static_cast<uint4 *>(c->inc.p);
-    sa.seat_idx = nullptr;
-    if (sa.perm_T && !full_state) { // the seats' strategy indices, resolved once by the seed kernel
-        rc = ensure(c, c->seat_idx, (size_t)sa.n_games * sa.k * 2);
-        if (rc) return rc;
-        sa.seat_idx = static_cast<uint16_t *>(c->seat_idx.p);
-    }
-    pa.seat_idx = sa.seat_idx;
-    if (sa.blocks) { // batched H2H: game -> block map first (the schedule classes and the seed kernel read it)
-        hipLaunchKernelGGL(fk_block_map_kernel, dim3((sa.n_games + 255u) / 256u), dim3(256), 0, c->stream, sa.blocks, sa.n_blocks,
-                           sa.n_games, const_cast<uint32_t *>(sa.game_block));
-        HIPCHK(c, hipGetLastError());
-    }
-    if ((sa.perm_T || sa.blocks) && c->longest_first) {
-        rc = ensure(c, c->order, (size_t)sa.n_games * 4);
-        if (rc) return rc;
-        sa.sched = static_cast<uint32_t *>(c->order.p);
-        sa.sched_ctr = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(c->misc.p) + 256);
-        rc = ensure(c, c->classes, 64);
-        if (rc) return rc;
-        HIPCHK(c, hipMemsetAsync(c->classes.p, 0, 64, c->stream));
-        sa.class_ctr = static_cast<const uint32_t *>(c->classes.p);
-        sa.patience = static_cast<const uint8_t *>(c->slow.p);
-        pa.sched = sa.sched;
-    } else {
-        sa.sched = nullptr;
-        pa.sched = nullptr;
-    }
+// The game kernel of the chunk prepared in the current chunk set, on the main stream.  `want_state`: the final state records
+// of every seat must be in the state store afterwards (rows, all-seat statistics); `want_rec0` / `want_recs`: the rec0 word /
+// the full result record of every game.  Launch only: the caller checks the error record (finish_play).
+int launch_play_stage(fk_ctx *c, const SeedArgs &sa, PlayArgs &pa, const LaunchPlan &plan, bool want_state, bool want_rec0, bool want_recs) {
+    ChunkSet &cs = CSET(c);
+    int rc;
     if (want_rec0) {
         rc = ensure(c, c->rec0, (size_t)sa.n_games * 4);
         if (rc) return rc;
@@ -402,24 +449,16 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
         rc = ensure(c, c->recs, (size_t)sa.n_games * REC_DW * 4);
         if (rc) return rc;
     }
-    {
-        Timer t(c, &c->timing.seed_ms, SLOT_SEED);
-        if (sa.sched) // class sizes first: a game's ticket is class offset + rank
-            hipLaunchKernelGGL(fk_class_count_kernel, dim3(std::min<uint32_t>((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK, 1024u)), dim3(SEED_BLOCK), 0,
-                               c->stream, sa.perm_T, sa.perm_slots, sa.S, sa.k, sa.n_sh, sa.n_games, sa.patience,
-                               sa.blocks ? sa.game_block : nullptr, static_cast<uint32_t *>(c->classes.p));
-        hipLaunchKernelGGL(fk_seed_kernel, dim3((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK), dim3(SEED_BLOCK), 0, c->stream, sa);
-        t.stop();
-        HIPCHK(c, hipGetLastError());
-    }
+    pa.sched = sa.sched;
+    pa.seat_idx = sa.seat_idx;
     pa.state = sa.state;
     pa.state_dw = sa.state_dw;
     pa.inc = sa.inc;
     pa.rec0 = want_rec0 ? static_cast<uint32_t *>(c->rec0.p) : nullptr;
     pa.recs = want_recs ? static_cast<uint32_t *>(c->recs.p) : nullptr;
     pa.gs_out = (want_state && !plan.gs) ? 1u : 0u;
-    pa.ticket = static_cast<uint32_t *>(c->misc.p);
-    pa.err = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(c->misc.p) + 16);
+    pa.ticket = static_cast<uint32_t *>(cs.misc.p);
+    pa.err = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(cs.misc.p) + 16);
     pa.batch_threshold = (uint32_t)std::max(1, std::min(64, c->batch_threshold));
     pa.use_lds_tally = plan.lds_tally ? 1u : 0u;
     {
@@ -436,16 +475,118 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
     c->timing.play_grid = plan.grid;
     c->timing.play_lds_bytes = (int32_t)plan.lds;
     c->timing.games += sa.n_games;
-    const int rc_dev = check_device_error(c, pa.err, game_base, what); // synchronises the stream
+    return FK_OK;
+}
+
+// waits for the game kernel, reads its error record and the kernel timers (incl. those of a preparation on the side stream)
+int finish_play(fk_ctx *c, const PlayArgs &pa, int64_t game_base, const char *what) {
+    const int rc_dev = check_device_error(c, pa.err, game_base, what); // synchronises the main stream
     HIPCHK(c, collect_timers(c));
+    ChunkSet &cs = CSET(c);
+    float ms = 0.f; // the preparation events precede the game kernel on the device (same stream, or waited for through `ready`)
+    if (hipEventElapsedTime(&ms, cs.ev[0], cs.ev[1]) == hipSuccess) c->timing.perm_ms += ms;
+    if (hipEventElapsedTime(&ms, cs.ev[2], cs.ev[3]) == hipSuccess) c->timing.seed_ms += ms;
     return rc_dev;
+}
+
+// Seeds + games of one chunk (explicit game lists, batched H2H): preparation and game kernel back to back on the main stream.
+int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &plan, bool want_state, bool want_rec0, bool want_recs,
+              int64_t game_base, const char *what) {
+    SeedArgs sa = sa_in;
+    ChunkSet &cs = CSET(c);
+    cs.prepared = false;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, cs.ready, 0)); // an unused side-stream preparation may still own the set
+    (void)hipEventRecord(cs.ev[0], c->stream); // no permutations here: an empty interval
+    (void)hipEventRecord(cs.ev[1], c->stream);
+    int rc = seed_stage(c, c->cur, c->stream, sa, plan.gs || want_state, true);
+    if (rc) return rc;
+    rc = launch_play_stage(c, sa, pa, plan, want_state, want_rec0, want_recs);
+    if (rc) return rc;
+    return finish_play(c, pa, game_base, what);
+}
+
+// Tournament chunk: permutations of shuffles [d.sh0, d.sh0 + d.n_sh), then schedule + seat seeding, into chunk set `si` on `st`.
+// `sa` comes back with every pointer the game kernel and the post-passes need.
+int prep_tournament_chunk(fk_ctx *c, int si, hipStream_t st, const ChunkDesc &d, SeedArgs &sa) {
+    ChunkSet &cs = c->sets[si];
+    cs.prepared = false;
+    if (st != c->prep_stream) HIPCHK(c, hipStreamWaitEvent(st, cs.ready, 0)); // an unused side-stream preparation may still own the set
+    const int32_t S = (int32_t)d.S;
+    const uint32_t n_sh = d.n_sh, slots = d.slots, gps = d.S / d.k;
+    const uint32_t perm_blocks = (n_sh + slots - 1u) / slots;
+    const SeedPool perm_prefix = seed_prefix(101u /* SHUFFLE_PERMUTATION */, d.root, (uint64_t)d.k);
+    int rc = ensure(c, cs.perm, (size_t)perm_blocks * S * slots * 2);
+    if (rc) return rc;
+    (void)hipEventRecord(cs.ev[0], st);
+    {
+        const size_t perm_lds = (size_t)slots * S * 2;
+        static bool perm_configured = false;
+        if (!perm_configured) {
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_apply_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_parallel_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_LIMIT - 1024))); // + its static words
+            perm_configured = true;
+        }
+        // large tables: the draws at full occupancy first (fk_perm_draw_kernel); then either the chain-free
+        // permutation (fk_perm_parallel_kernel, one workgroup per shuffle, 14 B of LDS per strategy) or, for tables
+        // beyond its LDS reach, the bare swap chains over LDS arrays (fk_perm_apply_kernel)
+        const bool split = c->perm_split >= 1 || (c->perm_split < 0 && S >= 1024 && n_sh >= 256);
+        const size_t pp_lds = (size_t)S * 14;
+        const bool parallel = split && c->perm_split != 1 && pp_lds <= LDS_LIMIT - 1024;
+        if (parallel) {
+            const uint32_t groups = ((uint32_t)S - 1u + 7u) / 8u, row_u4 = groups + 1u; // a row also holds the S results
+            rc = ensure(c, cs.draws, (size_t)n_sh * row_u4 * 16);
+            if (rc) return rc;
+            hipLaunchKernelGGL(fk_perm_draw_kernel, dim3((n_sh + DRAW_BLOCK - 1u) / DRAW_BLOCK), dim3(DRAW_BLOCK), 0, st,
+                               perm_prefix, d.sh0, n_sh, (uint32_t)S, 1u, row_u4, static_cast<uint4 *>(cs.draws.p));
+            hipLaunchKernelGGL(fk_perm_parallel_kernel, dim3(n_sh), dim3(PP_BLOCK), pp_lds, st,
+                               static_cast<uint4 *>(cs.draws.p), row_u4, n_sh, (uint32_t)S);
+            hipLaunchKernelGGL(fk_perm_block_kernel, dim3(((uint32_t)S + 255u) / 256u, perm_blocks), dim3(256), 0, st,
+                               static_cast<const uint16_t *>(cs.draws.p), row_u4 * 8u, n_sh, (uint32_t)S, slots,
+                               static_cast<uint16_t *>(cs.perm.p));
+        } else if (split) {
+            const uint32_t n_sh_pad = (n_sh + 63u) & ~63u, groups = ((uint32_t)S - 1u + 7u) / 8u;
+            rc = ensure(c, cs.draws, (size_t)groups * n_sh_pad * 16);
+            if (rc) return rc;
+            hipLaunchKernelGGL(fk_perm_draw_kernel, dim3((n_sh + DRAW_BLOCK - 1u) / DRAW_BLOCK), dim3(DRAW_BLOCK), 0, st,
+                               perm_prefix, d.sh0, n_sh, (uint32_t)S, n_sh_pad, 1u, static_cast<uint4 *>(cs.draws.p));
+            hipLaunchKernelGGL(fk_perm_apply_kernel, dim3(perm_blocks), dim3(PERM_BLOCK), perm_lds, st,
+                               static_cast<const uint4 *>(cs.draws.p), n_sh_pad, n_sh, (uint32_t)S, slots,
+                               static_cast<uint16_t *>(cs.perm.p));
+        } else {
+            hipLaunchKernelGGL(fk_perm_kernel, dim3(perm_blocks), dim3(PERM_BLOCK), perm_lds, st,
+                               perm_prefix, d.sh0, n_sh, (uint32_t)S, slots, static_cast<uint16_t *>(cs.perm.p));
+        }
+        HIPCHK(c, hipGetLastError());
+    }
+    (void)hipEventRecord(cs.ev[1], st);
+    sa = SeedArgs{};
+    sa.prefix = seed_prefix(103u /* TOURNAMENT_PLAYER */, d.root, (uint64_t)d.k);
+    sa.coords = nullptr;
+    sa.shuffle0 = d.sh0;
+    sa.gps = gps;
+    sa.k = d.k;
+    sa.n_games = n_sh * gps;
+    sa.perm_T = static_cast<const uint16_t *>(cs.perm.p);
+    sa.perm_slots = slots;
+    sa.S = d.S;
+    sa.n_sh = n_sh;
+    rc = seed_stage(c, si, st, sa, d.state_dw == STATE_DW, true);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(cs.ready, st));
+    cs.desc = d;
+    cs.prepared = true;
+    return FK_OK;
 }
 
 // state store + result records of the chunk just played -> rows at `d_rows` (device), game-id order
 int rows_pass(fk_ctx *c, const SeedArgs &sa, bool scheduled, uint32_t n_games, uint32_t gps, uint32_t n_sh, bool perm_mode, uint8_t *d_rows) {
     // `scheduled`: the caller has inverted the schedule into c->inv (fk_invert_sched_kernel)
     const uint32_t *inv = scheduled ? static_cast<const uint32_t *>(c->inv.p) : nullptr;
-    hipLaunchKernelGGL(fk_rows_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream, static_cast<const uint32_t *>(c->state.p),
+    hipLaunchKernelGGL(fk_rows_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream, static_cast<const uint32_t *>(CSET(c).state.p),
                        static_cast<const uint32_t *>(c->recs.p), inv, n_games, gps, n_sh, sa.k, perm_mode ? 1u : 0u, d_rows);
     HIPCHK(c, hipGetLastError());
     return FK_OK;
@@ -532,6 +673,20 @@ int fk_init(int device_ordinal, fk_ctx **out) {
             fk_destroy(c);
             return FK_ERR_HIP;
         }
+    {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        bool ok = hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, least) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->main_idle, hipEventDisableTiming) == hipSuccess;
+        for (auto &cs : c->sets) {
+            ok = ok && hipEventCreateWithFlags(&cs.ready, hipEventDisableTiming) == hipSuccess;
+            for (auto &e : cs.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+        }
+        if (!ok) {
+            fk_destroy(c);
+            return FK_ERR_HIP;
+        }
+    }
     // score table (fk_device.h): 512 KiB, built by one small kernel, read by every roll of the game kernel
     if (ensure(c, c->score_lut, SCORE_LUT_KEYS * sizeof(uint16_t)) != FK_OK) {
         fk_destroy(c);
@@ -560,10 +715,18 @@ void fk_destroy(fk_ctx *c) {
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     c->comm = nullptr;
     release(c->comm_buf);
-    for (DevBuf *b : {&c->strat, &c->perm, &c->draws, &c->state, &c->inc, &c->seat_idx, &c->recs, &c->rec0, &c->tally, &c->rows, &c->misc, &c->ov, &c->seatlist,
-                      &c->coords, &c->order, &c->inv, &c->slow, &c->score_lut, &c->discard_lut, &c->classes, &c->blocks, &c->game_block,
-                      &c->block_out, &c->stats})
+    if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
+    for (DevBuf *b : {&c->strat, &c->recs, &c->rec0, &c->tally, &c->rows, &c->ov, &c->seatlist, &c->coords, &c->inv, &c->slow, &c->score_lut,
+                      &c->discard_lut, &c->blocks, &c->game_block, &c->block_out, &c->stats})
         release(*b);
+    for (auto &cs : c->sets) {
+        for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc}) release(*b);
+        if (cs.ready) (void)hipEventDestroy(cs.ready);
+        for (auto &e : cs.ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (c->main_idle) (void)hipEventDestroy(c->main_idle);
+    if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
     for (auto &b : c->dbg) release(b);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
@@ -603,6 +766,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "lean") c->lean = (int32_t)value;
     else if (n == "state_store") c->gs = (int32_t)value;
     else if (n == "perm_split") c->perm_split = (int32_t)value;
+    else if (n == "pipeline") c->pipeline = (int32_t)value;
     else if (n == "uniform_flags") c->uniform_flags_opt = (int32_t)value;
     else if (n == "block") {
         if (value != 0 && value != 64 && value != 128 && value != 256 && value != 512 && value != 768 && value != 1024)
@@ -663,75 +827,56 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
     chunk_sh = std::min<uint64_t>(chunk_sh, (uint64_t)0x7fffffff / gps);
     chunk_sh = std::min<uint64_t>(chunk_sh, n_sh_total);
 
-    const SeedPool perm_prefix = seed_prefix(101u /* SHUFFLE_PERMUTATION */, root_seed, (uint64_t)k);
-    const SeedPool seat_prefix = seed_prefix(103u /* TOURNAMENT_PLAYER */, root_seed, (uint64_t)k);
-
     const hipEvent_t t0 = c->ev[SLOT_CALL], t1 = c->ev[SLOT_CALL + 1];
     HIPCHK(c, hipEventRecord(t0, c->stream));
+
+    const uint32_t slots = (uint32_t)std::max<size_t>(1, std::min<size_t>(PERM_BLOCK, LDS_LIMIT / ((size_t)S * 2)));
+    const uint32_t state_dw = (plan.gs || want_state) ? STATE_DW : 4u;
+    auto describe = [&](uint64_t first_shuffle, uint32_t count, uint32_t dw) {
+        ChunkDesc d;
+        d.epoch = c->table_epoch;
+        d.root = root_seed;
+        d.sh0 = first_shuffle;
+        d.n_sh = count;
+        d.S = (uint32_t)S;
+        d.k = (uint32_t)k;
+        d.state_dw = dw;
+        d.sched = c->longest_first ? 1u : 0u;
+        d.slots = slots;
+        return d;
+    };
+    // the hint (fk_tournament_hint_next) is for the call that FOLLOWS this one
+    const bool hinted = c->hint_valid && c->hint_end > c->hint_begin;
+    const uint64_t hint_begin = c->hint_begin, hint_end = c->hint_end;
+    const uint32_t hint_dw = (plan.gs || c->hint_state) ? STATE_DW : 4u;
+    c->hint_valid = false;
 
     std::vector<uint16_t> perm_host;
     for (uint64_t done = 0; done < n_sh_total; done += chunk_sh) {
         const uint32_t n_sh = (uint32_t)std::min<uint64_t>(chunk_sh, n_sh_total - done);
         const uint64_t sh0 = shuffle_begin + done;
         const uint32_t n_games = n_sh * gps;
-
-        const uint32_t slots = (uint32_t)std::max<size_t>(1, std::min<size_t>(PERM_BLOCK, LDS_LIMIT / ((size_t)S * 2)));
         const uint32_t perm_blocks = (n_sh + slots - 1u) / slots;
-        rc = ensure(c, c->perm, (size_t)perm_blocks * S * slots * 2);
-        if (rc) return rc;
-        {
-            Timer t(c, &c->timing.perm_ms, SLOT_PERM);
-            const size_t perm_lds = (size_t)slots * S * 2;
-            static bool perm_configured = false;
-            if (!perm_configured) {
-                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-                HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_apply_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-                perm_configured = true;
-            }
-            // large tables: the draws at full occupancy first (fk_perm_draw_kernel); then either the chain-free
-            // permutation (fk_perm_parallel_kernel, one workgroup per shuffle, 14 B of LDS per strategy) or, for tables
-            // beyond its LDS reach, the bare swap chains over LDS arrays (fk_perm_apply_kernel)
-            const bool split = c->perm_split >= 1 || (c->perm_split < 0 && S >= 1024 && n_sh >= 256);
-            const size_t pp_lds = (size_t)S * 14;
-            const bool parallel = split && c->perm_split != 1 && pp_lds <= LDS_LIMIT - 1024;
-            if (parallel) {
-                const uint32_t groups = ((uint32_t)S - 1u + 7u) / 8u, row_u4 = groups + 1u; // a row also holds the S results
-                rc = ensure(c, c->draws, (size_t)n_sh * row_u4 * 16);
-                if (rc) return rc;
-                static bool pp_configured = false;
-                if (!pp_configured) {
-                    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_parallel_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_LIMIT - 1024))); // + its static words
-                    pp_configured = true;
-                }
-                hipLaunchKernelGGL(fk_perm_draw_kernel, dim3((n_sh + DRAW_BLOCK - 1u) / DRAW_BLOCK), dim3(DRAW_BLOCK), 0, c->stream,
-                                   perm_prefix, sh0, n_sh, (uint32_t)S, 1u, row_u4, static_cast<uint4 *>(c->draws.p));
-                hipLaunchKernelGGL(fk_perm_parallel_kernel, dim3(n_sh), dim3(PP_BLOCK), pp_lds, c->stream,
-                                   static_cast<uint4 *>(c->draws.p), row_u4, n_sh, (uint32_t)S);
-                hipLaunchKernelGGL(fk_perm_block_kernel, dim3(((uint32_t)S + 255u) / 256u, perm_blocks), dim3(256), 0, c->stream,
-                                   static_cast<const uint16_t *>(c->draws.p), row_u4 * 8u, n_sh, (uint32_t)S, slots,
-                                   static_cast<uint16_t *>(c->perm.p));
-            } else if (split) {
-                const uint32_t n_sh_pad = (n_sh + 63u) & ~63u, groups = ((uint32_t)S - 1u + 7u) / 8u;
-                rc = ensure(c, c->draws, (size_t)groups * n_sh_pad * 16);
-                if (rc) return rc;
-                hipLaunchKernelGGL(fk_perm_draw_kernel, dim3((n_sh + DRAW_BLOCK - 1u) / DRAW_BLOCK), dim3(DRAW_BLOCK), 0, c->stream,
-                                   perm_prefix, sh0, n_sh, (uint32_t)S, n_sh_pad, 1u, static_cast<uint4 *>(c->draws.p));
-                hipLaunchKernelGGL(fk_perm_apply_kernel, dim3(perm_blocks), dim3(PERM_BLOCK), perm_lds, c->stream,
-                                   static_cast<const uint4 *>(c->draws.p), n_sh_pad, n_sh, (uint32_t)S, slots,
-                                   static_cast<uint16_t *>(c->perm.p));
-            } else {
-                hipLaunchKernelGGL(fk_perm_kernel, dim3(perm_blocks), dim3(PERM_BLOCK), perm_lds, c->stream,
-                                   perm_prefix, sh0, n_sh, (uint32_t)S, slots, static_cast<uint16_t *>(c->perm.p));
-            }
-            t.stop();
-            HIPCHK(c, hipGetLastError());
+
+        // the chunk's preparation: already made on the side stream (by the previous chunk, or by the previous call after a
+        // hint), or made now in front of the game kernel
+        const ChunkDesc d = describe(sh0, n_sh, state_dw);
+        int ready_set = -1;
+        for (int si : {c->cur ^ 1, c->cur})
+            if (c->sets[si].prepared && c->sets[si].desc == d) ready_set = si;
+        if (ready_set >= 0) {
+            c->cur = ready_set;
+            HIPCHK(c, hipStreamWaitEvent(c->stream, CSET(c).ready, 0));
+        } else {
+            if (c->sets[c->cur].prepared) c->cur ^= 1; // keep a prepared (hinted) chunk for its own call if there is room
+            rc = prep_tournament_chunk(c, c->cur, c->stream, d, CSET(c).sa);
+            if (rc) return rc;
         }
+        CSET(c).prepared = false; // consumed
+        const SeedArgs sa = CSET(c).sa;
         if (perms) {
             perm_host.resize((size_t)perm_blocks * S * slots);
-            HIPCHK(c, hipMemcpyAsync(perm_host.data(), c->perm.p, perm_host.size() * 2, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(perm_host.data(), CSET(c).perm.p, perm_host.size() * 2, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             for (uint32_t s = 0; s < n_sh; ++s)
                 for (int32_t i = 0; i < S; ++i)
@@ -746,9 +891,9 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
             if (ov[i].max_rounds > 65535u) return fail(c, FK_ERR_ARG, "override max_rounds must be <= 65535");
             const uint32_t game = (uint32_t)((ov[i].a - sh0) * gps + ov[i].b);
             bool replaced = false;
-            for (auto &d : dov)
-                if (d.game == game) {
-                    d.max_rounds = ov[i].max_rounds;
+            for (auto &dv : dov)
+                if (dv.game == game) {
+                    dv.max_rounds = ov[i].max_rounds;
                     replaced = true;
                 }
             if (!replaced) dov.push_back(DevOverride{game, ov[i].max_rounds});
@@ -760,26 +905,11 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
             if (rc) return rc;
         }
 
-        SeedArgs sa{};
-        sa.prefix = seat_prefix;
-        sa.coords = nullptr;
-        sa.shuffle0 = sh0;
-        sa.pair = 0;
-        sa.order = 0;
-        sa.game0 = 0;
-        sa.gps = gps;
-        sa.k = (uint32_t)k;
-        sa.n_games = n_games;
-        sa.perm_T = static_cast<const uint16_t *>(c->perm.p);
-        sa.perm_slots = slots;
-        sa.S = (uint32_t)S;
-        sa.n_sh = n_sh;
-
         PlayArgs pa{};
         pa.strat = static_cast<const uint2 *>(c->strat.p);
         pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
         pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
-        pa.perm_T = static_cast<const uint16_t *>(c->perm.p);
+        pa.perm_T = static_cast<const uint16_t *>(CSET(c).perm.p);
         pa.perm_slots = slots;
         pa.seat_strategy = nullptr;
         pa.tally = static_cast<unsigned long long *>(c->tally.p);
@@ -794,29 +924,50 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
         pa.target = target_score;
         pa.max_rounds = (uint32_t)max_rounds;
 
-        rc = run_chunk(c, sa, pa, plan, want_state, want_recs, want_recs, (int64_t)done * gps, "tournament");
+        HIPCHK(c, hipEventRecord(c->main_idle, c->stream)); // everything that used the other chunk set is in front of this point
+        rc = launch_play_stage(c, sa, pa, plan, want_state, want_recs, want_recs);
+        if (rc) return rc;
+        // While the game kernel runs: the preparation of the next chunk (or of the hinted next call) on the low-priority
+        // stream, into the other chunk set.  Its kernels are placed as the persistent game kernel's blocks retire.
+        if (c->pipeline) {
+            ChunkDesc next{};
+            bool have_next = false;
+            if (done + chunk_sh < n_sh_total) {
+                next = describe(sh0 + n_sh, (uint32_t)std::min<uint64_t>(chunk_sh, n_sh_total - done - chunk_sh), state_dw);
+                have_next = true;
+            } else if (hinted) {
+                next = describe(hint_begin, (uint32_t)std::min<uint64_t>(chunk_sh, hint_end - hint_begin), hint_dw);
+                have_next = true;
+            }
+            if (have_next) {
+                HIPCHK(c, hipStreamWaitEvent(c->prep_stream, c->main_idle, 0));
+                rc = prep_tournament_chunk(c, c->cur ^ 1, c->prep_stream, next, c->sets[c->cur ^ 1].sa);
+                if (rc) return rc;
+            }
+        }
+        rc = finish_play(c, pa, (int64_t)done * gps, "tournament");
         if (rc) return rc;
         const bool scheduled = c->longest_first != 0;
         if (want_state && scheduled) { // game id -> slot of its state records
             rc = ensure(c, c->inv, (size_t)n_games * 4);
             if (rc) return rc;
             hipLaunchKernelGGL(fk_invert_sched_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
-                               static_cast<const uint32_t *>(c->order.p), n_games, static_cast<uint32_t *>(c->inv.p));
+                               static_cast<const uint32_t *>(CSET(c).order.p), n_games, static_cast<uint32_t *>(c->inv.p));
         }
         if (seat_stats) {
-            rc = ensure(c, c->draws, (size_t)perm_blocks * S * slots * 2); // the draws buffer is free again: inverse permutations
+            rc = ensure(c, CSET(c).draws, (size_t)perm_blocks * S * slots * 2); // the draws buffer is free again: inverse permutations
             if (rc) return rc;
             const uint32_t cells = perm_blocks * (uint32_t)S * slots;
             hipLaunchKernelGGL(fk_invert_perm_kernel, dim3((cells + 255u) / 256u), dim3(256), 0, c->stream,
-                               static_cast<const uint16_t *>(c->perm.p), (uint32_t)S, slots, n_sh, static_cast<uint16_t *>(c->draws.p));
+                               static_cast<const uint16_t *>(CSET(c).perm.p), (uint32_t)S, slots, n_sh, static_cast<uint16_t *>(CSET(c).draws.p));
             const uint32_t first_batch = (uint32_t)(done / shuffles_per_batch);
             const uint32_t nb = (uint32_t)((done + n_sh - 1) / shuffles_per_batch) - first_batch + 1u;
             const uint32_t s_blocks = ((uint32_t)S + 255u) / 256u;
             // enough (strategy block, batch, part) workgroups to fill the chip; a part is at least 8 shuffles
             const uint32_t ppb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(shuffles_per_batch, n_sh) / 8, (4096u + nb * s_blocks - 1u) / (nb * s_blocks)));
             hipLaunchKernelGGL(fk_seat_stats_kernel, dim3(s_blocks, nb * ppb), dim3(256), 0, c->stream,
-                               static_cast<const uint32_t *>(c->state.p), static_cast<const uint32_t *>(c->recs.p),
-                               scheduled ? static_cast<const uint32_t *>(c->inv.p) : nullptr, static_cast<const uint16_t *>(c->draws.p),
+                               static_cast<const uint32_t *>(CSET(c).state.p), static_cast<const uint32_t *>(c->recs.p),
+                               scheduled ? static_cast<const uint32_t *>(c->inv.p) : nullptr, static_cast<const uint16_t *>(CSET(c).draws.p),
                                slots, (uint32_t)S, (uint32_t)k, gps, n_sh, (uint32_t)done, shuffles_per_batch, ppb, first_batch,
                                static_cast<long long *>(c->stats.p));
             HIPCHK(c, hipGetLastError());
@@ -842,12 +993,12 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
                 }
                 hipLaunchKernelGGL(fk_tally_reduce_kernel, dim3(ppb * nb, n_slices), dim3(REDUCE_BLOCK), (size_t)slice * RT_COLS * 8, c->stream,
                                    static_cast<const uint32_t *>(c->rec0.p), static_cast<const uint32_t *>(c->recs.p), n_games, gps,
-                                   (uint32_t)k, (uint32_t)S, static_cast<const uint16_t *>(c->perm.p), slots, (uint32_t)done,
+                                   (uint32_t)k, (uint32_t)S, static_cast<const uint16_t *>(CSET(c).perm.p), slots, (uint32_t)done,
                                    shuffles_per_batch, n_sh, ppb, slice, first_batch, d_tally);
             } else {
                 hipLaunchKernelGGL(fk_tally_direct_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
                                    static_cast<const uint32_t *>(c->recs.p), n_games, gps, (uint32_t)k, (uint32_t)S,
-                                   static_cast<const uint16_t *>(c->perm.p), slots, (uint32_t)done, shuffles_per_batch, d_tally);
+                                   static_cast<const uint16_t *>(CSET(c).perm.p), slots, (uint32_t)done, shuffles_per_batch, d_tally);
             }
             HIPCHK(c, hipGetLastError());
         }
@@ -1101,6 +1252,20 @@ int fk_h2h_run(fk_ctx *c, const fk_strategy seats[2], uint64_t root_seed, uint64
     return rc;
 }
 
+// The NEXT fk_tournament_run / _stats call on this context will play shuffles [shuffle_begin, shuffle_end) of the same table,
+// k and root seed as the call that follows this hint (need_state: it will ask for rows or all-seat statistics).  That call
+// then enqueues the hinted range's permutations and seat seeding on a low-priority stream behind its own game kernel, where
+// they fill the kernel's drain tail; the hinted call finds them done.  Purely a scheduling hint: a wrong one wastes work only.
+int fk_tournament_hint_next(fk_ctx *c, uint64_t shuffle_begin, uint64_t shuffle_end, int32_t need_state) {
+    if (!c) return FK_ERR_ARG;
+    if (shuffle_end < shuffle_begin) return fail(c, FK_ERR_ARG, "bad shuffle range");
+    c->hint_valid = shuffle_end > shuffle_begin;
+    c->hint_begin = shuffle_begin;
+    c->hint_end = shuffle_end;
+    c->hint_state = need_state ? 1 : 0;
+    return FK_OK;
+}
+
 // ---- multi-GPU: one RCCL sum of the tally (the analogue of OutcomeCounter.absorb, run_tournament.py:197-213) ----
 int fk_comm_unique_id(fk_comm_id *out) {
     if (!out) return FK_ERR_ARG;
@@ -1229,20 +1394,20 @@ static int debug_dice_common(fk_ctx *c, int64_t n, const fk_coord *coords, const
     const uint64_t *d_state = nullptr;
     if (coords) {
         if ((rc = ensure(c, c->coords, sizeof(fk_coord) * (size_t)n))) return rc;
-        if ((rc = ensure(c, c->state, (size_t)n * 16))) return rc;
-        if ((rc = ensure(c, c->inc, (size_t)n * 16))) return rc;
+        if ((rc = ensure(c, CSET(c).state, (size_t)n * 16))) return rc;
+        if ((rc = ensure(c, CSET(c).inc, (size_t)n * 16))) return rc;
         // one 1-seat "game" per coordinate; the seed kernel offsets the seat stream by coords[i].seat_index
         HIPCHK(c, hipMemcpyAsync(c->coords.p, coords, sizeof(fk_coord) * (size_t)n, hipMemcpyHostToDevice, c->stream));
         SeedArgs sa{};
         sa.coords = static_cast<const fk_coord *>(c->coords.p);
         sa.k = 1;
         sa.n_games = (uint32_t)n;
-        sa.state = static_cast<uint32_t *>(c->state.p);
+        sa.state = static_cast<uint32_t *>(CSET(c).state.p);
         sa.state_dw = 4;
-        sa.inc = static_cast<uint4 *>(c->inc.p);
+        sa.inc = static_cast<uint4 *>(CSET(c).inc.p);
         hipLaunchKernelGGL(fk_seed_kernel, dim3((unsigned)((n + SEED_BLOCK - 1) / SEED_BLOCK)), dim3(SEED_BLOCK), 0, c->stream, sa);
         HIPCHK(c, hipGetLastError());
-        d_seeds = static_cast<const uint4 *>(c->state.p);
+        d_seeds = static_cast<const uint4 *>(CSET(c).state.p);
         d_incs = sa.inc;
     } else {
         if (!state) return fail(c, FK_ERR_ARG, "state is required");

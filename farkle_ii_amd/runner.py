@@ -313,6 +313,15 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         local = np.zeros((b1 - b0 if per_batch else 1, S, 26), dtype=np.int64)
         row_records: list[dict] = []
         if hi > lo:
+            if j + 1 < len(pending) and hasattr(eng, "hint_next"):
+                # the launch group after this one (same table, k, root): prepared in the drain tail of this group's kernel
+                j2 = j + 1
+                while j2 + 1 < len(pending) and pending[j2 + 1] == pending[j2] + 1 and (j2 + 1 - (j + 1)) < group_batches:
+                    j2 += 1
+                lo2, hi2 = shard_shuffle_range(pending[j + 1] * spb, min((pending[j2] + 1) * spb, plan.required_shuffles), rank, world,
+                                               batch_size=spb)
+                if hi2 > lo2:
+                    eng.hint_next(lo2, hi2, need_state=want_rows)
             res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=spb if per_batch else hi - lo,
                                  target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows)
             first = lo // spb - b0 if per_batch else 0

@@ -124,7 +124,8 @@ int fk_get_timing(fk_ctx *ctx, fk_timing *out);
  * -1 auto, 0 full, 1 lean), "state_store" (-1 auto: seat records of k >= 3 tables live in the HBM state store with only the
  * turn owner's staged in LDS, 0 LDS records whenever they fit, 1 always), "blocks_per_cu", "longest_first" (1 = deal
  * never-banking pairings first), "uniform_flags" (-1 auto: tables whose strategies share all flag bits run the scalar-flag
- * kernel instance, 0 never), "perm_split" (-1 auto).  All of them are scheduling / layout choices: results are identical
+ * kernel instance, 0 never), "perm_split" (-1 auto), "pipeline" (1: the next chunk / hinted call is prepared on a side stream while
+ * the game kernel runs, 0: never).  All of them are scheduling / layout choices: results are identical
  * for every setting. */
 int fk_set_option(fk_ctx *ctx, const char *name, int64_t value);
 
@@ -153,6 +154,14 @@ int fk_tournament_run_stats(fk_ctx *ctx, const fk_strategy *strategies, int32_t 
                             uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch,
                             int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov,
                             int64_t *tally, void *rows, int32_t *perms, int64_t *seat_stats);
+
+/* Scheduling hint: the next fk_tournament_run / fk_tournament_run_stats call on this context — the one AFTER the call that
+ * follows this hint — will play shuffles [shuffle_begin, shuffle_end) of the same table, k and root seed (need_state != 0: it
+ * will ask for rows or seat_stats).  The call that follows the hint prepares that range (permutations, schedule, seat seeding)
+ * on a low-priority stream behind its own game kernel, in the kernel's drain tail.  Results never depend on hints; a hint
+ * that turns out wrong only wastes the preparation.  (The reference's process pool keeps `window = 4 * n_jobs` chunks in flight
+ * for the same reason, run_tournament.py:1576-1586.) */
+int fk_tournament_hint_next(fk_ctx *ctx, uint64_t shuffle_begin, uint64_t shuffle_end, int32_t need_state);
 
 /* Explicit game list: game g seats strategies table[seat_strategy[g*k+i]] with streams coords[g](seat i).
  * rows: n_games * (4+28k) bytes (required). */

@@ -65,6 +65,9 @@ class Engine:
     def set_option(self, name: str, value: int) -> None:
         pass
 
+    def hint_next(self, shuffle_begin: int, shuffle_end: int, need_state: bool = False) -> None:
+        pass
+
     def device_info(self) -> dict:
         return {"name": "CPU oracle stub", "arch": "host", "compute_units": 1, "clock_mhz": 1, "wavefront_size": 1,
                 "lds_bytes_per_cu": 0, "hbm_bytes": 0}

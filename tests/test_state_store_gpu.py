@@ -252,3 +252,51 @@ def test_permutation_kernels_agree_with_numpy_semantics(eng, po, S, k):
             assert np.array_equal(got["tally"], ref["tally"]), (S, mode)
     finally:
         eng.set_option("perm_split", -1)
+
+
+def test_pipelined_preparation_never_changes_results(eng, po):
+    """The next chunk's (or the hinted next call's) permutations and seat seeding run on a side stream behind the game kernel.
+    Same results with the pipeline on and off, for multi-chunk calls, right hints, wrong hints, hints followed by other entry
+    points, a table change after a hint, rows / statistics calls."""
+    from farkle_ii_amd.backend import make_coords
+
+    table = _strats(gu.load("grid_vectors.json")["g64"])
+    other = _random_valid_table(96, 11)
+    ref = {rng: po.tournament(table.view(po.STRATEGY_DTYPE), 2, 42, rng[0], rng[1], want_rows=True, n_threads=16)
+           for rng in [(0, 600), (600, 1200), (1200, 1500), (77, 300)]}
+    ref_other = po.tournament(other.view(po.STRATEGY_DTYPE), 3, 42, 600, 900, n_threads=16)
+
+    def check(rng, **kw):
+        got = eng.tournament(table, 2, 42, rng[0], rng[1], **kw)
+        assert np.array_equal(got["tally"], ref[rng]["tally"]), (rng, kw)
+        if kw.get("want_rows"):
+            assert got["rows"].tobytes() == ref[rng]["rows"].tobytes(), (rng, kw)
+
+    try:
+        for pipeline in (1, 0):
+            eng.set_option("pipeline", pipeline)
+            for chunk in (48 << 30, 400 << 10):   # one chunk / about ten chunks per call
+                eng.set_option("chunk_bytes", chunk)
+                eng.hint_next(600, 1200)            # right hint
+                check((0, 600))
+                eng.hint_next(1200, 1500, need_state=True)
+                check((600, 1200))
+                check((1200, 1500), want_rows=True)
+                eng.hint_next(0, 600)               # wrong hint: another range is played
+                check((77, 300), want_rows=True)
+                check((0, 600))                     # ... and the hinted one after all, a call later
+                eng.hint_next(600, 1200)            # hint, then other entry points use the context
+                check((0, 600))
+                coords = make_coords(10, 5, 2, 0, 0, 0, np.arange(50, dtype=np.uint64))
+                rows = eng.play_games(coords, table, np.tile(np.arange(2, dtype=np.int32), (50, 1)), 2)
+                want = po.play_games(coords.view(po.COORD_DTYPE), table.view(po.STRATEGY_DTYPE), np.tile(np.arange(2, dtype=np.int32), (50, 1)), 2)
+                assert rows.tobytes() == want.tobytes()
+                check((600, 1200))
+                eng.hint_next(600, 900)             # hint, then the table changes
+                check((0, 600))
+                got = eng.tournament(other, 3, 42, 600, 900)
+                assert np.array_equal(got["tally"], ref_other["tally"])
+                check((600, 1200), want_seat_stats=True)
+    finally:
+        eng.set_option("pipeline", 1)
+        eng.set_option("chunk_bytes", 48 << 30)
