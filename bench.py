@@ -85,7 +85,7 @@ def work_from_seat_stats(stats: np.ndarray, games: int, k: int) -> dict:
 
 def add_timing(acc: dict, t: dict) -> dict:
     """Accumulate fk_timing records (HIP events on the engine's stream) over the engine calls of a step."""
-    for key in ("play_ms", "seed_ms", "perm_ms", "play_launches", "games"):
+    for key in ("play_ms", "seed_ms", "perm_ms", "play_launches", "games", "prefetched_chunks"):
         acc[key] = acc.get(key, 0) + t.get(key, 0)
     for key in ("play_block", "play_grid", "play_lds_bytes"):
         acc[key] = t.get(key)
@@ -552,7 +552,10 @@ def main() -> None:
             "kernel_ms": kernel_ms, "games_per_launch": games_per_launch, "kernel_games_per_s": kernel_games_per_s, **wpg,
             "hbm": {"achieved": kernel_games_per_s * hbm_bpg / 1e9, "peak": 8000.0, "unit": "GB/s",
                     "frac": kernel_games_per_s * hbm_bpg / 8e12, "bytes_per_game": hbm_bpg},
-            "seed_kernel_ms": t.get("seed_ms", 0.0) / launches, "perm_kernel_ms": t.get("perm_ms", 0.0) / launches,
+            # preparation kernels of the launches that were NOT prepared on the side stream behind the previous game kernel
+            "seed_kernel_ms": t.get("seed_ms", 0.0) / max(launches - int(t.get("prefetched_chunks", 0)), 1),
+            "perm_kernel_ms": t.get("perm_ms", 0.0) / max(launches - int(t.get("prefetched_chunks", 0)), 1),
+            "launches_prepared_behind_the_previous_kernel": int(t.get("prefetched_chunks", 0)),
             "launch": {k2: t.get(k2) for k2 in ("play_block", "play_grid", "play_lds_bytes")},
         }
         cpu = None
@@ -598,11 +601,12 @@ def main() -> None:
 
 
 def kernel_source_sha() -> str:
-    """sha256 over the kernel sources: profiles carry it so that a stale HBM-traffic figure is never attached."""
+    """sha256 over the DEVICE sources (kernels + per-roll device functions): profiles carry it so that an HBM-traffic figure
+    taken on other kernels is never attached."""
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("farkle_hip.hip", "fk_kernels.h", "fk_device.h"):
+    for name in ("fk_kernels.h", "fk_device.h"):
         h.update((ROOT / "farkle_ii_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()
 

@@ -43,6 +43,7 @@ struct ChunkSet {
     hipEvent_t ready = nullptr;                       // recorded behind the preparation kernels
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // permutation begin / end, seeding begin / end (timing)
     bool prepared = false;
+    bool side = false; // prepared on the side stream: its event intervals include waiting behind a game kernel
     ChunkDesc desc;
     SeedArgs sa{}; // the prepared chunk's buffers as the kernels see them
 };
@@ -483,9 +484,13 @@ int finish_play(fk_ctx *c, const PlayArgs &pa, int64_t game_base, const char *wh
     const int rc_dev = check_device_error(c, pa.err, game_base, what); // synchronises the main stream
     HIPCHK(c, collect_timers(c));
     ChunkSet &cs = CSET(c);
-    float ms = 0.f; // the preparation events precede the game kernel on the device (same stream, or waited for through `ready`)
-    if (hipEventElapsedTime(&ms, cs.ev[0], cs.ev[1]) == hipSuccess) c->timing.perm_ms += ms;
-    if (hipEventElapsedTime(&ms, cs.ev[2], cs.ev[3]) == hipSuccess) c->timing.seed_ms += ms;
+    if (cs.side) { // prepared behind another game kernel: no kernel-time reading for it (the intervals include the wait)
+        c->timing.prefetched_chunks += 1;
+    } else {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, cs.ev[0], cs.ev[1]) == hipSuccess) c->timing.perm_ms += ms;
+        if (hipEventElapsedTime(&ms, cs.ev[2], cs.ev[3]) == hipSuccess) c->timing.seed_ms += ms;
+    }
     return rc_dev;
 }
 
@@ -495,6 +500,7 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
     SeedArgs sa = sa_in;
     ChunkSet &cs = CSET(c);
     cs.prepared = false;
+    cs.side = false;
     HIPCHK(c, hipStreamWaitEvent(c->stream, cs.ready, 0)); // an unused side-stream preparation may still own the set
     (void)hipEventRecord(cs.ev[0], c->stream); // no permutations here: an empty interval
     (void)hipEventRecord(cs.ev[1], c->stream);
@@ -579,6 +585,7 @@ int prep_tournament_chunk(fk_ctx *c, int si, hipStream_t st, const ChunkDesc &d,
     HIPCHK(c, hipEventRecord(cs.ready, st));
     cs.desc = d;
     cs.prepared = true;
+    cs.side = (st == c->prep_stream);
     return FK_OK;
 }
 

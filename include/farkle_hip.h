@@ -103,13 +103,16 @@ typedef struct {
 /* Timing of the last fk_tournament_run / fk_play_games / fk_h2h_run on this context, from HIP events
  * recorded on the context's stream. */
 typedef struct {
-    float perm_ms;    /* shuffle-permutation kernel(s) */
-    float seed_ms;    /* SeedSequence -> PCG64DXSM seeding kernel(s) */
+    float perm_ms;    /* shuffle-permutation kernel(s) of the chunks prepared in front of their game kernel */
+    float seed_ms;    /* SeedSequence -> PCG64DXSM seeding kernel(s) of the same chunks */
     float play_ms;    /* game kernel(s) */
     float total_ms;   /* first launch -> last kernel done (device time incl. memsets) */
     int32_t play_launches;
     int32_t play_block, play_grid, play_lds_bytes;
     int64_t games;
+    int32_t prefetched_chunks; /* chunks whose permutations / seeding ran on the side stream behind an earlier game kernel:
+                                  not in perm_ms / seed_ms */
+    int32_t pad;
 } fk_timing;
 
 typedef struct fk_ctx fk_ctx;
