@@ -61,3 +61,31 @@ def test_bench_other_baseline_configs_two_ranks(config, extra):
     assert line["n_gpus"] == 2 and f"config {config}" in line["metric"]
     assert line["scaling"] == ("weak" if config == 3 else "strong")
     assert line["roofline"]["ops_per_game"] > 0 and line["value"] > 0
+
+
+def test_bench_under_torch_distributed_run_like_the_driver(tmp_path):
+    """The driver's N > 1 launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` — ranks come from the environment, bench.py must NOT start ranks of its own."""
+    import socket
+
+    import golden_util as gu
+    import pyoracle as po
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "tally.npy"
+    env = dict(os.environ, FK_DIST_BACKEND="gloo", FK_BENCH_ENGINE="oracle_engine_stub:Engine",
+               PYTHONPATH=f"{ROOT / 'tests'}:{os.environ.get('PYTHONPATH', '')}")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--shuffles", "100", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--dump-tally", str(out)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["launcher"] == "torch.distributed.run" and line["dist_backend"] == "gloo"
+    table = gu.strategies_from_tuples(gu.load("grid_vectors.json")["g64"], po.STRATEGY_DTYPE)
+    assert np.array_equal(np.load(out), po.tournament(table, 2, 42, 200, 600)["tally"][0])
