@@ -425,6 +425,7 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    backend_note = None
     have_gpu = torch.cuda.is_available()
     # FK_DIST_BACKEND=gloo rehearses the multi-rank path on a one-GPU box (ranks share GPU 0, tallies reduced on CPU);
     # the real runs use nccl = RCCL over xGMI with one GPU per rank.
@@ -437,7 +438,13 @@ def main() -> None:
         if have_gpu:
             torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # eager: RCCL trouble shows up here
+            except Exception as exc:  # the exchange is one 13 KB reduce: a node whose RCCL does not come up is still measurable
+                backend_note = f"nccl (RCCL) initialisation failed ({type(exc).__name__}: {str(exc)[:200]}); tally reduced over gloo"
+                print(f"rank {rank}: {backend_note}", file=sys.stderr)
+                backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group(backend)
     n_gpus = dist.get_world_size() if distributed else 1
@@ -567,7 +574,7 @@ def main() -> None:
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None,
             "dtype": "int32", "data": "synthetic", "engine": engine_name, "tally_reduce": tally_reduce,
             "dist_backend": (f"{dist.get_backend()} (RCCL over xGMI)" if distributed and dist.get_backend() == "nccl"
-                             else (dist.get_backend() if distributed else None)),
+                             else ((backend_note or dist.get_backend()) if distributed else None)),
             "launcher": "self (bench.py started the ranks)" if os.environ.get("FK_BENCH_SELF_LAUNCHED") else
                         ("torch.distributed.run" if distributed else "single process"),
             "config": {**wl.describe(n_gpus), "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],
