@@ -233,13 +233,13 @@ def test_rccl_tally_reduce_through_the_c_abi_single_rank(eng):
     assert eng.tournament(table, 2, 42, 0, 4)["tally"].sum() > 0
 
 
-@pytest.mark.parametrize("S,k", [(8, 2), (64, 2), (96, 3), (1290, 2), (5160, 4)])
+@pytest.mark.parametrize("S,k", [(8, 2), (64, 2), (96, 3), (1290, 2), (5160, 4), (7140, 5)])
 def test_permutation_kernels_agree_with_numpy_semantics(eng, po, S, k):
     """Generator.permutation through the three device paths — one-kernel Fisher-Yates, draws + serial swap chains, draws +
     the chain-free kernel (bucket sort + pointer jumping) — against the oracle's restatement of NumPy's loop, permutations
     and tallies; shuffle counts that leave partial blocks and partial 8-draw groups."""
-    table = _default_table()[:S] if S > 96 else _random_valid_table(S, S)
-    n_sh = {8: 300, 64: 521, 96: 77, 1290: 70, 5160: 37}[S]
+    table = _random_valid_table(S, S) if (S <= 96 or S > 5160) else _default_table()[:S]  # 7 140: the reference's largest documented grid
+    n_sh = {8: 300, 64: 521, 96: 77, 1290: 70, 5160: 37, 7140: 260}[S]
     ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 21, 1000, 1000 + n_sh, want_perms=True, max_rounds=3, n_threads=16)
     try:
         for mode in (0, 1, 2, -1):
