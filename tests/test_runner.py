@@ -520,3 +520,45 @@ def test_two_gloo_ranks_write_the_same_artifacts_as_one_process(tmp_path):
             assert strip((a / rel).read_text()) == strip((b / rel).read_text()), rel
         elif rel.endswith("checkpoint.pkl"):
             assert pickle.loads((a / rel).read_bytes()) == pickle.loads((b / rel).read_bytes())
+
+
+def test_farkle_run_cli_under_torch_distributed_run_two_ranks(tmp_path):
+    """The documented multi-GPU command line, `python -m torch.distributed.run --nproc-per-node N -m farkle_ii_amd --config … run`,
+    with two ranks on a GPU-less host (gloo; the ranks get the oracle-backed engine through tests/stub_site/sitecustomize.py):
+    same artifacts as the single-process CLI run."""
+    import socket
+
+    import pyarrow.parquet as pq
+    import yaml
+
+    gold = gu.load("artifact_vectors.json")
+    env = dict(os.environ, FK_TEST_STUB_ENGINE="1",
+               PYTHONPATH=f"{ROOT / 'tests' / 'stub_site'}:{ROOT}:{ROOT / 'tests'}:{os.environ.get('PYTHONPATH', '')}")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    roots = {}
+    for name in ("one", "two"):
+        cfg_payload = dict(gold["config"])
+        cfg_payload["sim"] = {**cfg_payload["sim"], "n_players_list": [2]}
+        cfg_payload["io"] = {"results_dir_prefix": str(tmp_path / name), "analysis_subdir": "analysis"}
+        (tmp_path / f"{name}.yaml").write_text(yaml.safe_dump(cfg_payload))
+        roots[name] = tmp_path / f"{name}_seed_11"
+    one = subprocess.run([sys.executable, "-m", "farkle_ii_amd", "--config", str(tmp_path / "one.yaml"), "--log-level", "WARNING", "run", "--metrics"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert one.returncode == 0, one.stderr[-3000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), "-m", "farkle_ii_amd", "--config", str(tmp_path / "two.yaml"), "--log-level", "WARNING",
+                          "run", "--metrics"], env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert two.returncode == 0, two.stderr[-3000:]
+    a, b = roots["one"], roots["two"]
+    files_a = sorted(str(f.relative_to(a)) for f in a.rglob("*") if f.is_file())
+    files_b = sorted(str(f.relative_to(b)) for f in b.rglob("*") if f.is_file())
+    assert files_a == files_b and any(f.endswith("checkpoint.pkl") for f in files_a)
+    for rel in files_a:
+        if rel.endswith(".parquet"):
+            assert pq.read_table(a / rel).equals(pq.read_table(b / rel)), rel
+        elif rel.endswith("checkpoint.pkl"):
+            assert pickle.loads((a / rel).read_bytes()) == pickle.loads((b / rel).read_bytes())
