@@ -135,7 +135,7 @@ uint2 pack_strategy(const fk_strategy &s) {
     if (s.auto_hot_dice) bits |= SF_AUTO_HOT;
     if (s.run_up_score) bits |= SF_RUN_UP;
     if (s.favor_score) bits |= SF_FAVOR_SCORE;
-    return make_uint2((uint32_t)s.score_threshold, bits);
+    return make_uint2((uint32_t)ceil_div50(s.score_threshold), bits); // the kernels compare turn scores in units of 50 (fk_device.h)
 }
 
 int validate_strategies(fk_ctx *c, const fk_strategy *s, int64_t S) {
@@ -928,7 +928,8 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
         pa.n_sh = n_sh;
         pa.k = (uint32_t)k;
         pa.S = (uint32_t)S;
-        pa.target = target_score;
+        pa.target50 = ceil_div50(target_score);
+        pa.beat50 = floor_div50(target_score);
         pa.max_rounds = (uint32_t)max_rounds;
 
         HIPCHK(c, hipEventRecord(c->main_idle, c->stream)); // everything that used the other chunk set is in front of this point
@@ -1077,7 +1078,8 @@ int fk_play_games(fk_ctx *c, const fk_coord *coords, int64_t n_games, const fk_s
     pa.n_sh = 1;
     pa.k = (uint32_t)k;
     pa.S = (uint32_t)S;
-    pa.target = target_score;
+    pa.target50 = ceil_div50(target_score);
+    pa.beat50 = floor_div50(target_score);
     pa.max_rounds = (uint32_t)max_rounds;
     rc = run_chunk(c, sa, pa, plan, true, true, true, 0, "list");
     if (rc) return rc;
@@ -1212,7 +1214,8 @@ int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_
         pa.n_sh = 1;
         pa.k = 2;
         pa.S = nb * 2;
-        pa.target = target_score;
+        pa.target50 = ceil_div50(target_score);
+        pa.beat50 = floor_div50(target_score);
         pa.max_rounds = (uint32_t)max_rounds;
         rc = run_chunk(c, sa, pa, plan, false, true, false, 0, "h2h attempt (pass-local index)");
         if (rc) return rc;
@@ -1338,6 +1341,7 @@ int fk_debug_score(fk_ctx *c, int64_t n, const uint8_t *faces, const int32_t *le
     if (n == 0) return FK_OK;
     HIPCHK(c, hipSetDevice(c->device));
     for (int64_t i = 0; i < n; ++i) {
+        if (pre[i] < 0 || pre[i] % 50) return fail(c, FK_ERR_ARG, "turn_score_pre must be a non-negative multiple of 50 (every Farkle score is)");
         if (len[i] < 0 || len[i] > 6) return fail(c, FK_ERR_ARG, "roll cannot contain more than six dice");
         for (int32_t j = 0; j < len[i]; ++j)
             if (faces[i * 6 + j] < 1 || faces[i * 6 + j] > 6) return fail(c, FK_ERR_ARG, "dice faces must be between 1 and 6");
@@ -1370,6 +1374,9 @@ int fk_debug_should_continue(fk_ctx *c, int64_t n, const int32_t *args, const fk
     HIPCHK(c, hipSetDevice(c->device));
     int rc = validate_strategies(c, strategy, (int32_t)std::min<int64_t>(n, 0x7fffffff));
     if (rc) return rc;
+    for (int64_t i = 0; i < n; ++i)
+        if (args[i * 6] < 0 || args[i * 6] % 50 || args[i * 6 + 5] < 0 || args[i * 6 + 5] % 50)
+            return fail(c, FK_ERR_ARG, "turn_score and player_score must be non-negative multiples of 50 (every Farkle score is)");
     std::vector<uint2> packed((size_t)n);
     for (int64_t i = 0; i < n; ++i) packed[(size_t)i] = pack_strategy(strategy[i]);
     const size_t sz[3] = {(size_t)n * 24, (size_t)n * 8, (size_t)n * 4};

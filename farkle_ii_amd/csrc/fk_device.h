@@ -550,6 +550,80 @@ __device__ inline RollResult default_score_lut(const uint16_t *lut, const uint8_
     return apply_discards(raw, q.eligible ? (uint32_t)dlut[discard_key(q)] : 0u);
 }
 
+// ----------------------------------------------------------------------------------------
+// The kernels' arithmetic in UNITS OF 50 POINTS.  Every Farkle score is a multiple of 50 (scoring_lookup.py:123-172: 50,
+// 100, n * 100, 1000 ... 3000, 1500, 2500; discards take 50 / 100 away), so turn scores, banked scores and the score to
+// beat are carried as score / 50: the table entry is used as it is (no x 50), the threshold terms need no division, and a
+// seat's score fits 16 bits (the lean records of wide tables pack it beside the strategy index).  Thresholds and the
+// target are arbitrary integers; they enter through exact integer bounds:
+//     50 a <  thr   <=>  a <  ceil(thr / 50)         50 a >= target  <=>  a >= ceil(target / 50)
+//     50 a >  x     <=>  a >  floor(x / 50)          (x = the initial score to beat, i.e. the target, engine.py:451)
+// The functions above stay in points: they are the statement of the rule that the host-side exhaustive check
+// (tests/native/device_header_host_check.hip) compares these against, and they build the two tables.
+// ----------------------------------------------------------------------------------------
+__host__ __device__ inline int32_t ceil_div50(int32_t a) { return a >= 0 ? (a + 49) / 50 : -((-a) / 50); }
+__host__ __device__ inline int32_t floor_div50(int32_t a) { return a >= 0 ? a / 50 : -((-a + 49) / 50); }
+
+struct Strat50 {
+    int32_t thr50; // ceil(score_threshold / 50)
+    uint32_t bits;
+    __host__ __device__ int32_t dice_thr() const { return (int32_t)(int8_t)(bits & 0xffu); }
+    __host__ __device__ bool has(uint32_t f) const { return (bits & f) != 0u; }
+};
+
+__host__ __device__ inline Strat50 to_units50(const Strat &s) { return Strat50{ceil_div50(s.score_thr), s.bits}; }
+
+struct Roll50 {
+    int32_t score50, used, d5, d1;
+};
+
+// discard_query in units of 50: T = (turn score so far + raw score) / 50;  floor((50 T - thr) / 50) = T - ceil(thr / 50)
+__host__ __device__ inline DiscardQuery discard_query50(uint32_t entry, int32_t n, int32_t pre50, const Strat50 &s) {
+    DiscardQuery q;
+    const uint32_t raw50 = entry & 63u, used = (entry >> 6) & 7u, sf = (entry >> 9) & 7u, so = (entry >> 12) & 7u;
+    q.sf = sf;
+    q.m1 = s.has(SF_SMART_ONE) ? so : 0u;
+    q.eligible = s.has(SF_SMART_FIVE) & ((int32_t)used != n) & ((sf | so) != 0u); // :433
+    const bool cs = s.has(SF_CONSIDER_SCORE), cd = s.has(SF_CONSIDER_DICE);
+    q.rb = s.has(SF_REQUIRE_BOTH);
+    q.fav = s.has(SF_FAVOR_SCORE);
+    int32_t v = pre50 + (int32_t)raw50 - s.thr50 + 1;
+    v = v < 0 ? 0 : (v > 7 ? 7 : v);
+    q.vmin = cs ? (uint32_t)v : 0u;
+    int32_t cm = s.dice_thr() - (n - (int32_t)used) + 1;
+    cm = cm < 0 ? 0 : (cm > 5 ? 5 : cm);
+    q.cmin = cd ? (uint32_t)cm : 0u;
+    q.r15 = raw50 < 15u ? raw50 : 15u;
+    return q;
+}
+
+__host__ __device__ inline Roll50 apply_discards50(uint32_t entry, uint32_t choice) {
+    const int32_t d5 = (int32_t)(choice & 3u), d1 = (int32_t)((choice >> 2) & 3u);
+    return Roll50{(int32_t)(entry & 63u) - d5 - 2 * d1, (int32_t)((entry >> 6) & 7u) - d5 - d1, d5, d1};
+}
+
+// 3-bit-packed counts -> score table -> discard table (the game kernel's path), units of 50
+__host__ __device__ inline Roll50 default_score_lut50(const uint16_t *lut, const uint8_t *dlut, uint32_t key, int32_t n, int32_t pre50,
+                                                      const Strat50 &s) {
+    const uint32_t e = lut[key];
+    const DiscardQuery q = discard_query50(e, n, pre50, s);
+    return apply_discards50(e, q.eligible ? (uint32_t)dlut[discard_key(q)] : 0u);
+}
+
+// should_continue in units of 50; stb50 = floor(score_to_beat / 50)
+__host__ __device__ inline bool should_continue50(const Strat50 &s, int32_t turn50, int32_t dice_left, bool has_scored, bool final_round,
+                                                  int32_t stb50, int32_t score50) {
+    const bool above = score50 + turn50 > stb50;
+    const bool stop = final_round & above & !s.has(SF_RUN_UP);
+    const bool force = final_round & !above;
+    const bool entry = !has_scored & (turn50 < 10); // 500 points (strategies.py:249)
+    const bool cs = s.has(SF_CONSIDER_SCORE), cd = s.has(SF_CONSIDER_DICE);
+    const bool want_s = cs & (turn50 < s.thr50);
+    const bool want_d = cd & (dice_left > s.dice_thr());
+    const bool thr = (cs & cd & !s.has(SF_REQUIRE_BOTH)) ? (want_s & want_d) : (want_s | want_d);
+    return !stop & (force | entry | thr);
+}
+
 // FarklePlayer._should_continue (src/farkle/game/engine.py:156-205) with ThresholdStrategy.decide
 // (src/farkle/simulation/strategies.py:212-275) and _decide_continue (:125-162) folded into boolean algebra:
 //   stop  = final & running > to_beat & !run_up                      (engine.py:189)

@@ -39,7 +39,7 @@ enum : uint32_t {
     F_BUF, F_SCORE, F_CA, F_CB, F_CC, F_CD, F_CE, F_SPX, F_SPY, NF
 };
 // packed u16 counter pairs
-//   cA = rolls | farkles << 16        cB = highest_turn | n_turns << 16
+//   cA = rolls | farkles << 16        cB = highest_turn / 50 | n_turns << 16      (scores are carried in units of 50 points)
 //   cC = sf_uses | sf_dice << 16      cD = so_uses | so_dice << 16
 //   cE = hot_dice | flags << 16       flags: bit0 has_scored, bit1 has_buf
 constexpr uint32_t CE_HAS_SCORED = 1u << 16, CE_HAS_BUF = 1u << 17;
@@ -48,6 +48,7 @@ constexpr uint32_t CE_IDX_SHIFT = 18; // LEAN records in LDS: strategy index in 
 // State record of one seat in HBM (the seed kernel writes it, GS game kernels keep it current, the post-passes read the
 // final one): the eleven dwords a turn mutates, in the order of the LEAN LDS record, + the seat's strategy index.
 // 48 bytes = three 16-byte accesses; index = slot * k + seat (slot = ticket position of the game's schedule).
+// R_SCORE and the highest_turn half of R_CB are in units of 50 points (fk_device.h); the post-passes multiply them out.
 enum : uint32_t { R_LO0 = 0, R_LO1, R_HI0, R_HI1, R_BUF, R_SCORE, R_CA, R_CB, R_CC, R_CD, R_CE, R_IDX, STATE_DW = 12 };
 
 // Result record of one finished game (index = game id), written by the game kernel when the tallies are not privatised
@@ -127,7 +128,8 @@ struct PlayArgs {
     uint32_t n_ov;
     uint32_t mode;
     uint32_t n_games, gps, n_sh, k, S;
-    int32_t target;
+    int32_t target50;            // ceil(target_score / 50): a banked total of s / 50 reaches the target iff s / 50 >= target50
+    int32_t beat50;              // floor(target_score / 50): the initial score to beat (engine.py:451) in the same units
     uint32_t max_rounds;
     uint32_t batch_threshold;
     uint32_t use_lds_tally;
@@ -852,8 +854,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             widx = seat_strategy(0); // names the block of a safety-limit attempt
         }
         if (a.use_lds_tally && completed) {
-            const unsigned long long m[10] = {(unsigned long long)(uint32_t)best, rounds, wa >> 16, wa & 0xffffu,
-                                              wb & 0xffffu, wc & 0xffffu, wc >> 16, wd & 0xffffu, wd >> 16, we & 0xffffu};
+            const unsigned long long m[10] = {(unsigned long long)(uint32_t)best * 50u, rounds, wa >> 16, wa & 0xffffu,
+                                              (wb & 0xffffu) * 50u, wc & 0xffffu, wc >> 16, wd & 0xffffu, wd >> 16, we & 0xffffu};
             unsigned long long *t = tl + widx * LT_COLS;
             atomicAdd(&t[0], 1ull);
 #pragma unroll
@@ -869,7 +871,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             a.rec0[game_id] = d0;
             if (a.recs) {
                 uint4 *r = reinterpret_cast<uint4 *>(a.recs + (size_t)game_id * REC_DW);
-                r[0] = make_uint4(d0, completed ? (uint32_t)best : 0u, rounds | (wa & 0xffff0000u), (wa & 0xffffu) | (wb << 16));
+                r[0] = make_uint4(d0, completed ? (uint32_t)best * 50u : 0u, rounds | (wa & 0xffff0000u),
+                                  (wa & 0xffffu) | (((wb & 0xffffu) * 50u) << 16)); // points: highest_turn <= 65 500 by its guard band
                 r[1] = make_uint4(wc, wd, we & 0xffffu, 0u);
             }
         }
@@ -931,7 +934,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         trigger = 0;
         final_round = 0;
         safety = 0;
-        score_to_beat = a.target; // engine.py:451
+        score_to_beat = a.beat50; // engine.py:451 (units of 50)
         if (max_rounds == 0u) {   // `while rounds < max_rounds` never entered (engine.py:453)
             rounds = 0;
             safety = 1;
@@ -947,7 +950,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     // Written as selects: one predicated region per roll step instead of a tree of them. ----
     auto advance = [&](int32_t score) __attribute__((always_inline)) {
         const bool fr = final_round != 0u;
-        const bool trig = !fr & (score >= a.target);           // first trigger starts the final round (engine.py:462-468)
+        const bool trig = !fr & (score >= a.target50);         // first trigger starts the final round (engine.py:462-468)
         const bool normal = !fr & !trig;
         const uint32_t n1 = seat + 1u;
         const bool wrap = n1 == K;
@@ -979,28 +982,28 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         const uint32_t n = dice;
         const uint32_t key = roll_counts<3>(rng, n);
         rolls_this_turn += 1u;
-        const Strat sp{own_thr, (own_bits & (0xffu | MIXED)) | (a.uflags & (0xff00u & ~MIXED))};
-        const RollResult rr = default_score_lut(a.score_lut, a.discard_lut, key, (int32_t)n, turn_score, sp);
-        const bool farkle = rr.score == 0;                              // engine.py:135-137, 247-249
+        const Strat50 sp{own_thr, (own_bits & (0xffu | MIXED)) | (a.uflags & (0xff00u & ~MIXED))};
+        const Roll50 rr = default_score_lut50(a.score_lut, a.discard_lut, key, (int32_t)n, turn_score, sp); // turn_score, score: / 50
+        const bool farkle = rr.score50 == 0;                            // engine.py:135-137, 247-249
         cA += 1u + (farkle ? 0x10000u : 0u);                            // n_rolls (engine.py:98), n_farkles
         cC += (rr.d5 > 0) ? (1u + ((uint32_t)rr.d5 << 16)) : 0u;        // engine.py:139-144
         cD += (rr.d1 > 0) ? (1u + ((uint32_t)rr.d1 << 16)) : 0u;
         dice = (rr.used == (int32_t)n) ? 6u : (n - (uint32_t)rr.used);  // engine.py:146
-        turn_score = farkle ? 0 : (turn_score + rr.score);
+        turn_score = farkle ? 0 : (turn_score + rr.score50);
         const bool hot = !farkle & sp.has(SF_AUTO_HOT) & (dice == 6u);  // _apply_hot_dice, engine.py:149-154, 253
         cE += hot ? 1u : 0u;
-        const bool keep = should_continue(sp, turn_score, (int32_t)dice, (cE & CE_HAS_SCORED) != 0u, final_round != 0u,
-                                          score_to_beat, score);
+        const bool keep = should_continue50(sp, turn_score, (int32_t)dice, (cE & CE_HAS_SCORED) != 0u, final_round != 0u,
+                                            score_to_beat, score);
         const bool over = farkle | (!hot & !keep);
         // bank (engine.py:265-273), branch-free: a farkled turn has turn_score 0 and changes nothing
         const uint32_t ts = over ? (uint32_t)turn_score : 0u;
-        cE |= (ts >= 500u) ? CE_HAS_SCORED : 0u;
+        cE |= (ts >= 10u) ? CE_HAS_SCORED : 0u;                         // 500 points
         const uint32_t banked = (cE & CE_HAS_SCORED) ? ts : 0u;
         score += (int32_t)banked;
         cB = (banked > (cB & 0xffffu)) ? ((cB & 0xffff0000u) | banked) : cB;
         // one rare exit for all error conditions: the roll limit, then the u16 guard bands (a turn adds <= 1000 rolls
-        // and <= 2000 discarded dice; highest_turn must fit 16 bits)
-        const bool overflow = (turn_score > 0xffff) | ((cA & 0xffffu) > 64000u) | ((cC >> 16) > 63000u) | ((cD >> 16) > 63000u);
+        // and <= 2000 discarded dice; highest_turn must fit 16 bits IN POINTS: 1310 x 50 = 65 500)
+        const bool overflow = (turn_score > 1310) | ((cA & 0xffffu) > 64000u) | ((cC >> 16) > 63000u) | ((cD >> 16) > 63000u);
         if (roll_limit | overflow) {
             raise(roll_limit ? FK_ERR_ROLL_LIMIT : FK_ERR_COUNTER_OVERFLOW);
             return;
@@ -1262,7 +1265,7 @@ __global__ void fk_rows_kernel(const uint32_t *state, const uint32_t *recs, cons
     const uint32_t *g = state + (size_t)slot * k * STATE_DW;
     for (uint32_t s = 0; s < k; ++s) {
         const uint32_t *x = g + (size_t)s * STATE_DW;
-        const int32_t sc = (int32_t)x[R_SCORE];
+        const int32_t sc = (int32_t)x[R_SCORE]; // units of 50: ranks compare as they are, the row stores points
         uint32_t rank = 0;
         if (completed) {
             rank = 1;
@@ -1273,10 +1276,10 @@ __global__ void fk_rows_kernel(const uint32_t *state, const uint32_t *recs, cons
         }
         const uint32_t xa = x[R_CA], xb = x[R_CB], xe = x[R_CE];
         uint32_t *d = row + 1u + 7u * s;
-        d[0] = (uint32_t)sc;
+        d[0] = (uint32_t)sc * 50u;
         d[1] = x[R_IDX];
-        d[2] = (xa >> 16) | (xa << 16); // farkles, rolls
-        d[3] = (xb >> 16) | (xb << 16); // n_turns, highest_turn
+        d[2] = (xa >> 16) | (xa << 16);                    // farkles, rolls
+        d[3] = (xb >> 16) | (((xb & 0xffffu) * 50u) << 16); // n_turns, highest_turn
         d[4] = x[R_CC];                 // sf_uses, sf_dice
         d[5] = x[R_CD];                 // so_uses, so_dice
         d[6] = (xe & 0xffffu) | (rank << 16) | ((completed ? 0u : 1u) << 24); // hot_dice, rank, hit_max_rounds
@@ -1326,7 +1329,7 @@ __global__ __launch_bounds__(256) void fk_seat_stats_kernel(const uint32_t *stat
         const uint4 q0 = r[0];
         const bool completed = !(q0.x & REC_SAFETY);
         const uint32_t *gs = state + (size_t)slot * k * STATE_DW, *x = gs + (size_t)seat * STATE_DW;
-        const long long score = (int32_t)x[R_SCORE], rounds = q0.z & 0xffffu;
+        const long long score = (long long)(int32_t)x[R_SCORE] * 50, rounds = q0.z & 0xffffu; // the state store holds score / 50
         const uint32_t xa = x[R_CA], xb = x[R_CB], xc = x[R_CC], xd = x[R_CD], xe = x[R_CE];
         const long long turns = xb >> 16, tmr = turns - rounds;
         acc[0] += 1;
@@ -1341,7 +1344,7 @@ __global__ __launch_bounds__(256) void fk_seat_stats_kernel(const uint32_t *stat
         if (completed) {
             long long rank = 1;
             for (uint32_t j = 0; j < k; ++j) {
-                const long long o = (int32_t)gs[(size_t)j * STATE_DW + R_SCORE];
+                const long long o = (long long)(int32_t)gs[(size_t)j * STATE_DW + R_SCORE] * 50;
                 rank += (o > score || (o == score && j < seat)) ? 1 : 0;
             }
             const long long margin = (long long)q0.y - score; // winning score - own score
@@ -1351,7 +1354,7 @@ __global__ __launch_bounds__(256) void fk_seat_stats_kernel(const uint32_t *stat
             acc[13] += margin;
             acc[14] += margin * margin;
         }
-        const long long v[8] = {xa & 0xffffu, xa >> 16, xb & 0xffffu, xe & 0xffffu, xc & 0xffffu, xc >> 16, xd & 0xffffu, xd >> 16};
+        const long long v[8] = {xa & 0xffffu, xa >> 16, (xb & 0xffffu) * 50, xe & 0xffffu, xc & 0xffffu, xc >> 16, xd & 0xffffu, xd >> 16};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             acc[15 + 2 * j] += v[j];
@@ -1393,10 +1396,10 @@ __global__ void fk_dbg_score_kernel(int64_t n, const uint8_t *faces, const int32
                                     const uint2 *strat, const uint16_t *lut, const uint8_t *dlut, int32_t *out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const Strat s = unpack_strat(strat[i]);
-    // the game kernel's path: 3-bit count key -> score table -> discard choice
-    const RollResult r = default_score_lut(lut, dlut, nibbles_to_lut_key(pack_faces(faces + i * 6, len[i])), len[i], pre[i], s);
-    out[i * 5 + 0] = r.score;
+    const Strat50 s{(int32_t)strat[i].x, strat[i].y}; // packed strategies carry ceil(score_threshold / 50)
+    // the game kernel's path: 3-bit count key -> score table -> discard choice, in units of 50 (pre[i] is a multiple of 50)
+    const Roll50 r = default_score_lut50(lut, dlut, nibbles_to_lut_key(pack_faces(faces + i * 6, len[i])), len[i], pre[i] / 50, s);
+    out[i * 5 + 0] = r.score50 * 50;
     out[i * 5 + 1] = r.used;
     out[i * 5 + 2] = len[i] - r.used;
     out[i * 5 + 3] = r.d5;
@@ -1429,7 +1432,8 @@ __global__ void fk_dbg_continue_kernel(int64_t n, const int32_t *args, const uin
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t *g = args + i * 6;
-    out[i] = should_continue(unpack_strat(strat[i]), g[0], g[1], g[2] != 0, g[3] != 0, g[4], g[5]) ? 1 : 0;
+    // turn_score g[0] and player_score g[5] are multiples of 50; the score to beat g[4] may be any integer (the target)
+    out[i] = should_continue50(Strat50{(int32_t)strat[i].x, strat[i].y}, g[0] / 50, g[1], g[2] != 0, g[3] != 0, floor_div50(g[4]), g[5] / 50) ? 1 : 0;
 }
 
 __global__ void fk_dbg_dice_kernel(int64_t n, const uint4 *seeds, const uint4 *incs, const uint64_t *state_in, int32_t n_calls,
