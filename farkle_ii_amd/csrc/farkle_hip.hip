@@ -73,6 +73,7 @@ struct fk_ctx {
     std::vector<uint2> strat_host;   // the packed table currently resident in `strat` (uploaded once per table)
     int32_t longest_first = 1;
     int32_t blocks_per_cu = 0; // 0 = as many as fit
+    int32_t max_waves = 6;     // resident waves per SIMD the launch plan may count on
     int32_t lean = -1;         // -1 auto, 0 full 17-dword seat records, 1 lean 11-dword records
     int32_t gs = -1;           // -1 / 0: LDS records whenever k of them fit a wave's share of LDS, 1: state-store instances always
     int32_t uniform_flags_opt = -1; // -1 auto (scalar-flag instance when the table allows it), 0 never
@@ -198,10 +199,11 @@ SeedPool seed_prefix(uint32_t purpose, uint64_t root_seed, uint64_t k) {
 }
 
 struct LaunchPlan {
-    int block = 0, grid = 0;
+    int block = 0, grid = 0, cus = 1;
+    mutable int launched_grid = 0; // the grid after the occupancy clamp of the launch
     size_t lds = 0;
     bool lds_tally = false;
-    bool lean = false; // 11-dword seat records (increment + strategy re-read from HBM/L2 each turn)
+    bool lean = false; // 10-dword seat records (increment + strategy re-read from HBM/L2 each turn, 16-bit score / 50)
     bool gs = false;   // state-store instance: one LDS record per lane, the others in HBM
     bool blk = false;  // batched-H2H instance (strategy index from the lane's block index)
     int wpe = 4;       // waves per SIMD the chosen instance is compiled for
@@ -211,7 +213,7 @@ struct LaunchPlan {
 constexpr size_t LDS_LIMIT = 160 * 1024;
 
 size_t play_lds_bytes(int32_t k, int block, bool lean, bool gs, bool lds_tally, int32_t S, bool blocks_mode = false) {
-    const size_t per_lane = (size_t)(lean ? NF - 6 : NF) * 4 * (size_t)(gs ? 1 : k) + (blocks_mode ? 4 : 0);
+    const size_t per_lane = (size_t)(lean ? LEAN_DW : NF) * 4 * (size_t)(gs ? 1 : k) + (blocks_mode ? 4 : 0);
     return per_lane * (size_t)block + (lds_tally ? (size_t)S * LT_COLS * 8 : 0);
 }
 
@@ -219,9 +221,15 @@ size_t play_lds_bytes(int32_t k, int block, bool lean, bool gs, bool lds_tally, 
 // Instances are compiled for 4 waves/SIMD (<= 128 VGPRs); the 768-thread LEAN instances for 6 (80 VGPRs): their 12 waves
 // split evenly over the 4 SIMDs, so two blocks (24 waves) co-reside.  State-store (GS) instances are chosen for k >= 3:
 // their LDS use does not grow with k.
-LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, bool blocks_mode = false) {
+// Lean records carry the banked total / 50 in 16 bits: tables whose target is above 50 * LEAN_MAX_TARGET50 points play with
+// full records; block == 0 in the result = no instance fits (such a target with batched H2H, or with more seats than
+// LDS holds full records for).
+LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, int32_t target_score, bool blocks_mode = false) {
     LaunchPlan best;
-    if (blocks_mode) { // batched H2H: the one instance built for it (768 threads, lean LDS records of both seats + block index)
+    const bool lean_ok = ceil_div50(target_score) <= LEAN_MAX_TARGET50;
+    if (blocks_mode) {
+        if (!lean_ok) return best;
+        // batched H2H: the one instance built for it (768 threads, lean LDS records of both seats + block index)
         best.block = 768;
         best.lean = true;
         best.blk = true;
@@ -229,6 +237,7 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, b
         best.lds = play_lds_bytes(2, 768, true, false, false, 0, true);
         const int per_cu = c->blocks_per_cu > 0 ? std::min(2, c->blocks_per_cu) : 2;
         best.grid = c->prop.multiProcessorCount * per_cu;
+        best.cus = c->prop.multiProcessorCount;
         return best;
     }
     const bool want_tally = single_batch && !blocks_mode && (c->use_lds_tally != 0) && S <= 4096;
@@ -240,6 +249,7 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, b
         if (gs != (gs_wanted ? 1 : 0) && best_lanes >= 0) continue; // the other layout only if the wanted one does not fit
         for (int lean = 0; lean <= 1; ++lean) {
             if (gs && !lean) continue;
+            if (lean && !lean_ok) continue;
             if (!gs && c->lean >= 0 && lean != c->lean) continue;
             if (!gs && lean && !blocks_mode && S > (1 << (32 - CE_IDX_SHIFT))) continue; // strategy index must fit cE[31:18]
             for (int block : {1024, 768, 512, 256, 128, 64}) {
@@ -251,7 +261,11 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, b
                 size_t lds = play_lds_bytes(k, block, lean != 0, gs != 0, tally, (int32_t)S, blocks_mode);
                 if (lds > LDS_LIMIT) continue;
                 int per_cu = (int)(LDS_LIMIT / std::max<size_t>(lds, 1));
-                per_cu = std::min(per_cu, std::max(1, wpe * 4 * 64 / block));
+                // waves per SIMD: the occupancy an instance is compiled for (WPE) is a floor, not a ceiling — every instance
+                // allocates at most 80 VGPRs, so six waves fit (launch_play_u trims the grid to the occupancy HIP reports).
+                // Measured at k = 2 / 5160 strategies: 4 waves 25.8 ms, 6 waves (80 VGPRs) 22.4 ms, 7 waves (72 VGPRs) 23.5 ms.
+                (void)wpe;
+                per_cu = std::min(per_cu, std::max(1, c->max_waves * 4 * 64 / block));
                 if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
                 per_cu = std::max(per_cu, 1);
                 int lanes = (per_cu * block) * 4 + (tally ? 2 : 0) + (lean ? 0 : 1); // tie-breaks: tally, then full records
@@ -265,23 +279,37 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, b
                     best.gs = gs != 0;
                     best.wpe = wpe;
                     best.grid = c->prop.multiProcessorCount * per_cu;
+                    best.cus = c->prop.multiProcessorCount;
                 }
             }
         }
     }
-    return best; // always feasible: a GS instance needs 44 bytes of LDS per lane whatever k is
+    return best; // feasible whenever lean records are: a GS instance needs 40 bytes of LDS per lane whatever k is
 }
 
 template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS, bool BLK = false, int KC = 0>
 hipError_t launch_play_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     static bool configured = false; // the dynamic-LDS ceiling of an instance is raised once, not per launch
+    static size_t occ_lds = ~(size_t)0;
+    static int occ_blocks = 0;
+    const void *fn = reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS, BLK, KC>);
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS, BLK, KC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL((fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS, BLK, KC>), dim3((unsigned)p.grid), dim3(BLOCK), std::max<size_t>(p.lds, 16), s, a);
+    const size_t lds = std::max<size_t>(p.lds, 16);
+    if (occ_lds != lds) { // resident blocks per CU as the runtime counts them (registers, LDS, wave slots)
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK, lds);
+        if (e != hipSuccess) return e;
+        occ_blocks = std::max(nb, 1);
+        occ_lds = lds;
+    }
+    // a persistent grid: blocks beyond the resident ones would only queue behind them
+    const int grid = std::min(p.grid, occ_blocks * p.cus);
+    p.launched_grid = grid;
+    hipLaunchKernelGGL((fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS, BLK, KC>), dim3((unsigned)grid), dim3(BLOCK), lds, s, a);
     return hipGetLastError();
 }
 
@@ -470,10 +498,10 @@ int launch_play_stage(fk_ctx *c, const SeedArgs &sa, PlayArgs &pa, const LaunchP
         hipError_t e = launch_play(lp, pa, c->stream);
         t.stop();
         HIPCHK(c, e);
+        c->timing.play_grid = lp.launched_grid;
     }
     c->timing.play_launches += 1;
     c->timing.play_block = plan.block;
-    c->timing.play_grid = plan.grid;
     c->timing.play_lds_bytes = (int32_t)plan.lds;
     c->timing.games += sa.n_games;
     return FK_OK;
@@ -770,6 +798,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "use_lds_tally") c->use_lds_tally = (int32_t)value;
     else if (n == "longest_first") c->longest_first = (int32_t)value;
     else if (n == "blocks_per_cu") c->blocks_per_cu = (int32_t)value;
+    else if (n == "max_waves") c->max_waves = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8);
     else if (n == "lean") c->lean = (int32_t)value;
     else if (n == "state_store") c->gs = (int32_t)value;
     else if (n == "perm_split") c->perm_split = (int32_t)value;
@@ -818,7 +847,10 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->tally.p, 0, tally_bytes, c->stream));
 
-    const LaunchPlan plan = plan_play(c, k, S, n_batches == 1);
+    const LaunchPlan plan = plan_play(c, k, S, n_batches == 1, target_score);
+    if (plan.block == 0)
+        return fail(c, FK_ERR_ARG, "target_score %d: no kernel instance (lean records hold totals up to %d points; %d full records do not fit LDS)",
+                    target_score, 50 * LEAN_MAX_TARGET50, (int)k);
     const bool want_state = rows != nullptr || seat_stats != nullptr;
     const bool want_recs = !plan.lds_tally || want_state;
     const size_t stats_bytes = sizeof(int64_t) * (size_t)n_batches * (size_t)S * FK_SEAT_STAT_COLS;
@@ -1059,7 +1091,10 @@ int fk_play_games(fk_ctx *c, const fk_coord *coords, int64_t n_games, const fk_s
     HIPCHK(c, hipMemcpyAsync(c->coords.p, coords, sizeof(fk_coord) * (size_t)n_games, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->seatlist.p, seat_strategy, sizeof(int32_t) * (size_t)n_games * k, hipMemcpyHostToDevice, c->stream));
 
-    LaunchPlan plan = plan_play(c, k, S, false);
+    LaunchPlan plan = plan_play(c, k, S, false, target_score);
+    if (plan.block == 0)
+        return fail(c, FK_ERR_ARG, "target_score %d: no kernel instance (lean records hold totals up to %d points; %d full records do not fit LDS)",
+                    target_score, 50 * LEAN_MAX_TARGET50, (int)k);
 
     SeedArgs sa{};
     sa.coords = static_cast<const fk_coord *>(c->coords.p);
@@ -1124,7 +1159,10 @@ int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_
     if (rc) return rc;
     const SeedPool seat_prefix = seed_prefix(203u /* H2H_PLAYER */, root_seed, 2u);
     constexpr size_t MAX_BLOCKS_PER_PASS = (size_t)1 << 22; // rec0 holds the winner's table row in 24 bits
-    const LaunchPlan plan = plan_play(c, 2, n_blocks * 2, false, true);
+    const LaunchPlan plan = plan_play(c, 2, n_blocks * 2, false, target_score, true);
+    if (plan.block == 0)
+        return fail(c, FK_ERR_ARG, "target_score %d: batched head-to-head plays with lean records (totals up to %d points)", target_score,
+                    50 * LEAN_MAX_TARGET50);
     const uint64_t max_launch = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->chunk_bytes / (game_workspace_bytes(2, plan.gs, false, false) + 8), 1u << 30));
     rc = ensure(c, c->block_out, (size_t)n_blocks * 4 * 8);
     if (rc) return rc;

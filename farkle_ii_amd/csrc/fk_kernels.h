@@ -38,15 +38,21 @@ enum : uint32_t {
     F_LO0 = 0, F_LO1, F_HI0, F_HI1, F_INC_LO0, F_INC_LO1, F_INC_HI0, F_INC_HI1,
     F_BUF, F_SCORE, F_CA, F_CB, F_CC, F_CD, F_CE, F_SPX, F_SPY, NF
 };
-// packed u16 counter pairs
-//   cA = rolls | farkles << 16        cB = highest_turn / 50 | n_turns << 16      (scores are carried in units of 50 points)
+// packed u16 counter pairs, in the state store (R_*) and in full LDS records (scores are carried in units of 50 points)
+//   cA = rolls | farkles << 16        cB = highest_turn / 50 | n_turns << 16 (the n_turns half: state store only)
 //   cC = sf_uses | sf_dice << 16      cD = so_uses | so_dice << 16
 //   cE = hot_dice | flags << 16       flags: bit0 has_scored, bit1 has_buf
 constexpr uint32_t CE_HAS_SCORED = 1u << 16, CE_HAS_BUF = 1u << 17;
 constexpr uint32_t CE_IDX_SHIFT = 18; // LEAN records in LDS: strategy index in cE[31:18] (S <= 16384)
+// LEAN LDS record, ten dwords: LO0 LO1 | HI0 HI1 | BUF cA | cB cC | cD cE with
+//   cB = highest_turn / 50 | hot_dice << 16        cE = score / 50 | has_scored << 16 | has_buf << 17 | strategy << 18
+// (n_turns is a function of rounds, trigger seat and final round: restored when the game ends).  The banked total must fit
+// 16 bits in units of 50: it stays below target / 50 + one turn (<= 1310), so LEAN needs target / 50 <= LEAN_MAX_TARGET50.
+constexpr uint32_t LEAN_DW = 10;
+constexpr int32_t LEAN_MAX_TARGET50 = 64000;
 
 // State record of one seat in HBM (the seed kernel writes it, GS game kernels keep it current, the post-passes read the
-// final one): the eleven dwords a turn mutates, in the order of the LEAN LDS record, + the seat's strategy index.
+// final one): the eleven dwords a turn mutates with score, n_turns and hot dice spelled out, + the seat's strategy index.
 // 48 bytes = three 16-byte accesses; index = slot * k + seat (slot = ticket position of the game's schedule).
 // R_SCORE and the highest_turn half of R_CB are in units of 50 points (fk_device.h); the post-passes multiply them out.
 enum : uint32_t { R_LO0 = 0, R_LO1, R_HI0, R_HI1, R_BUF, R_SCORE, R_CA, R_CB, R_CC, R_CD, R_CE, R_IDX, STATE_DW = 12 };
@@ -673,19 +679,19 @@ __global__ void fk_finalize_tally(unsigned long long *tally, uint32_t n_rows, ui
 }
 
 // ---------------------------------------------------------------------------------------
-// The game kernel.  Every seat has a state record (PCG state, buffered half word, score, packed counters: the eleven
+// The game kernel.  Every seat has a state record (PCG state, buffered half word, score, packed counters: the ten
 // dwords a turn mutates); each roll step loads the turn owner's record from LDS, updates it and stores it back; nothing
 // but the turn registers and the owner's read-only data (increment, strategy) is carried in VGPRs across rolls.
 //
-//   LDS-record instances (GS = false): all k records of the lane's game sit in LDS.  LEAN records keep only the eleven
-//   mutable dwords (44 bytes instead of 68): the read-only PCG increment and the packed strategy are re-read from the
+//   LDS-record instances (GS = false): all k records of the lane's game sit in LDS.  LEAN records keep only the ten
+//   mutable dwords (40 bytes instead of 68): the read-only PCG increment and the packed strategy are re-read from the
 //   increment plane / the strategy table (L2-resident) at the start of each turn, the strategy index riding in the
 //   spare bits of cE.  Fewer LDS bytes per lane = more resident waves per SIMD (k = 2: 4 -> 6).
 //
 //   State-store instances (GS = true): LDS holds ONE record per lane, the turn owner's; the records of all seats live
 //   in the per-game state store in HBM (written by the seed kernel).  A record is touched twice per turn, at the
 //   hand-over to the next seat (already a divergent region): the owner's record is stored, the next seat's is loaded
-//   — three 16-byte accesses each, L2 / Infinity-Cache resident for the games in flight.  LDS bytes per lane (44) and
+//   — three 16-byte accesses each, L2 / Infinity-Cache resident for the games in flight.  LDS bytes per lane (40) and
 //   with them the resident waves per SIMD (6) no longer depend on k, there is no limit on k or on S, and the final
 //   records of every game stay in HBM for the streaming post-passes (rows, all-seat statistics).
 //
@@ -697,13 +703,13 @@ __global__ void fk_finalize_tally(unsigned long long *tally, uint32_t n_rows, ui
 // KC: compile-time player count (0 = run-time a.k).  The two-player instances (BASELINE config 2, every H2H launch) fold
 // the seat arithmetic of the table advance and the record addressing.
 template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS, bool BLK = false, int KC = 0>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void fk_play_kernel(PlayArgs a) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) void fk_play_kernel(PlayArgs a) {
     static_assert(!GS || LEAN, "state-store instances stage the lean record");
     static_assert(!BLK || (LEAN && !GS), "block-index instances use lean LDS records");
-    extern __shared__ uint32_t lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t K = KC ? (uint32_t)KC : a.k;
-    constexpr uint32_t NFIELDS = LEAN ? (uint32_t)NF - 6u : (uint32_t)NF; // 11 or 17 dwords per seat record
+    constexpr uint32_t NFIELDS = LEAN ? LEAN_DW : (uint32_t)NF; // 10 or 17 dwords per seat record
     unsigned long long *tl = reinterpret_cast<unsigned long long *>(lds + NFIELDS * (GS ? 1u : K) * BLOCK);
     // batched H2H launches (no LDS tally): one dword per lane behind the records holds the lane's block index — the strategy
     // index of seat s is 2 * block + s, whatever the number of blocks (the 14-bit index field of cE would cap it at 8 192)
@@ -725,6 +731,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     // turn registers
     uint32_t dice = 6, rolls_this_turn = 0;
     int32_t turn_score = 0;
+    uint32_t own_turns = 0; // state-store instances only: the owner's n_turns, kept out of the 10-dword LDS record
     // read-only data of the turn owner (PCG increment, packed strategy): the only per-seat values carried in registers
     // across roll iterations.  The mutable seat record (generator state, score, counters) is loaded from and stored to
     // LDS inside every roll step, so the hot loop carries no per-seat PHIs through its divergent turn hand-over.
@@ -733,15 +740,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     uint32_t own_bits = 0;
 
     // LDS records are contiguous per (seat, lane): record base = (seat * BLOCK + tid) * NFIELDS, field = immediate
-    // offset (one address VGPR per record, ds_read2/ds_write2 pairs).  The odd record stride (11 / 17 dwords) maps the
-    // 32 lanes of an LDS lane group to 32 distinct banks whatever seat each lane is on (BLOCK % 32 == 0).
-    // LEAN records have no increment / strategy slots: fields after the increment move up by four.
+    // offset (one address VGPR per record).  Full records: odd stride (17 dwords), ds_read2/ds_write2 dword pairs, the
+    // 32 lanes of an LDS lane group on 32 distinct banks whatever seat each lane is on (BLOCK % 32 == 0).  LEAN records:
+    // ten dwords = five 8-byte-aligned pairs moved by ds_read_b64 / ds_write_b64; the stride of five bank PAIRS is odd,
+    // so the 32 lanes of a group again cover all 64 banks once.
+    // LEAN records have no increment / strategy / score slots: BUF moves up by four, the counters by five.
     // Address = loop-invariant lane base + seat * compile-time stride: one full-rate v_mad_u32_u24 per record instead
     // of the quarter-rate 32-bit multiplies the plain index expression costs.  GS: one record per lane, no seat term.
     const uint32_t lane_base = tid * NFIELDS;
     constexpr uint32_t SEAT_STRIDE = (uint32_t)BLOCK * NFIELDS; // < 2^24
     auto L = [&](uint32_t field, uint32_t s) __attribute__((always_inline)) -> uint32_t & {
-        const uint32_t f = (LEAN && field > F_INC_HI1) ? field - 4u : field;
+        const uint32_t f = !LEAN ? field : (field > F_SCORE) ? field - 5u : (field > F_INC_HI1) ? field - 4u : field;
         if (GS) return lds[lane_base + f];
         return lds[__umul24(s, SEAT_STRIDE) + lane_base + f];
     };
@@ -766,31 +775,35 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         if (LEAN) return L(F_CE, s) >> CE_IDX_SHIFT;
         return strategy_index(game_id, s);
     };
-    auto seat_score = [&](uint32_t s) -> int32_t { return (int32_t)(GS ? G(s)[R_SCORE] : L(F_SCORE, s)); };
-    auto seat_counter = [&](uint32_t s, uint32_t field) -> uint32_t { // field in F_CA..F_CE
+    auto seat_score = [&](uint32_t s) -> int32_t {
+        return (int32_t)(GS ? G(s)[R_SCORE] : LEAN ? (L(F_CE, s) & 0xffffu) : L(F_SCORE, s));
+    };
+    auto seat_counter = [&](uint32_t s, uint32_t field) -> uint32_t { // field in F_CA..F_CD (same packing in every layout)
         return GS ? G(s)[R_CA + (field - F_CA)] : L(field, s);
     };
+    auto seat_hot_dice = [&](uint32_t s) -> uint32_t {
+        return GS ? (G(s)[R_CE] & 0xffffu) : LEAN ? (L(F_CB, s) >> 16) : (L(F_CE, s) & 0xffffu);
+    };
+    // n_turns of seat s of a game that has ended (engine.py:236 counts them turn by turn): every seat began `rounds` turns,
+    // minus the seats behind the trigger in its round, plus the final-round turn of every seat but the trigger's.
+    auto seat_turns = [&](uint32_t s) -> uint32_t { return rounds + ((final_round != 0u && s < trigger) ? 1u : 0u); };
 
-    // turn owner := seat s (engine.py:236-240): n_turns += 1 in its record, fresh turn registers, read-only data
+    // turn owner := seat s (engine.py:236-240): fresh turn registers, read-only data.  n_turns is not stored per turn in
+    // the LDS instances (seat_turns above restores it when the game ends).
     auto begin_turn = [&](uint32_t s) __attribute__((always_inline)) {
         uint32_t idx = 0;
         if (GS) { // stage the seat's record: HBM state store -> the lane's LDS record
             const uint4 *g = reinterpret_cast<const uint4 *>(G(s));
             const uint4 q0 = g[0], q1 = g[1], q2 = g[2];
-            lds[lane_base + 0] = q0.x;
-            lds[lane_base + 1] = q0.y;
-            lds[lane_base + 2] = q0.z;
-            lds[lane_base + 3] = q0.w;
-            lds[lane_base + 4] = q1.x;
-            lds[lane_base + 5] = q1.y;
-            lds[lane_base + 6] = q1.z;
-            lds[lane_base + 7] = q1.w + 0x10000u; // n_turns += 1 (engine.py:236)
-            lds[lane_base + 8] = q2.x;
-            lds[lane_base + 9] = q2.y;
-            lds[lane_base + 10] = q2.z;
+            uint2 *r = reinterpret_cast<uint2 *>(lds + lane_base);
+            r[0] = make_uint2(q0.x, q0.y);
+            r[1] = make_uint2(q0.z, q0.w);
+            r[2] = make_uint2(q1.x, q1.z);                                           // buf, cA
+            r[3] = make_uint2((q1.w & 0xffffu) | (q2.z << 16), q2.x);                 // highest_turn | hot_dice << 16, cC
+            r[4] = make_uint2(q2.y, (q1.y & 0xffffu) | (q2.z & (CE_HAS_SCORED | CE_HAS_BUF))); // cD, score | flags
+            own_turns = (q1.w >> 16) + 1u; // n_turns += 1 (engine.py:236)
             idx = q2.w;
         } else {
-            L(F_CB, s) += 0x10000u; // n_turns += 1 (engine.py:236)
             if (BLK) idx = 2u * *lane_block + s;
             else if (LEAN) idx = L(F_CE, s) >> CE_IDX_SHIFT;
         }
@@ -830,12 +843,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             }
         }
         if (!GS && a.gs_out) { // final records of every seat -> state store (rows / all-seat statistics post-passes)
-            for (uint32_t s = 0; s < K; ++s) {
+            for (uint32_t s = 0; s < K; ++s) { // the state store's format (R_*): score and n_turns spelled out
                 uint4 *g = reinterpret_cast<uint4 *>(G(s));
-                const uint32_t ce = L(F_CE, s);
                 g[0] = make_uint4(L(F_LO0, s), L(F_LO1, s), L(F_HI0, s), L(F_HI1, s));
-                g[1] = make_uint4(L(F_BUF, s), L(F_SCORE, s), L(F_CA, s), L(F_CB, s));
-                g[2] = make_uint4(L(F_CC, s), L(F_CD, s), LEAN ? (ce & ((1u << CE_IDX_SHIFT) - 1u)) : ce, seat_strategy(s));
+                g[1] = make_uint4(L(F_BUF, s), (uint32_t)seat_score(s), L(F_CA, s), (L(F_CB, s) & 0xffffu) | (seat_turns(s) << 16));
+                g[2] = make_uint4(L(F_CC, s), L(F_CD, s), seat_hot_dice(s) | (L(F_CE, s) & (CE_HAS_SCORED | CE_HAS_BUF)),
+                                  seat_strategy(s));
             }
         }
         if (a.use_lds_tally) {
@@ -849,13 +862,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         if (completed) {
             widx = seat_strategy(w);
             wa = seat_counter(w, F_CA), wb = seat_counter(w, F_CB), wc = seat_counter(w, F_CC), wd = seat_counter(w, F_CD),
-            we = seat_counter(w, F_CE);
+            we = seat_hot_dice(w);
         } else if (a.mode == MODE_BLOCKS) {
             widx = seat_strategy(0); // names the block of a safety-limit attempt
         }
         if (a.use_lds_tally && completed) {
             const unsigned long long m[10] = {(unsigned long long)(uint32_t)best * 50u, rounds, wa >> 16, wa & 0xffffu,
-                                              (wb & 0xffffu) * 50u, wc & 0xffffu, wc >> 16, wd & 0xffffu, wd >> 16, we & 0xffffu};
+                                              (wb & 0xffffu) * 50u, wc & 0xffffu, wc >> 16, wd & 0xffffu, wd >> 16, we};
             unsigned long long *t = tl + widx * LT_COLS;
             atomicAdd(&t[0], 1ull);
 #pragma unroll
@@ -873,7 +886,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                 uint4 *r = reinterpret_cast<uint4 *>(a.recs + (size_t)game_id * REC_DW);
                 r[0] = make_uint4(d0, completed ? (uint32_t)best * 50u : 0u, rounds | (wa & 0xffff0000u),
                                   (wa & 0xffffu) | (((wb & 0xffffu) * 50u) << 16)); // points: highest_turn <= 65 500 by its guard band
-                r[1] = make_uint4(wc, wd, we & 0xffffu, 0u);
+                r[1] = make_uint4(wc, wd, we, 0u);
             }
         }
     };
@@ -922,7 +935,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                     L(F_SPY, s) = pk.y;
                 }
                 L(F_BUF, s) = 0u;
-                L(F_SCORE, s) = 0u;
+                if (!LEAN) L(F_SCORE, s) = 0u;
                 L(F_CA, s) = 0u;
                 L(F_CB, s) = 0u;
                 L(F_CC, s) = 0u;
@@ -975,10 +988,24 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     auto roll_step = [&]() __attribute__((always_inline)) {
         const bool roll_limit = rolls_this_turn >= 1000u; // ROLL_LIMIT, engine.py:36,242 (raised below, before any store)
         const uint32_t s = seat;
-        uint32_t cA = L(F_CA, s), cB = L(F_CB, s), cC = L(F_CC, s), cD = L(F_CD, s), cE = L(F_CE, s);
-        int32_t score = (int32_t)L(F_SCORE, s);
-        Rng rng{(uint64_t)L(F_HI0, s) | ((uint64_t)L(F_HI1, s) << 32), (uint64_t)L(F_LO0, s) | ((uint64_t)L(F_LO1, s) << 32),
-                own_inc_hi, own_inc_lo, L(F_BUF, s), (cE & CE_HAS_BUF) ? 1u : 0u};
+        uint32_t cA, cB, cC, cD, cE, buf0;
+        int32_t score;
+        uint64_t lo0, hi0;
+        uint2 *const rec = reinterpret_cast<uint2 *>(&L(F_LO0, s)); // LEAN: five aligned pairs
+        if (LEAN) {
+            const uint2 p0 = rec[0], p1 = rec[1], p2 = rec[2], p3 = rec[3], p4 = rec[4];
+            lo0 = (uint64_t)p0.x | ((uint64_t)p0.y << 32);
+            hi0 = (uint64_t)p1.x | ((uint64_t)p1.y << 32);
+            buf0 = p2.x, cA = p2.y, cB = p3.x, cC = p3.y, cD = p4.x, cE = p4.y;
+            score = (int32_t)(cE & 0xffffu); // score / 50 rides in cE[15:0] (plan_play keeps target / 50 + a turn below 2^16)
+        } else {
+            cA = L(F_CA, s), cB = L(F_CB, s), cC = L(F_CC, s), cD = L(F_CD, s), cE = L(F_CE, s);
+            score = (int32_t)L(F_SCORE, s);
+            lo0 = (uint64_t)L(F_LO0, s) | ((uint64_t)L(F_LO1, s) << 32);
+            hi0 = (uint64_t)L(F_HI0, s) | ((uint64_t)L(F_HI1, s) << 32);
+            buf0 = L(F_BUF, s);
+        }
+        Rng rng{hi0, lo0, own_inc_hi, own_inc_lo, buf0, (cE & CE_HAS_BUF) ? 1u : 0u};
         const uint32_t n = dice;
         const uint32_t key = roll_counts<3>(rng, n);
         rolls_this_turn += 1u;
@@ -991,7 +1018,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         dice = (rr.used == (int32_t)n) ? 6u : (n - (uint32_t)rr.used);  // engine.py:146
         turn_score = farkle ? 0 : (turn_score + rr.score50);
         const bool hot = !farkle & sp.has(SF_AUTO_HOT) & (dice == 6u);  // _apply_hot_dice, engine.py:149-154, 253
-        cE += hot ? 1u : 0u;
+        if (LEAN) cB += hot ? 0x10000u : 0u; // hot-dice count: cB[31:16] (lean) or cE[15:0]
+        else cE += hot ? 1u : 0u;
         const bool keep = should_continue50(sp, turn_score, (int32_t)dice, (cE & CE_HAS_SCORED) != 0u, final_round != 0u,
                                             score_to_beat, score);
         const bool over = farkle | (!hot & !keep);
@@ -1000,6 +1028,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         cE |= (ts >= 10u) ? CE_HAS_SCORED : 0u;                         // 500 points
         const uint32_t banked = (cE & CE_HAS_SCORED) ? ts : 0u;
         score += (int32_t)banked;
+        if (LEAN) cE += banked;
         cB = (banked > (cB & 0xffffu)) ? ((cB & 0xffff0000u) | banked) : cB;
         // one rare exit for all error conditions: the roll limit, then the u16 guard bands (a turn adds <= 1000 rolls
         // and <= 2000 discarded dice; highest_turn must fit 16 bits IN POINTS: 1310 x 50 = 65 500)
@@ -1013,26 +1042,34 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             if (over) { // the turn is over: the record goes back to the state store, the next seat's comes in
                 uint4 *g = reinterpret_cast<uint4 *>(G(s));
                 g[0] = make_uint4((uint32_t)rng.lo, (uint32_t)(rng.lo >> 32), (uint32_t)rng.hi, (uint32_t)(rng.hi >> 32));
-                g[1] = make_uint4(rng.buf, (uint32_t)score, cA, cB);
+                g[1] = make_uint4(rng.buf, (uint32_t)score, cA, (cB & 0xffffu) | (own_turns << 16));
                 uint32_t *g2 = reinterpret_cast<uint32_t *>(g + 2); // R_IDX stays as the seed kernel wrote it
                 g2[0] = cC;
                 g2[1] = cD;
-                g2[2] = cE;
+                g2[2] = (cB >> 16) | (cE & (CE_HAS_SCORED | CE_HAS_BUF));
                 advance(score);
                 return;
             }
         }
-        L(F_LO0, s) = (uint32_t)rng.lo;
-        L(F_LO1, s) = (uint32_t)(rng.lo >> 32);
-        L(F_HI0, s) = (uint32_t)rng.hi;
-        L(F_HI1, s) = (uint32_t)(rng.hi >> 32);
-        L(F_BUF, s) = rng.buf;
-        L(F_SCORE, s) = (uint32_t)score;
-        L(F_CA, s) = cA;
-        L(F_CB, s) = cB;
-        L(F_CC, s) = cC;
-        L(F_CD, s) = cD;
-        L(F_CE, s) = cE;
+        if (LEAN) {
+            rec[0] = make_uint2((uint32_t)rng.lo, (uint32_t)(rng.lo >> 32));
+            rec[1] = make_uint2((uint32_t)rng.hi, (uint32_t)(rng.hi >> 32));
+            rec[2] = make_uint2(rng.buf, cA);
+            rec[3] = make_uint2(cB, cC);
+            rec[4] = make_uint2(cD, cE);
+        } else {
+            L(F_LO0, s) = (uint32_t)rng.lo;
+            L(F_LO1, s) = (uint32_t)(rng.lo >> 32);
+            L(F_HI0, s) = (uint32_t)rng.hi;
+            L(F_HI1, s) = (uint32_t)(rng.hi >> 32);
+            L(F_BUF, s) = rng.buf;
+            L(F_SCORE, s) = (uint32_t)score;
+            L(F_CA, s) = cA;
+            L(F_CB, s) = cB;
+            L(F_CC, s) = cC;
+            L(F_CD, s) = cD;
+            L(F_CE, s) = cE;
+        }
         if (!GS && over) advance(score);
     };
 

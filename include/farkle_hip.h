@@ -124,8 +124,9 @@ int fk_get_device_info(fk_ctx *ctx, fk_device_info *out);
 int fk_get_timing(fk_ctx *ctx, fk_timing *out);
 /* Tunables: "chunk_bytes" (device workspace budget per chunk), "batch_threshold" (lanes that must be waiting
  * before a wave runs its game hand-over), "use_lds_tally" (0/1/-1 auto), "block" (0 auto), "lean" (seat-record layout:
- * -1 auto, 0 full, 1 lean), "state_store" (-1 auto: seat records of k >= 3 tables live in the HBM state store with only the
- * turn owner's staged in LDS, 0 LDS records whenever they fit, 1 always), "blocks_per_cu", "longest_first" (1 = deal
+ * -1 auto, 0 full, 1 lean), "state_store" (-1 auto: seat records live in the HBM state store, with only the turn owner's staged in LDS, when
+ * k of them do not fit LDS; 0 the same; 1 always), "blocks_per_cu", "max_waves" (resident waves per SIMD the launch plan counts
+ * on, default 6), "longest_first" (1 = deal
  * never-banking pairings first), "uniform_flags" (-1 auto: tables whose strategies share all flag bits run the scalar-flag
  * kernel instance, 0 never), "perm_split" (-1 auto), "pipeline" (1: the next chunk / hinted call is prepared on a side stream while
  * the game kernel runs, 0: never).  All of them are scheduling / layout choices: results are identical
@@ -136,7 +137,9 @@ int fk_set_option(fk_ctx *ctx, const char *name, int64_t value);
  *   tally       int64 [n_batches][S][26], n_batches = ceil(n_shuffles / shuffles_per_batch); overwritten.
  *   rows        nullable; n_shuffles * (S/k) rows of 4+28k bytes, game-major in (shuffle, game) order.
  *   perms       nullable; int32 [n_shuffles][S] (the permutation of each shuffle; tests/diagnostics).
- * Requires S % k == 0 (run_tournament.py:274), S <= 65535, max_rounds <= 65535. */
+ * Requires S % k == 0 (run_tournament.py:274), S <= 65535, max_rounds <= 65535.  Targets above 3 200 000 points play with
+ * full LDS records (lean ones carry the banked total / 50 in 16 bits): FK_ERR_ARG if k of those do not fit LDS, and for the
+ * batched head-to-head entry points. */
 int fk_tournament_run(fk_ctx *ctx, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
                       uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch,
                       int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov,

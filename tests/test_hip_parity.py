@@ -348,7 +348,7 @@ def test_tournament_batches_chunks_options_and_overrides(eng, po):
     try:
         for name, value in [("chunk_bytes", 1 << 20), ("batch_threshold", 1), ("batch_threshold", 64), ("block", 256),
                             ("block", 64), ("use_lds_tally", 0), ("lean", 0), ("lean", 1), ("block", 768), ("block", 1024),
-                            ("longest_first", 0), ("uniform_flags", 0)]:
+                            ("longest_first", 0), ("uniform_flags", 0), ("block", 0), ("max_waves", 3), ("max_waves", 8)]:
             eng.set_option(name, value)
             got = eng.tournament(table, 2, 42, 0, 50, shuffles_per_batch=7, overrides=make_overrides(ovs), want_rows=True)
             assert np.array_equal(got["tally"], ref["tally"]), (name, value)
@@ -357,7 +357,7 @@ def test_tournament_batches_chunks_options_and_overrides(eng, po):
             assert np.array_equal(one["tally"][0], ref["tally"].sum(axis=0)), (name, value)
     finally:
         for name, value in [("chunk_bytes", 24 << 30), ("batch_threshold", 8), ("block", 0), ("use_lds_tally", -1), ("lean", -1),
-                            ("longest_first", 1), ("uniform_flags", -1)]:
+                            ("longest_first", 1), ("uniform_flags", -1), ("max_waves", 6)]:
             eng.set_option(name, value)
 
 

@@ -98,13 +98,21 @@ def test_state_store_limits_overrides_and_safety_games(eng, po):
             eng.set_option("state_store", store)
             gps = 64 // k
             ovs = [(9, 2, 1, k, 0), (9, 2, 3, k, 7), (9, 5, gps - 1, k, 1), (9, 0, 0, k, 3), (9, 7, 2, k, 250), (9, 2, 5, k, 5)]
-            for tbl, target, mr in [(table, 10_000, 200), (table, 2_000, 5), (never, 10_000, 12), (table, 50, 200), (table, 10_000, 0)]:
+            # targets that are not multiples of 50 exercise the unit-of-50 rounding (ceil for "reached", floor for "to beat");
+            # 3 200 001 is above what lean records hold (16-bit total / 50): the launch plan falls back to full records
+            for tbl, target, mr in [(table, 10_000, 200), (table, 2_000, 5), (never, 10_000, 12), (table, 50, 200), (table, 10_000, 0),
+                                    (table, 10_025, 200), (table, 1_030, 60), (table, 75, 200), (table, 1, 200),
+                                    (table, 3_200_001, 40), (table, 3_200_000, 40)]:
                 ref = po.tournament(tbl.view(po.STRATEGY_DTYPE), k, 9, 0, 10, shuffles_per_batch=3, target_score=target, max_rounds=mr,
                                     overrides=po.make_overrides(ovs), want_rows=True)
                 got = eng.tournament(tbl, k, 9, 0, 10, shuffles_per_batch=3, target_score=target, max_rounds=mr,
                                      overrides=make_overrides(ovs), want_rows=True)
                 assert np.array_equal(got["tally"], ref["tally"]), (k, target, mr)
                 assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, target, mr)
+        eng.set_option("state_store", -1)
+        with pytest.raises(Exception, match="lean records"):  # the batched head-to-head instance has lean records only
+            eng.h2h_blocks(np.stack([table[:2]]), 11, np.array([0], np.uint64), np.array([0], np.uint32), np.array([4], np.uint64),
+                           np.array([8], np.uint64), target_score=3_200_001, max_rounds=10)
     finally:
         eng.set_option("state_store", -1)
 
