@@ -559,10 +559,11 @@ def main() -> None:
             "kernel_ms": kernel_ms, "games_per_launch": games_per_launch, "kernel_games_per_s": kernel_games_per_s, **wpg,
             "hbm": {"achieved": kernel_games_per_s * hbm_bpg / 1e9, "peak": 8000.0, "unit": "GB/s",
                     "frac": kernel_games_per_s * hbm_bpg / 8e12, "bytes_per_game": hbm_bpg},
-            # preparation kernels of the launches that were NOT prepared on the side stream behind the previous game kernel
+            # permutations: every launch (they run on the main stream, in front of the previous game kernel when pipelined);
+            # seat seeding: only the launches that were NOT seeded on the side stream behind the previous game kernel
             "seed_kernel_ms": t.get("seed_ms", 0.0) / max(launches - int(t.get("prefetched_chunks", 0)), 1),
-            "perm_kernel_ms": t.get("perm_ms", 0.0) / max(launches - int(t.get("prefetched_chunks", 0)), 1),
-            "launches_prepared_behind_the_previous_kernel": int(t.get("prefetched_chunks", 0)),
+            "perm_kernel_ms": t.get("perm_ms", 0.0) / max(launches, 1),
+            "launches_seeded_behind_the_previous_kernel": int(t.get("prefetched_chunks", 0)),
             "launch": {k2: t.get(k2) for k2 in ("play_block", "play_grid", "play_lds_bytes")},
         }
         cpu = None

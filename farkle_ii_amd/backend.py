@@ -15,7 +15,8 @@ import numpy as np
 from .strategies import STRATEGY_DTYPE
 
 PKG_DIR = Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "libfarkle_hip.so"
+# FARKLE_HIP_LIB: load another build of the same C-ABI (A/B timing of kernel variants); the default is the in-tree library
+LIB_PATH = Path(os.environ.get("FARKLE_HIP_LIB", PKG_DIR / "libfarkle_hip.so"))
 SRC_DIR = PKG_DIR / "csrc"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

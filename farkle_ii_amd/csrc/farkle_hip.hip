@@ -26,9 +26,15 @@ struct DevBuf {
 };
 
 // Everything a chunk's preparation (permutations, schedule, seat seeding) writes and its game kernel reads.  There are two
-// sets: while the game kernel of one chunk runs, the preparation of the next chunk (of this call, or — after
-// fk_tournament_hint_next — of the next call) is enqueued on a low-priority stream into the other set; its kernels
-// find free CUs only as the persistent game kernel's blocks retire, i.e. they fill its drain tail.
+// sets: with option "pipeline" = 1 the next chunk (of this call, or — after fk_tournament_hint_next — of the next call) is
+// prepared into the other set around the game kernel of the current one: its permutations in front of that game kernel on
+// the main stream, its schedule and seat seeding on a low-priority stream.  Off by default, because it cannot win here
+// (rocprofv3 kernel traces, round 2): the persistent game kernel holds every byte of LDS the launch plan could give it
+// (160 KB per CU at k = 4), so any side-stream kernel with an LDS allocation — permutations, and the seed kernels' few
+// hundred bytes — only starts when the game kernel ends; and an LDS-free seed kernel that does run beside it takes the issue
+// cycles it uses away from the game kernel one for one (both are VALU-issue bound: game kernel 178 -> 184 ms while a 6 ms
+// seeding ran beside it), with one run stalling 120 ms per step behind the low-priority queue.  Serial preparation on the
+// main stream costs the same and cannot stall.
 struct ChunkDesc {
     uint64_t epoch = 0, root = 0, sh0 = 0; // strategy-table upload epoch, root seed, first shuffle
     uint32_t n_sh = 0, S = 0, k = 0, state_dw = 0, sched = 0, slots = 0;
@@ -39,7 +45,7 @@ struct ChunkDesc {
 };
 
 struct ChunkSet {
-    DevBuf perm, draws, state, inc, seat_idx, order, classes, misc;
+    DevBuf perm, draws, state, inc, seat_idx, order, classes, misc, pools;
     hipEvent_t ready = nullptr;                       // recorded behind the preparation kernels
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // permutation begin / end, seeding begin / end (timing)
     bool prepared = false;
@@ -57,7 +63,7 @@ struct fk_ctx {
     uint64_t table_epoch = 0;
     bool hint_valid = false;           // fk_tournament_hint_next
     uint64_t hint_begin = 0, hint_end = 0;
-    int32_t hint_state = 0, pipeline = 1;
+    int32_t hint_state = 0, pipeline = 0; // off by default: measured zero-sum (see ChunkDesc)
     hipDeviceProp_t prop{};
     std::string err;
     fk_timing timing{};
@@ -448,6 +454,15 @@ int seed_stage(fk_ctx *c, int si, hipStream_t st, SeedArgs &sa, bool full_state,
         sa.sched = nullptr;
     }
     if (timed) (void)hipEventRecord(cs.ev[2], st);
+    sa.pools = nullptr;
+    if (!sa.coords) { // the pool every game of a shuffle / of a block starts from
+        const uint32_t n = sa.blocks ? sa.n_blocks : (sa.gps ? (sa.n_games + sa.gps - 1u) / sa.gps : 1u);
+        rc = ensure(c, cs.pools, (size_t)n * 16);
+        if (rc) return rc;
+        sa.pools = static_cast<const uint4 *>(cs.pools.p);
+        hipLaunchKernelGGL(fk_pool_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, sa.prefix, sa.shuffle0, sa.pair, sa.order, sa.blocks, n,
+                           static_cast<uint4 *>(cs.pools.p));
+    }
     if (sa.sched) // class sizes first: a game's ticket is class offset + rank
         hipLaunchKernelGGL(fk_class_count_kernel, dim3(std::min<uint32_t>((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK, 1024u)), dim3(SEED_BLOCK), 0,
                            st, sa.perm_T, sa.perm_slots, sa.S, sa.k, sa.n_sh, sa.n_games, sa.patience,
@@ -512,12 +527,13 @@ int finish_play(fk_ctx *c, const PlayArgs &pa, int64_t game_base, const char *wh
     const int rc_dev = check_device_error(c, pa.err, game_base, what); // synchronises the main stream
     HIPCHK(c, collect_timers(c));
     ChunkSet &cs = CSET(c);
-    if (cs.side) { // prepared behind another game kernel: no kernel-time reading for it (the intervals include the wait)
+    float ms = 0.f;
+    // the permutations of a pipelined chunk ran on the main stream, in front of the previous game kernel: a clean interval
+    if (hipEventElapsedTime(&ms, cs.ev[0], cs.ev[1]) == hipSuccess) c->timing.perm_ms += ms;
+    if (cs.side) { // seeded behind another game kernel: no kernel-time reading for it (the interval includes the sharing)
         c->timing.prefetched_chunks += 1;
-    } else {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, cs.ev[0], cs.ev[1]) == hipSuccess) c->timing.perm_ms += ms;
-        if (hipEventElapsedTime(&ms, cs.ev[2], cs.ev[3]) == hipSuccess) c->timing.seed_ms += ms;
+    } else if (hipEventElapsedTime(&ms, cs.ev[2], cs.ev[3]) == hipSuccess) {
+        c->timing.seed_ms += ms;
     }
     return rc_dev;
 }
@@ -539,12 +555,19 @@ int run_chunk(fk_ctx *c, const SeedArgs &sa_in, PlayArgs pa, const LaunchPlan &p
     return finish_play(c, pa, game_base, what);
 }
 
-// Tournament chunk: permutations of shuffles [d.sh0, d.sh0 + d.n_sh), then schedule + seat seeding, into chunk set `si` on `st`.
-// `sa` comes back with every pointer the game kernel and the post-passes need.
-int prep_tournament_chunk(fk_ctx *c, int si, hipStream_t st, const ChunkDesc &d, SeedArgs &sa) {
+// Tournament chunk into chunk set `si`: permutations of shuffles [d.sh0, d.sh0 + d.n_sh) on the main stream, then schedule +
+// seat seeding on `st`.  `sa` comes back with every pointer the game kernel and the post-passes need.
+//   st == main stream: the chunk is about to be played.
+//   st == prep_stream: the chunk is the NEXT one; the caller launches the current game kernel right after this returns.  The
+//   permutation kernels want most of a CU's LDS, which a resident persistent game kernel does not leave them (on the side
+//   stream they would only start when it ends, with the seeding behind them): they go in front of that game kernel on the
+//   main stream (0.1 ms at 64 strategies, 5 ms per 10^8 games at 5 160), and only the LDS-free part — schedule classes and
+//   seat seeding — shares the chip with the game kernel.
+int prep_tournament_chunk(fk_ctx *c, int si, hipStream_t st_seed, const ChunkDesc &d, SeedArgs &sa) {
     ChunkSet &cs = c->sets[si];
     cs.prepared = false;
-    if (st != c->prep_stream) HIPCHK(c, hipStreamWaitEvent(st, cs.ready, 0)); // an unused side-stream preparation may still own the set
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipStreamWaitEvent(st, cs.ready, 0)); // an unused side-stream preparation may still own the set
     const int32_t S = (int32_t)d.S;
     const uint32_t n_sh = d.n_sh, slots = d.slots, gps = d.S / d.k;
     const uint32_t perm_blocks = (n_sh + slots - 1u) / slots;
@@ -608,12 +631,16 @@ int prep_tournament_chunk(fk_ctx *c, int si, hipStream_t st, const ChunkDesc &d,
     sa.perm_slots = slots;
     sa.S = d.S;
     sa.n_sh = n_sh;
-    rc = seed_stage(c, si, st, sa, d.state_dw == STATE_DW, true);
+    if (st_seed != st) {
+        HIPCHK(c, hipStreamWaitEvent(st_seed, cs.ev[1], 0));     // the permutations
+        HIPCHK(c, hipStreamWaitEvent(st_seed, c->main_idle, 0)); // the set's previous users (recorded by the caller)
+    }
+    rc = seed_stage(c, si, st_seed, sa, d.state_dw == STATE_DW, true);
     if (rc) return rc;
-    HIPCHK(c, hipEventRecord(cs.ready, st));
+    HIPCHK(c, hipEventRecord(cs.ready, st_seed));
     cs.desc = d;
     cs.prepared = true;
-    cs.side = (st == c->prep_stream);
+    cs.side = (st_seed == c->prep_stream);
     return FK_OK;
 }
 
@@ -755,7 +782,7 @@ void fk_destroy(fk_ctx *c) {
                       &c->discard_lut, &c->blocks, &c->game_block, &c->block_out, &c->stats})
         release(*b);
     for (auto &cs : c->sets) {
-        for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc}) release(*b);
+        for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc, &cs.pools}) release(*b);
         if (cs.ready) (void)hipEventDestroy(cs.ready);
         for (auto &e : cs.ev)
             if (e) (void)hipEventDestroy(e);
@@ -964,11 +991,9 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
         pa.beat50 = floor_div50(target_score);
         pa.max_rounds = (uint32_t)max_rounds;
 
+        // The next chunk (or the hinted next call) is prepared into the other chunk set around this game kernel: its permutations
+        // in front of it on the main stream, its schedule + seat seeding on the low-priority stream while it runs.
         HIPCHK(c, hipEventRecord(c->main_idle, c->stream)); // everything that used the other chunk set is in front of this point
-        rc = launch_play_stage(c, sa, pa, plan, want_state, want_recs, want_recs);
-        if (rc) return rc;
-        // While the game kernel runs: the preparation of the next chunk (or of the hinted next call) on the low-priority
-        // stream, into the other chunk set.  Its kernels are placed as the persistent game kernel's blocks retire.
         if (c->pipeline) {
             ChunkDesc next{};
             bool have_next = false;
@@ -980,11 +1005,12 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
                 have_next = true;
             }
             if (have_next) {
-                HIPCHK(c, hipStreamWaitEvent(c->prep_stream, c->main_idle, 0));
                 rc = prep_tournament_chunk(c, c->cur ^ 1, c->prep_stream, next, c->sets[c->cur ^ 1].sa);
                 if (rc) return rc;
             }
         }
+        rc = launch_play_stage(c, sa, pa, plan, want_state, want_recs, want_recs);
+        if (rc) return rc;
         rc = finish_play(c, pa, (int64_t)done * gps, "tournament");
         if (rc) return rc;
         const bool scheduled = c->longest_first != 0;

@@ -29,7 +29,9 @@ using namespace fk;
 
 namespace {
 
-constexpr uint32_t HC_AFTER_6_WORDS = ss_hc(24); // 4 + 12 (all pairs) + 2*4 hashmix calls
+constexpr uint32_t HC_AFTER_6_WORDS = ss_hc(24);  // 4 + 12 (all pairs) + 2*4 hashmix calls
+constexpr uint32_t HC_AFTER_12_WORDS = ss_hc(48); // + 6*4: shuffle, pair, order absorbed
+constexpr uint32_t HC_AFTER_14_WORDS = ss_hc(56); // + 2*4: game_index absorbed
 
 enum : uint32_t { MODE_PERM = 0, MODE_LIST = 1, MODE_BLOCKS = 2 };
 
@@ -109,6 +111,9 @@ struct SeedArgs {
     const DevBlock *blocks;
     uint32_t n_blocks;
     const uint32_t *game_block; // [n_games] block index of every game (fk_block_map_kernel)
+    // SeedSequence pool after entropy words 0..11 (…, shuffle, pair, order), shared by every game of a shuffle (tournament) or
+    // of a block (batched H2H): [n_sh] / [n_blocks], written by fk_pool_kernel
+    const uint4 *pools;
 };
 
 struct PlayArgs {
@@ -514,6 +519,33 @@ __global__ void fk_block_map_kernel(const DevBlock *blocks, uint32_t n_blocks, u
     game_block[t] = lo;
 }
 
+// Entropy words 6..11 (shuffle_index, pair_id, order: random.py:106-111) are the same for every game of a shuffle (tournament)
+// or of a block (batched H2H): absorbed once here instead of once per game (24 of the 32 + 16 k pool updates a game costs).
+__global__ void fk_pool_kernel(SeedPool prefix, uint64_t shuffle0, uint64_t pair, uint64_t order, const DevBlock *blocks, uint32_t n,
+                               uint4 *pools) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    SeedPool gp = prefix;
+    gp.hc = HC_AFTER_6_WORDS;
+    if (blocks) {
+        ss_absorb64(gp, 0); // shuffle_index
+        ss_absorb64(gp, blocks[i].pair);
+        ss_absorb64(gp, blocks[i].order);
+    } else {
+        ss_absorb64(gp, shuffle0 + i);
+        ss_absorb64(gp, pair);
+        ss_absorb64(gp, order);
+    }
+    pools[i] = make_uint4(gp.p[0], gp.p[1], gp.p[2], gp.p[3]);
+}
+
+// An index word pair whose high half is zero (every index below 2^32): the hash of the zero word is a compile-time constant.
+__device__ inline void ss_absorb_index(SeedPool &s, uint64_t v) {
+    ss_absorb(s, (uint32_t)v);
+    if ((uint32_t)(v >> 32) == 0u) ss_absorb(s, 0u);
+    else ss_absorb(s, (uint32_t)(v >> 32));
+}
+
 // Class sizes: one lane per game in the seed kernel's walk order (coalesced permutation reads), grid-stride so that few
 // blocks add to the same global words at the end.
 __global__ __launch_bounds__(SEED_BLOCK) void fk_class_count_kernel(const uint16_t *perm_T, uint32_t perm_slots, uint32_t S,
@@ -594,10 +626,11 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
             a.sched[slot] = id;
         }
     }
+    // Phase A, one lane per GAME: the pool after the game's own index word (entropy words 0..13).
+    SeedPool gp{};
+    uint64_t seat0 = 0, replicate = 0;
+    uint32_t blk = 0;
     if (valid) {
-        SeedPool gp;
-        uint64_t seat0 = 0, replicate = 0;
-        uint32_t blk = 0;
         if (a.coords) {
             const fk_coord c = a.coords[id];
             seat0 = c.seat_index;
@@ -611,51 +644,70 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
         } else if (a.blocks) { // batched H2H: the block holding game t (fk_block_map_kernel), then its attempt index
             blk = a.game_block[t];
             const DevBlock b = a.blocks[blk];
-            gp = a.prefix;
-            gp.hc = HC_AFTER_6_WORDS;
-            ss_absorb64(gp, 0);                        // shuffle_index
-            ss_absorb64(gp, b.pair);
-            ss_absorb64(gp, b.order);
-            ss_absorb64(gp, b.attempt0 + (t - b.start)); // attempt index in the game_index slot (random.py:106-111)
+            const uint4 q = a.pools[blk];
+            gp.p[0] = q.x, gp.p[1] = q.y, gp.p[2] = q.z, gp.p[3] = q.w;
+            gp.hc = HC_AFTER_12_WORDS;
+            ss_absorb_index(gp, b.attempt0 + (t - b.start)); // attempt index in the game_index slot (random.py:106-111)
         } else {
-            gp = a.prefix;
-            gp.hc = HC_AFTER_6_WORDS;
-            ss_absorb64(gp, a.shuffle0 + sh_local);
-            ss_absorb64(gp, a.pair);
-            ss_absorb64(gp, a.order);
-            ss_absorb64(gp, a.game0 + g_local);
+            const uint4 q = a.pools[sh_local];
+            gp.p[0] = q.x, gp.p[1] = q.y, gp.p[2] = q.z, gp.p[3] = q.w;
+            gp.hc = HC_AFTER_12_WORDS;
+            ss_absorb_index(gp, a.game0 + g_local);
         }
-        uint64_t idx_pack = 0;
-        for (uint32_t s = 0; s < a.k; ++s) {
-            SeedPool sp = gp;
-            ss_absorb64(sp, seat0 + s); // seat_index
-            ss_absorb64(sp, replicate); // replicate_index
-            uint32_t g8[8];
-            ss_generate<8>(sp, g8);
-            Rng r;
-            pcg_seed(r, g8);
-            const size_t rec = (size_t)slot * a.k + s; // ticket position (walk order without a schedule)
-            uint4 *dst = reinterpret_cast<uint4 *>(a.state + rec * a.state_dw);
-            dst[0] = make_uint4((uint32_t)r.lo, (uint32_t)(r.lo >> 32), (uint32_t)r.hi, (uint32_t)(r.hi >> 32));
-            if (a.state_dw == STATE_DW) { // full initial record: nothing buffered, score 0, counters 0, strategy index
-                uint32_t idx = s;
-                if (a.perm_T) idx = perm_at(a.perm_T, a.S, a.perm_slots, sh_local, g_local * a.k + s);
-                else if (a.seat_strategy) idx = (uint32_t)a.seat_strategy[(size_t)id * a.k + s];
-                else if (a.blocks) idx = 2u * blk + s;
-                dst[1] = make_uint4(0u, 0u, 0u, 0u);
-                dst[2] = make_uint4(0u, 0u, 0u, idx);
-            } else if (a.seat_idx && a.perm_T) { // packed: one 8-byte store per four seats, 4-byte per two (fewer partial lines)
-                const uint64_t idx = perm_at(a.perm_T, a.S, a.perm_slots, sh_local, g_local * a.k + s);
-                const uint32_t group = (a.k % 4u == 0u) ? 4u : (a.k % 2u == 0u) ? 2u : 1u, pos = s % group;
-                idx_pack = (pos == 0u ? 0ull : idx_pack) | (idx << (16u * pos));
-                if (pos + 1u == group) {
-                    if (group == 4u) *reinterpret_cast<uint64_t *>(a.seat_idx + rec - 3u) = idx_pack;
-                    else if (group == 2u) *reinterpret_cast<uint32_t *>(a.seat_idx + rec - 1u) = (uint32_t)idx_pack;
-                    else a.seat_idx[rec] = (uint16_t)idx_pack;
-                }
-            }
-            a.inc[rec] = make_uint4((uint32_t)r.inc_lo, (uint32_t)(r.inc_lo >> 32), (uint32_t)r.inc_hi, (uint32_t)(r.inc_hi >> 32));
+    }
+    // Phase B, one lane per (game, seat) PAIR of the wave's 64 games, pair p = game * k + seat: lanes that are neighbours
+    // hold seats that are neighbours in memory (records sit at slot * k + seat), so the 16-byte state / increment stores and
+    // the 2-byte index stores of a wave cover whole lines.  (One lane per game and a loop over its seats wrote 16 bytes at
+    // a stride of 16 k: partial lines that L2 evicted before their neighbours arrived, 2.2x the algorithmic HBM writes.)
+    // The game's values travel from its phase-A lane by ds_bpermute (no LDS allocation), with every lane active.
+    const uint32_t lane = lane_id();
+    for (uint32_t j = 0; j < a.k; ++j) {
+        const uint32_t p = j * 64u + lane;
+        const uint32_t src = p / a.k, s = p - src * a.k;
+        const int from = (int)src;
+        SeedPool sp;
+        sp.p[0] = (uint32_t)__shfl((int)gp.p[0], from);
+        sp.p[1] = (uint32_t)__shfl((int)gp.p[1], from);
+        sp.p[2] = (uint32_t)__shfl((int)gp.p[2], from);
+        sp.p[3] = (uint32_t)__shfl((int)gp.p[3], from);
+        sp.hc = HC_AFTER_14_WORDS;
+        const uint32_t p_slot = (uint32_t)__shfl((int)slot, from), p_id = (uint32_t)__shfl((int)id, from);
+        const uint32_t p_sh = (uint32_t)__shfl((int)sh_local, from), p_g = (uint32_t)__shfl((int)g_local, from);
+        const uint32_t p_blk = (uint32_t)__shfl((int)blk, from);
+        const bool p_valid = __shfl(valid ? 1 : 0, from) != 0;
+        uint64_t p_seat0 = 0, p_rep = 0;
+        if (a.coords) { // wave-uniform
+            p_seat0 = (uint64_t)(uint32_t)__shfl((int)(uint32_t)seat0, from) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(seat0 >> 32), from) << 32);
+            p_rep = (uint64_t)(uint32_t)__shfl((int)(uint32_t)replicate, from) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(replicate >> 32), from) << 32);
         }
+        if (!p_valid) continue;
+        if (a.coords) {
+            ss_absorb64(sp, p_seat0 + s); // seat_index
+            ss_absorb64(sp, p_rep);       // replicate_index
+        } else { // seat s, replicate 0: three of the four words are literal zeros, their hashes constants
+            ss_absorb(sp, s);
+            ss_absorb(sp, 0u);
+            ss_absorb(sp, 0u);
+            ss_absorb(sp, 0u);
+        }
+        uint32_t g8[8];
+        ss_generate<8>(sp, g8);
+        Rng r;
+        pcg_seed(r, g8);
+        const size_t rec = (size_t)p_slot * a.k + s; // ticket position (walk order without a schedule)
+        uint4 *dst = reinterpret_cast<uint4 *>(a.state + rec * a.state_dw);
+        dst[0] = make_uint4((uint32_t)r.lo, (uint32_t)(r.lo >> 32), (uint32_t)r.hi, (uint32_t)(r.hi >> 32));
+        if (a.state_dw == STATE_DW) { // full initial record: nothing buffered, score 0, counters 0, strategy index
+            uint32_t idx = s;
+            if (a.perm_T) idx = perm_at(a.perm_T, a.S, a.perm_slots, p_sh, p_g * a.k + s);
+            else if (a.seat_strategy) idx = (uint32_t)a.seat_strategy[(size_t)p_id * a.k + s];
+            else if (a.blocks) idx = 2u * p_blk + s;
+            dst[1] = make_uint4(0u, 0u, 0u, 0u);
+            dst[2] = make_uint4(0u, 0u, 0u, idx);
+        } else if (a.seat_idx && a.perm_T) {
+            a.seat_idx[rec] = perm_at(a.perm_T, a.S, a.perm_slots, p_sh, p_g * a.k + s);
+        }
+        a.inc[rec] = make_uint4((uint32_t)r.inc_lo, (uint32_t)(r.inc_lo >> 32), (uint32_t)r.inc_hi, (uint32_t)(r.inc_hi >> 32));
     }
 }
 
