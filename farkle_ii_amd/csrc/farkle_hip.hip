@@ -26,15 +26,15 @@ struct DevBuf {
 };
 
 // Everything a chunk's preparation (permutations, schedule, seat seeding) writes and its game kernel reads.  There are two
-// sets: with option "pipeline" = 1 the next chunk (of this call, or — after fk_tournament_hint_next — of the next call) is
-// prepared into the other set around the game kernel of the current one: its permutations in front of that game kernel on
-// the main stream, its schedule and seat seeding on a low-priority stream.  Off by default, because it cannot win here
-// (rocprofv3 kernel traces, round 2): the persistent game kernel holds every byte of LDS the launch plan could give it
-// (160 KB per CU at k = 4), so any side-stream kernel with an LDS allocation — permutations, and the seed kernels' few
-// hundred bytes — only starts when the game kernel ends; and an LDS-free seed kernel that does run beside it takes the issue
-// cycles it uses away from the game kernel one for one (both are VALU-issue bound: game kernel 178 -> 184 ms while a 6 ms
-// seeding ran beside it), with one run stalling 120 ms per step behind the low-priority queue.  Serial preparation on the
-// main stream costs the same and cannot stall.
+// sets: the next chunk (of this call, or — after fk_tournament_hint_next — of the next call) is prepared into the other set
+// around the game kernel of the current one (option "pipeline", default 1).  Its permutations run in front of that game
+// kernel on the main stream: they want most of a CU's LDS, which the resident persistent game kernel holds (on the side
+// stream they only started when it ended, with the seeding queued behind them).  Its schedule and seat seeding go to a
+// low-priority stream; their kernels allocate ~1 KB of LDS per block, so they are placed as the game kernel's blocks retire,
+// i.e. they fill its drain tail.  Measured (rocprofv3 traces + tools/time_pipeline.py, round 2): 10.33 -> 10.16 ms per
+// config-2 step, 193.4 -> 191.6 ms per config-3 step.  Running the seeding BESIDE the game kernel instead (an LDS-free
+// seed kernel) is zero-sum — both are VALU-issue bound: game kernel 178 -> 184 ms while a 6 ms seeding ran beside it — and
+// stalled one run by 120 ms per step behind the low-priority queue: not done.
 struct ChunkDesc {
     uint64_t epoch = 0, root = 0, sh0 = 0; // strategy-table upload epoch, root seed, first shuffle
     uint32_t n_sh = 0, S = 0, k = 0, state_dw = 0, sched = 0, slots = 0;
@@ -63,7 +63,7 @@ struct fk_ctx {
     uint64_t table_epoch = 0;
     bool hint_valid = false;           // fk_tournament_hint_next
     uint64_t hint_begin = 0, hint_end = 0;
-    int32_t hint_state = 0, pipeline = 0; // off by default: measured zero-sum (see ChunkDesc)
+    int32_t hint_state = 0, pipeline = 1;
     hipDeviceProp_t prop{};
     std::string err;
     fk_timing timing{};

@@ -128,9 +128,9 @@ int fk_get_timing(fk_ctx *ctx, fk_timing *out);
  * k of them do not fit LDS; 0 the same; 1 always), "blocks_per_cu", "max_waves" (resident waves per SIMD the launch plan counts
  * on, default 6), "longest_first" (1 = deal
  * never-banking pairings first), "uniform_flags" (-1 auto: tables whose strategies share all flag bits run the scalar-flag
- * kernel instance, 0 never), "perm_split" (-1 auto), "pipeline" (0, default: chunks are prepared on the main stream in front of their
- * game kernel; 1: the next chunk / hinted call is prepared around the current game kernel, permutations in front of it and
- * seeding on a low-priority stream — measured zero-sum on MI355X, see farkle_hip.hip).  All of them are scheduling / layout choices: results are identical
+ * kernel instance, 0 never), "perm_split" (-1 auto), "pipeline" (1, default: the next chunk / hinted call is prepared around the
+ * current game kernel — permutations in front of it, schedule and seat seeding on a low-priority stream in its drain tail;
+ * 0: every chunk is prepared on the main stream in front of its own game kernel).  All of them are scheduling / layout choices: results are identical
  * for every setting. */
 int fk_set_option(fk_ctx *ctx, const char *name, int64_t value);
 
@@ -164,10 +164,9 @@ int fk_tournament_run_stats(fk_ctx *ctx, const fk_strategy *strategies, int32_t 
 
 /* Scheduling hint: the next fk_tournament_run / fk_tournament_run_stats call on this context — the one AFTER the call that
  * follows this hint — will play shuffles [shuffle_begin, shuffle_end) of the same table, k and root seed (need_state != 0: it
- * will ask for rows or seat_stats).  With option "pipeline" = 1 the call that follows the hint prepares that range around its
- * own game kernel (permutations in front of it, schedule and seat seeding on a low-priority stream); with the default
- * "pipeline" = 0 the hint is recorded and ignored.  Results never depend on hints; a hint that turns out wrong only wastes the
- * preparation.  (The reference's process pool keeps `window = 4 * n_jobs` chunks in flight
+ * will ask for rows or seat_stats).  The call that follows the hint prepares that range around its own game kernel
+ * (permutations in front of it, schedule and seat seeding on a low-priority stream in its drain tail; option "pipeline" = 0
+ * ignores hints).  Results never depend on hints; a hint that turns out wrong only wastes the preparation.  (The reference's process pool keeps `window = 4 * n_jobs` chunks in flight
  * for the same reason, run_tournament.py:1576-1586.) */
 int fk_tournament_hint_next(fk_ctx *ctx, uint64_t shuffle_begin, uint64_t shuffle_end, int32_t need_state);
 

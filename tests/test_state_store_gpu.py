@@ -263,8 +263,8 @@ def test_permutation_kernels_agree_with_numpy_semantics(eng, po, S, k):
 
 
 def test_pipelined_preparation_never_changes_results(eng, po):
-    """Option "pipeline" = 1: the next chunk's (or the hinted next call's) permutations run in front of the current game kernel
-    and its seat seeding on a side stream beside it.  Same results with the pipeline on and off (the default), for multi-chunk calls, right hints, wrong hints, hints followed by other entry
+    """The next chunk's (or the hinted next call's) permutations run in front of the current game kernel and its seat seeding on a
+    side stream behind it.  Same results with the pipeline on (the default) and off, for multi-chunk calls, right hints, wrong hints, hints followed by other entry
     points, a table change after a hint, rows / statistics calls."""
     from farkle_ii_amd.backend import make_coords
 
@@ -306,5 +306,5 @@ def test_pipelined_preparation_never_changes_results(eng, po):
                 assert np.array_equal(got["tally"], ref_other["tally"])
                 check((600, 1200), want_seat_stats=True)
     finally:
-        eng.set_option("pipeline", 0)
+        eng.set_option("pipeline", 1)
         eng.set_option("chunk_bytes", 48 << 30)
