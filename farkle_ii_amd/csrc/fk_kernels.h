@@ -1235,29 +1235,50 @@ __global__ __launch_bounds__(REDUCE_BLOCK) void fk_tally_reduce_kernel(const uin
     const uint32_t s_lo = blockIdx.y * slice, s_n = min(slice, S - s_lo);
     for (uint32_t i = threadIdx.x; i < s_n * RT_COLS; i += REDUCE_BLOCK) rt[i] = 0ull;
     __syncthreads();
-    for (uint32_t id = first + threadIdx.x; id < last; id += REDUCE_BLOCK) {
-        const uint32_t d0 = rec0[id];
-        if (d0 & REC_SAFETY) {
-            const uint32_t sh = id / gps, g = id - sh * gps;
-            for (uint32_t s = 0; s < k; ++s) {
-                const uint32_t idx = perm_at(perm_T, S, perm_slots, sh, g * k + s) - s_lo;
-                if (idx < s_n) atomicAdd(&rt[idx * RT_COLS + 1u], 1ull);
-            }
-            continue;
-        }
-        const uint32_t idx = (d0 & 0xffffffu) - s_lo;
-        if (idx >= s_n) continue;
-        const uint4 *r = reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
-        const uint4 q0 = r[0], q1 = r[1];
-        const unsigned long long m[10] = {q0.y, q0.z & 0xffffu, q0.z >> 16, q0.w & 0xffffu, q0.w >> 16,
-                                          q1.x & 0xffffu, q1.x >> 16, q1.y & 0xffffu, q1.y >> 16, q1.z};
-        unsigned long long *t = rt + idx * RT_COLS;
-        atomicAdd(&t[0], 1ull);
+    // four games per thread and trip: the four rec0 words, then the (up to four) 32-byte records of this slice's winners, are
+    // in flight together before the first LDS atomic (one game per trip left a single dependent load pair per thread)
+    constexpr uint32_t U = 4;
+    for (uint32_t base = first + threadIdx.x; base < last; base += U * REDUCE_BLOCK) {
+        uint32_t d0[U];
+        uint4 q0[U], q1[U];
+        bool mine[U];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            if (m[j]) {
-                atomicAdd(&t[2 + j], m[j]);
-                atomicAdd(&t[12 + j], m[j] * m[j]);
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t id = base + u * REDUCE_BLOCK;
+            d0[u] = id < last ? rec0[id] : REC_SAFETY - 1u; // out of range: a strategy index no slice holds
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t id = base + u * REDUCE_BLOCK;
+            mine[u] = id < last && !(d0[u] & REC_SAFETY) && ((d0[u] & 0xffffffu) - s_lo) < s_n;
+            if (mine[u]) {
+                const uint4 *r = reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
+                q0[u] = r[0];
+                q1[u] = r[1];
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t id = base + u * REDUCE_BLOCK;
+            if (id < last && (d0[u] & REC_SAFETY)) {
+                const uint32_t sh = id / gps, g = id - sh * gps;
+                for (uint32_t s = 0; s < k; ++s) {
+                    const uint32_t idx = perm_at(perm_T, S, perm_slots, sh, g * k + s) - s_lo;
+                    if (idx < s_n) atomicAdd(&rt[idx * RT_COLS + 1u], 1ull);
+                }
+            }
+            if (!mine[u]) continue;
+            const uint32_t idx = (d0[u] & 0xffffffu) - s_lo;
+            const unsigned long long m[10] = {q0[u].y, q0[u].z & 0xffffu, q0[u].z >> 16, q0[u].w & 0xffffu, q0[u].w >> 16,
+                                              q1[u].x & 0xffffu, q1[u].x >> 16, q1[u].y & 0xffffu, q1[u].y >> 16, q1[u].z};
+            unsigned long long *t = rt + idx * RT_COLS;
+            atomicAdd(&t[0], 1ull);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                if (m[j]) {
+                    atomicAdd(&t[2 + j], m[j]);
+                    atomicAdd(&t[12 + j], m[j] * m[j]);
+                }
             }
         }
     }
