@@ -1283,7 +1283,7 @@ int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_
         pa.max_rounds = (uint32_t)max_rounds;
         rc = run_chunk(c, sa, pa, plan, false, true, false, 0, "h2h attempt (pass-local index)");
         if (rc) return rc;
-        hipLaunchKernelGGL(fk_h2h_reduce_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(fk_h2h_reduce_kernel, dim3((n_games + 256u * H2H_RUN - 1u) / (256u * H2H_RUN)), dim3(256), 0, c->stream,
                            static_cast<const uint32_t *>(c->rec0.p), n_games, nb, static_cast<unsigned long long *>(c->block_out.p));
         HIPCHK(c, hipGetLastError());
         out.resize((size_t)nb * 4);

@@ -1325,36 +1325,55 @@ __global__ void fk_tally_direct_kernel(const uint32_t *recs, uint32_t n_games, u
 }
 
 // Result records of a batched H2H launch -> per-block {completed, safety, wins_seat1, wins_seat2}.  A block's attempts
-// are contiguous games, so almost every wave sees one block: ballots + one atomic per counter and wave.
+// are contiguous games: a wave walks H2H_RUN consecutive 64-game groups and keeps the counts of the block it is in in
+// wave-uniform registers; they go out with one atomic per counter when the block changes or the run ends (one atomic per
+// counter and 64 games made 10^7 waves queue on the 4 x 132 words of a config-5 pass: 160 ms per 6 x 10^8 games).
+constexpr uint32_t H2H_RUN = 32;
+
 __global__ void fk_h2h_reduce_kernel(const uint32_t *recs, uint32_t n_games, uint32_t n_blocks,
                                      unsigned long long *out /* [n_blocks][4] */) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t d0 = id < n_games ? recs[id] : 0u;
-    const uint32_t blk = (d0 & 0xffffffu) >> 1;
-    const bool valid = id < n_games && blk < n_blocks; // (a record of a launch that raised an error may be garbage)
-    const bool safety = (d0 & REC_SAFETY) != 0u;
-    const uint32_t which = safety ? 1u : (2u + ((d0 >> 24) & 1u)); // completed games also count in column 0 below
-    const uint64_t live = __ballot(valid);
-    if (!live) return;
-    const uint32_t first_live = (uint32_t)(__ffsll((long long)live) - 1);
-    const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)blk, (int)__builtin_amdgcn_readfirstlane((int)first_live));
-    if (__ballot(valid && blk != lead) == 0ull) {
-        const uint32_t n_safe = (uint32_t)__popcll(__ballot(valid && safety));
-        const uint32_t n_w2 = (uint32_t)__popcll(__ballot(valid && which == 3u));
-        const uint32_t n_all = (uint32_t)__popcll(live);
-        if ((threadIdx.x & 63u) == first_live) {
-            unsigned long long *o = out + (size_t)blk * 4;
-            const uint32_t n_comp = n_all - n_safe;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const uint32_t lane = lane_id();
+    uint32_t cur = 0xffffffffu, n_comp = 0, n_safe = 0, n_w2 = 0; // wave-uniform: the block being counted
+    auto flush = [&]() {
+        if (cur != 0xffffffffu && lane == 0u) {
+            unsigned long long *o = out + (size_t)cur * 4;
             if (n_comp) atomicAdd(&o[0], (unsigned long long)n_comp);
             if (n_safe) atomicAdd(&o[1], (unsigned long long)n_safe);
             if (n_comp - n_w2) atomicAdd(&o[2], (unsigned long long)(n_comp - n_w2));
             if (n_w2) atomicAdd(&o[3], (unsigned long long)n_w2);
         }
-    } else if (valid) { // a wave that straddles blocks
-        unsigned long long *o = out + (size_t)blk * 4;
-        if (!safety) atomicAdd(&o[0], 1ull);
-        atomicAdd(&o[which], 1ull);
+        n_comp = n_safe = n_w2 = 0;
+    };
+    for (uint32_t g = 0; g < H2H_RUN; ++g) {
+        const uint64_t base = ((uint64_t)wave * H2H_RUN + g) * 64u;
+        if (base >= n_games) break; // wave-uniform
+        const uint32_t id = (uint32_t)base + lane;
+        const uint32_t d0 = id < n_games ? recs[id] : 0u;
+        const uint32_t blk = (d0 & 0xffffffu) >> 1;
+        const bool valid = id < n_games && blk < n_blocks; // (a record of a launch that raised an error may be garbage)
+        const bool safety = (d0 & REC_SAFETY) != 0u;
+        const uint32_t which = safety ? 1u : (2u + ((d0 >> 24) & 1u)); // completed games also count in column 0 below
+        const uint64_t live = __ballot(valid);
+        if (!live) continue;
+        const uint32_t first_live = (uint32_t)(__ffsll((long long)live) - 1);
+        const uint32_t lead = (uint32_t)__builtin_amdgcn_readlane((int)blk, (int)__builtin_amdgcn_readfirstlane((int)first_live));
+        if (__ballot(valid && blk != lead) == 0ull) {
+            if (lead != cur) {
+                flush();
+                cur = lead;
+            }
+            const uint32_t s_n = (uint32_t)__popcll(__ballot(valid && safety));
+            n_safe += s_n;
+            n_comp += (uint32_t)__popcll(live) - s_n;
+            n_w2 += (uint32_t)__popcll(__ballot(valid && which == 3u));
+        } else if (valid) { // a group that straddles blocks
+            unsigned long long *o = out + (size_t)blk * 4;
+            if (!safety) atomicAdd(&o[0], 1ull);
+            atomicAdd(&o[which], 1ull);
+        }
     }
+    flush();
 }
 
 // State store + result records -> rows (fk_row_hdr + k x fk_seat = 4 + 28k bytes, simulation.py:628-655), in game-id
