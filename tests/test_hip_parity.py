@@ -548,7 +548,7 @@ def test_fuzz_random_tables_limits_and_player_counts(eng, po):
     from farkle_ii_amd.strategies import STRATEGY_DTYPE
 
     rs = np.random.default_rng(2026)
-    for trial in range(40):
+    for trial in range(60):
         k = int(rs.choice([1, 2, 2, 3, 4, 5, 6, 7, 8, 10, 12]))
         S = k * int(rs.integers(1, 9))
         table = np.zeros(S, dtype=STRATEGY_DTYPE)
@@ -557,9 +557,9 @@ def test_fuzz_random_tables_limits_and_player_counts(eng, po):
             so = int(rs.integers(0, 2)) if sf else 0
             cs, cd = int(rs.integers(0, 2)), int(rs.integers(0, 2))
             rb = int(rs.integers(0, 2)) if (cs and cd) else 0
-            table[i] = (int(rs.choice([0, 50, 199, 250, 300, 500, 1000, 1350, 10_000])), int(rs.integers(-1, 7)), sf, so, cs, cd, rb,
+            table[i] = (int(rs.choice([0, 1, 49, 50, 51, 199, 250, 300, 500, 1000, 1001, 1350, 10_000])), int(rs.integers(-1, 7)), sf, so, cs, cd, rb,
                         int(rs.integers(0, 2)), int(rs.integers(0, 2)), int(rs.integers(0, 2)), 1000 + i)
-        target = int(rs.choice([100, 500, 2000, 10_000, 20_000]))
+        target = int(rs.choice([49, 100, 500, 1_234, 2000, 9_999, 10_000, 10_001, 20_000]))  # the kernels round to units of 50
         max_rounds = int(rs.choice([0, 1, 3, 50, 200, 300]))
         n_sh = int(rs.choice([1, 2, 7, 40]))
         root = int(rs.integers(0, 2**63))
