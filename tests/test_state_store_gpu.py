@@ -159,6 +159,12 @@ def test_h2h_blocks_batched_equal_serial_blocks(eng, po):
                                 int(max_attempts[b]) if chunk is None else chunk, max_rounds=60, overrides=po.make_overrides(ovs))
             assert np.array_equal(got[b], want), (chunk, b, got[b], want)
     assert got[5][1] == 0 and got[5][2] > 0
+    # a target that is not a multiple of 50 (the kernels count in units of 50 points)
+    got = eng.h2h_blocks(seats[:60], 11, pair[:60], order[:60], target[:60], max_attempts[:60], target_score=2_025, max_rounds=60)
+    for b in range(60):
+        want = po.h2h_block(seats[b].view(po.STRATEGY_DTYPE), 11, int(pair[b]), int(order[b]), int(target[b]), int(max_attempts[b]),
+                            int(max_attempts[b]), target_score=2_025, max_rounds=60)
+        assert np.array_equal(got[b], want), (b, got[b], want)
     # resumed blocks: the first chunk's states go back in
     first = eng.h2h_blocks(seats, 11, pair, order, target, max_attempts, chunk_games=25, max_rounds=60)
     second = eng.h2h_blocks(seats, 11, pair, order, target, max_attempts, chunk_games=10**9, max_rounds=60, states=first)
