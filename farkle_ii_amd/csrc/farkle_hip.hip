@@ -68,6 +68,7 @@ struct fk_ctx {
     std::string err;
     fk_timing timing{};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // see TimerSlot
+    int32_t *err_host = nullptr;    // pinned: the error record of a call's last game kernel (read with the tally)
     hipEvent_t main_idle = nullptr; // recorded on the main stream in front of a game kernel: what a side-stream preparation waits for
     struct PendingTimer {
         float *acc;
@@ -387,10 +388,8 @@ hipError_t collect_timers(fk_ctx *c) { // the stream has been synchronised
     return first;
 }
 
-int check_device_error(fk_ctx *c, const int32_t *d_err, int64_t game_base, const char *what) {
-    int32_t h[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(h, d_err, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+// the error record of a game kernel, once it is on the host
+int report_device_error(fk_ctx *c, const int32_t *h, int64_t game_base, const char *what) {
     if (h[0] == FK_ERR_ROLL_LIMIT)
         return fail(c, FK_ERR_ROLL_LIMIT, "Turn exceeded 1000 rolls - aborting. (%s game %lld)", what,
                     (long long)(game_base + h[1]));
@@ -399,6 +398,13 @@ int check_device_error(fk_ctx *c, const int32_t *d_err, int64_t game_base, const
                     (long long)(game_base + h[1]));
     if (h[0] != 0) return fail(c, h[0], "device error %d (%s game %lld)", h[0], what, (long long)(game_base + h[1]));
     return FK_OK;
+}
+
+int check_device_error(fk_ctx *c, const int32_t *d_err, int64_t game_base, const char *what) {
+    int32_t h[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(h, d_err, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return report_device_error(c, h, game_base, what);
 }
 
 // chunk-local overrides, sorted by game id, on the device
@@ -522,9 +528,8 @@ int launch_play_stage(fk_ctx *c, const SeedArgs &sa, PlayArgs &pa, const LaunchP
     return FK_OK;
 }
 
-// waits for the game kernel, reads its error record and the kernel timers (incl. those of a preparation on the side stream)
-int finish_play(fk_ctx *c, const PlayArgs &pa, int64_t game_base, const char *what) {
-    const int rc_dev = check_device_error(c, pa.err, game_base, what); // synchronises the main stream
+// the kernel timers of the chunk just played (incl. those of its preparation); the main stream has been synchronised
+int finish_timers(fk_ctx *c) {
     HIPCHK(c, collect_timers(c));
     ChunkSet &cs = CSET(c);
     float ms = 0.f;
@@ -535,7 +540,14 @@ int finish_play(fk_ctx *c, const PlayArgs &pa, int64_t game_base, const char *wh
     } else if (hipEventElapsedTime(&ms, cs.ev[2], cs.ev[3]) == hipSuccess) {
         c->timing.seed_ms += ms;
     }
-    return rc_dev;
+    return FK_OK;
+}
+
+// waits for the game kernel, reads its error record and the kernel timers
+int finish_play(fk_ctx *c, const PlayArgs &pa, int64_t game_base, const char *what) {
+    const int rc_dev = check_device_error(c, pa.err, game_base, what); // synchronises the main stream
+    const int rc = finish_timers(c);
+    return rc_dev ? rc_dev : rc;
 }
 
 // Seeds + games of one chunk (explicit game lists, batched H2H): preparation and game kernel back to back on the main stream.
@@ -740,6 +752,7 @@ int fk_init(int device_ordinal, fk_ctx **out) {
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         bool ok = hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, least) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->main_idle, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->err_host), 2 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
         for (auto &cs : c->sets) {
             ok = ok && hipEventCreateWithFlags(&cs.ready, hipEventDisableTiming) == hipSuccess;
             for (auto &e : cs.ev) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -788,6 +801,7 @@ void fk_destroy(fk_ctx *c) {
             if (e) (void)hipEventDestroy(e);
     }
     if (c->main_idle) (void)hipEventDestroy(c->main_idle);
+    if (c->err_host) (void)hipHostFree(c->err_host);
     if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
     for (auto &b : c->dbg) release(b);
     for (auto &e : c->ev)
@@ -918,6 +932,8 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
     c->hint_valid = false;
 
     std::vector<uint16_t> perm_host;
+    bool deferred = false;
+    int64_t deferred_base = 0;
     for (uint64_t done = 0; done < n_sh_total; done += chunk_sh) {
         const uint32_t n_sh = (uint32_t)std::min<uint64_t>(chunk_sh, n_sh_total - done);
         const uint64_t sh0 = shuffle_begin + done;
@@ -1011,8 +1027,17 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
         }
         rc = launch_play_stage(c, sa, pa, plan, want_state, want_recs, want_recs);
         if (rc) return rc;
-        rc = finish_play(c, pa, (int64_t)done * gps, "tournament");
-        if (rc) return rc;
+        // The last chunk of a call without rows: its error record travels with the tally, behind the post-passes — one host
+        // round trip per call instead of two (the post-passes only read; on an error their output is discarded).
+        const bool defer_check = done + chunk_sh >= n_sh_total && !rows && c->err_host;
+        if (defer_check) {
+            HIPCHK(c, hipMemcpyAsync(c->err_host, pa.err, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            deferred = true;
+            deferred_base = (int64_t)done * gps;
+        } else {
+            rc = finish_play(c, pa, (int64_t)done * gps, "tournament");
+            if (rc) return rc;
+        }
         const bool scheduled = c->longest_first != 0;
         if (want_state && scheduled) { // game id -> slot of its state records
             rc = ensure(c, c->inv, (size_t)n_games * 4);
@@ -1084,6 +1109,12 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
     HIPCHK(c, hipMemcpyAsync(tally, c->tally.p, tally_bytes, hipMemcpyDeviceToHost, c->stream));
     if (seat_stats) HIPCHK(c, hipMemcpyAsync(seat_stats, c->stats.p, stats_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (deferred) {
+        rc = report_device_error(c, c->err_host, deferred_base, "tournament");
+        const int rc_t = finish_timers(c);
+        if (rc) return rc;
+        if (rc_t) return rc_t;
+    }
     HIPCHK(c, hipEventElapsedTime(&c->timing.total_ms, t0, t1));
     return FK_OK;
 }
