@@ -567,7 +567,10 @@ __host__ __device__ inline int32_t floor_div50(int32_t a) { return a >= 0 ? a / 
 struct Strat50 {
     int32_t thr50; // ceil(score_threshold / 50)
     uint32_t bits;
-    __host__ __device__ int32_t dice_thr() const { return (int32_t)(int8_t)(bits & 0xffu); }
+    int32_t dthr;  // dice threshold, sign-extended from bits[7:0] once
+    __host__ __device__ Strat50(int32_t t, uint32_t b) : thr50(t), bits(b), dthr((int32_t)(int8_t)(b & 0xffu)) {}
+    __host__ __device__ Strat50(int32_t t, uint32_t b, int32_t d) : thr50(t), bits(b), dthr(d) {}
+    __host__ __device__ int32_t dice_thr() const { return dthr; }
     __host__ __device__ bool has(uint32_t f) const { return (bits & f) != 0u; }
 };
 

@@ -1065,7 +1065,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
         const uint32_t n = dice;
         const uint32_t key = roll_counts<3>(rng, n);
         rolls_this_turn += 1u;
-        const Strat50 sp{own_thr, (own_bits & (0xffu | MIXED)) | (a.uflags & (0xff00u & ~MIXED))};
+        int32_t dthr = (int32_t)(int8_t)(own_bits & 0xffu);
+        asm volatile("" : "+v"(dthr));
+        const Strat50 sp{own_thr, (own_bits & (0xffu | MIXED)) | (a.uflags & (0xff00u & ~MIXED)), dthr};
         const Roll50 rr = default_score_lut50(a.score_lut, a.discard_lut, key, (int32_t)n, turn_score, sp); // turn_score, score: / 50
         const bool farkle = rr.score50 == 0;                            // engine.py:135-137, 247-249
         cA += 1u + (farkle ? 0x10000u : 0u);                            // n_rolls (engine.py:98), n_farkles
