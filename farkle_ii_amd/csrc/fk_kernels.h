@@ -790,6 +790,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     uint64_t own_inc_lo = 0, own_inc_hi = 0;
     int32_t own_thr = 0;
     uint32_t own_bits = 0;
+    // two-player lean instances (KC = 2; not state-store): the packed strategies of both seats stay in registers for the game,
+    // so a turn start is one increment load instead of LDS read -> index -> strategy load
+    constexpr bool PK2 = (KC == 2) && LEAN && !GS;
+    uint2 pk_seat0 = make_uint2(0u, 0u), pk_seat1 = make_uint2(0u, 0u);
 
     // LDS records are contiguous per (seat, lane): record base = (seat * BLOCK + tid) * NFIELDS, field = immediate
     // offset (one address VGPR per record).  Full records: odd stride (17 dwords), ds_read2/ds_write2 dword pairs, the
@@ -855,13 +859,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
             r[4] = make_uint2(q2.y, (q1.y & 0xffffu) | (q2.z & (CE_HAS_SCORED | CE_HAS_BUF))); // cD, score | flags
             own_turns = (q1.w >> 16) + 1u; // n_turns += 1 (engine.py:236)
             idx = q2.w;
-        } else {
+        } else if (!PK2) {
             if (BLK) idx = 2u * *lane_block + s;
             else if (LEAN) idx = L(F_CE, s) >> CE_IDX_SHIFT;
         }
         if (LEAN) { // read-only per-seat data comes from HBM/L2; the loads overlap the first dice of the turn
             const uint4 inc = a.inc[(size_t)seed_slot * K + s];
-            const uint2 pk = a.strat[idx];
+            const uint2 pk = PK2 ? (s ? pk_seat1 : pk_seat0) : a.strat[idx];
             own_inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
             own_inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
             own_thr = (int32_t)pk.x;
@@ -993,6 +997,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
                 L(F_CC, s) = 0u;
                 L(F_CD, s) = 0u;
                 L(F_CE, s) = (LEAN && !BLK) ? (idx << CE_IDX_SHIFT) : 0u;
+                if (PK2) {
+                    const uint2 pk = a.strat[BLK ? 2u * a.game_block[id] + s : idx];
+                    if (s == 0u) pk_seat0 = pk;
+                    else pk_seat1 = pk;
+                }
             }
         }
         seat = 0;
