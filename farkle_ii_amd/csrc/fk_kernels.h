@@ -2,20 +2,28 @@
 //
 //   fk_perm_kernel         one lane per shuffle: SeedSequence(ns=101) -> PCG64DXSM -> Fisher-Yates
 //                          (Generator.permutation, run_tournament.py:312-318), arrays in LDS, written shuffle-minor.
+//   fk_perm_draw_kernel +  large tables: the accepted draws of every shuffle at full occupancy, then the permutation WITHOUT
+//   fk_perm_parallel_kernel  the serial swap chain (bucket sort + pointer jumping, one workgroup per shuffle), tiled into the
+//   (+ fk_perm_block_kernel, blocked shuffle-minor layout; fk_perm_apply_kernel = the serial chains for tables beyond the
+//    fk_perm_apply_kernel)  chain-free kernel's LDS reach.
+//   fk_pool_kernel         SeedSequence pool after the words a shuffle / an H2H block shares (16 B per shuffle / block).
 //   fk_class_count_kernel  sizes of the schedule classes (how patient the seats of a game are).
-//   fk_seed_kernel         one lane per game: coordinate -> SeedSequence -> PCG64DXSM (state, increment) of every seat
-//                          (random.py:80-188), longest-first schedule, per-seat state records stored in dealing order.
-//   fk_play_kernel         persistent lanes, one lane = one game at a time, one roll per loop trip.  Seat records live in
-//                          LDS (k <= 2) or, for wider tables, in a per-game state store in HBM of which only the turn
-//                          owner's record is staged in LDS (GS instances: LDS bytes per lane independent of k);
-//                          finished lanes are handed new games in wave-level batches; per-strategy tallies privatised in
-//                          LDS when they fit, otherwise one 32-byte result record per game.
+//   fk_seed_kernel         coordinate -> SeedSequence -> PCG64DXSM (state, increment) of every seat (random.py:80-188):
+//                          one lane per game for the longest-first schedule, then one lane per (game, seat) pair so that the
+//                          records of a wave — stored at the game's ticket — cover whole lines.
+//   fk_play_kernel         persistent lanes, one lane = one game at a time, one roll per loop trip.  The seat records of the
+//                          lane's game live in LDS (ten dwords per seat; loaded and stored inside every roll step).  State-
+//                          store (GS) instances — on request, or when k records do not fit LDS — keep only the turn owner's
+//                          record in LDS and the others in a per-game state store in HBM.  Finished lanes are handed new
+//                          games in wave-level batches; per-strategy tallies privatised in LDS when they fit, otherwise one
+//                          4-byte + one 32-byte result record per game.
 //   fk_tally_reduce_kernel result records -> per-(batch, strategy) tallies, privatised in LDS slices (no HBM atomics
 //                          from the game kernel).
 //   fk_rows_kernel         state store + result records -> per-game rows (4 + 28k bytes), a streaming post-pass.
 //   fk_seat_stats_kernel   state store + result records -> integer sufficient statistics of ALL seats per strategy.
-//   fk_h2h_reduce_kernel   result records of many H2H blocks -> per-block completed / safety / wins.
-//   fk_finalize_tally, fk_score_lut_kernel, fk_discard_lut_kernel, fk_coordinate_seed_kernel, fk_dbg_* probes.
+//   fk_block_map_kernel,   batched H2H: game -> block, and result records of many blocks -> per-block completed / safety /
+//   fk_h2h_reduce_kernel   wins.
+//   fk_finalize_tally, fk_score_lut_kernel, fk_discard_lut_kernel, fk_dbg_* probes.
 //
 // The per-roll arithmetic (SeedSequence, PCG64DXSM, dice, scoring, discards, decisions) lives in fk_device.h.
 #pragma once
