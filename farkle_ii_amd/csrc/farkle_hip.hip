@@ -75,7 +75,7 @@ struct fk_ctx {
         hipEvent_t a, b;
     };
     std::vector<PendingTimer> pending; // kernel timers recorded on the stream, read after the chunk's one sync
-    DevBuf strat, recs, rec0, tally, rows, ov, seatlist, coords, inv, slow, score_lut, discard_lut, blocks, game_block, block_out, stats,
+    DevBuf strat, recs, rec0, tally, rows, ov, seatlist, coords, inv, slow, score_lut, discard_lut, blocks, game_block, block_out, stats, digest,
         dbg[6];
     std::vector<uint2> strat_host;   // the packed table currently resident in `strat` (uploaded once per table)
     int32_t longest_first = 1;
@@ -791,7 +791,7 @@ void fk_destroy(fk_ctx *c) {
     c->comm = nullptr;
     release(c->comm_buf);
     if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
-    for (DevBuf *b : {&c->strat, &c->recs, &c->rec0, &c->tally, &c->rows, &c->ov, &c->seatlist, &c->coords, &c->inv, &c->slow, &c->score_lut,
+    for (DevBuf *b : {&c->strat, &c->recs, &c->rec0, &c->tally, &c->rows, &c->ov, &c->seatlist, &c->coords, &c->inv, &c->slow, &c->digest, &c->score_lut,
                       &c->discard_lut, &c->blocks, &c->game_block, &c->block_out, &c->stats})
         release(*b);
     for (auto &cs : c->sets) {
@@ -902,7 +902,8 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
     }
 
     // chunk planning: whole shuffles per chunk inside the workspace budget
-    const size_t bytes_per_shuffle = (size_t)S * 2 + (size_t)gps * game_workspace_bytes(k, plan.gs || want_state, want_recs, rows != nullptr);
+    const size_t bytes_per_shuffle = (size_t)S * 2 + (size_t)gps * (game_workspace_bytes(k, plan.gs || want_state, want_recs, rows != nullptr) +
+                                                                    (seat_stats ? (size_t)k * 32 : 0)); // + the exposure digests
     uint64_t chunk_sh = std::max<uint64_t>(1, (uint64_t)c->chunk_bytes / bytes_per_shuffle);
     chunk_sh = std::min<uint64_t>(chunk_sh, (uint64_t)0x7fffffff / gps);
     chunk_sh = std::min<uint64_t>(chunk_sh, n_sh_total);
@@ -1056,9 +1057,16 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
             const uint32_t s_blocks = ((uint32_t)S + 255u) / 256u;
             // enough (strategy block, batch, part) workgroups to fill the chip; a part is at least 8 shuffles
             const uint32_t ppb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(shuffles_per_batch, n_sh) / 8, (4096u + nb * s_blocks - 1u) / (nb * s_blocks)));
-            hipLaunchKernelGGL(fk_seat_stats_kernel, dim3(s_blocks, nb * ppb), dim3(256), 0, c->stream,
+            // phase 1, game-major: one 32-byte digest per exposure; phase 2 gathers them per strategy
+            rc = ensure(c, c->digest, (size_t)n_games * k * 32);
+            if (rc) return rc;
+            const size_t pairs = (size_t)n_games * k;
+            hipLaunchKernelGGL(fk_seat_digest_kernel, dim3((unsigned)((pairs + 255u) / 256u)), dim3(256), 0, c->stream,
                                static_cast<const uint32_t *>(CSET(c).state.p), static_cast<const uint32_t *>(c->recs.p),
-                               scheduled ? static_cast<const uint32_t *>(c->inv.p) : nullptr, static_cast<const uint16_t *>(CSET(c).draws.p),
+                               scheduled ? static_cast<const uint32_t *>(c->inv.p) : nullptr, n_games, gps, n_sh, (uint32_t)k,
+                               static_cast<uint4 *>(c->digest.p));
+            hipLaunchKernelGGL(fk_seat_stats_kernel, dim3(s_blocks, nb * ppb), dim3(256), 0, c->stream,
+                               static_cast<const uint4 *>(c->digest.p), static_cast<const uint16_t *>(CSET(c).draws.p),
                                slots, (uint32_t)S, (uint32_t)k, gps, n_sh, (uint32_t)done, shuffles_per_batch, ppb, first_batch,
                                static_cast<long long *>(c->stats.p));
             HIPCHK(c, hipGetLastError());

@@ -1442,9 +1442,9 @@ __global__ void fk_rows_kernel(const uint32_t *state, const uint32_t *recs, cons
 // metrics are sums of (analysis/all_player_metrics.py:257-340): exposures, completed / safety / wins, sums and square
 // sums of final score, n_turns, turns - rounds, rank, loss margin and the eight behaviour counters.  Exact in int64; the
 // two ratio statistics of that module (score / n_turns, score / n_rounds) are float64 sums in row order and stay on the host.
-// A strategy is seated exactly once per shuffle, so the kernel GATHERS: thread = (strategy, part of a batch's shuffles);
-// for every shuffle it finds the strategy's seat through the inverse permutation, reads that game's result record and state
-// records, and accumulates in registers — no atomics per exposure, nothing read twice.
+// A strategy is seated exactly once per shuffle, so the statistics are GATHERED: thread = (strategy, part of a batch's
+// shuffles); for every shuffle it finds the strategy's seat through the inverse permutation, reads that exposure's 32-byte
+// digest (written game-major by fk_seat_digest_kernel) and accumulates in registers — no atomics per exposure.
 //   columns: 0 exposures 1 completed 2 safety 3 wins 4 score 5 score^2 6 turns 7 turns^2 8 [turns != rounds]
 //            9 (turns - rounds) 10 (turns - rounds)^2, then (sum, sum of squares) of rank, loss_margin [completed games
 //            only], rolls, farkles, highest_turn, hot_dice, smart_five_uses, n_smart_five_dice, smart_one_uses, n_smart_one_dice
@@ -1457,8 +1457,42 @@ __global__ void fk_invert_perm_kernel(const uint16_t *perm_T, uint32_t S, uint32
     inv_T[((size_t)b * S + perm_T[t]) * slots + l] = (uint16_t)e;
 }
 
-__global__ __launch_bounds__(256) void fk_seat_stats_kernel(const uint32_t *state, const uint32_t *recs, const uint32_t *inv_sched,
-                                                            const uint16_t *inv_T, uint32_t perm_slots, uint32_t S, uint32_t k,
+// Phase 1 of the all-seat statistics, game-major: one lane per (game, seat) digests what the statistics need of that exposure
+// into 32 bytes at digest[game id * k + seat] (coalesced stores; the state records of a game are one contiguous 48 k-byte
+// read, its result record one 32-byte read shared by the k lanes):
+//   q0 = score / 50,   n_rounds | rank << 16 | completed << 24 | won << 25,   rolls | farkles << 16,
+//        highest_turn / 50 | hot_dice << 16
+//   q1 = sf_uses | sf_dice << 16,   so_uses | so_dice << 16,   (winning score - own score) / 50,   n_turns
+// The gather of phase 2 then touches one 32-byte record per exposure instead of the result record plus k state records.
+__global__ __launch_bounds__(256) void fk_seat_digest_kernel(const uint32_t *state, const uint32_t *recs, const uint32_t *inv_sched,
+                                                             uint32_t n_games, uint32_t gps, uint32_t n_sh, uint32_t k, uint4 *digest) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n_games * k) return;
+    const uint32_t id = (uint32_t)(t / k), seat = (uint32_t)(t - (size_t)id * k);
+    const uint32_t slot = inv_sched ? inv_sched[id] : walk_slot(id, gps, n_sh, true);
+    const uint4 q0 = *reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
+    const bool completed = !(q0.x & REC_SAFETY);
+    const uint32_t *gs = state + (size_t)slot * k * STATE_DW, *x = gs + (size_t)seat * STATE_DW;
+    const int32_t score = (int32_t)x[R_SCORE]; // units of 50
+    uint32_t rank = 0, margin = 0, won = 0;
+    if (completed) {
+        rank = 1;
+        for (uint32_t j = 0; j < k; ++j) { // stable sort on score desc (engine.py:477-483)
+            const int32_t o = (int32_t)gs[(size_t)j * STATE_DW + R_SCORE];
+            rank += (o > score || (o == score && j < seat)) ? 1u : 0u;
+        }
+        margin = q0.y / 50u - (uint32_t)score; // winning score - own score
+        won = (((q0.x >> 24) & 0x7fu) == seat) ? 1u : 0u;
+    }
+    const uint32_t xb = x[R_CB], xe = x[R_CE];
+    uint4 *d = digest + t * 2;
+    d[0] = make_uint4((uint32_t)score, (q0.z & 0xffffu) | (rank << 16) | ((completed ? 1u : 0u) << 24) | (won << 25), x[R_CA],
+                      (xb & 0xffffu) | (xe << 16));
+    d[1] = make_uint4(x[R_CC], x[R_CD], margin, xb >> 16);
+}
+
+// Phase 2: thread = (strategy, part of a batch's shuffles); one digest record per exposure, accumulated in registers.
+__global__ __launch_bounds__(256) void fk_seat_stats_kernel(const uint4 *digest, const uint16_t *inv_T, uint32_t perm_slots, uint32_t S, uint32_t k,
                                                             uint32_t gps, uint32_t n_sh, uint32_t sh_offset, uint32_t spb,
                                                             uint32_t parts_per_batch, uint32_t first_batch, long long *stats) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1474,16 +1508,12 @@ __global__ __launch_bounds__(256) void fk_seat_stats_kernel(const uint32_t *stat
 #pragma unroll
     for (int c = 0; c < FK_SEAT_STAT_COLS; ++c) acc[c] = 0;
     for (uint32_t sh = first; sh < last; ++sh) {
-        const uint32_t p = perm_at(inv_T, S, perm_slots, sh, s), g = p / k, seat = p - g * k;
-        const uint32_t id = sh * gps + g;
-        const uint32_t slot = inv_sched ? inv_sched[id] : walk_slot(id, gps, n_sh, true);
-        const uint4 *r = reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
-        const uint4 q0 = r[0];
-        const bool completed = !(q0.x & REC_SAFETY);
-        const uint32_t *gs = state + (size_t)slot * k * STATE_DW, *x = gs + (size_t)seat * STATE_DW;
-        const long long score = (long long)(int32_t)x[R_SCORE] * 50, rounds = q0.z & 0xffffu; // the state store holds score / 50
-        const uint32_t xa = x[R_CA], xb = x[R_CB], xc = x[R_CC], xd = x[R_CD], xe = x[R_CE];
-        const long long turns = xb >> 16, tmr = turns - rounds;
+        const uint32_t p = perm_at(inv_T, S, perm_slots, sh, s); // position = game * k + seat of the strategy in this shuffle
+        const uint4 *d = digest + ((size_t)sh * gps * k + p) * 2;
+        const uint4 q0 = d[0], q1 = d[1];
+        const bool completed = (q0.y >> 24) & 1u;
+        const long long score = (long long)(int32_t)q0.x * 50, rounds = q0.y & 0xffffu;
+        const long long turns = q1.w, tmr = turns - rounds;
         acc[0] += 1;
         acc[completed ? 1 : 2] += 1;
         acc[4] += score;
@@ -1494,19 +1524,15 @@ __global__ __launch_bounds__(256) void fk_seat_stats_kernel(const uint32_t *stat
         acc[9] += tmr;
         acc[10] += tmr * tmr;
         if (completed) {
-            long long rank = 1;
-            for (uint32_t j = 0; j < k; ++j) {
-                const long long o = (long long)(int32_t)gs[(size_t)j * STATE_DW + R_SCORE] * 50;
-                rank += (o > score || (o == score && j < seat)) ? 1 : 0;
-            }
-            const long long margin = (long long)q0.y - score; // winning score - own score
-            acc[3] += (((q0.x >> 24) & 0x7fu) == seat) ? 1 : 0;
+            const long long rank = (q0.y >> 16) & 0xffu, margin = (long long)q1.z * 50;
+            acc[3] += (q0.y >> 25) & 1u;
             acc[11] += rank;
             acc[12] += rank * rank;
             acc[13] += margin;
             acc[14] += margin * margin;
         }
-        const long long v[8] = {xa & 0xffffu, xa >> 16, (xb & 0xffffu) * 50, xe & 0xffffu, xc & 0xffffu, xc >> 16, xd & 0xffffu, xd >> 16};
+        const long long v[8] = {q0.z & 0xffffu, q0.z >> 16, (long long)(q0.w & 0xffffu) * 50, q0.w >> 16,
+                                q1.x & 0xffffu, q1.x >> 16, q1.y & 0xffffu, q1.y >> 16};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             acc[15 + 2 * j] += v[j];
