@@ -1460,9 +1460,8 @@ __global__ void fk_invert_perm_kernel(const uint16_t *perm_T, uint32_t S, uint32
 // Phase 1 of the all-seat statistics, game-major: one lane per (game, seat) digests what the statistics need of that exposure
 // into 32 bytes at digest[game id * k + seat] (coalesced stores; the state records of a game are one contiguous 48 k-byte
 // read, its result record one 32-byte read shared by the k lanes):
-//   q0 = score / 50,   n_rounds | rank << 16 | completed << 24 | won << 25,   rolls | farkles << 16,
-//        highest_turn / 50 | hot_dice << 16
-//   q1 = sf_uses | sf_dice << 16,   so_uses | so_dice << 16,   (winning score - own score) / 50,   n_turns
+//   q0 = score / 50,   n_rounds | completed << 16 | won << 17,   rolls | farkles << 16,   highest_turn / 50 | hot_dice << 16
+//   q1 = sf_uses | sf_dice << 16,   so_uses | so_dice << 16,   (winning score - own score) / 50,   n_turns | rank << 16
 // The gather of phase 2 then touches one 32-byte record per exposure instead of the result record plus k state records.
 __global__ __launch_bounds__(256) void fk_seat_digest_kernel(const uint32_t *state, const uint32_t *recs, const uint32_t *inv_sched,
                                                              uint32_t n_games, uint32_t gps, uint32_t n_sh, uint32_t k, uint4 *digest) {
@@ -1486,9 +1485,9 @@ __global__ __launch_bounds__(256) void fk_seat_digest_kernel(const uint32_t *sta
     }
     const uint32_t xb = x[R_CB], xe = x[R_CE];
     uint4 *d = digest + t * 2;
-    d[0] = make_uint4((uint32_t)score, (q0.z & 0xffffu) | (rank << 16) | ((completed ? 1u : 0u) << 24) | (won << 25), x[R_CA],
+    d[0] = make_uint4((uint32_t)score, (q0.z & 0xffffu) | ((completed ? 1u : 0u) << 16) | (won << 17), x[R_CA],
                       (xb & 0xffffu) | (xe << 16));
-    d[1] = make_uint4(x[R_CC], x[R_CD], margin, xb >> 16);
+    d[1] = make_uint4(x[R_CC], x[R_CD], margin, (xb >> 16) | (rank << 16)); // rank <= k <= 65 535
 }
 
 // Phase 2: thread = (strategy, part of a batch's shuffles); one digest record per exposure, accumulated in registers.
@@ -1511,9 +1510,9 @@ __global__ __launch_bounds__(256) void fk_seat_stats_kernel(const uint4 *digest,
         const uint32_t p = perm_at(inv_T, S, perm_slots, sh, s); // position = game * k + seat of the strategy in this shuffle
         const uint4 *d = digest + ((size_t)sh * gps * k + p) * 2;
         const uint4 q0 = d[0], q1 = d[1];
-        const bool completed = (q0.y >> 24) & 1u;
+        const bool completed = (q0.y >> 16) & 1u;
         const long long score = (long long)(int32_t)q0.x * 50, rounds = q0.y & 0xffffu;
-        const long long turns = q1.w, tmr = turns - rounds;
+        const long long turns = q1.w & 0xffffu, tmr = turns - rounds;
         acc[0] += 1;
         acc[completed ? 1 : 2] += 1;
         acc[4] += score;
@@ -1524,8 +1523,8 @@ __global__ __launch_bounds__(256) void fk_seat_stats_kernel(const uint4 *digest,
         acc[9] += tmr;
         acc[10] += tmr * tmr;
         if (completed) {
-            const long long rank = (q0.y >> 16) & 0xffu, margin = (long long)q1.z * 50;
-            acc[3] += (q0.y >> 25) & 1u;
+            const long long rank = q1.w >> 16, margin = (long long)q1.z * 50;
+            acc[3] += (q0.y >> 17) & 1u;
             acc[11] += rank;
             acc[12] += rank * rank;
             acc[13] += margin;
