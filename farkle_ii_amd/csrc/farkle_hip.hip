@@ -90,6 +90,13 @@ struct fk_ctx {
     int32_t batch_threshold = 8;
     int32_t use_lds_tally = -1;
     int32_t block = 0;
+    int32_t hc = -1;           // hot / cold game kernel (fk_play_hc.h): -1 auto, 0 never, 1 whenever the table allows it
+    int32_t hc_waves = 5;      // resident waves per SIMD the plan counts on for it
+    int32_t hc_block = 256;    // its block size: 256, 768 or 1024
+    int32_t hc_tables = 1;     // 1: score / discard tables in LDS (LT instances)
+    DevBuf lds_tables;         // their LDS image (fk_play_hc.h)
+    DevBuf cold;
+    bool ran_hc = false;       // the current tournament call launched the hot / cold kernel
     int32_t perm_split = -1;   // -1 auto, 0 one-kernel Fisher-Yates, 1 draws + serial swap chains, 2 draws + chain-free kernel
     void *comm = nullptr;      // RCCL communicator (fk_comm_init), one per context / GPU
     int comm_rank = 0, comm_world = 1;
@@ -213,6 +220,8 @@ struct LaunchPlan {
     bool lean = false; // 10-dword seat records (increment + strategy re-read from HBM/L2 each turn, 16-bit score / 50)
     bool gs = false;   // state-store instance: one LDS record per lane, the others in HBM
     bool blk = false;  // batched-H2H instance (strategy index from the lane's block index)
+    bool hc = false;   // hot / cold instance (fk_play_hc.h): 20 bytes of LDS per seat, cold records in an L2-resident plane
+    bool hc_lt = false; // ... with the score / discard tables in LDS
     int wpe = 4;       // waves per SIMD the chosen instance is compiled for
     uint32_t mixed_flags = 0xff00u; // flag bits that differ between strategies of the table (selects the kernel instance)
 };
@@ -294,16 +303,93 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, i
     return best; // feasible whenever lean records are: a GS instance needs 40 bytes of LDS per lane whatever k is
 }
 
+// The hot / cold instance (fk_play_hc.h) for a tournament launch, when the table allows it and it seats more waves than
+// the LDS-record plan: 20 bytes of LDS per seat and lane, 256-thread blocks (one wave per SIMD each).
+bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const LaunchPlan &base, LaunchPlan &out) {
+    if (c->hc == 0 || c->gs == 1 || base.lds_tally) return false;
+    if (k < 3 || k > (int32_t)HC_MAX_K || ceil_div50(target_score) > HC_MAX_TARGET50) return false;
+    const int block = (c->hc_block == 1024 || c->hc_block == 768) ? c->hc_block : 256;
+    const bool lt = c->hc_tables != 0;
+    const size_t lds = (size_t)block * 20 * (size_t)k + (lt ? LT_BYTES : 0);
+    if (lds > LDS_LIMIT) return false;
+    const int max_lanes = 256 * std::max(1, std::min(c->hc_waves, c->max_waves));
+    int per_cu = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)std::max(1, max_lanes / block));
+    if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
+    per_cu = std::max(per_cu, 1);
+    const int base_lanes = base.block * std::max(1, base.grid / std::max(1, base.cus));
+    // auto: where LDS records seat fewer than three waves per SIMD (k >= 5 with lean records; measured on the 5 160-strategy
+    // grid, round 3: k = 6 +8 %, k = 8 +12 % games/s; k = 4 -6 %, k = 3 -20 %)
+    if (c->hc < 0 && (base_lanes >= 768 || per_cu * block <= base_lanes)) return false;
+    out = base;
+    out.hc = true;
+    out.hc_lt = lt;
+    out.lean = true;
+    out.gs = false;
+    out.blk = false;
+    out.block = block;
+    out.lds = lds;
+    out.wpe = per_cu * block / 256;
+    out.grid = c->prop.multiProcessorCount * per_cu;
+    out.cus = c->prop.multiProcessorCount;
+    return true;
+}
+
+// LDS image of the score / discard tables (fk_play_hc.h), from the same __host__ __device__ functions that build the
+// global tables
+std::vector<uint8_t> build_lds_tables() {
+    std::vector<uint8_t> img(LT_BYTES, 0);
+    uint32_t *pair = reinterpret_cast<uint32_t *>(img.data() + LT_PAIR_OFF);
+    uint16_t *score = reinterpret_cast<uint16_t *>(img.data() + LT_SCORE_OFF);
+    auto hsum = [](uint32_t h) { return (h & 7u) + ((h >> 3) & 7u) + ((h >> 6) & 7u); };
+    auto valid = [&](uint32_t h) { return (h & 7u) <= 6u && ((h >> 3) & 7u) <= 6u && ((h >> 6) & 7u) <= 6u && hsum(h) <= 6u; };
+    std::vector<uint32_t> order;
+    for (uint32_t h = 0; h < 512; ++h)
+        if (valid(h)) order.push_back(h);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return hsum(x) < hsum(y); });
+    uint32_t rank[512] = {0}, upto[8] = {0};
+    for (uint32_t i = 0; i < order.size(); ++i) {
+        rank[order[i]] = i;
+        for (uint32_t t = hsum(order[i]); t <= 6; ++t) upto[t] += 1; // halves with at most t dice
+    }
+    uint32_t running = 0, base[512] = {0};
+    for (uint32_t h = 0; h < 512; ++h)
+        if (valid(h)) {
+            base[h] = running;
+            running += upto[6u - hsum(h)];
+        }
+    // running == 924: every multiset of at most six dice (the empty one included)
+    for (uint32_t h = 0; h < 512; ++h) pair[h] = valid(h) ? (base[h] | (rank[h] << 16)) : 0u;
+    for (uint32_t lo = 0; lo < 512; ++lo)
+        for (uint32_t hi = 0; hi < 512; ++hi)
+            if (valid(lo) && valid(hi) && hsum(lo) + hsum(hi) <= 6u) score[base[lo] + rank[hi]] = score_lut_entry(lo | (hi << 9));
+    uint8_t *disc = img.data() + LT_DISC_OFF;
+    for (uint32_t fav = 0; fav < 2; ++fav)
+        for (uint32_t rb = 0; rb < 2; ++rb)
+            for (uint32_t r7 = 0; r7 < 8; ++r7)
+                for (uint32_t cmin = 0; cmin < 6; ++cmin)
+                    for (uint32_t vmin = 0; vmin < 8; ++vmin)
+                        for (uint32_t m1 = 0; m1 < 3; ++m1)
+                            for (uint32_t sf = 0; sf < 3; ++sf) {
+                                const uint32_t idx = (((((fav * 2u + rb) * 8u + r7) * 6u + cmin) * 8u + vmin) * 9u) + m1 * 3u + sf;
+                                const uint32_t ch = discard_choice(sf, m1, vmin, cmin, r7, rb != 0u, fav != 0u) & 15u;
+                                disc[idx >> 1] |= (uint8_t)(ch << ((idx & 1u) * 4u));
+                            }
+    return img;
+}
+
 template <int BLOCK, bool LEAN, int WPE, uint32_t MIXED, bool GS, bool BLK = false, int KC = 0>
 hipError_t launch_play_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    static bool configured = false; // the dynamic-LDS ceiling of an instance is raised once, not per launch
+    static int configured_dev = -1; // the dynamic-LDS ceiling of an instance is raised once per device, not per launch
     static size_t occ_lds = ~(size_t)0;
     static int occ_blocks = 0;
     const void *fn = reinterpret_cast<const void *>(&fk_play_kernel<BLOCK, LEAN, WPE, MIXED, GS, BLK, KC>);
-    if (!configured) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (configured_dev != dev) { // a context on another device of this process: the attribute and the occupancy are per device
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
         if (e != hipSuccess) return e;
-        configured = true;
+        configured_dev = dev;
+        occ_lds = ~(size_t)0;
     }
     const size_t lds = std::max<size_t>(p.lds, 16);
     if (occ_lds != lds) { // resident blocks per CU as the runtime counts them (registers, LDS, wave slots)
@@ -330,8 +416,51 @@ hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) 
     return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS, BLK, KC>(p, a, s);
 }
 
+template <int BLOCK, uint32_t MIXED, bool LT>
+hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
+    static int configured_dev = -1; // dynamic-LDS ceiling and occupancy are per device
+    static size_t occ_lds = ~(size_t)0;
+    static int occ_blocks = 0;
+    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT>);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (configured_dev != dev) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);
+        if (e != hipSuccess) return e;
+        configured_dev = dev;
+        occ_lds = ~(size_t)0;
+    }
+    if (occ_lds != p.lds) {
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, BLOCK, p.lds);
+        if (e != hipSuccess) return e;
+        occ_blocks = std::max(nb, 1);
+        occ_lds = p.lds;
+    }
+    const int grid = std::min(p.grid, occ_blocks * p.cus);
+    p.launched_grid = grid;
+    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
+    return hipGetLastError();
+}
+
+template <int BLOCK, bool LT>
+hipError_t launch_play_hc_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
+    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT>(p, a, s);
+    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT>(p, a, s);
+    return launch_play_hc_u<BLOCK, MIXED_ALL, LT>(p, a, s);
+}
+
+hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
+    switch (p.block) {
+    case 1024: return p.hc_lt ? launch_play_hc_t<1024, true>(p, a, s) : launch_play_hc_t<1024, false>(p, a, s);
+    case 768: return p.hc_lt ? launch_play_hc_t<768, true>(p, a, s) : launch_play_hc_t<768, false>(p, a, s);
+    default: return p.hc_lt ? launch_play_hc_t<256, true>(p, a, s) : launch_play_hc_t<256, false>(p, a, s);
+    }
+}
+
 hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     if (p.lds > LDS_LIMIT) return hipErrorInvalidValue;
+    if (p.hc) return launch_play_hc(p, a, s);
     if (p.blk) return launch_play_t<768, true, 6, false, true, 2>(p, a, s); // batched H2H: k = 2, lean LDS records
     if (p.gs) {
         switch (p.block) {
@@ -589,15 +718,15 @@ int prep_tournament_chunk(fk_ctx *c, int si, hipStream_t st_seed, const ChunkDes
     (void)hipEventRecord(cs.ev[0], st);
     {
         const size_t perm_lds = (size_t)slots * S * 2;
-        static bool perm_configured = false;
-        if (!perm_configured) {
+        static int perm_configured = -1; // per device (a second context may sit on another GPU of this process)
+        if (perm_configured != c->device) {
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_apply_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
             HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_perm_parallel_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_LIMIT - 1024))); // + its static words
-            perm_configured = true;
+            perm_configured = c->device;
         }
         // large tables: the draws at full occupancy first (fk_perm_draw_kernel); then either the chain-free
         // permutation (fk_perm_parallel_kernel, one workgroup per shuffle, 14 B of LDS per strategy) or, for tables
@@ -775,6 +904,15 @@ int fk_init(int device_ordinal, fk_ctx **out) {
                        static_cast<uint16_t *>(c->score_lut.p));
     hipLaunchKernelGGL(fk_discard_lut_kernel, dim3(DISCARD_LUT_KEYS / 256), dim3(256), 0, c->stream,
                        static_cast<uint8_t *>(c->discard_lut.p));
+    {
+        const std::vector<uint8_t> img = build_lds_tables();
+        if (ensure(c, c->lds_tables, img.size()) != FK_OK ||
+            hipMemcpyAsync(c->lds_tables.p, img.data(), img.size(), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) {
+            fk_destroy(c);
+            return FK_ERR_HIP;
+        }
+    }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
         fk_destroy(c);
         return FK_ERR_HIP;
@@ -792,7 +930,7 @@ void fk_destroy(fk_ctx *c) {
     release(c->comm_buf);
     if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     for (DevBuf *b : {&c->strat, &c->recs, &c->rec0, &c->tally, &c->rows, &c->ov, &c->seatlist, &c->coords, &c->inv, &c->slow, &c->digest, &c->score_lut,
-                      &c->discard_lut, &c->blocks, &c->game_block, &c->block_out, &c->stats})
+                      &c->discard_lut, &c->blocks, &c->game_block, &c->block_out, &c->stats, &c->cold, &c->lds_tables})
         release(*b);
     for (auto &cs : c->sets) {
         for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc, &cs.pools}) release(*b);
@@ -842,6 +980,10 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "max_waves") c->max_waves = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8);
     else if (n == "lean") c->lean = (int32_t)value;
     else if (n == "state_store") c->gs = (int32_t)value;
+    else if (n == "hot_cold") c->hc = (int32_t)value;
+    else if (n == "hot_cold_waves") c->hc_waves = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8);
+    else if (n == "hot_cold_block") c->hc_block = (int32_t)value;
+    else if (n == "hot_cold_tables") c->hc_tables = (int32_t)value;
     else if (n == "perm_split") c->perm_split = (int32_t)value;
     else if (n == "pipeline") c->pipeline = (int32_t)value;
     else if (n == "uniform_flags") c->uniform_flags_opt = (int32_t)value;
@@ -860,11 +1002,36 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
                                    max_rounds, ov, n_ov, tally, rows, perms, nullptr);
 }
 
+static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                               uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
+                               int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
+                               int64_t *seat_stats);
+
 int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
                             uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
                             int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
                             int64_t *seat_stats) {
     if (!c) return FK_ERR_ARG;
+    c->ran_hc = false;
+    int rc = tournament_run_impl(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds,
+                                 ov, n_ov, tally, rows, perms, seat_stats);
+    if (rc == FK_ERR_COUNTER_OVERFLOW && c->ran_hc) {
+        // the hot / cold kernel's narrower counter fields (fk_play_hc.h) left their guard bands: the call is replayed on
+        // fk_play_kernel, whose 16-bit fields are the ABI's stated limits
+        const int32_t saved = c->hc;
+        c->hc = 0;
+        for (auto &cs : c->sets) cs.prepared = false;
+        rc = tournament_run_impl(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds,
+                                 ov, n_ov, tally, rows, perms, seat_stats);
+        c->hc = saved;
+    }
+    return rc;
+}
+
+static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                               uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
+                               int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
+                               int64_t *seat_stats) {
     if (!strategies || !tally) return fail(c, FK_ERR_ARG, "strategies and tally are required");
     if (k < 1 || S < k || S % k != 0) return fail(c, FK_ERR_ARG, "n_players must divide %d", S); // run_tournament.py:274
     if (S > 65535) return fail(c, FK_ERR_ARG, "S=%d exceeds 65535 strategies", S);
@@ -888,10 +1055,19 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->tally.p, 0, tally_bytes, c->stream));
 
-    const LaunchPlan plan = plan_play(c, k, S, n_batches == 1, target_score);
+    LaunchPlan plan = plan_play(c, k, S, n_batches == 1, target_score);
     if (plan.block == 0)
         return fail(c, FK_ERR_ARG, "target_score %d: no kernel instance (lean records hold totals up to %d points; %d full records do not fit LDS)",
                     target_score, 50 * LEAN_MAX_TARGET50, (int)k);
+    {
+        LaunchPlan hc_plan;
+        if (plan_play_hc(c, k, target_score, plan, hc_plan)) plan = hc_plan;
+    }
+    if (plan.hc) { // cold seat records of every lane the grid can seat
+        c->ran_hc = true;
+        rc = ensure(c, c->cold, (size_t)plan.grid * (size_t)plan.block * (size_t)k * 16);
+        if (rc) return rc;
+    }
     const bool want_state = rows != nullptr || seat_stats != nullptr;
     const bool want_recs = !plan.lds_tally || want_state;
     const size_t stats_bytes = sizeof(int64_t) * (size_t)n_batches * (size_t)S * FK_SEAT_STAT_COLS;
@@ -1007,6 +1183,8 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
         pa.target50 = ceil_div50(target_score);
         pa.beat50 = floor_div50(target_score);
         pa.max_rounds = (uint32_t)max_rounds;
+        pa.cold = static_cast<uint4 *>(c->cold.p);
+        pa.lds_tables = static_cast<const uint8_t *>(c->lds_tables.p);
 
         // The next chunk (or the hinted next call) is prepared into the other chunk set around this game kernel: its permutations
         // in front of it on the main stream, its schedule + seat seeding on the low-priority stream while it runs.
@@ -1084,11 +1262,11 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
                 const uint32_t nb = last_batch - first_batch + 1u;
                 // enough parts to fill the chip, at least ~16 K games each
                 uint32_t ppb = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(games_per_batch / 16384, (2048u + nb * n_slices - 1u) / (nb * n_slices)));
-                static bool reduce_configured = false;
-                if (!reduce_configured) {
+                static int reduce_configured = -1;
+                if (reduce_configured != c->device) {
                     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_tally_reduce_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-                    reduce_configured = true;
+                    reduce_configured = c->device;
                 }
                 hipLaunchKernelGGL(fk_tally_reduce_kernel, dim3(ppb * nb, n_slices), dim3(REDUCE_BLOCK), (size_t)slice * RT_COLS * 8, c->stream,
                                    static_cast<const uint32_t *>(c->rec0.p), static_cast<const uint32_t *>(c->recs.p), n_games, gps,
@@ -1171,6 +1349,7 @@ int fk_play_games(fk_ctx *c, const fk_coord *coords, int64_t n_games, const fk_s
     pa.strat = static_cast<const uint2 *>(c->strat.p);
     pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
     pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
+    pa.lds_tables = static_cast<const uint8_t *>(c->lds_tables.p);
     pa.seat_strategy = static_cast<const int32_t *>(c->seatlist.p);
     pa.mode = MODE_LIST;
     pa.n_games = (uint32_t)n_games;
@@ -1308,6 +1487,7 @@ int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_
         pa.strat = static_cast<const uint2 *>(c->strat.p);
         pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
         pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
+        pa.lds_tables = static_cast<const uint8_t *>(c->lds_tables.p);
         pa.game_block = sa.game_block;
         pa.ov = static_cast<const DevOverride *>(c->ov.p);
         pa.n_ov = (uint32_t)dov.size();

@@ -613,6 +613,44 @@ __host__ __device__ inline Roll50 default_score_lut50(const uint16_t *lut, const
     return apply_discards50(e, q.eligible ? (uint32_t)dlut[discard_key(q)] : 0u);
 }
 
+// ----------------------------------------------------------------------------------------
+// The two per-roll tables as an LDS IMAGE (LT instances of the game kernels; built once per context on the host from the
+// functions above, copied in by every block at kernel start).  A gather from the 512 KiB / 64 KiB global tables costs the
+// CU's texture addresser one cycle per lane (PMC, round 3: TA busy 49 % of the game kernel, two gathers per roll); the same
+// look-ups from LDS cost three ds_read + ~8 VALU and no vector-memory instruction:
+//   pair table  u32[512]: key half h (three 3-bit face counts) -> base(h) [15:0] | rank(h) << 16.  A roll's 18-bit key is two
+//               halves (faces 1-3, faces 4-6); with rank() ordering the halves by dice count first, the roll's dense index is
+//               base(low half) + rank(high half): 924 multisets of <= 6 dice
+//   score table u16[924]: the entry of fk_device.h's score table for that multiset
+//   discard table, 4 bits per entry: the choice of fk_device.h's discard_choice() for
+//               index = ((((fav * 2 + rb) * 8 + min(r15, 7)) * 6 + cmin) * 8 + vmin) * 9 + m1 * 3 + sf   (13 824 entries)
+constexpr uint32_t LT_PAIR_OFF = 0, LT_SCORE_OFF = 2048, LT_SCORE_N = 924, LT_DISC_OFF = LT_SCORE_OFF + 2 * LT_SCORE_N + 8 /* 3904 */,
+                   LT_DISC_N = 13824, LT_BYTES = LT_DISC_OFF + LT_DISC_N / 2 /* 10816 */;
+static_assert(LT_DISC_OFF % 16 == 0 && LT_BYTES % 16 == 0, "table image is copied in 16-byte pieces");
+
+__host__ __device__ inline uint32_t lt_discard_index(const DiscardQuery &q) {
+    const uint32_t r7 = q.r15 < 7u ? q.r15 : 7u, sf = q.sf < 2u ? q.sf : 2u, m1 = q.m1 < 2u ? q.m1 : 2u;
+    const uint32_t top = ((q.fav ? 2u : 0u) + (q.rb ? 1u : 0u)) * 8u + r7;
+    return ((top * 6u + q.cmin) * 8u + q.vmin) * 9u + m1 * 3u + sf;
+}
+
+// score + discard choice of one roll from the LDS image (the kernels' path of default_score_lut50, same results)
+__device__ inline Roll50 default_score_lds50(const uint8_t *img, uint32_t key, int32_t n, int32_t pre50, const Strat50 &s) {
+    const uint32_t *pair = reinterpret_cast<const uint32_t *>(img + LT_PAIR_OFF);
+    const uint32_t pa = pair[key & 511u], pb = pair[key >> 9];
+    const uint32_t e = reinterpret_cast<const uint16_t *>(img + LT_SCORE_OFF)[(pa & 0xffffu) + (pb >> 16)];
+    const DiscardQuery q = discard_query50(e, n, pre50, s);
+    uint32_t choice = 0u;
+    if (q.eligible) {
+        const uint32_t di = lt_discard_index(q);
+        choice = ((uint32_t)(img + LT_DISC_OFF)[di >> 1] >> ((di & 1u) * 4u)) & 15u;
+    }
+    return apply_discards50(e, choice);
+}
+constexpr uint32_t HC_HI_MASK = 0x7ffu, HC_SCORE_SHIFT = 11, HC_SCORE_MASK = 0xfffu, HC_HAS_SCORED = 1u << 23, HC_HOT_SHIFT = 24;
+constexpr int32_t HC_MAX_TARGET50 = 2700; // 2700 + 1310 < 4096
+constexpr uint32_t HC_HOT_GUARD = 250;
+
 // should_continue in units of 50; stb50 = floor(score_to_beat / 50)
 __host__ __device__ inline bool should_continue50(const Strat50 &s, int32_t turn50, int32_t dice_left, bool has_scored, bool final_round,
                                                   int32_t stb50, int32_t score50) {

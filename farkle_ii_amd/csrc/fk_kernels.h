@@ -153,6 +153,8 @@ struct PlayArgs {
     uint32_t batch_threshold;
     uint32_t use_lds_tally;
     uint32_t uflags;             // the flag bits (8..15) every strategy of the table shares, see MIXED below
+    uint4 *cold;                 // fk_play_hc_kernel: [resident lanes][k] cold seat records (fk_play_hc.h)
+    const uint8_t *lds_tables;   // fk_play_hc_kernel, LT instances: the LDS image of the score / discard tables (LT_BYTES, fk_device.h)
 };
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -1219,6 +1221,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
         }
     }
 }
+
+#include "fk_play_hc.h" // the hot / cold variant of the game kernel (k >= 3 seats)
 
 // ---------------------------------------------------------------------------------------
 // Post-passes over the result records / the state store (streaming kernels, one thread per game).

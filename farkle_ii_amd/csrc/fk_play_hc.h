@@ -1,0 +1,311 @@
+// fk_play_hc.h — the hot / cold game kernel: tournament launches whose k seat records do not leave LDS room for more
+// than a few waves per SIMD (included by fk_kernels.h; same rules, same registers, same hand-over as fk_play_kernel).
+//
+// fk_play_kernel keeps the ten dwords a turn mutates of EVERY seat in LDS: 40 k bytes per lane, i.e. 4 waves per SIMD at
+// k = 4, 2.5 at k = 6 and 2 at k = 8 — and a wave alone issues one vector instruction per 4 cycles where the SIMD could
+// take one per 2 (MI355X_MICROARCH.md): below ~4 resident waves the kernel is bound by its own stalls.  Round 2 measured
+// the alternative that keeps ONE record per lane in LDS and the rest in HBM (state-store instances): 2x slower, because
+// every turn then moves 96 bytes in six 16-byte requests per lane and the L2s take ~3 x 10^11 requests per second in all
+// (fk_play_kernel already spends 40 % of that on the increment and strategy loads of its turn starts).
+//
+// This kernel splits the record by how often it is touched instead:
+//   HOT   per roll: generator state (16 B) + buffered half word (4 B) = 20 bytes per seat, in LDS for every seat
+//         (k = 8: 160 B per lane = 4 waves per SIMD; k = 6: 5; k <= 5: the register file's 5);
+//   COLD  per turn: the eight behaviour counters, the banked total and has_scored = 16 bytes per seat.  The turn owner's
+//         live in four registers; at a turn hand-over they go to a PLANE indexed by (resident lane, seat) — 16 k bytes
+//         per lane, 34 MB for the whole chip at k = 8: L2-resident, never written back while the launch runs — and the next
+//         owner's come in.  One store + one load per turn; the load is issued at the hand-over and first read in the
+//         middle of the next roll (behind the score-table gather that every roll waits for anyway), so its latency is
+//         not on the roll's dependency chain.
+//   has_buf of all seats is one bit mask per lane; the seats' strategy indices are eight 16-bit fields in four registers.
+// Cold record (uint4):
+//   x = rolls | farkles << 16
+//   y = highest_turn / 50 [10:0] | banked total / 50 [22:11] | has_scored [23] | hot_dice [31:24]
+//   z = smart_five_uses | n_smart_five_dice << 16        w = smart_one_uses | n_smart_one_dice << 16
+// The 12-bit total needs target / 50 + one turn (<= 1310) < 4096, the 8-bit hot-dice count a guard band at 250 (a seat
+// rolls hot dice in ~3 % of its turns); the launch plan keeps other tables on fk_play_kernel, and a count that leaves the
+// band is FK_ERR_COUNTER_OVERFLOW like every other guarded counter (the host then replays the chunk on fk_play_kernel).
+#pragma once
+
+constexpr uint32_t HC_MAX_K = 8;
+
+template <int HC_BLOCK_I, uint32_t MIXED, bool LT>
+__global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(HC_BLOCK_I == 256 ? 5 : HC_BLOCK_I / 256))) void fk_play_hc_kernel(PlayArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    constexpr uint32_t HC_BLOCK = (uint32_t)HC_BLOCK_I;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t K = a.k;
+    uint4 *const lds_state = reinterpret_cast<uint4 *>(lds) + tid;   // [seat][lane] generator state
+    uint32_t *const lds_buf = lds + 4u * K * HC_BLOCK + tid;          // [seat][lane] buffered half word
+    const uint8_t *const lt_img = reinterpret_cast<const uint8_t *>(lds + 5u * K * HC_BLOCK); // LT: the two tables
+    if (LT) {
+        uint4 *dst = reinterpret_cast<uint4 *>(lds + 5u * K * HC_BLOCK);
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.lds_tables);
+        for (uint32_t i = tid; i < LT_BYTES / 16u; i += HC_BLOCK) dst[i] = src[i];
+        __syncthreads();
+    }
+    uint4 *const cold = a.cold + (size_t)(blockIdx.x * HC_BLOCK + tid) * K; // [resident lane][seat]
+
+    enum : uint32_t { ST_FRESH = 0, ST_ACTIVE = 1, ST_ENDED = 2, ST_DONE = 3 };
+    uint32_t st = ST_FRESH;
+    uint32_t pool_next = 0, pool_end = 0, exhausted = 0; // wave-uniform ticket pool
+
+    // game registers
+    uint32_t game_id = 0, seat = 0, rounds = 0, max_rounds = 0, trigger = 0, seed_slot = 0;
+    uint32_t final_round = 0, safety = 0;
+    int32_t score_to_beat = 0;
+    uint32_t hasbuf = 0;                          // bit s: seat s holds a buffered half word
+    uint32_t ix01 = 0, ix23 = 0, ix45 = 0, ix67 = 0; // strategy indices of the seats, 16 bits each
+    // turn registers
+    uint32_t dice = 6, rolls_this_turn = 0;
+    int32_t turn_score = 0;
+    uint64_t own_inc_lo = 0, own_inc_hi = 0;
+    int32_t own_thr = 0;
+    uint32_t own_bits = 0;
+    uint32_t cA = 0, cB = 0, cC = 0, cD = 0;      // the owner's cold record
+
+    auto seat_index = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t lo = (s & 2u) ? ix23 : ix01, hi = (s & 2u) ? ix67 : ix45;
+        const uint32_t w = (s & 4u) ? hi : lo;
+        return (s & 1u) ? (w >> 16) : (w & 0xffffu);
+    };
+    auto G = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t * {
+        return a.state + ((size_t)seed_slot * K + s) * a.state_dw;
+    };
+
+    // turn owner := seat s (engine.py:236-240).  Three loads, none of them read before the next roll: the increment at
+    // its first generator step, the strategy and the cold record behind the score-table gather.
+    auto begin_turn = [&](uint32_t s) __attribute__((always_inline)) {
+        const uint4 inc = a.inc[(size_t)seed_slot * K + s];
+        const uint2 pk = a.strat[seat_index(s)];
+        const uint4 c = cold[s];
+        own_inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
+        own_inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
+        own_thr = (int32_t)pk.x;
+        own_bits = pk.y;
+        cA = c.x, cB = c.y, cC = c.z, cD = c.w;
+        dice = 6;
+        turn_score = 0;
+        rolls_this_turn = 0;
+    };
+
+    auto raise = [&](int32_t code) {
+        if (atomicCAS(&a.err[0], 0, code) == 0) a.err[1] = (int32_t)game_id;
+        st = ST_DONE;
+    };
+
+    auto seat_turns = [&](uint32_t s) -> uint32_t { return rounds + ((final_round != 0u && s < trigger) ? 1u : 0u); };
+
+    // ---- finished game -> one result record (run_tournament.py:375-391), final seat records on request ----
+    auto finish_game = [&]() {
+        const bool completed = (safety == 0u);
+        // the owner's cold record is in registers (its store may still be on its way), the others come from the plane
+        uint32_t w = 0;
+        int32_t best = -1;
+        uint4 wrec = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t s = 0; s < K; ++s) { // stable sort on score desc: first maximum wins (engine.py:477)
+            const uint4 c = (s == seat) ? make_uint4(cA, cB, cC, cD) : cold[s];
+            const int32_t sc = (int32_t)((c.y >> HC_SCORE_SHIFT) & HC_SCORE_MASK);
+            if (sc > best) {
+                best = sc;
+                w = s;
+                wrec = c;
+            }
+            if (a.gs_out) { // the state store's format (R_*): score, n_turns and hot dice spelled out
+                uint4 *g = reinterpret_cast<uint4 *>(G(s));
+                g[0] = lds_state[s * HC_BLOCK];
+                g[1] = make_uint4(lds_buf[s * HC_BLOCK], (uint32_t)sc, c.x, (c.y & HC_HI_MASK) | (seat_turns(s) << 16));
+                g[2] = make_uint4(c.z, c.w,
+                                  (c.y >> HC_HOT_SHIFT) | ((c.y & HC_HAS_SCORED) ? CE_HAS_SCORED : 0u) | (((hasbuf >> s) & 1u) ? CE_HAS_BUF : 0u),
+                                  seat_index(s));
+            }
+        }
+        if (!a.rec0) return;
+        const uint32_t widx = completed ? seat_index(w) : 0u;
+        const uint32_t d0 = widx | (completed ? (w << 24) : REC_SAFETY);
+        a.rec0[game_id] = d0;
+        if (a.recs) {
+            const uint32_t wa = completed ? wrec.x : 0u, wh = completed ? (wrec.y & HC_HI_MASK) : 0u;
+            uint4 *r = reinterpret_cast<uint4 *>(a.recs + (size_t)game_id * REC_DW);
+            r[0] = make_uint4(d0, completed ? (uint32_t)best * 50u : 0u, rounds | (wa & 0xffff0000u), (wa & 0xffffu) | ((wh * 50u) << 16));
+            r[1] = make_uint4(completed ? wrec.z : 0u, completed ? wrec.w : 0u, completed ? (wrec.y >> HC_HOT_SHIFT) : 0u, 0u);
+        }
+    };
+
+    // ---- fresh game for this lane ----
+    auto init_game = [&](uint32_t id, uint32_t ticket) {
+        game_id = id;
+        max_rounds = a.max_rounds;
+        if (a.n_ov) { // sorted by game id: binary search
+            uint32_t lo = 0, hi = a.n_ov;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (a.ov[mid].game < id) lo = mid + 1u;
+                else hi = mid;
+            }
+            if (lo < a.n_ov && a.ov[lo].game == id) max_rounds = a.ov[lo].max_rounds;
+        }
+        uint32_t slot = a.sched ? ticket : id;
+        if (!a.sched) { // the seed kernel's walk order (shuffle-minor)
+            const uint32_t sh = id / a.gps, g = id - sh * a.gps;
+            slot = g * a.n_sh + sh;
+        }
+        seed_slot = slot;
+        uint32_t iw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (uint32_t s = 0; s < HC_MAX_K; ++s) {
+            if (s < K) {
+                const uint32_t *src = G(s);
+                lds_state[s * HC_BLOCK] = *reinterpret_cast<const uint4 *>(src);
+                lds_buf[s * HC_BLOCK] = 0u;
+                cold[s] = make_uint4(0u, 0u, 0u, 0u); // the previous game's record of this lane
+                const uint32_t idx = (a.state_dw == STATE_DW) ? src[R_IDX] : (uint32_t)a.seat_idx[(size_t)slot * K + s];
+                iw[s >> 1] |= idx << (16u * (s & 1u));
+            }
+        }
+        ix01 = iw[0], ix23 = iw[1], ix45 = iw[2], ix67 = iw[3];
+        hasbuf = 0;
+        cA = cB = cC = cD = 0u;
+        seat = 0;
+        trigger = 0;
+        final_round = 0;
+        safety = 0;
+        score_to_beat = a.beat50; // engine.py:451 (units of 50)
+        if (max_rounds == 0u) {   // `while rounds < max_rounds` never entered (engine.py:453)
+            rounds = 0;
+            safety = 1;
+            st = ST_ENDED;
+        } else {
+            rounds = 1;
+            begin_turn(0);
+            st = ST_ACTIVE;
+        }
+    };
+
+    // ---- after a turn: advance the table (engine.py:453-472, 523-550), as selects ----
+    auto advance = [&](int32_t score) __attribute__((always_inline)) {
+        const bool fr = final_round != 0u;
+        const bool trig = !fr & (score >= a.target50);
+        const bool normal = !fr & !trig;
+        const uint32_t n1 = seat + 1u;
+        const bool wrap = n1 == K;
+        const bool last = normal & wrap & (rounds >= max_rounds);
+        uint32_t next_fr = n1 + ((n1 == trigger) ? 1u : 0u);
+        uint32_t next_tr = (seat == 0u) ? 1u : 0u, next_nm = wrap ? 0u : n1;
+        asm volatile("" : "+v"(next_fr), "+v"(next_tr), "+v"(next_nm));
+        const uint32_t next = fr ? next_fr : trig ? next_tr : next_nm;
+        rounds += (normal & wrap & !last) ? 1u : 0u;
+        safety = last ? 1u : safety;
+        score_to_beat = trig ? score : (fr & (score > score_to_beat)) ? score : score_to_beat;
+        trigger = trig ? seat : trigger;
+        final_round = (fr | trig) ? 1u : 0u;
+        const bool ended = last | ((fr | trig) & (next >= K));
+        if (ended) {
+            st = ST_ENDED;
+        } else {
+            seat = next;
+            begin_turn(next);
+        }
+    };
+
+    // ---- one roll of the current turn (engine.py:241-273) ----
+    auto roll_step = [&]() __attribute__((always_inline)) {
+        const bool roll_limit = rolls_this_turn >= 1000u; // ROLL_LIMIT, engine.py:36,242
+        const uint32_t s = seat;
+        const uint4 sv = lds_state[s * HC_BLOCK];
+        const uint32_t buf0 = lds_buf[s * HC_BLOCK];
+        Rng rng{(uint64_t)sv.z | ((uint64_t)sv.w << 32), (uint64_t)sv.x | ((uint64_t)sv.y << 32), own_inc_hi, own_inc_lo, buf0, (hasbuf >> s) & 1u};
+        const uint32_t n = dice;
+        const uint32_t key = roll_counts<3>(rng, n);
+        rolls_this_turn += 1u;
+        int32_t dthr = (int32_t)(int8_t)(own_bits & 0xffu);
+        asm volatile("" : "+v"(dthr));
+        const Strat50 sp{own_thr, (own_bits & (0xffu | MIXED)) | (a.uflags & (0xff00u & ~MIXED)), dthr};
+        const Roll50 rr = LT ? default_score_lds50(lt_img, key, (int32_t)n, turn_score, sp)
+                             : default_score_lut50(a.score_lut, a.discard_lut, key, (int32_t)n, turn_score, sp);
+        const bool farkle = rr.score50 == 0;
+        const int32_t score = (int32_t)((cB >> HC_SCORE_SHIFT) & HC_SCORE_MASK);
+        cA += 1u + (farkle ? 0x10000u : 0u);
+        cC += (rr.d5 > 0) ? (1u + ((uint32_t)rr.d5 << 16)) : 0u;
+        cD += (rr.d1 > 0) ? (1u + ((uint32_t)rr.d1 << 16)) : 0u;
+        dice = (rr.used == (int32_t)n) ? 6u : (n - (uint32_t)rr.used);
+        turn_score = farkle ? 0 : (turn_score + rr.score50);
+        const bool hot = !farkle & sp.has(SF_AUTO_HOT) & (dice == 6u);
+        cB += hot ? (1u << HC_HOT_SHIFT) : 0u;
+        const bool keep = should_continue50(sp, turn_score, (int32_t)dice, (cB & HC_HAS_SCORED) != 0u, final_round != 0u, score_to_beat, score);
+        const bool over = farkle | (!hot & !keep);
+        const uint32_t ts = over ? (uint32_t)turn_score : 0u;
+        cB |= (ts >= 10u) ? HC_HAS_SCORED : 0u; // 500 points
+        const uint32_t banked = (cB & HC_HAS_SCORED) ? ts : 0u;
+        cB += banked << HC_SCORE_SHIFT;
+        cB = (banked > (cB & HC_HI_MASK)) ? ((cB & ~HC_HI_MASK) | banked) : cB;
+        const bool overflow = (turn_score > 1310) | ((cA & 0xffffu) > 64000u) | ((cC >> 16) > 63000u) | ((cD >> 16) > 63000u) |
+                              ((cB >> HC_HOT_SHIFT) > HC_HOT_GUARD);
+        if (roll_limit | overflow) {
+            raise(roll_limit ? FK_ERR_ROLL_LIMIT : FK_ERR_COUNTER_OVERFLOW);
+            return;
+        }
+        lds_state[s * HC_BLOCK] = make_uint4((uint32_t)rng.lo, (uint32_t)(rng.lo >> 32), (uint32_t)rng.hi, (uint32_t)(rng.hi >> 32));
+        lds_buf[s * HC_BLOCK] = rng.buf;
+        hasbuf = (hasbuf & ~(1u << s)) | (rng.has_buf << s);
+        if (over) {
+            cold[s] = make_uint4(cA, cB, cC, cD);
+            advance(score + (int32_t)banked);
+        }
+    };
+
+    // ---- wave-level hand-over (as fk_play_kernel) ----
+    auto handover = [&](uint64_t waiting) {
+        const bool mine = (st == ST_FRESH || st == ST_ENDED);
+        if (st == ST_ENDED) finish_game();
+        const uint32_t n = (uint32_t)__popcll(waiting);
+        const uint32_t avail = pool_end - pool_next;
+        uint32_t new_base = 0, new_avail = 0;
+        if (avail < n && !exhausted) {
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(__ffsll((long long)waiting) - 1);
+            uint32_t base = 0;
+            if (mine && lane_id() == first) base = atomicAdd(a.ticket, TICKET_CHUNK);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)first);
+            if (base >= a.n_games) {
+                exhausted = 1;
+            } else {
+                new_base = base;
+                new_avail = min(TICKET_CHUNK, a.n_games - base);
+                if (new_avail < TICKET_CHUNK) exhausted = 1;
+            }
+        }
+        if (mine) {
+            const uint32_t rank = mbcnt(waiting);
+            uint32_t ticket = 0xffffffffu;
+            if (rank < avail) ticket = pool_next + rank;
+            else if (rank - avail < new_avail) ticket = new_base + (rank - avail);
+            if (ticket != 0xffffffffu) init_game(a.sched ? a.sched[ticket] : ticket, ticket);
+            else st = ST_DONE;
+        }
+        if (n <= avail) {
+            pool_next += n;
+        } else {
+            const uint32_t used_new = min(n - avail, new_avail);
+            pool_next = new_base + used_new;
+            pool_end = new_base + new_avail;
+        }
+    };
+
+    auto handover_due = [&](uint64_t waiting, uint64_t active) -> bool {
+        return waiting && (!active || (uint32_t)__popcll(waiting) >= a.batch_threshold || exhausted);
+    };
+    while (true) {
+        uint64_t waiting = __ballot(st == ST_FRESH || st == ST_ENDED);
+        uint64_t active = __ballot(st == ST_ACTIVE);
+        if (!(waiting | active)) break;
+        if (handover_due(waiting, active)) {
+            handover(waiting);
+            continue;
+        }
+        do {
+            if (st == ST_ACTIVE) roll_step();
+            waiting = __ballot(st == ST_ENDED);
+            active = __ballot(st == ST_ACTIVE);
+        } while (active && !handover_due(waiting, active));
+    }
+}

@@ -1,0 +1,142 @@
+"""GPU parity tests of the hot / cold game kernel (``fk_play_hc_kernel``, csrc/fk_play_hc.h) through the C-ABI, bit-exact
+against the CPU oracle: generator state of every seat in LDS, the behaviour counters / banked totals in a per-lane plane.
+
+The kernel is chosen by the launch plan for k >= 5 (option ``hot_cold`` = -1) and forced here for every k it supports."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from test_state_store_gpu import _random_valid_table, _strats
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from farkle_ii_amd.backend import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def po():
+    import pyoracle
+
+    return pyoracle
+
+
+LDS_TABLE_BYTES = 10816  # LT_BYTES of csrc/fk_play_hc.h
+
+
+def _ran_hot_cold(eng, k: int, block: int = 256, tables: int = 1) -> bool:
+    t = eng.timing()
+    return t["play_block"] == block and t["play_lds_bytes"] == block * 20 * k + (LDS_TABLE_BYTES if tables else 0)
+
+
+@pytest.mark.parametrize("k,block,tables", [(4, 256, 1), (3, 768, 1), (6, 1024, 1), (8, 768, 1), (5, 1024, 0), (7, 768, 0), (6, 256, 0)])
+def test_hot_cold_blocks_and_lds_tables_agree_with_oracle(eng, po, k, block, tables):
+    """The kernel's block sizes, and its LT instances (score / discard tables in LDS, dense multiset index): per-batch
+    tallies and rows against the oracle on a random table (every flag combination) and on the reference's grid slice."""
+    S = {3: 96, 4: 96, 5: 100, 6: 96, 7: 98, 8: 96}[k]
+    try:
+        eng.set_option("hot_cold", 1)
+        eng.set_option("hot_cold_block", block)
+        eng.set_option("hot_cold_tables", tables)
+        for table, root in [(_random_valid_table(S, 500 + k), 8), (_random_valid_table(S, 900 + 7 * k), 1234567)]:
+            ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, root, 0, 30, shuffles_per_batch=11, want_rows=True, n_threads=8)
+            got = eng.tournament(table, k, root, 0, 30, shuffles_per_batch=11, want_rows=True)
+            assert _ran_hot_cold(eng, k, block, tables), eng.timing()
+            assert np.array_equal(got["tally"], ref["tally"]), (k, block, tables)
+            assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, block, tables)
+    finally:
+        eng.set_option("hot_cold", -1)
+        eng.set_option("hot_cold_block", 256)
+        eng.set_option("hot_cold_tables", 1)
+
+
+@pytest.mark.parametrize("k", [3, 4, 5, 6, 7, 8])
+def test_hot_cold_kernel_agrees_with_oracle(eng, po, k):
+    """Per-batch tallies, rows and all-seat statistics of the same shuffles: hot / cold kernel, LDS-record kernel, oracle."""
+    S = {3: 96, 4: 96, 5: 100, 6: 96, 7: 98, 8: 96}[k]
+    table = _random_valid_table(S, 300 + k)
+    n_sh = 36
+    ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 6, 2, 2 + n_sh, shuffles_per_batch=16, want_rows=True, n_threads=8)
+    try:
+        for hc in (1, 0):
+            eng.set_option("hot_cold", hc)
+            got = eng.tournament(table, k, 6, 2, 2 + n_sh, shuffles_per_batch=16, want_rows=True, want_seat_stats=True)
+            assert _ran_hot_cold(eng, k) == bool(hc), (k, hc, eng.timing())
+            assert np.array_equal(got["tally"], ref["tally"]), (k, hc)
+            assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, hc)
+            if hc:
+                stats = got["seat_stats"]
+            else:
+                assert np.array_equal(got["seat_stats"], stats), k
+            eng.set_option("use_lds_tally", 0)  # one batch through result records, no final state records wanted
+            rec = eng.tournament(table, k, 6, 2, 2 + n_sh)
+            eng.set_option("use_lds_tally", -1)
+            assert _ran_hot_cold(eng, k) == bool(hc)
+            assert np.array_equal(rec["tally"][0], ref["tally"].sum(axis=0)), (k, hc)
+    finally:
+        eng.set_option("hot_cold", -1)
+        eng.set_option("use_lds_tally", -1)
+
+
+def test_hot_cold_limits_overrides_and_safety_games(eng, po):
+    """max_rounds / target variants (units-of-50 rounding), per-game overrides, never-banking tables, max_rounds = 0, and a
+    target beyond the kernel's 12-bit totals (the launch plan then stays on the LDS-record kernel)."""
+    from farkle_ii_amd.backend import make_overrides
+
+    table = _strats(gu.load("grid_vectors.json")["g64"])
+    never = table.copy()
+    never["dice_threshold"], never["require_both"] = 0, 1
+    k, gps = 4, 16
+    ovs = [(9, 2, 1, k, 0), (9, 2, 3, k, 7), (9, 5, gps - 1, k, 1), (9, 0, 0, k, 3), (9, 7, 2, k, 250), (9, 2, 5, k, 5)]
+    try:
+        eng.set_option("hot_cold", 1)
+        for tbl, target, mr, expect_hc in [(table, 10_000, 200, True), (table, 2_000, 5, True), (never, 10_000, 12, True),
+                                           (table, 50, 200, True), (table, 10_000, 0, True), (table, 10_025, 200, True),
+                                           (table, 1_030, 60, True), (table, 75, 200, True), (table, 1, 200, True),
+                                           (table, 135_000, 40, True), (table, 135_001, 40, False), (table, 3_200_000, 40, False)]:
+            ref = po.tournament(tbl.view(po.STRATEGY_DTYPE), k, 9, 0, 10, shuffles_per_batch=3, target_score=target, max_rounds=mr,
+                                overrides=po.make_overrides(ovs), want_rows=True)
+            got = eng.tournament(tbl, k, 9, 0, 10, shuffles_per_batch=3, target_score=target, max_rounds=mr,
+                                 overrides=make_overrides(ovs), want_rows=True)
+            assert _ran_hot_cold(eng, k) == expect_hc, (target, mr)
+            assert np.array_equal(got["tally"], ref["tally"]), (target, mr)
+            assert got["rows"].tobytes() == ref["rows"].tobytes(), (target, mr)
+    finally:
+        eng.set_option("hot_cold", -1)
+
+
+def test_hot_cold_counter_guard_replays_on_the_lds_record_kernel(eng, po):
+    """A seat that rolls hot dice more than 250 times in one game leaves the hot / cold kernel's 8-bit field: the call is
+    replayed on the LDS-record kernel (16-bit fields) and still equals the oracle."""
+    table = _strats(gu.load("grid_vectors.json")["g64"])[:8].copy()
+    table["dice_threshold"], table["require_both"], table["auto_hot_dice"] = 0, 1, 1   # nobody banks: games run to the round limit
+    table["strategy_id"] = np.arange(8)
+    ref = po.tournament(table.view(po.STRATEGY_DTYPE), 4, 3, 0, 2, max_rounds=6000, want_rows=True)
+    assert int(ref["rows"]["seats"]["hot_dice"].max()) > 250
+    try:
+        eng.set_option("hot_cold", 1)
+        got = eng.tournament(table, 4, 3, 0, 2, max_rounds=6000, want_rows=True)
+        assert not _ran_hot_cold(eng, 4)  # the replay's kernel is the one the timing record describes
+        assert np.array_equal(got["tally"], ref["tally"])
+        assert got["rows"].tobytes() == ref["rows"].tobytes()
+    finally:
+        eng.set_option("hot_cold", -1)
+
+
+def test_hot_cold_is_the_default_for_wide_tables(eng, po):
+    """k = 8 on the reference's 5 160-strategy grid (BASELINE config 4's widest table): auto plan = hot / cold kernel."""
+    from test_state_store_gpu import _default_table
+
+    table = _default_table()
+    ref = po.tournament(table.view(po.STRATEGY_DTYPE), 8, 0, 0, 6, shuffles_per_batch=4, n_threads=8)
+    got = eng.tournament(table, 8, 0, 0, 6, shuffles_per_batch=4)
+    assert _ran_hot_cold(eng, 8)
+    assert np.array_equal(got["tally"], ref["tally"])
