@@ -89,6 +89,8 @@ def add_timing(acc: dict, t: dict) -> dict:
         acc[key] = acc.get(key, 0) + t.get(key, 0)
     for key in ("play_block", "play_grid", "play_lds_bytes"):
         acc[key] = t.get(key)
+    for k, sub in (t.get("per_k") or {}).items():  # config 4: one record per player count
+        add_timing(acc.setdefault("per_k", {}).setdefault(k, {}), sub)
     return acc
 
 
@@ -213,7 +215,7 @@ class KSweep:
             if hi > lo:
                 out[i] = eng.tournament(self.table, k, self.root, lo, hi)["tally"][0]
                 games += (hi - lo) * (self.S // k)
-                add_timing(timing, eng.timing())
+                add_timing(timing, {**eng.timing(), "per_k": {k: eng.timing()}})
         return out, games, timing
 
     def verify(self, tot: np.ndarray, games: int) -> None:
@@ -227,7 +229,9 @@ class KSweep:
         for k in self.ks:
             res = eng.tournament(self.table, k, self.root, 0, self.n_sh[k], want_seat_stats=True)
             parts.append(work_from_seat_stats(res["seat_stats"], self.n_sh[k] * (self.S // k), k))
-        return {key: float(np.mean([p[key] for p in parts])) for key in parts[0]}, None, "per k: all games of one full-size launch (all-seat statistics)"
+        mean = {key: float(np.mean([p[key] for p in parts])) for key in parts[0]}
+        mean["per_k"] = {k: p for k, p in zip(self.ks, parts)}
+        return mean, None, "per k: all games of one full-size launch (all-seat statistics)"
 
     def hbm_bytes_per_game(self) -> int:
         return int(np.mean([32 * k + 2 * k + 4 for k in self.ks]))
@@ -275,34 +279,72 @@ class H2H:
         self.local_shape = (len(self.blocks), 5)
         self.config = 5
         self.k = 2
+        self._manifest = None
+        self.last_attempts = None
 
     def games_per_step(self, world: int) -> int:
         return len(self.blocks) * self.per_block  # completed games required; attempts are reported separately
 
+    def block_dicts(self, index: int) -> list[dict]:
+        """The step's blocks as the dictionaries the reference's schedule holds (h2h_schedule.py:1149-1243); a fresh pair-id
+        range per step = fresh attempt coordinates."""
+        return [{"block_id": f"s{index}-p{pid}-o{order}", "family_hash": "bench", "schedule_hash": "bench", "pair_id": pid + index * 10_000,
+                 "root_index": 0, "root_seed": self.root, "order": order, "seat1_strategy": a, "seat2_strategy": b,
+                 "n_completed_required": self.per_block, "max_attempts": 2 * self.per_block}
+                for pid, order, a, b in self.blocks]
+
+    def manifest(self):
+        """Strategy manifest frame of the candidates (the columns strategies.py:762-800 decodes)."""
+        if self._manifest is None:
+            import pandas as pd
+
+            t = self.table[self.cand]
+            cols = {"strategy_id": list(self.cand), "score_threshold": t["score_threshold"].astype(int), "dice_threshold": t["dice_threshold"].astype(int)}
+            for name in ("smart_five", "smart_one", "consider_score", "consider_dice", "require_both", "auto_hot_dice", "run_up_score"):
+                cols[name] = t[name].astype(bool)
+            cols["favor_dice_or_score"] = np.where(t["favor_score"] != 0, "score", "dice")
+            self._manifest = pd.DataFrame(cols)
+        return self._manifest
+
     def step(self, eng, index: int, rank: int, world: int, next_index: int | None = None):
+        # the product's schedule-level runner: blocks dealt over the ranks, one fk_h2h_run_blocks per root and rank, every
+        # rank gets every block's result back (h2h.run_blocks); this rank's own blocks go into the tally the job reduces
+        from farkle_ii_amd.h2h import run_blocks
+
+        res = run_blocks(self.block_dicts(index), self.manifest(), None, engine=eng, rank=rank, world=world)
         out = np.zeros(self.local_shape, dtype=np.int64)
-        timing: dict = {}
-        mine = list(range(rank, len(self.blocks), world))
-        if mine:
-            seats = np.stack([self.table[[self.blocks[b][2], self.blocks[b][3]]] for b in mine])
-            pair = [self.blocks[b][0] + index * 10_000 for b in mine]  # a fresh coordinate range per step
-            order = [self.blocks[b][1] for b in mine]
-            res = eng.h2h_blocks(seats, self.root, pair, order, self.per_block, 2 * self.per_block)
-            out[mine] = res.astype(np.int64)
-            add_timing(timing, eng.timing())
+        for b in range(rank, len(self.blocks), world):
+            out[b] = [res[b][key] for key in ("games_attempted", "games_completed", "games_safety_limit", "wins_seat1", "wins_seat2")]
+        self.last_attempts = np.array([r["games_attempted"] for r in res], dtype=np.int64)
+        timing = add_timing({}, eng.timing()) if len(range(rank, len(self.blocks), world)) else {}
         return out, int(out[:, 0].sum()), timing
 
     def verify(self, tot: np.ndarray, games: int) -> None:
         assert (tot[:, 0] == tot[:, 1] + tot[:, 2]).all() and (tot[:, 1] == tot[:, 3] + tot[:, 4]).all()
 
-    def sample(self, eng):
+    def sample(self, eng, per_block: int = 1500):
+        """R, T, W of the attempts the timed launches play: the first `per_block` attempts of EVERY block (attempts of a block
+        are i.i.d.), weighted by the attempts each block needed in the last timed step — never-banking pairings run every
+        attempt to the round limit and need twice the attempts, so an unweighted or one-block sample is not this workload."""
         from farkle_ii_amd.backend import make_coords
 
-        n = 200_000
-        b = self.blocks[len(self.blocks) // 2]
-        coords = make_coords(203, self.root, 2, 0, b[0], b[1], np.arange(n, dtype=np.uint64))
-        rows = eng.play_games(coords, self.table[[b[2], b[3]]], np.tile(np.arange(2, dtype=np.int32), (n, 1)), 2)
-        return rows, 2, f"attempts 0..{n - 1} of block (pair {b[0]}, order {b[1]})"
+        nb = len(self.blocks)
+        pair = np.repeat(np.array([b[0] for b in self.blocks], dtype=np.uint64), per_block)
+        order = np.repeat(np.array([b[1] for b in self.blocks], dtype=np.uint64), per_block)
+        attempt = np.tile(np.arange(per_block, dtype=np.uint64), nb)
+        coords = make_coords(203, self.root, 2, 0, pair, order, attempt)
+        pos = {sid: i for i, sid in enumerate(self.cand)}
+        seats = np.repeat(np.array([[pos[b[2]], pos[b[3]]] for b in self.blocks], dtype=np.int32), per_block, axis=0)
+        rows = eng.play_games(coords, self.table[self.cand], seats, 2)
+        R = rows["seats"]["rolls"].astype(np.int64).sum(axis=1).reshape(nb, per_block).mean(axis=1)
+        T = rows["seats"]["n_turns"].astype(np.int64).sum(axis=1).reshape(nb, per_block).mean(axis=1)
+        w = self.last_attempts.astype(np.float64) if getattr(self, "last_attempts", None) is not None else np.ones(nb)
+        w = w / w.sum()
+        Rm, Tm = float((R * w).sum()), float((T * w).sum())
+        wpg = {"rolls_per_game": Rm, "turns_per_game": Tm, "ops_per_game": 229.0 * Rm + 30.0 * Tm + 850.0 * 2,
+               "rolls_per_attempt_by_block_min_max": [float(R.min()), float(R.max())]}
+        return wpg, None, (f"first {per_block} attempts of each of the {nb} blocks ({nb * per_block} attempts), block means weighted by the "
+                           "attempts each block played in the last timed step")
 
     def hbm_bytes_per_game(self) -> int:
         return 64
@@ -566,6 +608,21 @@ def main() -> None:
             "launches_seeded_behind_the_previous_kernel": int(t.get("prefetched_chunks", 0)),
             "launch": {k2: t.get(k2) for k2 in ("play_block", "play_grid", "play_lds_bytes")},
         }
+        if "per_k" in wpg:  # config 4: one roofline record per player count (kernel time, W and fraction of each k's launches)
+            per_k = []
+            for k2, w2 in wpg.pop("per_k").items():
+                tk = (t.get("per_k") or {}).get(k2, {})
+                n_l = max(int(tk.get("play_launches", 0)), 1)
+                ms = tk.get("play_ms", 0.0) / n_l
+                gpl = tk.get("games", 0) / n_l
+                rate = gpl / max(ms * 1e-3, 1e-12)
+                hc = tk.get("play_block") and tk.get("play_lds_bytes") in (tk["play_block"] * 20 * int(k2), tk["play_block"] * 20 * int(k2) + 10816)
+                per_k.append({"k": int(k2), "kernel": "fk_play_hc_kernel" if hc else "fk_play_kernel", "kernel_ms": ms,
+                              "games_per_launch": gpl, "kernel_games_per_s": rate, **w2,
+                              "frac": rate * w2["ops_per_game"] / peak_ops,
+                              "launch": {k3: tk.get(k3) for k3 in ("play_block", "play_grid", "play_lds_bytes")}})
+            roofline["per_k"] = per_k
+            roofline["frac_mean_over_k"] = float(np.mean([r["frac"] for r in per_k]))
         cpu = None
         if not args.no_cpu_baseline and n_gpus == 1:  # the CPU leg runs on rank 0 of the single-GPU run only
             cpu = wl.cpu_baseline(eng)

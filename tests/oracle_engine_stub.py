@@ -100,12 +100,17 @@ class Engine:
         return po.h2h_block(np.ascontiguousarray(seats).view(po.STRATEGY_DTYPE), root_seed, pair_id, order, target, max_attempts,
                             chunk_games, target_score=target_score, max_rounds=max_rounds, overrides=ov, state=state)
 
-    def h2h_blocks(self, seats, root_seed, pair_ids, orders, target, max_attempts, target_score=10_000, max_rounds=200,
-                   overrides=None):
+    def h2h_blocks(self, seats, root_seed, pair_ids, orders, target, max_attempts, chunk_games=None, target_score=10_000,
+                   max_rounds=200, overrides=None, states=None):
         seats = np.ascontiguousarray(seats).reshape(-1, 2)
-        out = np.zeros((len(seats), 5), dtype=np.uint64)
-        for b in range(len(seats)):
-            out[b] = self.h2h(seats[b], root_seed, int(pair_ids[b]), int(orders[b]), target, max_attempts, max_attempts,
-                              target_score=target_score, max_rounds=max_rounds, overrides=overrides)
+        n = len(seats)
+        target = np.broadcast_to(np.asarray(target, dtype=np.uint64), (n,))
+        max_attempts = np.broadcast_to(np.asarray(max_attempts, dtype=np.uint64), (n,))
+        chunk = int(max_attempts.max()) if chunk_games is None and n else int(chunk_games or 0)
+        out = np.zeros((n, 5), dtype=np.uint64)
+        for b in range(n):
+            out[b] = self.h2h(seats[b], root_seed, int(pair_ids[b]), int(orders[b]), int(target[b]), int(max_attempts[b]), chunk,
+                              target_score=target_score, max_rounds=max_rounds, overrides=overrides,
+                              state=None if states is None else np.asarray(states, dtype=np.uint64).reshape(n, 5)[b])
             self._games = int(out[b][0])
         return out

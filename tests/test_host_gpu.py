@@ -232,3 +232,26 @@ def test_h2h_block_two_ranks_matches_single_engine(tmp_path):
         st = eng.h2h(seats, 42, 5, 0, 200_000, 300_000, 90_000, state=st)
     got = np.load(out)
     assert np.array_equal(got, st.astype(np.int64)) and got[1] == 200_000 and got[0] >= got[1]
+
+
+def test_prefetching_block_runner_equals_the_per_block_runner_on_10000_blocks():
+    """The schedule-level runner (h2h.PrefetchingBlockRunner -> h2h.run_blocks -> fk_h2h_run_blocks) serves the reference's
+    serial custom-runner loop (h2h_schedule.py:2038-2093) block by block with exactly what gpu_block_runner returns."""
+    from h2h_schedule_util import make_schedule, manifest_frame, serial_schedule_loop
+
+    from farkle_ii_amd.h2h import PrefetchingBlockRunner, gpu_block_runner, run_blocks
+    from farkle_ii_amd.strategies import STRATEGY_DTYPE
+
+    table = gu.strategies_from_tuples(gu.load("grid_vectors.json")["g64"], STRATEGY_DTYPE)
+    table["strategy_id"] = np.arange(len(table))
+    manifest = manifest_frame(table)
+    blocks = make_schedule(table, 10_000, seed=11, target_range=(20, 120))
+    want, calls = serial_schedule_loop(blocks, gpu_block_runner(), manifest, 64)
+    runner = PrefetchingBlockRunner(blocks)
+    got, calls2 = serial_schedule_loop(blocks, runner, manifest, 64)
+    assert calls == calls2 and got == want
+    assert runner.single_block_calls == 0 and runner.generations <= 8  # (the checkpoint limit is learned from the calls)
+    told = PrefetchingBlockRunner(blocks, chunk_games=64)
+    got, _ = serial_schedule_loop(blocks, told, manifest, 64)
+    assert got == want and told.single_block_calls == 0 and told.generations <= 3  # 180 attempts at most = three chunks
+    assert run_blocks(blocks, manifest, None) == want  # and in one call, to the terminal states
