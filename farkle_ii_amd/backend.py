@@ -96,7 +96,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
             "fk_tournament_run", "fk_tournament_run_stats", "fk_tournament_hint_next", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
-            "fk_debug_dice", "fk_debug_dice_state", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy"]
+            "fk_debug_dice", "fk_debug_dice_state", "fk_debug_dice_keys", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy"]
 _lib = None
 
 
@@ -349,3 +349,14 @@ class Engine:
         out = np.zeros((n, 6), dtype=np.uint64)
         self._check(self._lib.fk_debug_dice_state(self._ctx, C.c_int64(n), _p(state), C.c_int32(len(sizes)), _p(sizes), _p(faces), _p(out)))
         return faces, out
+
+    def debug_dice_keys(self, state: np.ndarray, sizes):
+        """The game kernels' dice instantiation (``roll_counts<3>``) from explicit generator states: ``(keys[n][n_calls],
+        state_out[n][6])``; key = six 3-bit face counts."""
+        state = np.ascontiguousarray(state, dtype=np.uint64).reshape(-1, 6)
+        sizes = np.ascontiguousarray(sizes, dtype=np.int32)
+        n = len(state)
+        keys = np.zeros((n, len(sizes)), dtype=np.uint32)
+        out = np.zeros((n, 6), dtype=np.uint64)
+        self._check(self._lib.fk_debug_dice_keys(self._ctx, C.c_int64(n), _p(state), C.c_int32(len(sizes)), _p(sizes), _p(keys), _p(out)))
+        return keys, out

@@ -30,6 +30,9 @@ def build_parser() -> argparse.ArgumentParser:
     run = sub.add_parser("run", help="Run a tournament")
     run.add_argument("--metrics", action="store_true", help="Collect per-strategy metrics in addition to win counts")
     run.add_argument("--row-dir", type=Path, help="Write full per-game rows to this directory")
+    run.add_argument("--all-player-batches", nargs="?", const=Path("all_player_batches"), type=Path, default=None, metavar="DIR",
+                     help="Write the unconditional all-player batch metrics (integer columns of the reference's "
+                          "all_player_batch_schema) per deterministic batch, from device accumulators, without rows")
     run.add_argument("--force", action="store_true", help="Recompute even when existing run artifacts are available")
     t = sub.add_parser("time", help="Benchmark simulation throughput")
     t.add_argument("--players", type=int, default=5, help="Players per game (default: 5)")
@@ -79,6 +82,8 @@ def main(argv: Sequence[str] | None = None) -> None:
         cfg.sim.expanded_metrics = True
     if args.row_dir is not None:
         cfg.sim.row_dir = args.row_dir
+    if args.all_player_batches is not None:
+        cfg.sim.all_player_batch_dir = args.all_player_batches
     _maybe_init_distributed()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("FK_TALLY_REDUCE", "") == "rccl":
         # the per-group tally reduction through the C-ABI's own RCCL communicator (fk_comm_init / fk_reduce_tally)

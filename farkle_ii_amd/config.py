@@ -60,6 +60,7 @@ class SimConfig:
     expanded_metrics: bool = False
     row_dir: Path | None = None
     metric_chunk_dir: Path | None = None
+    all_player_batch_dir: Path | None = None  # this engine's option: all-player batch metrics without rows (all_player.py)
     per_n: dict = field(default_factory=dict)
     n_jobs: int | None = None
     mp_start_method: str | None = None
@@ -137,6 +138,9 @@ class AppConfig:
     def metric_chunk_dir(self, n: int) -> Path | None:
         return self._per_n_dir(self.sim.metric_chunk_dir, n, "metric-chunk-dir")
 
+    def all_player_batch_dir(self, n: int) -> Path | None:
+        return self._per_n_dir(self.sim.all_player_batch_dir, n, "all-player-batch-dir")
+
     def checkpoint_path(self, n: int) -> Path:
         return self.n_dir(n) / f"{n}p_checkpoint.pkl"
 
@@ -180,7 +184,7 @@ def _fill(section_obj, data: Mapping[str, Any], section_name: str) -> None:
     for key, value in data.items():
         if key not in known:
             raise ValueError(f"Unknown option {key!r} in config section {section_name!r}")
-        if key in {"row_dir", "metric_chunk_dir", "results_dir_prefix"} and value is not None:
+        if key in {"row_dir", "metric_chunk_dir", "all_player_batch_dir", "results_dir_prefix"} and value is not None:
             value = Path(value)
         setattr(section_obj, key, value)
 
@@ -277,7 +281,7 @@ def apply_dot_overrides(cfg: AppConfig, pairs: Sequence[str]) -> AppConfig:
         if not hasattr(section, option):
             raise AttributeError(f"Unknown option {option!r} in section {section_name!r}")
         value = _coerce(raw, getattr(section, option))
-        if option in {"row_dir", "metric_chunk_dir", "results_dir_prefix"} and value is not None:
+        if option in {"row_dir", "metric_chunk_dir", "all_player_batch_dir", "results_dir_prefix"} and value is not None:
             value = Path(value)
         setattr(section, option, value)
     return cfg

@@ -1759,4 +1759,29 @@ int fk_debug_dice_state(fk_ctx *c, int64_t n, const uint64_t *state, int32_t n_c
     return debug_dice_common(c, n, nullptr, state, n_calls, sizes, faces, nullptr, state_out);
 }
 
+int fk_debug_dice_keys(fk_ctx *c, int64_t n, const uint64_t *state, int32_t n_calls, const int32_t *sizes, uint32_t *keys,
+                       uint64_t *state_out) {
+    if (!c) return FK_ERR_ARG;
+    if (n < 0 || n_calls < 1 || !state || !sizes || !keys || !state_out) return fail(c, FK_ERR_ARG, "bad arguments");
+    for (int32_t i = 0; i < n_calls; ++i)
+        if (sizes[i] < 1 || sizes[i] > 6) return fail(c, FK_ERR_ARG, "roll sizes must be in 1..6");
+    if (n == 0) return FK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->dbg[0], (size_t)n * 48))) return rc;
+    if ((rc = ensure(c, c->dbg[1], (size_t)n_calls * 4))) return rc;
+    if ((rc = ensure(c, c->dbg[2], (size_t)n * n_calls * 4))) return rc;
+    if ((rc = ensure(c, c->dbg[4], (size_t)n * 48))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->dbg[0].p, state, (size_t)n * 48, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->dbg[1].p, sizes, (size_t)n_calls * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(fk_dbg_dice_key_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, n,
+                       static_cast<const uint64_t *>(c->dbg[0].p), n_calls, static_cast<const int32_t *>(c->dbg[1].p),
+                       static_cast<uint32_t *>(c->dbg[2].p), static_cast<uint64_t *>(c->dbg[4].p));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(keys, c->dbg[2].p, (size_t)n * n_calls * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(state_out, c->dbg[4].p, (size_t)n * 48, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FK_OK;
+}
+
 } // extern "C"

@@ -1661,4 +1661,17 @@ __global__ void fk_dbg_dice_kernel(int64_t n, const uint4 *seeds, const uint4 *i
     }
 }
 
+// The game kernels' own dice instantiation: roll_counts<3> (one 6w product per die, 18-bit count key, rejection test
+// `min low word < 4`) from explicit generator states — keys[i * n_calls + c] = key of call c, state_out as fk_dbg_dice_kernel.
+__global__ void fk_dbg_dice_key_kernel(int64_t n, const uint64_t *state_in, int32_t n_calls, const int32_t *sizes, uint32_t *keys,
+                                       uint64_t *state_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t *s = state_in + i * 6;
+    Rng r{s[0], s[1], s[2], s[3], (uint32_t)s[5], (uint32_t)s[4]};
+    for (int32_t c = 0; c < n_calls; ++c) keys[i * n_calls + c] = roll_counts<3>(r, (uint32_t)sizes[c]);
+    uint64_t *o = state_out + i * 6;
+    o[0] = r.hi, o[1] = r.lo, o[2] = r.inc_hi, o[3] = r.inc_lo, o[4] = r.has_buf, o[5] = r.buf;
+}
+
 } // namespace

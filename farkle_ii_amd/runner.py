@@ -10,6 +10,9 @@ loop of ``src/farkle/simulation/run_tournament.py:1050-1839`` for the v2 (no-sid
     <results_root>/<k>_players/<k>p_metrics.parquet       expanded metrics (runner.py:1651-1712), with sim.expanded_metrics
     <row_dir>/rows_<root>_<k>p_<shuffle:012d>.parquet + manifest.jsonl        (with sim.row_dir)
     <metric_chunk_dir>/metrics_<batch:06d>.parquet + metrics_manifest.jsonl   (with sim.metric_chunk_dir)
+    <all_player_batch_dir>/all_player_batch_<batch:06d>.parquet + all_player_manifest.jsonl   (with sim.all_player_batch_dir:
+                                                            the all-player batch metrics of analysis/all_player_metrics.py
+                                                            from device accumulators, no rows; see all_player.py)
     <results_root>/<k>_players/simulation.done.json       plain completion marker (v3 sidecars are out of scope)
 
 Resume ownership is the deterministic batch, as in the reference (``completed_process_block_indices``).  With
@@ -34,6 +37,8 @@ from .config import AppConfig
 from .distributed import barrier, gather_objects, reduce_tally, shard_shuffle_range
 from .engine import get_engine
 from .game_profile import GameProfile
+from .all_player import ROW_ORDER_FLOAT_FIELDS, all_player_batch_table
+from .backend import SEAT_STAT_COLS
 from .rows import OUTCOME_SCHEMA_VERSION, TOURNAMENT_METHOD_VERSION
 from .strategies import (STRATEGY_TUPLE_FIELDS, FavorDiceOrScore, ThresholdStrategy, generate_strategy_grid,
                          prepare_public_helper_strategies, strategy_tuple)
@@ -189,40 +194,61 @@ def _prune_manifest(path: Path, owned: set[int], batch_of) -> int:
     return len(records) - len(kept)
 
 
-def _recover_from_metric_chunks(metric_chunk_dir: Path, ids: Sequence[int]) -> tuple[np.ndarray, set[int]]:
+def _recover_from_metric_chunks(metric_chunk_dir: Path, ids: Sequence[int], owned: set[int]) -> tuple[np.ndarray, set[int]] | None:
     """Aggregates and completed batches rebuilt from the metric chunk files a manifest lists — the reference's recovery
     authority when the periodic checkpoint is missing or behind (``_load_metric_chunk_aggregates``,
-    run_tournament.py:871-941)."""
+    run_tournament.py:871-941).  The manifest is read first; chunk files are only opened when it lists a batch the
+    checkpoint does not own (None otherwise).  A listed file that is missing is an error, as in the reference (:887)."""
     import pyarrow.parquet as pq
 
-    index = {int(sid): i for i, sid in enumerate(ids)}
-    label_col = {label: j for j, label in enumerate(rt.METRIC_LABELS)}
-    tally = np.zeros((len(ids), 26), dtype=np.int64)
-    done: set[int] = set()
+    records, seen = [], set()
     for rec in _read_manifest(metric_chunk_dir / "metrics_manifest.jsonl"):
         batch = int(rec["chunk_index"]) - 1
-        path = metric_chunk_dir / str(rec["path"])
-        if batch in done or not path.exists():
-            continue
-        t = pq.read_table(path).to_pydict()
-        for metric, strat, total, sq, wins, att, comp, saf in zip(t["metric"], t["strategy"], t["sum"], t["square_sum"], t["wins"],
-                                                                   t["attempted_exposures"], t["completed_exposures"],
-                                                                   t["safety_limit_exposures"]):
-            i, j = index[int(strat)], label_col[metric]
-            tally[i, 4 + j] += int(total)
-            tally[i, 15 + j] += int(sq)
-            if j == 0:  # the outcome columns repeat on every metric's row: count them once (run_tournament.py:905-922)
-                tally[i, 0] += int(wins)
-                tally[i, 1] += int(att)
-                tally[i, 2] += int(comp)
-                tally[i, 3] += int(saf)
-        done.add(batch)
-    return tally, done
+        if batch not in seen:
+            seen.add(batch)
+            records.append((batch, metric_chunk_dir / str(rec["path"])))
+    if not (seen - owned):
+        return None
+    sid = np.asarray([int(x) for x in ids], dtype=np.int64)
+    order = np.argsort(sid, kind="stable")
+    labels = list(rt.METRIC_LABELS)
+    tally = np.zeros((len(ids), 26), dtype=np.int64)
+    for batch, path in records:
+        if not path.exists():
+            raise FileNotFoundError(f"metric chunk manifest lists a missing file: {path}")
+        t = pq.read_table(path)
+        strat = np.asarray(t.column("strategy").to_numpy(zero_copy_only=False), dtype=np.int64)
+        pos = np.searchsorted(sid[order], strat)
+        if (pos >= len(sid)).any() or (sid[order][np.minimum(pos, len(sid) - 1)] != strat).any():
+            raise ValueError(f"{path} names a strategy that is not in the configured grid")
+        row = order[pos]
+        metric = np.asarray([labels.index(m) for m in t.column("metric").to_pylist()], dtype=np.int64)
+        col = lambda name: np.asarray(t.column(name).to_numpy(zero_copy_only=False)).astype(np.int64)  # noqa: E731
+        np.add.at(tally, (row, 4 + metric), col("sum"))
+        np.add.at(tally, (row, 15 + metric), col("square_sum"))
+        first = metric == 0  # the outcome columns repeat on every metric's row: count them once (run_tournament.py:905-922)
+        for c, name in enumerate(("wins", "attempted_exposures", "completed_exposures", "safety_limit_exposures")):
+            np.add.at(tally[:, c], row[first], col(name)[first])
+    return tally, seen
+
+
+def _check_ownership(total: np.ndarray, done_batches: set[int], spb: int, required_shuffles: int, what: str) -> None:
+    """Every strategy is seated exactly once per shuffle, so the attempted exposures of each strategy must equal the number
+    of shuffles the owned batches hold: totals that include a batch the run will replay (or miss one it will skip) would
+    otherwise be counted twice (or never) without any other check noticing."""
+    owned = sum(min((b + 1) * spb, required_shuffles) - b * spb for b in done_batches)
+    att = total[:, 1]
+    if not ((att == owned).all() and np.array_equal(att, total[:, 2] + total[:, 3])):
+        raise ValueError(
+            f"{what}: the recovered totals cover {int(att.min())}..{int(att.max())} shuffles per strategy but the batches it owns hold "
+            f"{owned}; its shuffle list and block list disagree (a checkpoint written after a partial artifact recovery). "
+            "Resume needs metric chunk files to rebuild from, or use --force")
 
 
 def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[ThresholdStrategy], plan: TournamentWorkloadPlan,
                    checkpoint_path: Path, collect_metrics: bool, row_dir: Path | None, metric_chunk_dir: Path | None,
-                   resume: bool, checkpoint_metadata: Mapping[str, Any], oracle_game_profile: GameProfile | None = None) -> dict:
+                   resume: bool, checkpoint_metadata: Mapping[str, Any], oracle_game_profile: GameProfile | None = None,
+                   all_player_dir: Path | None = None) -> dict:
     """Play every deterministic batch not yet owned by the checkpoint and persist the aggregates."""
     rank, world = _rank_world()
     eng = get_engine()
@@ -249,36 +275,54 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
     done_batches: set[int] = set()
     row_manifest = (row_dir / "manifest.jsonl") if row_dir is not None else None
     metrics_manifest = (metric_chunk_dir / "metrics_manifest.jsonl") if metric_chunk_dir is not None else None
+    all_player_manifest = (all_player_dir / "all_player_manifest.jsonl") if all_player_dir is not None else None
+    resume_error: str | None = None
     if resume and rank == 0:
-        if checkpoint_path.exists():
-            payload = ckpt.load_checkpoint(checkpoint_path)  # written by this engine or by the reference
-            old = payload.get("meta", {})
-            stale = [key for key in ("n_players", "num_shuffles", "global_seed", "n_strategies", "deterministic_batch_size",
-                                     "strategy_manifest_sha", "rng_scheme_version")
-                     if key in old and old.get(key) != meta.get(key)]
-            if stale:
-                raise ValueError(f"checkpoint {checkpoint_path} was written under a different contract: {stale}; use --force")
-            done_batches = set(int(b) - 1 for b in old.get("completed_process_block_indices", []))  # recorded 1-based
-            shuffles_done = set(int(i) for i in old.get("completed_shuffle_indices", []))
-            if shuffles_done:  # a batch the shuffle list does not fully cover is not owned
-                done_batches = {b for b in done_batches if all(i in shuffles_done for i in range(b * spb, min((b + 1) * spb, plan.required_shuffles)))}
-            if done_batches:
-                total = ckpt.payload_to_tally(payload, ids, rt.METRIC_LABELS)
-                if collect_metrics and not payload.get("metric_sums"):
-                    raise ValueError(f"checkpoint {checkpoint_path} holds no metric sums but this run collects metrics; use --force")
-        if metric_chunk_dir is not None:
-            chunk_tally, chunk_done = _recover_from_metric_chunks(metric_chunk_dir, ids)
-            if chunk_done - done_batches:  # the chunk files are ahead of the pickle: they are the recovery authority
-                LOGGER.info("Recovered %d batches from metric chunks (checkpoint owned %d)", len(chunk_done), len(done_batches))
-                total, done_batches = chunk_tally, chunk_done
-        # manifests hold exactly what the recovered state owns (no record of a replayed group survives twice)
-        if metrics_manifest is not None:
-            _prune_manifest(metrics_manifest, done_batches, lambda r: (int(r["chunk_index"]), int(r["chunk_index"]) - 1))
-        if row_manifest is not None:
-            _prune_manifest(row_manifest, done_batches, lambda r: (int(r["shuffle_index"]), int(r["shuffle_index"]) // spb))
-        LOGGER.info("Resuming: %d of %d batches already complete", len(done_batches), n_batches)
-    if world > 1:  # every rank plans against rank 0's recovered state
-        done_batches = set(gather_objects(sorted(done_batches), broadcast_from=0))
+        try:
+            if checkpoint_path.exists():
+                payload = ckpt.load_checkpoint(checkpoint_path)  # written by this engine or by the reference
+                old = payload.get("meta", {})
+                stale = [key for key in ("n_players", "num_shuffles", "global_seed", "n_strategies", "deterministic_batch_size",
+                                         "strategy_manifest_sha", "rng_scheme_version")
+                         if key in old and old.get(key) != meta.get(key)]
+                if stale:
+                    raise ValueError(f"checkpoint {checkpoint_path} was written under a different contract: {stale}; use --force")
+                done_batches = set(int(b) - 1 for b in old.get("completed_process_block_indices", []))  # recorded 1-based
+                if done_batches:
+                    total = ckpt.payload_to_tally(payload, ids, rt.METRIC_LABELS)
+                    if collect_metrics and not payload.get("metric_sums"):
+                        raise ValueError(f"checkpoint {checkpoint_path} holds no metric sums but this run collects metrics; use --force")
+            if metric_chunk_dir is not None:
+                try:
+                    _check_ownership(total, done_batches, spb, plan.required_shuffles, "checkpoint")
+                    consistent = True
+                except ValueError:
+                    consistent = False  # totals and block list disagree: rebuild from the chunk files if they can
+                recovered = _recover_from_metric_chunks(metric_chunk_dir, ids, done_batches if consistent else set())
+                if recovered is not None:  # the chunk files are ahead of the pickle (or it is inconsistent): they are the authority
+                    LOGGER.info("Recovered %d batches from metric chunks (checkpoint owned %d)", len(recovered[1]), len(done_batches))
+                    total, done_batches = recovered
+            # the totals must be exactly the owned batches (the reference trusts the block list, run_tournament.py:1289-1330;
+            # its checkpoints after an artifact recovery can list shuffles of blocks they do not list, and blocks without
+            # their shuffles)
+            _check_ownership(total, done_batches, spb, plan.required_shuffles, f"checkpoint {checkpoint_path}")
+            # manifests hold exactly what the recovered state owns (no record of a replayed group survives twice)
+            if metrics_manifest is not None:
+                _prune_manifest(metrics_manifest, done_batches, lambda r: (int(r["chunk_index"]), int(r["chunk_index"]) - 1))
+            if row_manifest is not None:
+                _prune_manifest(row_manifest, done_batches, lambda r: (int(r["shuffle_index"]), int(r["shuffle_index"]) // spb))
+            if all_player_manifest is not None:
+                _prune_manifest(all_player_manifest, done_batches, lambda r: (int(r["deterministic_batch_id"]), int(r["deterministic_batch_id"])))
+            LOGGER.info("Resuming: %d of %d batches already complete", len(done_batches), n_batches)
+        except (ValueError, FileNotFoundError, KeyError) as exc:
+            if world == 1:
+                raise
+            resume_error = f"{type(exc).__name__}: {exc}"
+    if world > 1:  # every rank plans against rank 0's recovered state — or raises rank 0's recovery error with it
+        resume_error, shared = gather_objects((resume_error, sorted(done_batches)), broadcast_from=0)
+        if resume_error is not None:
+            raise ValueError(f"resume failed on rank 0: {resume_error}")
+        done_batches = set(shared)
     pending = [b for b in range(n_batches) if b not in done_batches]
     target = oracle_game_profile.default_target_score if oracle_game_profile else 10_000
     max_rounds = oracle_game_profile.default_max_rounds if oracle_game_profile else 200
@@ -309,8 +353,9 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         lo, hi = shard_shuffle_range(b0 * spb, min(b1 * spb, plan.required_shuffles), rank, world, batch_size=spb)
         # Per-batch tallies are only needed for the metric chunk files; without them the group is one tally, which the
         # engine keeps in LDS when the table is small.
-        per_batch = metric_chunk_dir is not None
+        per_batch = metric_chunk_dir is not None or all_player_dir is not None
         local = np.zeros((b1 - b0 if per_batch else 1, S, 26), dtype=np.int64)
+        local_stats = np.zeros((b1 - b0, S, SEAT_STAT_COLS), dtype=np.int64) if all_player_dir is not None else None
         row_records: list[dict] = []
         if hi > lo:
             if j + 1 < len(pending) and hasattr(eng, "hint_next"):
@@ -323,9 +368,12 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 if hi2 > lo2:
                     eng.hint_next(lo2, hi2, need_state=want_rows)
             res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=spb if per_batch else hi - lo,
-                                 target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows)
+                                 target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows,
+                                 **({"want_seat_stats": True} if all_player_dir is not None else {}))
             first = lo // spb - b0 if per_batch else 0
             local[first:first + len(res["tally"])] = res["tally"]
+            if local_stats is not None:
+                local_stats[first:first + len(res["seat_stats"])] = res["seat_stats"]
             if want_rows:  # every rank writes the shards of its own shuffles; rank 0 appends the manifest lines
                 tasks = rt.shuffle_tasks(cfg.sim.seed, k, lo, hi, spb)
                 sha = oracle_game_profile.sha256 if oracle_game_profile else None
@@ -333,14 +381,22 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 # file creation — one vectorised conversion per 1 024 shuffles, shards written by a small thread pool
                 row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS))
         group = reduce_tally(local, dst=0)
+        group_stats = reduce_tally(local_stats, dst=0) if local_stats is not None else None  # integer sums, like the tally
         if want_rows and world > 1:
             gathered = gather_objects(row_records, dst=0)
             row_records = [r for part in (gathered or []) for r in part]
         if rank == 0:
             if want_rows:
                 rt.append_manifest_records(row_manifest, sorted(row_records, key=lambda r: r["shuffle_index"]))
-            chunk_records = []
+            chunk_records, all_player_records = [], []
             for n, b in enumerate(range(b0, b1)):
+                if all_player_dir is not None:
+                    ap = all_player_batch_table(group_stats[n], ids, cfg.sim.seed, k, b)
+                    name = f"all_player_batch_{b + 1:06d}.parquet"
+                    _write_parquet_atomic(ap, all_player_dir / name)
+                    all_player_records.append({"path": name, "rows": ap.num_rows, "root_seed": cfg.sim.seed, "n_players": k,
+                                               "deterministic_batch_id": b, "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
+                                               "absent_columns": list(ROW_ORDER_FLOAT_FIELDS)})
                 if metric_chunk_dir is not None:
                     chunk = _metric_chunk_table(group[n], ids, k)
                     name = f"metrics_{b + 1:06d}.parquet"  # chunk / process-block indices count from 1 (run_tournament.py:1603-1642)
@@ -363,6 +419,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 done_batches.add(b)
             if chunk_records:
                 rt.append_manifest_records(metrics_manifest, chunk_records)
+            if all_player_records:
+                rt.append_manifest_records(all_player_manifest, all_player_records)
             if not per_batch:
                 total += group[0]
             games_done += (min(b1 * spb, plan.required_shuffles) - b0 * spb) * gps
@@ -394,6 +452,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
     plan_path = n_dir / "simulation_workload_plan.json"
     row_dir = cfg.simulation_row_dir(n)
     metric_chunk_dir = cfg.metric_chunk_dir(n)
+    all_player_dir = cfg.all_player_batch_dir(n)
     if plan.cap_exceeded:
         if rank == 0:
             write_workload_plan(plan_path, plan)
@@ -405,7 +464,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         if force:
             for path in (ckpt_path, n_dir / f"{n}p_checkpoint.parquet", cfg.metrics_path(n), simulation_done_path(cfg, n)):
                 path.unlink(missing_ok=True)
-            for d in (row_dir, metric_chunk_dir):
+            for d in (row_dir, metric_chunk_dir, all_player_dir):
                 if d is not None and d.exists():
                     for f in d.iterdir():
                         if f.suffix in {".parquet", ".jsonl", ".tmp"}:
@@ -420,14 +479,14 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         else:
             _write_parquet_atomic(table, manifest_path)
         write_workload_plan(plan_path, plan)
-    for d in (row_dir, metric_chunk_dir):
+    for d in (row_dir, metric_chunk_dir, all_player_dir):
         if d is not None:
             d.mkdir(parents=True, exist_ok=True)
     barrier()  # rank 0's --force cleanup and manifest write are complete before any rank plays or writes a shard
     result = run_tournament(cfg=cfg, n_players=n, strategies=strategies, plan=plan, checkpoint_path=ckpt_path,
                             collect_metrics=cfg.sim.expanded_metrics, row_dir=row_dir, metric_chunk_dir=metric_chunk_dir,
                             resume=not force, checkpoint_metadata={"strategy_manifest_sha": manifest_sha},
-                            oracle_game_profile=oracle_game_profile)
+                            oracle_game_profile=oracle_game_profile, all_player_dir=all_player_dir)
     if rank != 0:
         return plan.required_games
     ids = [int(s.strategy_id) for s in strategies]

@@ -77,12 +77,16 @@ def worst_case_wilson_width(n: int, *, confidence: float = 0.95) -> float:
         raise ValueError("n must be a positive integer")
     _check_level(confidence)
     z = float(norm.ppf(0.5 + confidence / 2.0))
-    zz_over_n = z * z / n
+    zz = z * z
+    # The value lands in simulation_workload_plan.json (achieved_resolution) and decides minimum_shuffles_for_resolution, so
+    # every operation is in the reference's order (workload_planner.py:87-93): the Wilson radicand is
+    # p(1-p)/n + z^2/(4 n^2) with the product 4.0 * n * n formed first — z^2/n/(4n) rounds differently at 1 in ~9 000 sizes.
     widths = []
-    for successes in {n // 2, n - n // 2}:
+    for successes in (n // 2, (n + 1) // 2):
         p_hat = successes / n
-        half = z * math.sqrt(p_hat * (1.0 - p_hat) / n + zz_over_n / (4.0 * n))
-        widths.append(2.0 * half / (1.0 + zz_over_n))
+        shrink = 1.0 + zz / n
+        half = z * math.sqrt(p_hat * (1.0 - p_hat) / n + zz / (4.0 * n * n))
+        widths.append(2.0 * half / shrink)
     return max(widths)
 
 

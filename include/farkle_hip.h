@@ -237,6 +237,11 @@ int fk_debug_dice(fk_ctx *ctx, int64_t n, const fk_coord *coords, int32_t n_call
 /* Same but from explicit generator states: state[i*6..] = state_hi, state_lo, inc_hi, inc_lo, has_uint32, uinteger. */
 int fk_debug_dice_state(fk_ctx *ctx, int64_t n, const uint64_t *state, int32_t n_calls, const int32_t *sizes,
                         uint8_t *faces, uint64_t *state_out);
+/* The game kernels' own dice path from explicit generator states: keys[i * n_calls + c] = the 18-bit key of call c (six 3-bit
+ * face counts, face 1 in the low bits — what the score table is indexed by), produced by the roll_counts<3> instantiation of
+ * fk_play_kernel / fk_play_hc_kernel incl. its Lemire-rejection replay (engine.py:101 -> Generator.integers). */
+int fk_debug_dice_keys(fk_ctx *ctx, int64_t n, const uint64_t *state, int32_t n_calls, const int32_t *sizes, uint32_t *keys,
+                       uint64_t *state_out);
 
 #ifdef __cplusplus
 }

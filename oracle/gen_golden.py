@@ -459,6 +459,81 @@ def gen_runner():
     _dump({"plans": plans, "paths": paths}, open(OUT / "runner_vectors.json", "w"))
 
 
+def gen_all_player():
+    """The reference's unconditional all-player batch metrics (analysis/all_player_metrics.py:_iter_batch_tables -> _update_
+    exposure_columns -> _finish_row, :257-470) over raw rows the reference itself simulated: rows of `_play_one_shuffle` for a
+    few deterministic batches are written with the reference's raw row schema and fed to its own accumulation.  Cases include
+    a never-banking table at a small round limit (safety-limit exposures: null rank / loss_margin, hit_max_rounds)."""
+    import shutil
+    import tempfile
+
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    from farkle.analysis import all_player_metrics as apm
+    from farkle.utils.schema_helpers import raw_simulation_schema_for
+
+    class _Guard:
+        def check_before_schedule(self, force: bool = False) -> None:
+            return None
+
+    never = [ThresholdStrategy(300, 0, True, True, True, True, True, True, True, s.favor_dice_or_score) for s in grid64()[:8]]
+    cases = []
+    tmp = Path(tempfile.mkdtemp(prefix="fk_apm_"))
+    try:
+        for name, strategies, k, root, n_sh, spb, max_rounds in [
+            ("g64_k2", grid64(), 2, 42, 4, 2, 200), ("g64_k4", grid64(), 4, 7, 3, 2, 200), ("g64_k8", grid64(), 8, 3, 2, 2, 200),
+            ("never8_k4_mr6", never, 4, 5, 4, 2, 6), ("g64_k2_mr12", grid64(), 2, 9, 3, 3, 12),
+        ]:
+            gp = GameProfile(default_target_score=10_000, default_max_rounds=max_rounds)
+            cfg = rt.TournamentConfig(n_players=k, n_strategies=len(strategies))
+            rt._init_worker(strategies, cfg, gp)
+            rows = []
+            for sh in range(n_sh):
+                task = rt.ShuffleTask(root_seed=root, k=k, shuffle_index=sh, shuffle_seed=0, deterministic_batch_id=sh // spb)
+                rows.extend(rt._play_one_shuffle(task, collect_rows=True)[3])
+            schema = raw_simulation_schema_for(k)
+            path = tmp / f"{name}.parquet"
+            pq.write_table(pa.Table.from_pylist([{f.name: r.get(f.name) for f in schema} for r in rows], schema=schema), path)
+            out_rows = []
+            for table in apm._iter_batch_tables(path, k, max_batch_bytes=1 << 30, max_batch_rows=1 << 20, memory_guard=_Guard()):
+                out_rows.extend(table.to_pylist())
+            cases.append({"name": name, "k": k, "root_seed": root, "n_shuffles": n_sh, "shuffles_per_batch": spb, "max_rounds": max_rounds,
+                          "strategies": [strat_tuple(s) for s in strategies], "columns": apm.all_player_batch_schema().names,
+                          "batch_rows": [[r[c] for c in apm.all_player_batch_schema().names] for r in out_rows]})
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    _dump({"cases": cases}, open(OUT / "all_player_vectors.json", "w"))
+
+
+def gen_wilson():
+    """worst_case_wilson_width / minimum_shuffles_for_resolution of the reference, bit patterns (float.hex): every sample size
+    below 20 000 at which a re-associated form of the radicand (z^2 / n / (4 n) instead of z^2 / (4 n^2)) rounds differently,
+    a spread of other sizes, and the resolution searches they feed."""
+    import math
+
+    from farkle.simulation.workload_planner import minimum_shuffles_for_resolution, worst_case_wilson_width
+    from scipy.stats import norm
+
+    def reassociated(n, confidence):
+        z = float(norm.ppf(0.5 + confidence / 2.0))
+        q = z * z / n
+        best = 0.0
+        for successes in {n // 2, n - n // 2}:
+            p_hat = successes / n
+            best = max(best, 2.0 * z * math.sqrt(p_hat * (1.0 - p_hat) / n + q / (4.0 * n)) / (1.0 + q))
+        return best
+
+    widths = []
+    for confidence in (0.8, 0.9, 0.95, 0.99, 0.999):
+        for n in range(1, 20001):
+            ref = worst_case_wilson_width(n, confidence=confidence)
+            if n <= 40 or n % 997 == 0 or ref != reassociated(n, confidence):
+                widths.append([confidence, n, ref.hex()])
+    searches = [[delta, confidence, minimum_shuffles_for_resolution(delta, confidence=confidence)]
+                for confidence in (0.9, 0.95, 0.99) for delta in (0.5, 0.2, 0.1, 0.05, 0.03, 0.02, 0.01, 0.004, 0.0123)]
+    _dump({"widths": widths, "searches": searches}, open(OUT / "wilson_vectors.json", "w"))
+
+
 ARTIFACT_CONFIG = {
     # the reference's tiny oracle config (tests/helpers/raw_simulation_oracle.py:80-190) with a finer screening
     # resolution (more shuffles) and three deterministic batches; artifact_contract v3 sidecars are out of scope
@@ -626,6 +701,8 @@ if __name__ == "__main__":
     gen_artifacts()
     gen_resume()
     gen_runner()
+    gen_wilson()
+    gen_all_player()
     gen_fuzz()
     gen_rng()
     gen_scoring()

@@ -147,6 +147,33 @@ def test_lemire_rejection_slow_path(eng, po):
             assert np.array_equal(f, faces[i]), (i, sizes)
             assert np.array_equal(o, out[i]), (i, sizes)
         assert faces.min() >= 1 and faces.max() <= 6
+        # the game kernels' own instantiation: roll_counts<3> (18-bit count key, rejection test on the 6w product)
+        keys, out3 = eng.debug_dice_keys(states, sizes)
+        starts = np.concatenate([[0], np.cumsum(sizes)])
+        for i, st in enumerate(states):
+            f, o = po.dice_from_state(st, sizes)
+            assert np.array_equal(o, out3[i]), (i, sizes)
+            for c in range(len(sizes)):
+                want = sum(1 << (3 * (int(face) - 1)) for face in f[starts[c]:starts[c + 1]])
+                assert int(keys[i, c]) == want, (i, sizes, c)
+
+
+def test_kernel_dice_instantiation_on_random_states(eng, po):
+    """roll_counts<3> (fast path) against the oracle's sequential dice on random generator states, every roll size."""
+    rs = np.random.default_rng(17)
+    states = np.zeros((512, 6), dtype=np.uint64)
+    states[:, :4] = rs.integers(0, 2**63, (512, 4), dtype=np.uint64)
+    states[:, 3] |= np.uint64(1)
+    states[:, 4] = rs.integers(0, 2, 512)
+    states[:, 5] = np.where(states[:, 4] == 1, rs.integers(0, 2**32, 512, dtype=np.uint64), 0)
+    sizes = [6, 5, 4, 3, 2, 1, 6, 1, 5, 2]
+    keys, out = eng.debug_dice_keys(states, sizes)
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    for i, st in enumerate(states):
+        f, o = po.dice_from_state(st, sizes)
+        assert np.array_equal(o, out[i]), i
+        for c in range(len(sizes)):
+            assert int(keys[i, c]) == sum(1 << (3 * (int(face) - 1)) for face in f[starts[c]:starts[c + 1]]), (i, c)
 
 
 # ------------------------------------------------------------------ scoring / decisions

@@ -186,6 +186,20 @@ def test_workload_plans_match_reference():
         plan_tournament_workload(root_seed=0, k=3, strategy_count=80, resolution_delta=0.1)
 
 
+def test_wilson_width_is_bit_identical_to_the_reference():
+    """worst_case_wilson_width lands in simulation_workload_plan.json and decides minimum_shuffles_for_resolution: float
+    bit patterns (float.hex) of the reference at every sample size below 20 000 where a re-associated radicand rounds
+    differently (e.g. confidence 0.99, n = 165), a spread of other sizes, and the searches (tests/golden/wilson_vectors.json)."""
+    from farkle_ii_amd.workload_planner import minimum_shuffles_for_resolution, worst_case_wilson_width
+
+    data = gu.load("wilson_vectors.json")
+    assert len(data["widths"]) > 250 and [0.99, 165] in [w[:2] for w in data["widths"]]
+    for confidence, n, want in data["widths"]:
+        assert worst_case_wilson_width(n, confidence=confidence).hex() == want, (confidence, n)
+    for delta, confidence, want in data["searches"]:
+        assert minimum_shuffles_for_resolution(delta, confidence=confidence) == want, (delta, confidence)
+
+
 def test_config_paths_match_reference():
     from pathlib import Path
 

@@ -562,3 +562,135 @@ def test_farkle_run_cli_under_torch_distributed_run_two_ranks(tmp_path):
             assert pq.read_table(a / rel).equals(pq.read_table(b / rel)), rel
         elif rel.endswith("checkpoint.pkl"):
             assert pickle.loads((a / rel).read_bytes()) == pickle.loads((b / rel).read_bytes())
+
+
+def _tiny_config(tmp_path, extra_sim: str = "") -> Path:
+    cfg_path = tmp_path / "tiny.yaml"
+    cfg_path.write_text(f"""
+io:
+  results_dir_prefix: "{tmp_path / 'out'}"
+sim:
+  n_players_list: [2]
+  seed_list: [7]
+  expanded_metrics: true
+  row_dir: null
+  metric_chunk_dir: null
+{extra_sim}  score_thresholds: [300, 500]
+  dice_thresholds: [1, 2]
+  smart_five_opts: [true]
+  smart_one_opts: [true, false]
+  consider_score_opts: [true]
+  consider_dice_opts: [true]
+  auto_hot_dice_opts: [true]
+  run_up_score_opts: [false]
+screening:
+  resolution_delta: 0.3
+batching:
+  target_batches: 4
+  min_shuffles_per_batch: 2
+""")
+    return cfg_path
+
+
+def test_resume_refuses_a_checkpoint_whose_shuffle_list_and_block_list_disagree(engine, tmp_path):
+    """After its own artifact recovery the reference can write a checkpoint whose totals hold shuffles of a block that its
+    block list does not name, or name a block without its shuffles (run_tournament.py:1289-1330).  Resuming from such totals
+    would count the replayed batch twice (or never): without chunk files to rebuild from, the run stops with a clear error;
+    with them, the totals are rebuilt from the chunk files."""
+    import pyoracle as po
+
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.cli import main
+    from farkle_ii_amd.config import load_app_config
+    from farkle_ii_amd.strategies import pack_strategies
+
+    cfg_path = _tiny_config(tmp_path)
+    main(["--config", str(cfg_path), "run"])
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    n_dir = cfg.n_dir(2)
+    payload = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    strategies, _ = runner._resolve_strategies(cfg, None)
+    table = pack_strategies(strategies).view(po.STRATEGY_DTYPE)
+    spb, n_sh = payload["meta"]["shuffles_per_batch"], payload["meta"]["num_shuffles"]
+    ref = po.tournament(table, 2, 7, 0, n_sh)["tally"][0]
+    three = po.tournament(table, 2, 7, 0, 3 * spb)["tally"][0]
+    ids = list(range(len(ref)))
+    # (a) totals of blocks 1..3, block list names only 1..2 (block 3's shuffles are in the totals and in the shuffle list)
+    _write_partial_checkpoint(n_dir / "2p_checkpoint.pkl", three, ids, 2, payload["meta"], [1, 2], spb)
+    (n_dir / "simulation.done.json").unlink()
+    with pytest.raises(ValueError, match="shuffle list and block list disagree"):
+        main(["--config", str(cfg_path), "run"])
+    # (b) totals of blocks 1..2, block list names 1..3
+    two = po.tournament(table, 2, 7, 0, 2 * spb)["tally"][0]
+    _write_partial_checkpoint(n_dir / "2p_checkpoint.pkl", two, ids, 2, payload["meta"], [1, 2, 3], spb)
+    with pytest.raises(ValueError, match="shuffle list and block list disagree"):
+        main(["--config", str(cfg_path), "run"])
+    # --force starts over
+    main(["--config", str(cfg_path), "run", "--force"])
+    assert np.array_equal(_tally(pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes()), len(ref)), ref)
+    # (c) with metric chunk files the inconsistent pickle is not trusted: the chunk files rebuild the totals
+    cfg2 = _tiny_config(tmp_path, '  metric_chunk_dir: "metric_chunks"\n')
+    main(["--config", str(cfg2), "run", "--force"])
+    _write_partial_checkpoint(n_dir / "2p_checkpoint.pkl", three, ids, 2, payload["meta"], [1, 2], spb)
+    (n_dir / "simulation.done.json").unlink()
+    played = []
+    real = engine.tournament
+    engine.tournament = lambda *a, **kw: (played.append(a[3:5]), real(*a, **kw))[1]
+    try:
+        main(["--config", str(cfg2), "run"])
+    finally:
+        engine.tournament = real
+    assert played == []  # every batch was recovered from its chunk file
+    assert np.array_equal(_tally(pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes()), len(ref)), ref)
+    # a chunk file the manifest lists but the disk lacks is an error, as in the reference (run_tournament.py:887)
+    _write_partial_checkpoint(n_dir / "2p_checkpoint.pkl", two, ids, 2, payload["meta"], [1, 2], spb)
+    (n_dir / "simulation.done.json").unlink()
+    (n_dir / "2p_metric_chunks" / "metrics_000004.parquet").unlink()
+    with pytest.raises(FileNotFoundError, match="metric chunk manifest lists a missing file"):
+        main(["--config", str(cfg2), "run"])
+
+
+def test_farkle_run_all_player_batches_artifact(engine, tmp_path):
+    """`farkle run --all-player-batches`: one parquet per deterministic batch in the reference's all_player_batch_schema column
+    order, integer columns from the engine's all-seat accumulators, the row-order float columns null; resume keeps the files
+    of owned batches and replays the rest."""
+    import pyarrow.parquet as pq
+    import pyoracle as po
+    from oracle_engine_stub import seat_stats_from_rows
+
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.all_player import ROW_ORDER_FLOAT_FIELDS, all_player_batch_schema, all_player_batch_table
+    from farkle_ii_amd.cli import main
+    from farkle_ii_amd.config import load_app_config
+    from farkle_ii_amd.strategies import pack_strategies
+
+    cfg_path = _tiny_config(tmp_path)
+    main(["--config", str(cfg_path), "run", "--all-player-batches"])
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    n_dir = cfg.n_dir(2)
+    out_dir = n_dir / "2p_all_player_batches"
+    payload = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    spb, n_sh = payload["meta"]["shuffles_per_batch"], payload["meta"]["num_shuffles"]
+    strategies, _ = runner._resolve_strategies(cfg, None)
+    table = pack_strategies(strategies)
+    S = len(table)
+    rows = po.tournament(table.view(po.STRATEGY_DTYPE), 2, 7, 0, n_sh, want_rows=True)["rows"]
+    stats = seat_stats_from_rows(rows, 2, S, S // 2, spb)
+    manifest = [json.loads(line) for line in (out_dir / "all_player_manifest.jsonl").read_text().splitlines()]
+    assert [r["deterministic_batch_id"] for r in manifest] == [0, 1, 2, 3] and manifest[0]["absent_columns"] == list(ROW_ORDER_FLOAT_FIELDS)
+    for b in range(4):
+        got = pq.read_table(out_dir / f"all_player_batch_{b + 1:06d}.parquet")
+        assert got.schema.names == all_player_batch_schema().names
+        assert got.equals(all_player_batch_table(stats[b], list(range(S)), 7, 2, b))
+        assert got.column("raw_player_game_exposures").to_pylist() == [min(spb, n_sh - b * spb)] * S
+        assert all(v is None for name in ROW_ORDER_FLOAT_FIELDS for v in got.column(name).to_pylist())
+    # resume after losing the last batch: its file is rewritten, the others are kept, the manifest lists each batch once
+    ref = po.tournament(table.view(po.STRATEGY_DTYPE), 2, 7, 0, n_sh)["tally"][0]
+    last = po.tournament(table.view(po.STRATEGY_DTYPE), 2, 7, 3 * spb, n_sh)["tally"][0]
+    _write_partial_checkpoint(n_dir / "2p_checkpoint.pkl", ref - last, list(range(S)), 2, payload["meta"], [1, 2, 3], spb)
+    (n_dir / "simulation.done.json").unlink()
+    before = (out_dir / "all_player_batch_000001.parquet").stat().st_mtime_ns
+    main(["--config", str(cfg_path), "run", "--all-player-batches"])
+    assert (out_dir / "all_player_batch_000001.parquet").stat().st_mtime_ns == before
+    manifest = [json.loads(line) for line in (out_dir / "all_player_manifest.jsonl").read_text().splitlines()]
+    assert sorted(r["deterministic_batch_id"] for r in manifest) == [0, 1, 2, 3]
