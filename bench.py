@@ -474,21 +474,38 @@ def main() -> None:
     backend = os.environ.get("FK_DIST_BACKEND", "nccl")
     if backend == "gloo":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    data_group = None  # the process group the tally reduction runs on (RCCL when it came up on EVERY rank)
     if distributed:
+        import datetime
+
         import torch.distributed as dist
 
         if have_gpu:
             torch.cuda.set_device(local_rank)
-        if backend == "nccl":
+        # Control plane (rendezvous, barriers, agreement flags): gloo over TCP.  The data path's one exchange gets its own
+        # RCCL group, and whether it is used is decided COLLECTIVELY: every rank tries it, the ranks agree on the minimum of
+        # their success flags over gloo, so no rank can end up on another backend than its peers (a per-rank fallback inside
+        # an `except` would split the job and hang it).  FK_DIST_BACKEND=gloo skips RCCL altogether (CPU rehearsals).
+        dist.init_process_group("gloo")
+        if backend == "nccl" and have_gpu:
+            ok, why = 1, ""
             try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # eager: RCCL trouble shows up here
-            except Exception as exc:  # the exchange is one 13 KB reduce: a node whose RCCL does not come up is still measurable
-                backend_note = f"nccl (RCCL) initialisation failed ({type(exc).__name__}: {str(exc)[:200]}); tally reduced over gloo"
-                print(f"rank {rank}: {backend_note}", file=sys.stderr)
+                data_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=180))
+                probe = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local_rank))
+                dist.all_reduce(probe, group=data_group)  # eager: RCCL trouble shows up here, not inside the timed region
+                torch.cuda.synchronize()
+                ok = int(int(probe.item()) == world)
+            except Exception as exc:
+                ok, why = 0, f"{type(exc).__name__}: {str(exc)[:200]}"
+            flag = torch.tensor([ok], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) != 1:
+                data_group = None
                 backend = "gloo"
-                dist.init_process_group("gloo")
+                backend_note = f"RCCL group did not come up on every rank ({why or 'failed on another rank'}); tally reduced over gloo"
+                print(f"rank {rank}: {backend_note}", file=sys.stderr)
         else:
-            dist.init_process_group(backend)
+            backend = "gloo"
     n_gpus = dist.get_world_size() if distributed else 1
     if args.gpus != n_gpus and rank == 0:
         print(f"note: --gpus {args.gpus} but the process group has {n_gpus} ranks; reporting n_gpus={n_gpus}", file=sys.stderr)
@@ -498,7 +515,7 @@ def main() -> None:
     eng = make_engine(local_rank)
     info = eng.device_info()
     dev = torch.device("cuda", local_rank) if have_gpu else torch.device("cpu")
-    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the tally reduction runs
+    red_dev = dev if data_group is not None else torch.device("cpu")  # where the tally reduction runs
 
     def sync() -> None:
         if distributed:
@@ -506,27 +523,46 @@ def main() -> None:
         if have_gpu:
             torch.cuda.synchronize(dev)
 
-    # FK_TALLY_REDUCE=rccl: the tally reduction runs as fk_reduce_tally (ncclReduce on the engine's stream through the
-    # C-ABI, no PyTorch in the data path) instead of torch.distributed's reduce; both are RCCL over xGMI under `nccl`.
+    # The tally reduction itself.  Default under RCCL: the engine's own communicator (fk_comm_init) — ncclReduce on the engine's
+    # stream through the C-ABI, no PyTorch in the data path; for the tournament workloads the tally stays in HBM from the
+    # game kernels' post-pass to the reduce (fk_tally_resident_reduce: one D2H, on the root).  FK_TALLY_REDUCE=torch keeps
+    # torch.distributed's reduce on the RCCL group; both are RCCL over xGMI.  Again decided collectively.
     tally_reduce = "single process"
     use_fk_comm = False
+    resident = False
     if distributed:
-        tally_reduce = f"torch.distributed.reduce ({backend})"
-        if os.environ.get("FK_TALLY_REDUCE", "") == "rccl":
+        tally_reduce = f"torch.distributed.reduce ({'nccl = RCCL' if data_group is not None else 'gloo'})"
+        if data_group is not None and os.environ.get("FK_TALLY_REDUCE", "rccl") == "rccl":
             from farkle_ii_amd.distributed import init_engine_comm
 
-            use_fk_comm = init_engine_comm(eng)
+            ok = 0
+            try:
+                ok = int(bool(init_engine_comm(eng)))
+            except Exception as exc:
+                print(f"rank {rank}: fk_comm_init failed ({type(exc).__name__}: {str(exc)[:200]}); torch.distributed reduce instead", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            use_fk_comm = int(flag.item()) == 1
             if use_fk_comm:
-                tally_reduce = "fk_reduce_tally (ncclReduce int64 sum through the C-ABI)"
+                resident = isinstance(wl, Tournament) and hasattr(eng, "reduce_resident_tally")
+                tally_reduce = ("fk_tally_resident_reduce (tally resident in HBM, ncclReduce int64 sum through the C-ABI, one D2H on the root)"
+                                if resident else "fk_reduce_tally (ncclReduce int64 sum through the C-ABI)")
+                if resident:
+                    eng.set_option("resident_tally", 1)
+    rccl_ranks = (eng.comm_ranks() if use_fk_comm and hasattr(eng, "comm_ranks") else
+                  (dist.get_world_size(data_group) if data_group is not None else 0))
 
     def reduce_to_rank0(local: np.ndarray):
         """The path's only exchange: one SUM of the int64 tally to rank 0 at the end of the job, the
         analogue of OutcomeCounter.absorb — RCCL over xGMI when there is more than one rank."""
+        if resident:
+            tot = eng.reduce_resident_tally((1,) + tuple(local.shape), 0)
+            return torch.from_numpy(tot[0] if tot is not None else local)
         if use_fk_comm:
             return torch.from_numpy(eng.reduce_tally(local, 0))
         t = torch.from_numpy(local).to(red_dev)
         if distributed:
-            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM, group=data_group)
         return t
 
     # one-time initialisation outside any step: device workspace, lazily loaded torch kernels, RCCL communicator
@@ -534,7 +570,7 @@ def main() -> None:
     warm = torch.zeros(wl.local_shape, dtype=torch.int64, device=red_dev)
     warm += torch.from_numpy(np.zeros(wl.local_shape, dtype=np.int64)).to(red_dev)
     if distributed:
-        dist.reduce(warm, dst=0, op=dist.ReduceOp.SUM)
+        dist.reduce(warm, dst=0, op=dist.ReduceOp.SUM, group=data_group)
     local = np.zeros(wl.local_shape, dtype=np.int64)
     for i in range(args.warmup):  # (the last warm-up step does not prepare the first timed step)
         tally, _, _ = wl.step(eng, i, rank, n_gpus, next_index=i + 1 if i + 1 < args.warmup else None)
@@ -554,10 +590,10 @@ def main() -> None:
     sync()
     elapsed = time.perf_counter() - t0
     if distributed:
-        e = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        e = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = float(e.item())
-        g_all = torch.tensor([my_games], dtype=torch.int64, device=red_dev)
+        g_all = torch.tensor([my_games], dtype=torch.int64)
         dist.all_reduce(g_all, op=dist.ReduceOp.SUM)
         played = int(g_all.item())
     else:
@@ -631,8 +667,9 @@ def main() -> None:
             "value": value, "unit": "games/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None,
             "dtype": "int32", "data": "synthetic", "engine": engine_name, "tally_reduce": tally_reduce,
-            "dist_backend": (f"{dist.get_backend()} (RCCL over xGMI)" if distributed and dist.get_backend() == "nccl"
-                             else ((backend_note or dist.get_backend()) if distributed else None)),
+            "dist_backend": (("nccl (RCCL over xGMI) for the tally reduce; gloo control plane" if data_group is not None
+                              else (backend_note or "gloo")) if distributed else None),
+            "rccl_ranks": rccl_ranks if distributed else None,
             "launcher": "self (bench.py started the ranks)" if os.environ.get("FK_BENCH_SELF_LAUNCHED") else
                         ("torch.distributed.run" if distributed else "single process"),
             "config": {**wl.describe(n_gpus), "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],

@@ -96,7 +96,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
             "fk_tournament_run", "fk_tournament_run_stats", "fk_tournament_hint_next", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
-            "fk_debug_dice", "fk_debug_dice_state", "fk_debug_dice_keys", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy"]
+            "fk_debug_dice", "fk_debug_dice_state", "fk_debug_dice_keys", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy", "fk_tally_resident_reduce", "fk_comm_ranks"]
 _lib = None
 
 
@@ -156,6 +156,7 @@ class Engine:
             raise FarkleHipError(rc, f"fk_init({device}) failed: {names.get(rc, rc)}")
         self.device = device
         self.comm_world = 1
+        self.comm_rank = 0
 
     # -- plumbing -------------------------------------------------------------------------
     def close(self) -> None:
@@ -294,12 +295,24 @@ class Engine:
             raise ValueError("communicator id must be 128 bytes")
         self._check(self._lib.fk_comm_init(self._ctx, C.create_string_buffer(comm_id, COMM_ID_BYTES), C.c_int32(rank), C.c_int32(world_size)))
         self.comm_world = world_size
+        self.comm_rank = rank
 
     def reduce_tally(self, tally: np.ndarray, root: int = 0) -> np.ndarray:
         """Collective: int64 SUM over the communicator; the total on ``root`` (the rank's own tally elsewhere)."""
         t = np.ascontiguousarray(tally, dtype=np.int64).copy()
         self._check(self._lib.fk_reduce_tally(self._ctx, _p(t), C.c_int64(t.size), C.c_int32(root)))
         return t
+
+    def reduce_resident_tally(self, shape, root: int = 0) -> np.ndarray | None:
+        """Collective: the device-resident tally accumulator (option ``resident_tally``) summed over the communicator on the
+        device; the total on ``root`` (None elsewhere).  Clears the accumulator."""
+        out = np.zeros(shape, dtype=np.int64)
+        self._check(self._lib.fk_tally_resident_reduce(self._ctx, _p(out), C.c_int64(out.size), C.c_int32(root)))
+        return out if (self.comm_world == 1 or self.comm_rank == root) else None
+
+    def comm_ranks(self) -> int:
+        """Ranks of the engine's RCCL communicator as RCCL counts them (1 without one)."""
+        return int(self._lib.fk_comm_ranks(self._ctx))
 
     def comm_destroy(self) -> None:
         self._check(self._lib.fk_comm_destroy(self._ctx))

@@ -85,12 +85,24 @@ def main(argv: Sequence[str] | None = None) -> None:
     if args.all_player_batches is not None:
         cfg.sim.all_player_batch_dir = args.all_player_batches
     _maybe_init_distributed()
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("FK_TALLY_REDUCE", "") == "rccl":
-        # the per-group tally reduction through the C-ABI's own RCCL communicator (fk_comm_init / fk_reduce_tally)
-        from .distributed import init_engine_comm
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("FK_TALLY_REDUCE", "rccl") == "rccl":
+        # The per-group tally reduction through the C-ABI's own RCCL communicator (fk_comm_init / fk_reduce_tally): the default
+        # whenever it comes up on EVERY rank (the ranks agree on the minimum of their success flags, so none is left on another
+        # path); otherwise — and with FK_TALLY_REDUCE=torch — torch.distributed's reduce on the process group.
+        from .distributed import agree, init_engine_comm
         from .engine import get_engine
 
-        init_engine_comm(get_engine())
+        ok = False
+        try:
+            ok = bool(init_engine_comm(get_engine()))
+        except Exception as exc:  # librccl missing, ncclCommInitRank failed, a CPU-only engine ...
+            LOGGER.warning("fk_comm_init failed (%s: %s)", type(exc).__name__, exc)
+        everywhere = agree(ok)
+        if not everywhere:
+            from . import distributed
+
+            distributed._ENGINE_COMM = None
+        LOGGER.info("tally reduce: %s", "fk_reduce_tally (RCCL through the C-ABI)" if everywhere else "torch.distributed.reduce")
     rank = int(os.environ.get("RANK", "0"))
     if rank == 0:
         runner.write_active_config(cfg, cfg.results_root)

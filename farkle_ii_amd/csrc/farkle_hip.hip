@@ -101,6 +101,12 @@ struct fk_ctx {
     void *comm = nullptr;      // RCCL communicator (fk_comm_init), one per context / GPU
     int comm_rank = 0, comm_world = 1;
     DevBuf comm_buf;
+    // resident tally (option "resident_tally"): every tournament call adds its [n_batches][S][26] tally to this device
+    // accumulator; fk_tally_resident_reduce sums it over the communicator on the device (the tally never leaves HBM before
+    // the reduce; one D2H, on the root)
+    int32_t resident = 0;
+    DevBuf acc;
+    size_t acc_n = 0;
 };
 
 #define CSET(c) ((c)->sets[(c)->cur])
@@ -930,7 +936,7 @@ void fk_destroy(fk_ctx *c) {
     release(c->comm_buf);
     if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     for (DevBuf *b : {&c->strat, &c->recs, &c->rec0, &c->tally, &c->rows, &c->ov, &c->seatlist, &c->coords, &c->inv, &c->slow, &c->digest, &c->score_lut,
-                      &c->discard_lut, &c->blocks, &c->game_block, &c->block_out, &c->stats, &c->cold, &c->lds_tables})
+                      &c->discard_lut, &c->blocks, &c->game_block, &c->block_out, &c->stats, &c->cold, &c->lds_tables, &c->acc})
         release(*b);
     for (auto &cs : c->sets) {
         for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc, &cs.pools}) release(*b);
@@ -980,7 +986,10 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "max_waves") c->max_waves = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8);
     else if (n == "lean") c->lean = (int32_t)value;
     else if (n == "state_store") c->gs = (int32_t)value;
-    else if (n == "hot_cold") c->hc = (int32_t)value;
+    else if (n == "resident_tally") {
+        c->resident = value != 0;
+        c->acc_n = 0; // the next tournament call starts a fresh accumulator
+    } else if (n == "hot_cold") c->hc = (int32_t)value;
     else if (n == "hot_cold_waves") c->hc_waves = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8);
     else if (n == "hot_cold_block") c->hc_block = (int32_t)value;
     else if (n == "hot_cold_tables") c->hc_tables = (int32_t)value;
@@ -1291,6 +1300,18 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
     hipLaunchKernelGGL(fk_finalize_tally, dim3((n_rows + 255u) / 256u), dim3(256), 0, c->stream,
                        static_cast<unsigned long long *>(c->tally.p), n_rows, (uint32_t)S, shuffles_per_batch, n_sh_total, 1u);
     HIPCHK(c, hipGetLastError());
+    if (c->resident) { // the call's tally joins the resident accumulator (shape changes start a new one)
+        const size_t n_el = tally_bytes / sizeof(int64_t);
+        if (c->acc_n != n_el) {
+            rc = ensure(c, c->acc, tally_bytes);
+            if (rc) return rc;
+            HIPCHK(c, hipMemsetAsync(c->acc.p, 0, tally_bytes, c->stream));
+            c->acc_n = n_el;
+        }
+        hipLaunchKernelGGL(fk_add_i64_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, c->stream,
+                           static_cast<unsigned long long *>(c->acc.p), static_cast<const unsigned long long *>(c->tally.p), n_el);
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipEventRecord(t1, c->stream));
     HIPCHK(c, hipMemcpyAsync(tally, c->tally.p, tally_bytes, hipMemcpyDeviceToHost, c->stream));
     if (seat_stats) HIPCHK(c, hipMemcpyAsync(seat_stats, c->stats.p, stats_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1603,6 +1624,39 @@ int fk_reduce_tally(fk_ctx *c, int64_t *tally, int64_t n, int32_t root_rank) {
     if (c->comm_rank == root_rank) HIPCHK(c, hipMemcpyAsync(tally, c->comm_buf.p, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FK_OK;
+}
+
+// The resident accumulator summed over the communicator ON THE DEVICE (ncclReduce on the engine's stream) and copied to the
+// host on the root rank only; single-rank contexts (no communicator) just copy it.  The accumulator is cleared afterwards.
+int fk_tally_resident_reduce(fk_ctx *c, int64_t *out, int64_t n, int32_t root_rank) {
+    if (!c) return FK_ERR_ARG;
+    if (n < 0 || (size_t)n != c->acc_n || !c->acc.p) return fail(c, FK_ERR_ARG, "resident tally holds %lld elements, %lld asked for", (long long)c->acc_n, (long long)n);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * sizeof(int64_t);
+    bool root = true;
+    if (c->comm && c->comm_world > 1) {
+        if (root_rank < 0 || root_rank >= c->comm_world) return fail(c, FK_ERR_ARG, "root rank outside the communicator");
+        const int nrc = rccl().Reduce(c->acc.p, c->acc.p, (size_t)n, 4 /* ncclInt64 */, 0 /* ncclSum */, root_rank, c->comm, c->stream);
+        if (nrc != 0) return rccl_fail(c, "ncclReduce", nrc);
+        root = c->comm_rank == root_rank;
+    }
+    if (root) {
+        if (!out) return fail(c, FK_ERR_ARG, "the root rank needs an output buffer");
+        HIPCHK(c, hipMemcpyAsync(out, c->acc.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipMemsetAsync(c->acc.p, 0, bytes, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FK_OK;
+}
+
+// ranks of the communicator as RCCL itself counts them (ncclCommCount); 1 without a communicator
+int fk_comm_ranks(fk_ctx *c) {
+    if (!c) return FK_ERR_ARG;
+    if (!c->comm) return 1;
+    int n = 0;
+    auto count = reinterpret_cast<int (*)(void *, int *)>(dlsym(rccl().lib, "ncclCommCount"));
+    if (!count || count(c->comm, &n) != 0) return c->comm_world;
+    return n;
 }
 
 int fk_comm_destroy(fk_ctx *c) {

@@ -721,6 +721,12 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
     }
 }
 
+// resident tally accumulator (fk_tally_resident_*): acc += tally, both int64 on the device
+__global__ void fk_add_i64_kernel(unsigned long long *acc, const unsigned long long *src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] += src[i];
+}
+
 // attempted = completed + safety for every (batch, strategy) row
 // Tournament mode: every strategy is seated exactly once per shuffle (S % k == 0), so its attempted exposures in a
 // batch equal the batch's shuffle count and only the (rare) safety-limit exposures are counted by the game kernel:

@@ -68,7 +68,10 @@ def tcp_broadcast(payload: bytes | None, rank: int, world: int, addr: str, port:
             with socket.create_connection((addr, port), timeout=5.0) as conn:
                 head = b""
                 while len(head) < 4:
-                    head += conn.recv(4 - len(head))
+                    piece = conn.recv(4 - len(head))
+                    if not piece:  # the peer closed before the header was complete: retry the rendezvous, do not spin
+                        raise ConnectionError("rendezvous closed before the header")
+                    head += piece
                 n, = struct.unpack("<I", head)
                 data = b""
                 while len(data) < n:
@@ -152,6 +155,19 @@ def gather_objects(obj, dst: int | None = None, broadcast_from: int | None = Non
     out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
     dist.gather_object(obj, out, dst=dst)
     return out
+
+
+def agree(ok: bool) -> bool:
+    """True iff ``ok`` is true on EVERY rank (one MIN all-reduce on the process group): how optional fast paths are switched
+    on without ever leaving ranks on different paths.  Single process: ``ok``."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=collective_device())
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag.item()) == 1
 
 
 def barrier() -> None:

@@ -213,6 +213,15 @@ typedef struct {
 int fk_comm_unique_id(fk_comm_id *out);
 int fk_comm_init(fk_ctx *ctx, const fk_comm_id *id, int32_t rank, int32_t world_size);
 int fk_reduce_tally(fk_ctx *ctx, int64_t *tally, int64_t n, int32_t root_rank);
+/* Device-resident form of the same reduction.  With fk_set_option(ctx, "resident_tally", 1) every fk_tournament_run* call also
+ * adds its [n_batches][S][26] tally to an accumulator in HBM (calls of one shape; a shape change starts a new accumulator).
+ * fk_tally_resident_reduce sums the accumulators of all ranks with ncclReduce on the engine's stream — the tally does not leave
+ * the device before it is reduced — copies the total to `out` on `root_rank` only (out may be NULL elsewhere) and clears the
+ * accumulator.  Without a communicator (one rank) it is the plain copy.  n = elements the accumulator holds.
+ * Replaces: OutcomeCounter.absorb over worker results (run_tournament.py:197-213). */
+int fk_tally_resident_reduce(fk_ctx *ctx, int64_t *out, int64_t n, int32_t root_rank);
+/* Ranks of the context's communicator as RCCL counts them (ncclCommCount); 1 when there is none. */
+int fk_comm_ranks(fk_ctx *ctx);
 int fk_comm_destroy(fk_ctx *ctx);
 
 /* SeedSequence fingerprints of n coordinates (all nine coordinate words of the record, seat_index included):

@@ -247,6 +247,32 @@ def test_rccl_tally_reduce_through_the_c_abi_single_rank(eng):
     assert eng.tournament(table, 2, 42, 0, 4)["tally"].sum() > 0
 
 
+def test_resident_tally_accumulates_on_the_device_and_reduces_through_rccl(eng):
+    """Option resident_tally: every tournament call adds its tally to an accumulator in HBM; fk_tally_resident_reduce sums it
+    over the communicator on the device (here: none, then a one-rank RCCL communicator), returns it on the root and clears it."""
+    table = _strats(gu.load("grid_vectors.json")["g64"])
+    try:
+        eng.set_option("resident_tally", 1)
+        a = eng.tournament(table, 2, 42, 0, 50)["tally"]
+        b = eng.tournament(table, 2, 42, 50, 120)["tally"]
+        assert np.array_equal(eng.reduce_resident_tally(a.shape), a + b)      # no communicator: the plain copy
+        c = eng.tournament(table, 2, 42, 120, 130)["tally"]
+        assert np.array_equal(eng.reduce_resident_tally(c.shape), c)          # ... which cleared the accumulator
+        assert eng.comm_ranks() == 1
+        eng.comm_init(eng.comm_unique_id(), 0, 1)
+        try:
+            assert eng.comm_ranks() == 1                                       # ncclCommCount
+            d = eng.tournament(table, 4, 7, 0, 30, shuffles_per_batch=10)["tally"]  # another shape: a new accumulator
+            e = eng.tournament(table, 4, 7, 30, 60, shuffles_per_batch=10)["tally"]
+            assert np.array_equal(eng.reduce_resident_tally(d.shape, 0), d + e)
+            with pytest.raises(Exception, match="resident tally holds"):
+                eng.reduce_resident_tally((5, 5))
+        finally:
+            eng.comm_destroy()
+    finally:
+        eng.set_option("resident_tally", 0)
+
+
 @pytest.mark.parametrize("S,k", [(8, 2), (64, 2), (96, 3), (1290, 2), (5160, 4), (7140, 5)])
 def test_permutation_kernels_agree_with_numpy_semantics(eng, po, S, k):
     """Generator.permutation through the three device paths — one-kernel Fisher-Yates, draws + serial swap chains, draws +
