@@ -145,19 +145,39 @@ def simulation_is_complete(cfg: AppConfig, n_players: int, plan: TournamentWorkl
 
 
 def _metric_chunk_table(batch_tally: np.ndarray, ids: Sequence[int], k: int):
-    """Rows of one ``metrics_<idx>.parquet`` (run_tournament.py:1603-1642)."""
+    """Rows of one ``metrics_<idx>.parquet`` (run_tournament.py:1603-1642): for every metric label, one row per strategy that
+    was seated in the batch, strategies in the order of their decimal strings (the reference sorts with ``key=str``).
+    Columns are built as arrays (a 5 160-strategy grid has 56 760 rows per chunk)."""
     import pyarrow as pa
 
-    wins, sums, sqs = rt.tally_to_counters(batch_tally, ids, k)
-    rows = []
-    for label in rt.METRIC_LABELS:
-        for strat in sorted(set(sums[label]) | set(wins.attempted_exposures), key=str):
-            rows.append({"metric": label, "strategy": strat, "sum": sums[label].get(strat, 0.0),
-                         "square_sum": sqs[label].get(strat, 0.0), "wins": int(wins.get(strat, 0)),
-                         "attempted_exposures": int(wins.attempted_exposures.get(strat, 0)),
-                         "completed_exposures": int(wins.completed_exposures.get(strat, 0)),
-                         "safety_limit_exposures": int(wins.safety_limit_exposures.get(strat, 0))})
-    return pa.Table.from_pylist(rows)
+    del k
+    t = np.asarray(batch_tally, dtype=np.int64)
+    sid = np.asarray([int(x) for x in ids], dtype=np.int64)
+    seated = np.flatnonzero((t[:, 1] > 0) | (t[:, 0] > 0))
+    seated = seated[np.argsort(sid[seated].astype(str), kind="stable")]
+    n, labels = len(seated), list(rt.METRIC_LABELS)
+    rows = t[seated]
+    return pa.table({
+        "metric": pa.array(np.repeat(np.asarray(labels, dtype=object), n), type=pa.string()),
+        "strategy": pa.array(np.tile(sid[seated], len(labels)), type=pa.int64()),
+        "sum": pa.array(rows[:, 4:4 + len(labels)].T.reshape(-1).astype(np.float64)),
+        "square_sum": pa.array(rows[:, 15:15 + len(labels)].T.reshape(-1).astype(np.float64)),
+        "wins": pa.array(np.tile(rows[:, 0], len(labels)), type=pa.int64()),
+        "attempted_exposures": pa.array(np.tile(rows[:, 1], len(labels)), type=pa.int64()),
+        "completed_exposures": pa.array(np.tile(rows[:, 2], len(labels)), type=pa.int64()),
+        "safety_limit_exposures": pa.array(np.tile(rows[:, 3], len(labels)), type=pa.int64()),
+    })
+
+
+def _shuffle_seeds(eng, root_seed: int, k: int, first: int, last: int) -> np.ndarray:
+    """ns-100 uint32 fingerprints of shuffles [first, last) (the manifests' ``shuffle_seeds``): on the device when the engine
+    offers ``fk_coordinate_seeds`` (312 500 of them are 0.4 s of NumPy hashing, microseconds of GPU)."""
+    idx = np.arange(first, last, dtype=np.uint64)
+    if hasattr(eng, "coordinate_seeds") and len(idx):
+        from .backend import make_coords
+
+        return eng.coordinate_seeds(make_coords(int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE), root_seed, k, idx), want32=True)[0]
+    return urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_SHUFFLE, root_seed=root_seed, k=k, shuffle_index=idx, dtype=np.uint32)
 
 
 def _read_manifest(path: Path) -> list[dict]:
@@ -389,6 +409,9 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             if want_rows:
                 rt.append_manifest_records(row_manifest, sorted(row_records, key=lambda r: r["shuffle_index"]))
             chunk_records, all_player_records = [], []
+            if metric_chunk_dir is not None:  # the shuffle fingerprints of the whole group in one vectorised pass
+                g_first, g_last = b0 * spb, min(b1 * spb, plan.required_shuffles)
+                group_seeds = _shuffle_seeds(eng, cfg.sim.seed, k, g_first, g_last)
             for n, b in enumerate(range(b0, b1)):
                 if all_player_dir is not None:
                     ap = all_player_batch_table(group_stats[n], ids, cfg.sim.seed, k, b)
@@ -402,11 +425,11 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                     name = f"metrics_{b + 1:06d}.parquet"  # chunk / process-block indices count from 1 (run_tournament.py:1603-1642)
                     _write_parquet_atomic(chunk, metric_chunk_dir / name)
                     first_sh, last_sh = b * spb, min((b + 1) * spb, plan.required_shuffles)
-                    tasks = rt.shuffle_tasks(cfg.sim.seed, k, first_sh, last_sh, spb)
                     record = {"path": name, "rows": chunk.num_rows, "chunk_index": b + 1, "process_block_index": b + 1,
                               "root_seed": cfg.sim.seed, "n_players": k, "deterministic_batch_id": b,
                               "shuffle_index_start": first_sh, "shuffle_index_end": last_sh - 1, "shuffle_count": last_sh - first_sh,
-                              "shuffle_indices": [t.shuffle_index for t in tasks], "shuffle_seeds": [t.shuffle_seed for t in tasks],
+                              "shuffle_indices": list(range(first_sh, last_sh)),
+                              "shuffle_seeds": group_seeds[first_sh - g_first:last_sh - g_first].tolist(),
                               "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
                               "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
                               "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
