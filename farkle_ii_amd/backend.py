@@ -96,7 +96,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
             "fk_tournament_run", "fk_tournament_run_stats", "fk_tournament_hint_next", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
-            "fk_debug_dice", "fk_debug_dice_state", "fk_debug_dice_keys", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy", "fk_tally_resident_reduce", "fk_comm_ranks"]
+            "fk_debug_dice", "fk_debug_dice_state", "fk_debug_dice_keys", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy", "fk_tally_resident_reduce", "fk_comm_ranks", "fk_host_alloc", "fk_host_free", "fk_game_seeds"]
 _lib = None
 
 
@@ -200,7 +200,7 @@ class Engine:
     def tournament(self, table: np.ndarray, k: int, root_seed: int, shuffle_begin: int, shuffle_end: int,
                    shuffles_per_batch: int | None = None, target_score: int = 10_000, max_rounds: int = 200,
                    overrides: np.ndarray | None = None, want_rows: bool = False, want_perms: bool = False,
-                   want_seat_stats: bool = False) -> dict:
+                   want_seat_stats: bool = False, rows_out: np.ndarray | None = None) -> dict:
         """All games of shuffles ``[shuffle_begin, shuffle_end)``: per-batch tallies (+ rows / permutations / the all-seat
         integer statistics ``[n_batches][S][SEAT_STAT_COLS]``, columns ``SEAT_STAT_NAMES``)."""
         table = np.ascontiguousarray(table, dtype=STRATEGY_DTYPE)
@@ -211,7 +211,15 @@ class Engine:
         n_batches = max((n_sh + spb - 1) // spb, 0)
         gps = S // k if k > 0 else 0
         tally = np.zeros((max(n_batches, 1), S, TALLY_COLS), dtype=np.int64)
-        rows = np.zeros(max(n_sh, 0) * gps, dtype=row_dtype(k)) if want_rows else None
+        rows = None
+        if want_rows:
+            n_rows = max(n_sh, 0) * gps
+            if rows_out is not None:  # e.g. a page-locked buffer from pinned_empty(): rows cross PCIe by DMA while the next chunk plays
+                if rows_out.dtype != row_dtype(k) or len(rows_out) < n_rows or not rows_out.flags["C_CONTIGUOUS"]:
+                    raise ValueError("rows_out must be a contiguous array of row_dtype(k) with room for every game")
+                rows = rows_out[:n_rows]
+            else:
+                rows = np.zeros(n_rows, dtype=row_dtype(k))
         perms = np.zeros((max(n_sh, 0), S), dtype=np.int32) if want_perms else None
         ov = overrides if overrides is not None else np.zeros(0, dtype=OVERRIDE_DTYPE)
         ov = np.ascontiguousarray(ov, dtype=OVERRIDE_DTYPE)
@@ -222,6 +230,21 @@ class Engine:
             C.c_int32(len(ov)), _p(tally), _p(rows), _p(perms), _p(stats)))
         return {"tally": tally[:n_batches], "rows": rows, "perms": perms,
                 "seat_stats": None if stats is None else stats[:n_batches]}
+
+    def pinned_empty(self, n: int, dtype) -> np.ndarray:
+        """``n`` elements of ``dtype`` in page-locked host memory (``fk_host_alloc``), freed when the array is collected — the
+        ``rows_out`` buffer of rows mode.  Keep the engine alive while the array is."""
+        import weakref
+
+        dtype = np.dtype(dtype)
+        nbytes = max(int(n) * dtype.itemsize, 1)
+        ptr = C.c_void_p()
+        self._check(self._lib.fk_host_alloc(self._ctx, C.c_size_t(nbytes), C.byref(ptr)))
+        raw = (C.c_char * nbytes).from_address(ptr.value)
+        arr = np.frombuffer(raw, dtype=dtype, count=int(n))
+        lib, ctx, addr = self._lib, self._ctx, ptr.value
+        weakref.finalize(raw, lambda: lib.fk_host_free(ctx, C.c_void_p(addr)) if ctx else None)
+        return arr
 
     def hint_next(self, shuffle_begin: int, shuffle_end: int, need_state: bool = False) -> None:
         """The call after the next ``tournament`` call will play this shuffle range of the same table, k and root: its
@@ -326,6 +349,14 @@ class Engine:
         s64 = np.zeros(n, dtype=np.uint64) if want64 else None
         self._check(self._lib.fk_coordinate_seeds(self._ctx, C.c_int64(n), _p(coords), _p(s32), _p(s64)))
         return s32, s64
+
+    def game_seeds(self, purpose: int, root_seed: int, k: int, shuffle_begin: int, shuffle_end: int, games_per_shuffle: int) -> np.ndarray:
+        """uint32 ``coordinate_seed`` fingerprints ``[n_shuffles][games_per_shuffle]`` of (purpose, root, k, shuffle, game_index)."""
+        n_sh = max(int(shuffle_end) - int(shuffle_begin), 0)
+        out = np.zeros((n_sh, int(games_per_shuffle)), dtype=np.uint32)
+        self._check(self._lib.fk_game_seeds(self._ctx, C.c_uint32(int(purpose)), C.c_uint64(root_seed), C.c_uint64(k), C.c_uint64(shuffle_begin),
+                                            C.c_uint64(n_sh), C.c_uint32(int(games_per_shuffle)), _p(out)))
+        return out
 
     # -- single-op probes ------------------------------------------------------------------
     def debug_score(self, faces: np.ndarray, lens, pre, strategies: np.ndarray) -> np.ndarray:

@@ -104,6 +104,11 @@ struct fk_ctx {
     // resident tally (option "resident_tally"): every tournament call adds its [n_batches][S][26] tally to this device
     // accumulator; fk_tally_resident_reduce sums it over the communicator on the device (the tally never leaves HBM before
     // the reduce; one D2H, on the root)
+    // rows mode: the device row buffer exists twice and a copy stream moves chunk i's rows to the host while chunk i + 1 plays
+    DevBuf rows_alt;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
+    int64_t rows_chunk_games = 4000000; // rows mode plays in chunks of about this many games (overlap granularity)
     int32_t resident = 0;
     DevBuf acc;
     size_t acc_n = 0;
@@ -795,8 +800,25 @@ int prep_tournament_chunk(fk_ctx *c, int si, hipStream_t st_seed, const ChunkDes
 int rows_pass(fk_ctx *c, const SeedArgs &sa, bool scheduled, uint32_t n_games, uint32_t gps, uint32_t n_sh, bool perm_mode, uint8_t *d_rows) {
     // `scheduled`: the caller has inverted the schedule into c->inv (fk_invert_sched_kernel)
     const uint32_t *inv = scheduled ? static_cast<const uint32_t *>(c->inv.p) : nullptr;
-    hipLaunchKernelGGL(fk_rows_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream, static_cast<const uint32_t *>(CSET(c).state.p),
-                       static_cast<const uint32_t *>(c->recs.p), inv, n_games, gps, n_sh, sa.k, perm_mode ? 1u : 0u, d_rows);
+    const uint32_t row_dw = 1u + 7u * sa.k;
+    // rows of a block leave through an LDS tile as whole lines: the largest block whose tile fits 64 KiB
+    uint32_t block = 256;
+    while (block > 64 && (size_t)block * row_dw * 4 > 65536) block -= 64;
+    const size_t tile = (size_t)block * row_dw * 4;
+    if (tile <= 65536) {
+        static int configured = -1;
+        if (configured != c->device) {
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fk_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+            configured = c->device;
+        }
+        hipLaunchKernelGGL(fk_rows_kernel<true>, dim3((n_games + block - 1u) / block), dim3(block), tile, c->stream,
+                           static_cast<const uint32_t *>(CSET(c).state.p), static_cast<const uint32_t *>(c->recs.p), inv, n_games, gps, n_sh,
+                           sa.k, perm_mode ? 1u : 0u, d_rows);
+    } else { // tables of more than 36 seats: one thread stores its own row
+        hipLaunchKernelGGL(fk_rows_kernel<false>, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
+                           static_cast<const uint32_t *>(CSET(c).state.p), static_cast<const uint32_t *>(c->recs.p), inv, n_games, gps, n_sh,
+                           sa.k, perm_mode ? 1u : 0u, d_rows);
+    }
     HIPCHK(c, hipGetLastError());
     return FK_OK;
 }
@@ -886,6 +908,11 @@ int fk_init(int device_ordinal, fk_ctx **out) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         bool ok = hipStreamCreateWithPriority(&c->prep_stream, hipStreamNonBlocking, least) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 2; ++i) {
+            ok = ok && hipEventCreateWithFlags(&c->ev_rows[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming) == hipSuccess;
+        }
         ok = ok && hipEventCreateWithFlags(&c->main_idle, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->err_host), 2 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
         for (auto &cs : c->sets) {
@@ -936,13 +963,21 @@ void fk_destroy(fk_ctx *c) {
     release(c->comm_buf);
     if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     for (DevBuf *b : {&c->strat, &c->recs, &c->rec0, &c->tally, &c->rows, &c->ov, &c->seatlist, &c->coords, &c->inv, &c->slow, &c->digest, &c->score_lut,
-                      &c->discard_lut, &c->blocks, &c->game_block, &c->block_out, &c->stats, &c->cold, &c->lds_tables, &c->acc})
+                      &c->discard_lut, &c->blocks, &c->game_block, &c->block_out, &c->stats, &c->cold, &c->lds_tables, &c->acc, &c->rows_alt})
         release(*b);
     for (auto &cs : c->sets) {
         for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc, &cs.pools}) release(*b);
         if (cs.ready) (void)hipEventDestroy(cs.ready);
         for (auto &e : cs.ev)
             if (e) (void)hipEventDestroy(e);
+    }
+    if (c->copy_stream) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamDestroy(c->copy_stream);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (c->ev_rows[i]) (void)hipEventDestroy(c->ev_rows[i]);
+        if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
     }
     if (c->main_idle) (void)hipEventDestroy(c->main_idle);
     if (c->err_host) (void)hipHostFree(c->err_host);
@@ -969,6 +1004,20 @@ int fk_get_device_info(fk_ctx *c, fk_device_info *out) {
     return FK_OK;
 }
 
+int fk_host_alloc(fk_ctx *c, size_t bytes, void **out) {
+    if (!c || !out) return FK_ERR_ARG;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault));
+    return FK_OK;
+}
+
+int fk_host_free(fk_ctx *c, void *p) {
+    if (!c) return FK_ERR_ARG;
+    if (p) HIPCHK(c, hipHostFree(p));
+    return FK_OK;
+}
+
 int fk_get_timing(fk_ctx *c, fk_timing *out) {
     if (!c || !out) return FK_ERR_ARG;
     *out = c->timing;
@@ -986,6 +1035,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "max_waves") c->max_waves = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8);
     else if (n == "lean") c->lean = (int32_t)value;
     else if (n == "state_store") c->gs = (int32_t)value;
+    else if (n == "rows_chunk_games") c->rows_chunk_games = std::max<int64_t>(value, 1);
     else if (n == "resident_tally") {
         c->resident = value != 0;
         c->acc_n = 0; // the next tournament call starts a fresh accumulator
@@ -1091,6 +1141,8 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
                                                                     (seat_stats ? (size_t)k * 32 : 0)); // + the exposure digests
     uint64_t chunk_sh = std::max<uint64_t>(1, (uint64_t)c->chunk_bytes / bytes_per_shuffle);
     chunk_sh = std::min<uint64_t>(chunk_sh, (uint64_t)0x7fffffff / gps);
+    if (rows) // rows mode: several chunks per call, so that the rows of chunk i cross PCIe while chunk i + 1 plays
+        chunk_sh = std::min<uint64_t>(chunk_sh, std::max<uint64_t>(1, (uint64_t)c->rows_chunk_games / gps));
     chunk_sh = std::min<uint64_t>(chunk_sh, n_sh_total);
 
     const hipEvent_t t0 = c->ev[SLOT_CALL], t1 = c->ev[SLOT_CALL + 1];
@@ -1168,8 +1220,11 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
         }
         rc = upload_overrides(c, dov);
         if (rc) return rc;
+        const int rb = (int)((done / chunk_sh) & 1u);
+        DevBuf &row_buf = rb ? c->rows_alt : c->rows;
         if (rows) {
-            rc = ensure(c, c->rows, (size_t)n_games * row_bytes);
+            if ((size_t)n_games * row_bytes > row_buf.cap) HIPCHK(c, hipStreamSynchronize(c->copy_stream)); // growing: no copy may be reading it
+            rc = ensure(c, row_buf, (size_t)n_games * row_bytes);
             if (rc) return rc;
         }
 
@@ -1289,13 +1344,19 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
             HIPCHK(c, hipGetLastError());
         }
         if (rows) {
-            rc = rows_pass(c, sa, scheduled, n_games, gps, n_sh, true, static_cast<uint8_t *>(c->rows.p));
+            // rows kernel on the main stream (behind this buffer's previous copy), the copy to the host on the copy stream: it
+            // runs beside the next chunk's game kernel.  With a pinned destination (fk_host_alloc) it is one DMA at PCIe rate.
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy[rb], 0));
+            rc = rows_pass(c, sa, scheduled, n_games, gps, n_sh, true, static_cast<uint8_t *>(row_buf.p));
             if (rc) return rc;
-            HIPCHK(c, hipMemcpyAsync(static_cast<uint8_t *>(rows) + (size_t)done * gps * row_bytes, c->rows.p,
-                                     (size_t)n_games * row_bytes, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipEventRecord(c->ev_rows[rb], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_rows[rb], 0));
+            HIPCHK(c, hipMemcpyAsync(static_cast<uint8_t *>(rows) + (size_t)done * gps * row_bytes, row_buf.p,
+                                     (size_t)n_games * row_bytes, hipMemcpyDeviceToHost, c->copy_stream));
+            HIPCHK(c, hipEventRecord(c->ev_copy[rb], c->copy_stream));
         }
     }
+    if (rows) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     const uint32_t n_rows = (uint32_t)(n_batches * (uint64_t)S);
     hipLaunchKernelGGL(fk_finalize_tally, dim3((n_rows + 255u) / 256u), dim3(256), 0, c->stream,
                        static_cast<unsigned long long *>(c->tally.p), n_rows, (uint32_t)S, shuffles_per_batch, n_sh_total, 1u);
@@ -1798,6 +1859,24 @@ int fk_coordinate_seeds(fk_ctx *c, int64_t n, const fk_coord *coords, uint32_t *
     HIPCHK(c, hipGetLastError());
     if (seed32) HIPCHK(c, hipMemcpyAsync(seed32, c->dbg[0].p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (seed64) HIPCHK(c, hipMemcpyAsync(seed64, c->dbg[1].p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FK_OK;
+}
+
+int fk_game_seeds(fk_ctx *c, uint32_t purpose, uint64_t root_seed, uint64_t k, uint64_t shuffle_begin, uint64_t n_shuffles,
+                  uint32_t games_per_shuffle, uint32_t *seed32) {
+    if (!c) return FK_ERR_ARG;
+    if (!seed32 || games_per_shuffle == 0 || n_shuffles > 0xffffffffull || n_shuffles * games_per_shuffle > ((uint64_t)1 << 33))
+        return fail(c, FK_ERR_ARG, "bad arguments");
+    if (n_shuffles == 0) return FK_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)n_shuffles * games_per_shuffle;
+    int rc = ensure(c, c->dbg[5], n * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fk_game_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, seed_prefix(purpose, root_seed, k),
+                       shuffle_begin, (uint32_t)n_shuffles, games_per_shuffle, static_cast<uint32_t *>(c->dbg[5].p));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(seed32, c->dbg[5].p, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FK_OK;
 }

@@ -1410,17 +1410,15 @@ __global__ void fk_h2h_reduce_kernel(const uint32_t *recs, uint32_t n_games, uin
 }
 
 // State store + result records -> rows (fk_row_hdr + k x fk_seat = 4 + 28k bytes, simulation.py:628-655), in game-id
-// order.  One thread per game; ranks by stable sort on score desc (engine.py:477-483).
-__global__ void fk_rows_kernel(const uint32_t *state, const uint32_t *recs, const uint32_t *inv_sched, uint32_t n_games, uint32_t gps,
-                               uint32_t n_sh, uint32_t k, uint32_t perm_mode, uint8_t *rows) {
-    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_games) return;
+// order; ranks by stable sort on score desc (engine.py:477-483).  One thread builds one row; with STAGE the rows of a block go
+// through an LDS tile (blockDim x row dwords, fk_rows_lds_bytes) and leave as whole lines: consecutive threads store
+// consecutive dwords of the block's contiguous row range (a thread writing its own 60-byte row touched 15 scattered lines
+// per wave store instruction: 1.7 ms per 10^7 k=2 rows, now HBM-write bound).
+__device__ inline void build_row(const uint32_t *state, const uint32_t *recs, const uint32_t *inv_sched, uint32_t id, uint32_t gps, uint32_t n_sh,
+                                 uint32_t k, uint32_t perm_mode, uint32_t *row) {
     const uint32_t slot = inv_sched ? inv_sched[id] : walk_slot(id, gps, n_sh, perm_mode != 0u);
-    const uint4 *r = reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
-    const uint4 q0 = r[0];
+    const uint4 q0 = *reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
     const bool completed = !(q0.x & REC_SAFETY);
-    const size_t row_bytes = sizeof(fk_row_hdr) + sizeof(fk_seat) * (size_t)k;
-    uint32_t *row = reinterpret_cast<uint32_t *>(rows + (size_t)id * row_bytes);
     // header: n_rounds u16 | status u8 | winner_seat i8
     row[0] = (q0.z & 0xffffu) | ((completed ? (uint32_t)FK_COMPLETED : (uint32_t)FK_SAFETY_LIMIT) << 16) |
              ((completed ? ((q0.x >> 24) & 0x7fu) : 0xffu) << 24);
@@ -1446,6 +1444,24 @@ __global__ void fk_rows_kernel(const uint32_t *state, const uint32_t *recs, cons
         d[5] = x[R_CD];                 // so_uses, so_dice
         d[6] = (xe & 0xffffu) | (rank << 16) | ((completed ? 0u : 1u) << 24); // hot_dice, rank, hit_max_rounds
     }
+}
+
+template <bool STAGE>
+__global__ void fk_rows_kernel(const uint32_t *state, const uint32_t *recs, const uint32_t *inv_sched, uint32_t n_games, uint32_t gps,
+                               uint32_t n_sh, uint32_t k, uint32_t perm_mode, uint8_t *rows) {
+    extern __shared__ uint32_t row_tile[];
+    const uint32_t row_dw = 1u + 7u * k; // (4 + 28 k) / 4
+    const uint32_t first = blockIdx.x * blockDim.x, id = first + threadIdx.x;
+    uint32_t *out = reinterpret_cast<uint32_t *>(rows);
+    if (!STAGE) {
+        if (id < n_games) build_row(state, recs, inv_sched, id, gps, n_sh, k, perm_mode, out + (size_t)id * row_dw);
+        return;
+    }
+    if (id < n_games) build_row(state, recs, inv_sched, id, gps, n_sh, k, perm_mode, row_tile + threadIdx.x * row_dw);
+    __syncthreads();
+    const uint32_t n_rows = min(blockDim.x, n_games - first), n_dw = n_rows * row_dw;
+    uint32_t *dst = out + (size_t)first * row_dw;
+    for (uint32_t i = threadIdx.x; i < n_dw; i += blockDim.x) dst[i] = row_tile[i];
 }
 
 // Integer sufficient statistics of ALL seats per (batch, strategy) — what the reference's unconditional all-player
@@ -1613,6 +1629,25 @@ __global__ void fk_coordinate_seed_kernel(int64_t n, const fk_coord *coords, uin
     ss_generate<2>(p, w);
     if (out32) out32[i] = w[0];
     if (out64) out64[i] = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+}
+
+// ns-102 game fingerprints of a shuffle range (the game_seed column of the row contract, run_tournament.py:340-350):
+// out[(shuffle - shuffle0) * gps + g] = generate_state(1, uint32)[0] of coordinate (purpose, root, k, shuffle, game_index = g)
+__global__ void fk_game_seed_kernel(SeedPool prefix, uint64_t shuffle0, uint32_t n_sh, uint32_t gps, uint32_t *out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n_sh * gps) return;
+    const uint32_t sh = (uint32_t)(t / gps), g = (uint32_t)(t - (size_t)sh * gps);
+    SeedPool p = prefix; // entropy words 0..5: version, namespace, root, k
+    p.hc = HC_AFTER_6_WORDS;
+    ss_absorb64(p, shuffle0 + sh);
+    ss_absorb64(p, 0); // pair_id
+    ss_absorb64(p, 0); // order
+    ss_absorb64(p, g); // game_index
+    ss_absorb64(p, 0); // seat_index
+    ss_absorb64(p, 0); // replicate_index
+    uint32_t w[1];
+    ss_generate<1>(p, w);
+    out[t] = w[0];
 }
 
 __global__ void fk_dbg_continue_kernel(int64_t n, const int32_t *args, const uint2 *strat, int32_t *out) {

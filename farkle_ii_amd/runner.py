@@ -46,7 +46,7 @@ from .workload_planner import TournamentWorkloadPlan, WorkloadCapExceeded, plan_
 
 LOGGER = logging.getLogger(__name__)
 MAX_GAMES_PER_LAUNCH = 200_000_000  # checkpoint cadence on the GPU: a launch group is at most this many games
-ROW_WRITER_THREADS = max(1, min(16, (os.cpu_count() or 1)))  # row-shard writers (rows mode)
+ROW_WRITER_THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))  # row-shard writer PROCESSES (rows mode)
 
 
 def _rank_world() -> tuple[int, int]:
@@ -351,6 +351,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
     gps = S // k
     group_batches = max(1, MAX_GAMES_PER_LAUNCH // max(spb * gps, 1))
     want_rows = row_dir is not None
+    pinned_rows = None
     t_start = time.perf_counter()
     games_done = 0
 
@@ -387,9 +388,19 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                                                batch_size=spb)
                 if hi2 > lo2:
                     eng.hint_next(lo2, hi2, need_state=want_rows)
+            extra: dict[str, Any] = {"want_seat_stats": True} if all_player_dir is not None else {}
+            if want_rows and hasattr(eng, "pinned_empty"):
+                # rows land in a page-locked buffer (one per run, sized for the largest launch group): one DMA per chunk at PCIe
+                # rate, under the next chunk's game kernel
+                need = (hi - lo) * gps
+                if pinned_rows is None or len(pinned_rows) < need:
+                    from .backend import row_dtype
+
+                    pinned_rows = None
+                    pinned_rows = eng.pinned_empty(need, row_dtype(k))
+                extra["rows_out"] = pinned_rows
             res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=spb if per_batch else hi - lo,
-                                 target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows,
-                                 **({"want_seat_stats": True} if all_player_dir is not None else {}))
+                                 target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows, **extra)
             first = lo // spb - b0 if per_batch else 0
             local[first:first + len(res["tally"])] = res["tally"]
             if local_stats is not None:
@@ -399,7 +410,10 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 sha = oracle_game_profile.sha256 if oracle_game_profile else None
                 # one parquet file per shuffle is the reference's format: the host side of rows mode is Arrow encoding and
                 # file creation — one vectorised conversion per 1 024 shuffles, shards written by a small thread pool
-                row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS))
+                seeds102 = (eng.game_seeds(int(urandom.RandomPurpose.TOURNAMENT_GAME), cfg.sim.seed, k, lo, hi, gps)
+                            if hasattr(eng, "game_seeds") else None)  # the rows' game_seed column, hashed on the device
+                row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
+                                                       game_seeds=seeds102))
         group = reduce_tally(local, dst=0)
         group_stats = reduce_tally(local_stats, dst=0) if local_stats is not None else None  # integer sums, like the tally
         if want_rows and world > 1:

@@ -322,76 +322,104 @@ def write_row_shard(row_dir: Path, manifest_path: Path | None, task: ShuffleTask
     return (out, record) if return_record else out
 
 
-def write_row_shards(row_dir: Path, tasks: Sequence[ShuffleTask], rows: np.ndarray, ids: Sequence[int],
-                     game_profile_sha256: str | None = None, *, threads: int = 1, group: int = 1024) -> list[dict]:
-    """Row shards of many shuffles of one (root, k) cell: the same files and manifest records as ``write_row_shard`` per
-    shuffle (run_tournament.py:530-558), but the Arrow conversion runs once per ``group`` shuffles (vectorised over all their
-    rows) and every shard is a zero-copy slice of that table, written by a small thread pool (pyarrow encodes and writes
-    outside the GIL).  Returns the manifest records in task order; the caller appends them."""
+def _shard_record(name: str, gps: int, root_seed: int, k: int, shuffle_index: int, shuffle_seed: int, batch_id: int, pid: int,
+                  game_profile_sha256: str | None) -> dict:
+    record = {"path": name, "rows": gps, "root_seed": root_seed, "n_players": k, "shuffle_index": shuffle_index,
+              "shuffle_seed": shuffle_seed, "deterministic_batch_id": batch_id, "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
+              "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
+              "outcome_schema_version": OUTCOME_SCHEMA_VERSION, "tournament_method_version": TOURNAMENT_METHOD_VERSION, "pid": pid}
+    if game_profile_sha256 is not None:  # run_tournament.py:549-553
+        record["game_profile_sha256"] = game_profile_sha256
+    return record
+
+
+def _write_shard_group(row_dir: str, k: int, ids: np.ndarray, gps: int, root_seed: int, rows: np.ndarray, shuffle_index: np.ndarray,
+                       shuffle_seed: np.ndarray, batch_id: np.ndarray, game_seeds: np.ndarray | None,
+                       game_profile_sha256: str | None) -> list[dict]:
+    """Shards of a run of shuffles (rows = their games, shuffle-major): one vectorised Arrow conversion, then one parquet
+    file per shuffle — a zero-copy slice of that table (run_tournament.py:530-558).  Runs in a writer process or inline."""
     import os
 
     import pyarrow.parquet as pq
 
+    n_sh = len(shuffle_index)
+    sh = np.repeat(shuffle_index.astype(np.uint64), gps)
+    gi = np.tile(np.arange(gps, dtype=np.uint64), n_sh)
+    if game_seeds is None:
+        game_seeds = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=root_seed, k=k, shuffle_index=sh,
+                                              game_index=gi, dtype=np.uint32)
+    table = rows_to_table(rows, k, ids, root_seed=root_seed, shuffle_index=sh.astype(np.int64), game_index=gi.astype(np.int32),
+                          deterministic_batch_id=np.repeat(batch_id.astype(np.int32), gps),
+                          shuffle_seed=np.repeat(shuffle_seed.astype(np.int64), gps),
+                          game_seed=np.asarray(game_seeds).reshape(-1).astype(np.int64),
+                          rng_purpose_namespace=int(urandom.RandomPurpose.TOURNAMENT_GAME))
+    pid = os.getpid()
+    records = []
+    for i in range(n_sh):
+        name = f"rows_{root_seed}_{k}p_{int(shuffle_index[i]):012d}.parquet"
+        out = os.path.join(row_dir, name)
+        # a 32-row file: column statistics and dictionary pages are a third of its encoding time and nobody prunes on them
+        pq.write_table(table.slice(i * gps, gps), out + ".tmp", write_statistics=False, use_dictionary=False)
+        os.replace(out + ".tmp", out)
+        records.append(_shard_record(name, gps, root_seed, k, int(shuffle_index[i]), int(shuffle_seed[i]), int(batch_id[i]), pid,
+                                     game_profile_sha256))
+    return records
+
+
+def _shard_worker_init() -> None:
+    import pyarrow as pa
+
+    pa.set_cpu_count(1)  # 32-row files: Arrow's per-column pool only adds contention (3.1 ms per shard with it, 0.9 ms without)
+    pa.set_io_thread_count(1)
+
+
+_SHARD_POOL = None
+
+
+def _shard_pool(workers: int):
+    """The run's row-shard writer processes (shard_writer.py), started on first use."""
+    global _SHARD_POOL
+    if _SHARD_POOL is None or _SHARD_POOL[1] != workers:
+        import atexit
+
+        from .shard_writer import ShardWriters
+
+        if _SHARD_POOL is not None:
+            _SHARD_POOL[0].close()
+        pool = ShardWriters(workers)
+        atexit.register(pool.close)
+        _SHARD_POOL = (pool, workers)
+    return _SHARD_POOL[0]
+
+
+def write_row_shards(row_dir: Path, tasks: Sequence[ShuffleTask], rows: np.ndarray, ids: Sequence[int],
+                     game_profile_sha256: str | None = None, *, threads: int = 1, group: int = 64,
+                     game_seeds: np.ndarray | None = None) -> list[dict]:
+    """Row shards of many shuffles of one (root, k) cell: the same files and manifest records as ``write_row_shard`` per
+    shuffle (run_tournament.py:530-558).  The shuffles are cut into runs of ``group``; each run is converted to Arrow once and
+    written shard by shard, by ``threads`` writer processes (``threads`` <= 1: inline).  ``game_seeds``: the ns-102
+    fingerprints ``[n_shuffles][gps]`` when the caller has them (``Engine.game_seeds``), else they are hashed here.
+    Returns the manifest records in task order; the caller appends them."""
     if not tasks:
         return []
-    k = tasks[0].k
+    k, root = tasks[0].k, tasks[0].root_seed
     gps = len(rows) // len(tasks)
     row_dir.mkdir(parents=True, exist_ok=True)
-    pid = os.getpid()
-    records: list[dict] = []
-
-    def write_one(item):
-        table, task = item
-        out = row_dir / f"rows_{task.root_seed}_{task.k}p_{task.shuffle_index:012d}.parquet"
-        tmp = out.with_suffix(".parquet.tmp")
-        pq.write_table(table, tmp)
-        os.replace(tmp, out)
-        record = {"path": out.name, "rows": gps, "root_seed": task.root_seed, "n_players": task.k,
-                  "shuffle_index": task.shuffle_index, "shuffle_seed": task.shuffle_seed,
-                  "deterministic_batch_id": task.deterministic_batch_id, "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
-                  "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
-                  "outcome_schema_version": OUTCOME_SCHEMA_VERSION, "tournament_method_version": TOURNAMENT_METHOD_VERSION,
-                  "pid": pid}
-        if game_profile_sha256 is not None:  # run_tournament.py:549-553
-            record["game_profile_sha256"] = game_profile_sha256
-        return record
-
-    pool = None
-    arrow_threads = None
-    if threads > 1:
-        from concurrent.futures import ThreadPoolExecutor
-
-        import pyarrow as pa
-
-        pool = ThreadPoolExecutor(max_workers=threads)
-        # 32-row files: Arrow's own per-column thread pool only adds contention under several writer threads
-        # (measured: 3.1 ms per shard with it, 0.9 ms without, 8 writers)
-        arrow_threads = pa.cpu_count()
-        pa.set_cpu_count(1)
-    try:
-        for g0 in range(0, len(tasks), group):
-            part = tasks[g0:g0 + group]
-            n = len(part) * gps
-            sh = np.repeat(np.array([t.shuffle_index for t in part], dtype=np.uint64), gps)
-            gi = np.tile(np.arange(gps, dtype=np.uint64), len(part))
-            game_seeds = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=part[0].root_seed, k=k,
-                                                  shuffle_index=sh, game_index=gi, dtype=np.uint32)
-            table = rows_to_table(rows[g0 * gps:g0 * gps + n], k, ids, root_seed=part[0].root_seed, shuffle_index=sh.astype(np.int64),
-                                  game_index=gi.astype(np.int32),
-                                  deterministic_batch_id=np.repeat(np.array([t.deterministic_batch_id for t in part], dtype=np.int32), gps),
-                                  shuffle_seed=np.repeat(np.array([t.shuffle_seed for t in part], dtype=np.int64), gps),
-                                  game_seed=game_seeds.astype(np.int64),
-                                  rng_purpose_namespace=int(urandom.RandomPurpose.TOURNAMENT_GAME))
-            items = [(table.slice(i * gps, gps), t) for i, t in enumerate(part)]
-            records.extend(pool.map(write_one, items) if pool else map(write_one, items))
-    finally:
-        if pool:
-            pool.shutdown()
-        if arrow_threads is not None:
-            import pyarrow as pa
-
-            pa.set_cpu_count(arrow_threads)
-    return records
+    ids = np.asarray(ids, dtype=np.int32)
+    sh = np.array([t.shuffle_index for t in tasks], dtype=np.int64)
+    seeds = np.array([t.shuffle_seed for t in tasks], dtype=np.int64)
+    batch = np.array([t.deterministic_batch_id for t in tasks], dtype=np.int32)
+    gs = None if game_seeds is None else np.asarray(game_seeds).reshape(len(tasks), gps)
+    jobs = []
+    for g0 in range(0, len(tasks), group):
+        g1 = min(g0 + group, len(tasks))
+        jobs.append((str(row_dir), k, ids, gps, root, rows[g0 * gps:g1 * gps], sh[g0:g1], seeds[g0:g1], batch[g0:g1],
+                     None if gs is None else gs[g0:g1], game_profile_sha256))
+    if threads > 1 and len(jobs) > 1:
+        parts = _shard_pool(threads).map(jobs)
+    else:
+        parts = [_write_shard_group(*job) for job in jobs]
+    return [r for part in parts for r in part]
 
 
 def shuffle_tasks(root_seed: int, k: int, shuffle_begin: int, shuffle_end: int, deterministic_batch_size: int) -> list[ShuffleTask]:

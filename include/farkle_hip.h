@@ -122,6 +122,11 @@ void fk_destroy(fk_ctx *ctx);
 const char *fk_last_error(fk_ctx *ctx);
 int fk_get_device_info(fk_ctx *ctx, fk_device_info *out);
 int fk_get_timing(fk_ctx *ctx, fk_timing *out);
+/* Page-locked host memory for the caller-owned output buffers (rows above all: 60 bytes per k=2 game).  A buffer from here is
+ * copied to by one DMA per chunk at PCIe rate, while the next chunk plays; any other host pointer works too (staged by the HIP
+ * runtime, about a third of the rate, the host thread waits).  Free with fk_host_free before fk_destroy. */
+int fk_host_alloc(fk_ctx *ctx, size_t bytes, void **out);
+int fk_host_free(fk_ctx *ctx, void *p);
 /* Tunables: "chunk_bytes" (device workspace budget per chunk), "batch_threshold" (lanes that must be waiting
  * before a wave runs its game hand-over), "use_lds_tally" (0/1/-1 auto), "block" (0 auto), "lean" (seat-record layout:
  * -1 auto, 0 full, 1 lean), "state_store" (-1 auto: seat records live in the HBM state store, with only the turn owner's staged in LDS, when
@@ -230,6 +235,11 @@ int fk_comm_destroy(fk_ctx *ctx);
  * (namespace 102) columns of rows and manifests (run_tournament.py:318-351), the per-game seed of
  * simulate_many_games (namespace 1, simulation.py:700-713). */
 int fk_coordinate_seeds(fk_ctx *ctx, int64_t n, const fk_coord *coords, uint32_t *seed32, uint64_t *seed64);
+/* The same uint32 fingerprints for the games of a shuffle range without a coordinate list: seed32[(s - shuffle_begin) * gps + g] =
+ * coordinate_seed(purpose, root_seed, k, shuffle_index = s, game_index = g) — the game_seed column of the row contract
+ * (run_tournament.py:340-350; purpose 102 for tournaments). */
+int fk_game_seeds(fk_ctx *ctx, uint32_t purpose, uint64_t root_seed, uint64_t k, uint64_t shuffle_begin, uint64_t n_shuffles,
+                  uint32_t games_per_shuffle, uint32_t *seed32);
 
 /* ---- single-op probes of the device functions (parity tests) ---- */
 /* n rolls: roll i scores faces[i*6 .. i*6+len[i]) for strategy[i] with turn_score_pre[i];

@@ -247,6 +247,31 @@ def test_rccl_tally_reduce_through_the_c_abi_single_rank(eng):
     assert eng.tournament(table, 2, 42, 0, 4)["tally"].sum() > 0
 
 
+def test_rows_leave_in_overlapped_chunks_into_pageable_and_pinned_buffers(eng, po):
+    """Rows mode plays in several chunks per call; the rows of chunk i cross PCIe on a copy stream (two device row buffers)
+    while chunk i + 1 plays, into a caller buffer that may be page-locked (Engine.pinned_empty -> fk_host_alloc) or not.  Rows,
+    tallies and all-seat statistics equal the oracle's whatever the chunking; k = 2 / 3 / 8 cover the staged row kernel's tile
+    shapes."""
+    from farkle_ii_amd.backend import row_dtype
+
+    try:
+        for k, S, n_sh, chunk in [(2, 96, 70, 300), (3, 96, 33, 64), (8, 96, 21, 50), (2, 96, 9, 10**9)]:
+            table = _random_valid_table(S, 40 + k)
+            ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 3, 5, 5 + n_sh, shuffles_per_batch=7, want_rows=True, n_threads=8)
+            eng.set_option("rows_chunk_games", chunk)
+            got = eng.tournament(table, k, 3, 5, 5 + n_sh, shuffles_per_batch=7, want_rows=True, want_seat_stats=True)
+            assert got["rows"].tobytes() == ref["rows"].tobytes() and np.array_equal(got["tally"], ref["tally"]), (k, chunk)
+            pinned = eng.pinned_empty(n_sh * (S // k) + 5, row_dtype(k))
+            pinned[:] = np.zeros(1, dtype=row_dtype(k))[0]
+            again = eng.tournament(table, k, 3, 5, 5 + n_sh, shuffles_per_batch=7, want_rows=True, want_seat_stats=True, rows_out=pinned)
+            assert again["rows"].tobytes() == ref["rows"].tobytes() and np.array_equal(again["seat_stats"], got["seat_stats"]), (k, chunk)
+            assert np.shares_memory(again["rows"], pinned)
+            with pytest.raises(ValueError, match="rows_out"):
+                eng.tournament(table, k, 3, 5, 5 + n_sh, want_rows=True, rows_out=pinned[:3])
+    finally:
+        eng.set_option("rows_chunk_games", 4_000_000)
+
+
 def test_resident_tally_accumulates_on_the_device_and_reduces_through_rccl(eng):
     """Option resident_tally: every tournament call adds its tally to an accumulator in HBM; fk_tally_resident_reduce sums it
     over the communicator on the device (here: none, then a one-rank RCCL communicator), returns it on the root and clears it."""

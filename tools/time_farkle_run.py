@@ -14,7 +14,7 @@ from farkle_ii_amd.engine import get_engine
 ROOT = Path(__file__).resolve().parent.parent
 rows_shuffles = int(sys.argv[1]) if len(sys.argv) > 1 else 6400
 base = yaml.safe_load((ROOT / "configs" / "bench_config2.yaml").read_text())
-eng = get_engine()
+eng = get_engine()  # (module-level script: the row-shard writers are separate `python -m farkle_ii_amd.shard_writer` processes, not forks of this one)
 acc = {"engine_s": 0.0, "shard_s": 0.0, "calls": 0}
 real_t, real_w = eng.tournament, rt.write_row_shards
 
