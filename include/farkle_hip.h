@@ -27,6 +27,7 @@
 #ifndef FARKLE_HIP_H
 #define FARKLE_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
