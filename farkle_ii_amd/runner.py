@@ -359,7 +359,10 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         wins, sums, sqs = rt.tally_to_counters(total, ids, k, dense=metric_chunk_dir is not None)
         completed = sorted(done_batches)
         # process blocks are numbered from 1 (run_tournament.py:1576-1586); one block = one deterministic batch here
-        ck_meta = {**meta, "completed_shuffle_indices": [s for b in completed for s in range(b * spb, min((b + 1) * spb, plan.required_shuffles))],
+        shuffle_list: list[int] = []
+        for b in completed:  # (extend by ranges: 312 500 indices are a list comprehension's 20 ms otherwise)
+            shuffle_list.extend(range(b * spb, min((b + 1) * spb, plan.required_shuffles)))
+        ck_meta = {**meta, "completed_shuffle_indices": shuffle_list,
                    "completed_process_block_indices": [b + 1 for b in completed], "complete": final}
         _atomic_write_bytes(checkpoint_path, ckpt.dump_checkpoint(wins, sums if collect_metrics else None,
                                                                   sqs if collect_metrics else None, ck_meta))
@@ -461,7 +464,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             if not per_batch:
                 total += group[0]
             games_done += (min(b1 * spb, plan.required_shuffles) - b0 * spb) * gps
-            save(final=False)  # the checkpoint that owns the manifest lines just appended
+            if j + 1 < len(pending):
+                save(final=False)  # the checkpoint that owns the manifest lines just appended (the last group's is the final one below)
             LOGGER.info("Batches %d..%d done: %.3g games/s so far", b0, b1 - 1,
                         games_done / max(time.perf_counter() - t_start, 1e-9))
         i = j + 1

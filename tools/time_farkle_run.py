@@ -64,7 +64,7 @@ with tempfile.TemporaryDirectory(prefix="fk_e2e_") as tmp:
 r = out["runs"]
 out["host_bottleneck"] = ("rows on: one parquet file + one manifest line per shuffle of 32 games (the reference's row-shard format, "
                           "run_tournament.py:530-558): %.2f ms of host wall time per shard, %.2f ms of it Arrow conversion (one per 1 024 "
-                          "shuffles) + parquet encoding + file creation on %d writer threads, against %.4f ms of engine time per shuffle"
+                          "shuffles) + parquet encoding + file creation on %d writer processes, against %.4f ms of engine time per shuffle"
                           % (1e3 * r["rows_on"]["host_s"] / r["rows_on"]["shuffles"],
                              1e3 * r["rows_on"]["row_shard_write_s"] / r["rows_on"]["shuffles"], runner.ROW_WRITER_THREADS,
                              1e3 * r["rows_on"]["engine_s"] / r["rows_on"]["shuffles"]))
