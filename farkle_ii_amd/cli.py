@@ -33,6 +33,8 @@ def build_parser() -> argparse.ArgumentParser:
     run.add_argument("--all-player-batches", nargs="?", const=Path("all_player_batches"), type=Path, default=None, metavar="DIR",
                      help="Write the unconditional all-player batch metrics (integer columns of the reference's "
                           "all_player_batch_schema) per deterministic batch, from device accumulators, without rows")
+    run.add_argument("--sidecars", action="store_true",
+                     help="Write <artifact>.sidecar.json (producer contract + SHA-256 / size of the artifact) beside every output")
     run.add_argument("--force", action="store_true", help="Recompute even when existing run artifacts are available")
     t = sub.add_parser("time", help="Benchmark simulation throughput")
     t.add_argument("--players", type=int, default=5, help="Players per game (default: 5)")
@@ -82,6 +84,8 @@ def main(argv: Sequence[str] | None = None) -> None:
         cfg.sim.expanded_metrics = True
     if args.row_dir is not None:
         cfg.sim.row_dir = args.row_dir
+    if args.sidecars:
+        cfg.sim.sidecars = True
     if args.all_player_batches is not None:
         cfg.sim.all_player_batch_dir = args.all_player_batches
     _maybe_init_distributed()

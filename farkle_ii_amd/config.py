@@ -60,6 +60,7 @@ class SimConfig:
     expanded_metrics: bool = False
     row_dir: Path | None = None
     metric_chunk_dir: Path | None = None
+    sidecars: bool = False  # this engine's option: per-artifact <name>.sidecar.json (sidecars.py; contract version 2)
     all_player_batch_dir: Path | None = None  # this engine's option: all-player batch metrics without rows (all_player.py)
     per_n: dict = field(default_factory=dict)
     n_jobs: int | None = None

@@ -180,6 +180,27 @@ def _shuffle_seeds(eng, root_seed: int, k: int, first: int, last: int) -> np.nda
     return urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_SHUFFLE, root_seed=root_seed, k=k, shuffle_index=idx, dtype=np.uint32)
 
 
+class _Sidecars:
+    """Sidecar templates of one (root, k) run (sidecars.py; reference: runner.py:1470-1505) — or a no-op when they are off."""
+
+    def __init__(self, cfg: AppConfig, n_players: int, sources: Sequence[Path], enabled: bool):
+        self.cfg, self.k, self.sources, self.enabled = cfg, n_players, list(sources), enabled
+
+    def template(self, kind: str, path: Path, *, sources: Sequence[Path] | None = None, support_counts: Sequence[int] | None = None):
+        if not self.enabled:
+            return None
+        from .sidecars import OPERATIONS, simulation_output_sidecar
+
+        return simulation_output_sidecar(self.cfg, path, n_players=self.k, operation=OPERATIONS[kind],
+                                         sources=self.sources if sources is None else sources, support_counts=support_counts)
+
+    def write(self, kind: str, path: Path, **kw) -> None:
+        if self.enabled and Path(path).exists():
+            from .sidecars import write_sidecar
+
+            write_sidecar(path, self.template(kind, path, **kw))
+
+
 def _read_manifest(path: Path) -> list[dict]:
     if not path.exists():
         return []
@@ -268,11 +289,12 @@ def _check_ownership(total: np.ndarray, done_batches: set[int], spb: int, requir
 def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[ThresholdStrategy], plan: TournamentWorkloadPlan,
                    checkpoint_path: Path, collect_metrics: bool, row_dir: Path | None, metric_chunk_dir: Path | None,
                    resume: bool, checkpoint_metadata: Mapping[str, Any], oracle_game_profile: GameProfile | None = None,
-                   all_player_dir: Path | None = None) -> dict:
+                   all_player_dir: Path | None = None, sidecars: "_Sidecars | None" = None) -> dict:
     """Play every deterministic batch not yet owned by the checkpoint and persist the aggregates."""
     rank, world = _rank_world()
     eng = get_engine()
     k = n_players
+    sidecars = sidecars or _Sidecars(cfg, n_players, (), False)
     S = len(strategies)
     ids = [int(s.strategy_id) for s in strategies]
     spb = plan.shuffles_per_batch
@@ -416,7 +438,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 seeds102 = (eng.game_seeds(int(urandom.RandomPurpose.TOURNAMENT_GAME), cfg.sim.seed, k, lo, hi, gps)
                             if hasattr(eng, "game_seeds") else None)  # the rows' game_seed column, hashed on the device
                 row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
-                                                       game_seeds=seeds102))
+                                                       game_seeds=seeds102,
+                                                       sidecar=sidecars.template("row_shard", row_dir / "rows_template.parquet")))
         group = reduce_tally(local, dst=0)
         group_stats = reduce_tally(local_stats, dst=0) if local_stats is not None else None  # integer sums, like the tally
         if want_rows and world > 1:
@@ -441,6 +464,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                     chunk = _metric_chunk_table(group[n], ids, k)
                     name = f"metrics_{b + 1:06d}.parquet"  # chunk / process-block indices count from 1 (run_tournament.py:1603-1642)
                     _write_parquet_atomic(chunk, metric_chunk_dir / name)
+                    sidecars.write("metric_chunk", metric_chunk_dir / name)
                     first_sh, last_sh = b * spb, min((b + 1) * spb, plan.required_shuffles)
                     record = {"path": name, "rows": chunk.num_rows, "chunk_index": b + 1, "process_block_index": b + 1,
                               "root_seed": cfg.sim.seed, "n_players": k, "deterministic_batch_id": b,
@@ -471,6 +495,10 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         i = j + 1
     if rank == 0:
         save(final=True)
+        sidecars.write("checkpoint", checkpoint_path)
+        for manifest in (row_manifest, metrics_manifest):  # the manifests are final now: their sidecars bind the complete files
+            if manifest is not None:
+                sidecars.write("shard_manifest", manifest)
     barrier()
     return {"tally": total, "games": games_done, "seconds": time.perf_counter() - t_start}
 
@@ -505,10 +533,11 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         if force:
             for path in (ckpt_path, n_dir / f"{n}p_checkpoint.parquet", cfg.metrics_path(n), simulation_done_path(cfg, n)):
                 path.unlink(missing_ok=True)
+                path.with_name(path.name + ".sidecar.json").unlink(missing_ok=True)
             for d in (row_dir, metric_chunk_dir, all_player_dir):
                 if d is not None and d.exists():
                     for f in d.iterdir():
-                        if f.suffix in {".parquet", ".jsonl", ".tmp"}:
+                        if f.suffix in {".parquet", ".jsonl", ".tmp", ".json"}:  # (.json: the sidecars of a previous run)
                             f.unlink()
         manifest_path = cfg.strategy_manifest_root_path()
         table = pa.Table.from_pandas(manifest, preserve_index=False)
@@ -520,6 +549,11 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         else:
             _write_parquet_atomic(table, manifest_path)
         write_workload_plan(plan_path, plan)
+    sidecars = _Sidecars(cfg, n, [cfg.strategy_manifest_root_path(), plan_path], bool(cfg.sim.sidecars))
+    if rank == 0:
+        sidecars.write("strategy_manifest", cfg.strategy_manifest_root_path(), sources=(),
+                       support_counts=sorted({int(v) for v in cfg.sim.n_players_list}))
+        sidecars.write("workload_plan", plan_path, sources=[cfg.strategy_manifest_root_path()])
     for d in (row_dir, metric_chunk_dir, all_player_dir):
         if d is not None:
             d.mkdir(parents=True, exist_ok=True)
@@ -527,7 +561,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
     result = run_tournament(cfg=cfg, n_players=n, strategies=strategies, plan=plan, checkpoint_path=ckpt_path,
                             collect_metrics=cfg.sim.expanded_metrics, row_dir=row_dir, metric_chunk_dir=metric_chunk_dir,
                             resume=not force, checkpoint_metadata={"strategy_manifest_sha": manifest_sha},
-                            oracle_game_profile=oracle_game_profile, all_player_dir=all_player_dir)
+                            oracle_game_profile=oracle_game_profile, all_player_dir=all_player_dir, sidecars=sidecars)
     if rank != 0:
         return plan.required_games
     ids = [int(s.strategy_id) for s in strategies]
@@ -566,8 +600,10 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
             metrics_rows.append(base)
     if summary:
         _write_parquet_atomic(pa.Table.from_pylist(summary), n_dir / f"{n}p_checkpoint.parquet")
+        sidecars.write("checkpoint_summary", n_dir / f"{n}p_checkpoint.parquet", sources=[ckpt_path])
     if metrics_rows:
         _write_parquet_atomic(pa.Table.from_pylist(metrics_rows), cfg.metrics_path(n))
+        sidecars.write("metrics_summary", cfg.metrics_path(n), sources=[ckpt_path])
     done = {"stage": "simulation", "status": "success", "engine": "farkle_ii_amd/hip-gfx950",
             "metadata": {"n_players": n, "seed": cfg.sim.seed, "root_seed": cfg.sim.seed, "k": n,
                          "num_shuffles": plan.required_shuffles, "shuffle_index_start": 0,

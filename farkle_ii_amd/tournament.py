@@ -249,9 +249,9 @@ def _run_chunk_metrics(shuffle_tasks: Sequence[ShuffleTask | int], *, collect_ro
                        row_dir: Path | None = None, manifest_path: Path | None = None, row_sidecar: Any = None):
     """Play shuffles and accumulate metrics: (wins, sums, square_sums).  With ``collect_rows`` and ``row_dir``
     one ``rows_{root}_{k}p_{shuffle:012d}.parquet`` shard per shuffle is written and recorded in ``manifest.jsonl``
-    (run_tournament.py:530-558; v3 sidecars are out of scope, ``row_sidecar`` must be None)."""
-    if row_sidecar is not None:
-        raise NotImplementedError("v3 artifact sidecars are outside this engine's scope")
+    (run_tournament.py:530-558).  ``row_sidecar``: a sidecar template (``sidecars.simulation_output_sidecar``, the
+    counterpart of the reference's ``_simulation_output_sidecar`` object, run_tournament.py:557): every shard then gets its
+    ``<shard>.sidecar.json`` bound to the shard's bytes (contract version 2; see sidecars.py for what is not built)."""
     tasks = [_coerce_shuffle_task(t) for t in shuffle_tasks]
     state = _STATE
     ids = [int(s.strategy_id) for s in state.strats]  # type: ignore[union-attr]
@@ -269,8 +269,12 @@ def _run_chunk_metrics(shuffle_tasks: Sequence[ShuffleTask | int], *, collect_ro
         if row_dir is not None and collect_rows:
             gps = len(res["rows"]) // len(group)
             for n, task in enumerate(group):
-                write_row_shard(Path(row_dir), manifest_path, task, res["rows"][n * gps:(n + 1) * gps], ids,
-                                game_profile_sha256=state.game_profile.sha256 if state.game_profile else None)  # :549-553
+                shard = write_row_shard(Path(row_dir), manifest_path, task, res["rows"][n * gps:(n + 1) * gps], ids,
+                                        game_profile_sha256=state.game_profile.sha256 if state.game_profile else None)  # :549-553
+                if row_sidecar is not None:
+                    from .sidecars import write_sidecar
+
+                    write_sidecar(shard, row_sidecar)
     return wins_total, sums_total, sq_total
 
 
@@ -335,7 +339,7 @@ def _shard_record(name: str, gps: int, root_seed: int, k: int, shuffle_index: in
 
 def _write_shard_group(row_dir: str, k: int, ids: np.ndarray, gps: int, root_seed: int, rows: np.ndarray, shuffle_index: np.ndarray,
                        shuffle_seed: np.ndarray, batch_id: np.ndarray, game_seeds: np.ndarray | None,
-                       game_profile_sha256: str | None) -> list[dict]:
+                       game_profile_sha256: str | None, sidecar: Mapping[str, Any] | None = None) -> list[dict]:
     """Shards of a run of shuffles (rows = their games, shuffle-major): one vectorised Arrow conversion, then one parquet
     file per shuffle — a zero-copy slice of that table (run_tournament.py:530-558).  Runs in a writer process or inline."""
     import os
@@ -361,6 +365,10 @@ def _write_shard_group(row_dir: str, k: int, ids: np.ndarray, gps: int, root_see
         # a 32-row file: column statistics and dictionary pages are a third of its encoding time and nobody prunes on them
         pq.write_table(table.slice(i * gps, gps), out + ".tmp", write_statistics=False, use_dictionary=False)
         os.replace(out + ".tmp", out)
+        if sidecar is not None:
+            from .sidecars import write_sidecar
+
+            write_sidecar(out, sidecar)
         records.append(_shard_record(name, gps, root_seed, k, int(shuffle_index[i]), int(shuffle_seed[i]), int(batch_id[i]), pid,
                                      game_profile_sha256))
     return records
@@ -394,7 +402,7 @@ def _shard_pool(workers: int):
 
 def write_row_shards(row_dir: Path, tasks: Sequence[ShuffleTask], rows: np.ndarray, ids: Sequence[int],
                      game_profile_sha256: str | None = None, *, threads: int = 1, group: int = 64,
-                     game_seeds: np.ndarray | None = None) -> list[dict]:
+                     game_seeds: np.ndarray | None = None, sidecar: Mapping[str, Any] | None = None) -> list[dict]:
     """Row shards of many shuffles of one (root, k) cell: the same files and manifest records as ``write_row_shard`` per
     shuffle (run_tournament.py:530-558).  The shuffles are cut into runs of ``group``; each run is converted to Arrow once and
     written shard by shard, by ``threads`` writer processes (``threads`` <= 1: inline).  ``game_seeds``: the ns-102
@@ -414,7 +422,7 @@ def write_row_shards(row_dir: Path, tasks: Sequence[ShuffleTask], rows: np.ndarr
     for g0 in range(0, len(tasks), group):
         g1 = min(g0 + group, len(tasks))
         jobs.append((str(row_dir), k, ids, gps, root, rows[g0 * gps:g1 * gps], sh[g0:g1], seeds[g0:g1], batch[g0:g1],
-                     None if gs is None else gs[g0:g1], game_profile_sha256))
+                     None if gs is None else gs[g0:g1], game_profile_sha256, sidecar))
     if threads > 1 and len(jobs) > 1:
         parts = _shard_pool(threads).map(jobs)
     else:

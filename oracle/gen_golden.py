@@ -505,6 +505,57 @@ def gen_all_player():
     _dump({"cases": cases}, open(OUT / "all_player_vectors.json", "w"))
 
 
+def gen_sidecars():
+    """The reference's simulation sidecar payloads (`_simulation_output_sidecar`, runner.py:338-376, canonical JSON) for every
+    operation it publishes, and — the acceptance check — sidecars written by THIS engine's farkle_ii_amd/sidecars.py run through
+    the reference's own `load_artifact_sidecar` + `validate_artifact_sidecar` (artifact_contract.py:607-668): the fixture is only
+    written when the reference accepts them and rejects a tampered artifact."""
+    import shutil
+    import tempfile
+
+    from farkle.config import AppConfig
+    from farkle.simulation import runner
+    from farkle.utils import artifact_contract as ac
+
+    sys.path.insert(0, str(HERE.parent))
+    from farkle_ii_amd import sidecars as mine
+    from farkle_ii_amd.config import AppConfig as MyConfig
+
+    cfg = AppConfig()
+    sources = [Path("results_seed_0/strategy_manifest.parquet"), Path("results_seed_0/2_players/simulation_workload_plan.json")]
+    payloads = {}
+    for kind, operation in mine.OPERATIONS.items():
+        sc = runner._simulation_output_sidecar(cfg, Path(f"out/{kind}.bin"), n_players=2, operation=operation,
+                                               sources=() if kind == "strategy_manifest" else sources,
+                                               support_counts=[2, 4] if kind == "strategy_manifest" else None)
+        payloads[kind] = json.loads(ac._canonical_json(sc))
+    tmp = Path(tempfile.mkdtemp(prefix="fk_sidecar_"))
+    accepted = []
+    try:
+        for kind, operation in mine.OPERATIONS.items():
+            art = tmp / f"{kind}.parquet"
+            art.write_bytes(f"artifact bytes of {kind}".encode() * 7)
+            template = mine.simulation_output_sidecar(MyConfig(), art, n_players=2, operation=operation,
+                                                      sources=() if kind == "strategy_manifest" else sources,
+                                                      support_counts=[2, 4] if kind == "strategy_manifest" else None)
+            mine.write_sidecar(art, template)
+            meta = ac.validate_artifact_sidecar(art, expected={"producer": "simulation", "operation": operation, "scope": "diagnostics"})
+            assert meta.artifact_sha256 == mine.sha256_file(art)
+            art.write_bytes(art.read_bytes() + b"!")
+            try:
+                ac.validate_artifact_sidecar(art)
+            except ac.ArtifactContractError:
+                accepted.append(kind)
+            else:
+                raise AssertionError("the reference accepted a tampered artifact")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    assert accepted == list(mine.OPERATIONS)
+    _dump({"reference_payloads": payloads, "reference_validator_accepts_this_engines_sidecars": accepted,
+           "engine_specific_fields": ["artifact_contract_version", "config_hash", "code_revision", "artifact_name", "artifact_sha256",
+                                      "artifact_size_bytes"]}, open(OUT / "sidecar_vectors.json", "w"))
+
+
 def gen_wilson():
     """worst_case_wilson_width / minimum_shuffles_for_resolution of the reference, bit patterns (float.hex): every sample size
     below 20 000 at which a re-associated form of the radicand (z^2 / n / (4 n) instead of z^2 / (4 n^2)) rounds differently,
@@ -703,6 +754,7 @@ if __name__ == "__main__":
     gen_runner()
     gen_wilson()
     gen_all_player()
+    gen_sidecars()
     gen_fuzz()
     gen_rng()
     gen_scoring()

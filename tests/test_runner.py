@@ -694,3 +694,52 @@ def test_farkle_run_all_player_batches_artifact(engine, tmp_path):
     assert (out_dir / "all_player_batch_000001.parquet").stat().st_mtime_ns == before
     manifest = [json.loads(line) for line in (out_dir / "all_player_manifest.jsonl").read_text().splitlines()]
     assert sorted(r["deterministic_batch_id"] for r in manifest) == [0, 1, 2, 3]
+
+
+def test_farkle_run_sidecars(engine, tmp_path):
+    """`farkle run --sidecars`: every artifact gets an adjacent <name>.sidecar.json whose fields are those of the reference's
+    `_simulation_output_sidecar` (tests/golden/sidecar_vectors.json holds the reference's payloads per operation, and records
+    that the reference's own validate_artifact_sidecar accepted this engine's sidecars), bound to the artifact's bytes."""
+    from farkle_ii_amd import sidecars as sc
+    from farkle_ii_amd.cli import main
+    from farkle_ii_amd.config import load_app_config
+
+    gold = gu.load("sidecar_vectors.json")
+    assert gold["reference_validator_accepts_this_engines_sidecars"] == list(sc.OPERATIONS)
+    cfg_path = _tiny_config(tmp_path, '  metric_chunk_dir: "metric_chunks"\n  row_dir: "rows"\n')
+    main(["--config", str(cfg_path), "run", "--sidecars"])
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    n_dir = cfg.n_dir(2)
+    expect = {"strategy_manifest": [cfg.strategy_manifest_root_path()], "workload_plan": [n_dir / "simulation_workload_plan.json"],
+              "checkpoint": [n_dir / "2p_checkpoint.pkl"], "row_shard": sorted((n_dir / "2p_rows").glob("rows_*.parquet")),
+              "metric_chunk": sorted((n_dir / "2p_metric_chunks").glob("metrics_0*.parquet")),
+              "shard_manifest": [n_dir / "2p_rows" / "manifest.jsonl", n_dir / "2p_metric_chunks" / "metrics_manifest.jsonl"],
+              "checkpoint_summary": [n_dir / "2p_checkpoint.parquet"], "metrics_summary": [n_dir / "2p_metrics.parquet"]}
+    assert len(expect["row_shard"]) == pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())["meta"]["num_shuffles"]
+    assert len(expect["metric_chunk"]) == 4
+    engine_fields = set(gold["engine_specific_fields"]) | {"source_artifacts", "player_counts", "required_player_counts"}
+    for kind, paths in expect.items():
+        want = gold["reference_payloads"][kind]
+        for path in paths:
+            got = sc.validate_sidecar(path, expected={"producer": "simulation", "operation": sc.OPERATIONS[kind], "scope": "diagnostics"})
+            assert set(got) == set(want)
+            for key in set(want) - engine_fields:
+                assert got[key] == want[key], (kind, key)
+            assert got["artifact_contract_version"] == 2 and got["code_revision"].startswith("farkle_ii_amd-")
+    # the identity is the artifact's bytes
+    shard = expect["row_shard"][0]
+    shard.write_bytes(shard.read_bytes() + b"x")
+    with pytest.raises(ValueError, match="size does not match"):
+        sc.validate_sidecar(shard)
+    # the chunk function of the reference's seam accepts a sidecar template now (run_tournament.py:473-585)
+    from farkle_ii_amd import runner
+    from farkle_ii_amd import tournament as rt
+
+    strategies, _ = runner._resolve_strategies(cfg, None)
+    rt._init_worker(strategies, rt.TournamentConfig(n_players=2, n_strategies=len(strategies)))
+    out = tmp_path / "seam_rows"
+    template = sc.simulation_output_sidecar(cfg, out / "rows_template.parquet", n_players=2, operation=sc.OPERATIONS["row_shard"])
+    rt._run_chunk_metrics(rt.shuffle_tasks(7, 2, 0, 3, 2), collect_rows=True, row_dir=out, row_sidecar=template)
+    for shard in sorted(out.glob("rows_*.parquet")):
+        sc.validate_sidecar(shard, expected={"operation": "publish_simulation_row_shard"})
+    assert len(list(out.glob("rows_*.parquet.sidecar.json"))) == 3
