@@ -708,7 +708,7 @@ def kernel_source_sha() -> str:
     import hashlib
 
     h = hashlib.sha256()
-    for name in ("fk_kernels.h", "fk_device.h"):
+    for name in ("fk_kernels.h", "fk_play_hc.h", "fk_device.h"):
         h.update((ROOT / "farkle_ii_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()
 

@@ -1065,6 +1065,38 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
         }
     };
 
+    // ---- two-player tables (PK2): the table advance as straight-line selects for EVERY lane of the trip ----
+    // Some lane of a 64-lane wave ends its turn in nearly every trip, so `advance` above — an exec-masked region of ~47
+    // instructions for the third of the lanes whose turn ended — is paid by the whole wave every trip.  With two seats the
+    // rules collapse (engine.py:453-472, 523-550): the next seat is always the other one; a turn played in the final round
+    // is the last of the game; the first score at or above the target starts the final round.  That is ~20 predicated
+    // instructions with no region; only the next owner's increment load stays under the exec mask.
+    auto advance2 = [&](bool over, int32_t score) __attribute__((always_inline)) {
+        const bool fr = final_round != 0u;
+        const bool trig = over & !fr & (score >= a.target50);                 // engine.py:462-468
+        const bool close = over & !fr & !trig & (seat != 0u);                 // seat 1 closes a normal round
+        const bool last = close & (rounds >= max_rounds);                     // `while rounds < max_rounds` ends (engine.py:453, 472)
+        const bool ended = last | (over & fr);                                // the final round's one turn has been played
+        rounds += (close & !last) ? 1u : 0u;
+        safety = last ? 1u : safety;
+        score_to_beat = trig ? score : score_to_beat;                         // engine.py:464
+        trigger = trig ? seat : trigger;
+        final_round = (fr | trig) ? 1u : 0u;
+        const bool sw = over & !ended;
+        st = ended ? (uint32_t)ST_ENDED : st;
+        seat ^= sw ? 1u : 0u;
+        if (sw) { // the new owner's increment: the one memory request of a turn start
+            const uint4 inc = a.inc[(size_t)seed_slot * 2u + seat];
+            own_inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
+            own_inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
+        }
+        own_thr = (int32_t)(seat ? pk_seat1.x : pk_seat0.x);
+        own_bits = seat ? pk_seat1.y : pk_seat0.y;
+        dice = sw ? 6u : dice;
+        turn_score = sw ? 0 : turn_score;
+        rolls_this_turn = sw ? 0u : rolls_this_turn;
+    };
+
     // ---- one roll of the current turn (engine.py:241-273): record in, roll, score, decide, record out ----
     auto roll_step = [&]() __attribute__((always_inline)) {
         const bool roll_limit = rolls_this_turn >= 1000u; // ROLL_LIMIT, engine.py:36,242 (raised below, before any store)
@@ -1153,7 +1185,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
             L(F_CD, s) = cD;
             L(F_CE, s) = cE;
         }
-        if (!GS && over) advance(score);
+        if (PK2) advance2(over, score);
+        else if (!GS && over) advance(score);
     };
 
     // ---- wave-level hand-over: finish ended games, deal new tickets ----

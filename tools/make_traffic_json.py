@@ -1,6 +1,6 @@
 """HBM-traffic record of one PMC run of tools/pmc_cfg.sh, stamped with the kernel sources it was taken on.
-usage: python tools/make_traffic_json.py <tag> <config> <algorithmic_bytes_per_launch> "<source command>"
-Writes profiles/r02_hbm_traffic_config<config>.json; bench.py attaches `hbm_bytes_corrected` as roofline.traffic only while
+usage: python tools/make_traffic_json.py <tag> <config> <algorithmic_bytes_per_launch> "<source command>" [round=3]
+Writes profiles/r<round>_hbm_traffic_config<config>.json; bench.py attaches `hbm_bytes_corrected` as roofline.traffic only while
 the sha256 of the kernel sources still matches."""
 import collections, csv, glob, os, json, subprocess, sys
 from pathlib import Path
@@ -9,6 +9,7 @@ sys.path.insert(0, str(ROOT))
 from bench import kernel_source_sha
 
 tag, config, algo, source = sys.argv[1], int(sys.argv[2]), float(sys.argv[3]), sys.argv[4]
+rnd = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 agg = collections.defaultdict(dict)
 def newest(paths):
     """one file per directory: the most recent run (gpurun merges every run's files into the same directory)"""
@@ -23,7 +24,7 @@ def newest(paths):
 for f in newest(glob.glob(str(ROOT / f"gpurun_out/{tag}_pmc[456]/**/*_counter_collection.csv"), recursive=True)):
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        name = next((k for k in ("fk_play_kernel", "fk_seed_kernel", "fk_perm_parallel", "fk_perm_draw", "fk_perm_kernel", "fk_tally_reduce")
+        name = next((k for k in ("fk_play_hc_kernel", "fk_play_kernel", "fk_seed_kernel", "fk_perm_parallel", "fk_perm_draw", "fk_perm_kernel", "fk_tally_reduce")
                      if k in r["Kernel_Name"]), None)
         if name:
             per[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
@@ -38,11 +39,11 @@ for name, c in agg.items():
     kernels[name] = rec
 kernels.setdefault("fk_play_kernel", {})["algorithmic_bytes"] = algo
 head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
-out = {"source": source, "round": 2, "config": config, "commit": head, "kernel_source_sha256": kernel_source_sha(),
+out = {"source": source, "round": rnd, "config": config, "commit": head, "kernel_source_sha256": kernel_source_sha(),
        "units": "FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; hbm_bytes_corrected = 2 x FETCH_SIZE + WRITE_SIZE "
                 "(the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md applied to the whole read side: an upper bound for this "
                 "access mix); per launch, mean over the launches of the run",
        "kernels": kernels}
-path = ROOT / "profiles" / f"r02_hbm_traffic_config{config}.json"
+path = ROOT / "profiles" / f"r{rnd:02d}_hbm_traffic_config{config}.json"
 path.write_text(json.dumps(out, indent=1) + "\n")
 print(path, json.dumps(kernels.get("fk_play_kernel"), indent=0)[:400])

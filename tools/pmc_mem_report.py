@@ -4,7 +4,7 @@ usage: python3 tools/pmc_mem_report.py <tag> [kernel-name substring, default pla
 import collections, csv, glob, sys
 
 tag = sys.argv[1]
-which = sys.argv[2] if len(sys.argv) > 2 else "play"
+which = sys.argv[2] if len(sys.argv) > 2 else "fk_play"
 agg = {}
 for i in range(1, 9):
     fs = sorted(glob.glob(f"gpurun_out/{tag}_mem{i}/**/*_counter_collection.csv", recursive=True))
@@ -16,8 +16,8 @@ for i in range(1, 9):
             per[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for name, v in per.items():
         agg[name] = sum(v) / len(v)
-gui = agg.get("GRBM_GUI_ACTIVE", 0.0)
-print(f"{tag}: kernel duration {gui:.4g} GRBM cycles per launch")
+gui = agg.get("GRBM_GUI_ACTIVE", 0.0) / 8.0  # the counter is summed over the eight XCDs
+print(f"{tag}: kernel duration {gui:.4g} cycles per launch (GRBM_GUI_ACTIVE / 8 XCDs)")
 CUS, XCD_CH = 256, 8 * 16
 for name in sorted(agg):
     v = agg[name]
