@@ -94,6 +94,7 @@ struct fk_ctx {
     int32_t hc_waves = 5;      // resident waves per SIMD the plan counts on for it
     int32_t hc_block = 256;    // its block size: 256, 768 or 1024
     int32_t hc_tables = 1;     // 1: score / discard tables in LDS (LT instances)
+    int32_t hc_inc_regs = 1;   // 1: the seats' PCG increments in registers (k >= 5, 256-thread blocks, LDS tables)
     DevBuf lds_tables;         // their LDS image (fk_play_hc.h)
     DevBuf cold;
     bool ran_hc = false;       // the current tournament call launched the hot / cold kernel
@@ -233,6 +234,7 @@ struct LaunchPlan {
     bool blk = false;  // batched-H2H instance (strategy index from the lane's block index)
     bool hc = false;   // hot / cold instance (fk_play_hc.h): 20 bytes of LDS per seat, cold records in an L2-resident plane
     bool hc_lt = false; // ... with the score / discard tables in LDS
+    bool hc_ki = false; // ... with every seat's PCG increment in registers
     int wpe = 4;       // waves per SIMD the chosen instance is compiled for
     uint32_t mixed_flags = 0xff00u; // flag bits that differ between strategies of the table (selects the kernel instance)
 };
@@ -328,12 +330,15 @@ bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const Launch
     if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
     per_cu = std::max(per_cu, 1);
     const int base_lanes = base.block * std::max(1, base.grid / std::max(1, base.cus));
-    // auto: where LDS records seat fewer than three waves per SIMD (k >= 5 with lean records; measured on the 5 160-strategy
-    // grid, round 3: k = 6 +8 %, k = 8 +12 % games/s; k = 4 -6 %, k = 3 -20 %)
-    if (c->hc < 0 && (base_lanes >= 768 || per_cu * block <= base_lanes)) return false;
+    // auto: k >= 6.  Measured on the 5 160-strategy grid against the LDS-record kernel in the same process (round 3,
+    // tools/exp_hc2.py; LDS tables + register-resident increments / strategies, three 256-thread blocks per CU):
+    // k = 8 +27 %, k = 7 +20 %, k = 6 +13 % games/s; k = 5 +-0, k = 4 -3 %, k = 3 -10 %.
+    if (c->hc < 0 && (k < 6 || per_cu * block <= base_lanes)) return false;
     out = base;
     out.hc = true;
     out.hc_lt = lt;
+    out.hc_ki = c->hc_inc_regs != 0 && lt && block == 256;
+    if (out.hc_ki) per_cu = std::min(per_cu, k <= 4 ? 4 : 3); // 128 / 168 registers per lane: room for the seats' increments and strategies
     out.lean = true;
     out.gs = false;
     out.blk = false;
@@ -427,12 +432,12 @@ hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) 
     return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS, BLK, KC>(p, a, s);
 }
 
-template <int BLOCK, uint32_t MIXED, bool LT>
+template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0>
 hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     static int configured_dev = -1; // dynamic-LDS ceiling and occupancy are per device
     static size_t occ_lds = ~(size_t)0;
     static int occ_blocks = 0;
-    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT>);
+    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI>);
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (configured_dev != dev) {
@@ -450,18 +455,23 @@ hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t 
     }
     const int grid = std::min(p.grid, occ_blocks * p.cus);
     p.launched_grid = grid;
-    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
+    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
     return hipGetLastError();
 }
 
-template <int BLOCK, bool LT>
+template <int BLOCK, bool LT, int KI = 0>
 hipError_t launch_play_hc_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT>(p, a, s);
-    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT>(p, a, s);
-    return launch_play_hc_u<BLOCK, MIXED_ALL, LT>(p, a, s);
+    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI>(p, a, s);
+    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI>(p, a, s);
+    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI>(p, a, s);
 }
 
 hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
+    if (p.hc_ki && p.block == 256 && p.hc_lt) { // increments + strategies in registers: 256-thread blocks with LDS tables
+        if (a.k <= 4u) return launch_play_hc_t<256, true, 4>(p, a, s);
+        if (a.k <= 6u) return launch_play_hc_t<256, true, 6>(p, a, s);
+        return launch_play_hc_t<256, true, 8>(p, a, s);
+    }
     switch (p.block) {
     case 1024: return p.hc_lt ? launch_play_hc_t<1024, true>(p, a, s) : launch_play_hc_t<1024, false>(p, a, s);
     case 768: return p.hc_lt ? launch_play_hc_t<768, true>(p, a, s) : launch_play_hc_t<768, false>(p, a, s);
@@ -1043,6 +1053,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "hot_cold_waves") c->hc_waves = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8);
     else if (n == "hot_cold_block") c->hc_block = (int32_t)value;
     else if (n == "hot_cold_tables") c->hc_tables = (int32_t)value;
+    else if (n == "hot_cold_inc_regs") c->hc_inc_regs = (int32_t)value;
     else if (n == "perm_split") c->perm_split = (int32_t)value;
     else if (n == "pipeline") c->pipeline = (int32_t)value;
     else if (n == "uniform_flags") c->uniform_flags_opt = (int32_t)value;

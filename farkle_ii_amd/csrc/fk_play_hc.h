@@ -1,36 +1,50 @@
-// fk_play_hc.h — the hot / cold game kernel: tournament launches whose k seat records do not leave LDS room for more
-// than a few waves per SIMD (included by fk_kernels.h; same rules, same registers, same hand-over as fk_play_kernel).
+// fk_play_hc.h — the hot / cold game kernel: tournament launches of six and more seats, whose k seat records do not leave
+// LDS room for more than two or three waves per SIMD (included by fk_kernels.h; same rules, same turn registers, same
+// hand-over as fk_play_kernel).
 //
 // fk_play_kernel keeps the ten dwords a turn mutates of EVERY seat in LDS: 40 k bytes per lane, i.e. 4 waves per SIMD at
 // k = 4, 2.5 at k = 6 and 2 at k = 8 — and a wave alone issues one vector instruction per 4 cycles where the SIMD could
-// take one per 2 (MI355X_MICROARCH.md): below ~4 resident waves the kernel is bound by its own stalls.  Round 2 measured
-// the alternative that keeps ONE record per lane in LDS and the rest in HBM (state-store instances): 2x slower, because
-// every turn then moves 96 bytes in six 16-byte requests per lane and the L2s take ~3 x 10^11 requests per second in all
-// (fk_play_kernel already spends 40 % of that on the increment and strategy loads of its turn starts).
-//
-// This kernel splits the record by how often it is touched instead:
+// take one per 2 (MI355X_MICROARCH.md): PMC puts the k = 8 launch at 6.2 cycles per vector instruction against 3.3 at six
+// waves.  Round 2 measured the alternative that keeps ONE record per lane in LDS and the rest in HBM (state-store
+// instances): 2x slower.  Round 3 found out why, and what the budget really is (profiles/r03_*):
+//   * the texture addresser takes one cycle per lane of a scattered access: fk_play_kernel keeps it 49 % busy (two table
+//     gathers per roll, two loads per turn), six more 16-byte accesses per turn saturate it;
+//   * a CU has 128 KB of L2 to itself (4 MB per XCD / 32 CUs) — LESS than its LDS.  The increment plane's live lines are
+//     16 k bytes per resident game; anything spilled beside them overflows that share from three waves per SIMD on (first
+//     version of this kernel at k = 8: 0.8 L2 misses per turn, 105 GB fetched + 107 GB written back per 1.5 x 10^7 games);
+//   * what such a launch has to spare is REGISTERS: at three waves per SIMD a lane may hold 168 VGPRs, the game needs ~85.
+// So the seat record is split by how often it is touched, and each part goes where there is room:
 //   HOT   per roll: generator state (16 B) + buffered half word (4 B) = 20 bytes per seat, in LDS for every seat
-//         (k = 8: 160 B per lane = 4 waves per SIMD; k = 6: 5; k <= 5: the register file's 5);
+//         (k = 8: 160 B per lane; three 256-thread blocks per CU with the tables below);
 //   COLD  per turn: the eight behaviour counters, the banked total and has_scored = 16 bytes per seat.  The turn owner's
-//         live in four registers; at a turn hand-over they go to a PLANE indexed by (resident lane, seat) — 16 k bytes
-//         per lane, 34 MB for the whole chip at k = 8: L2-resident, never written back while the launch runs — and the next
-//         owner's come in.  One store + one load per turn; the load is issued at the hand-over and first read in the
-//         middle of the next roll (behind the score-table gather that every roll waits for anyway), so its latency is
-//         not on the roll's dependency chain.
+//         live in four registers; at a turn hand-over they go to a PLANE indexed by (resident lane, seat) — 16 k bytes per
+//         lane, 25 MB for the whole chip at k = 8, L2-resident once the increments no longer compete for it — and the next
+//         owner's come in.  One store + one load per turn; the load is issued at the hand-over and first read in the middle
+//         of the next roll, so its latency is not on the roll's dependency chain;
+//   READ-ONLY per seat (KI instances, k <= 8): the PCG increment (4 dwords) and the packed strategy (2 dwords, k <= 6) of
+//         EVERY seat stay in registers for the whole game and are picked by a select tree on the seat index at a turn start
+//         (7 v_cndmask per dword at k = 8): no increment / strategy request per turn, no increment lines in L2;
+//   TABLES (LT instances): the score / discard tables are read from an LDS image (fk_device.h) instead of the 512 KiB /
+//         64 KiB global tables — two gathers per roll less for the texture addresser (-14 % kernel time here; in
+//         fk_play_kernel, which does not saturate it, the same change measured +1.7 % and was dropped);
 //   has_buf of all seats is one bit mask per lane; the seats' strategy indices are eight 16-bit fields in four registers.
+// Measured against fk_play_kernel in the same process on the 5 160-strategy grid (tools/exp_hc2.py): k = 8 +27 %, k = 7
+// +20 %, k = 6 +13 % games/s; k = 5 +-0, k = 4 -3 %, k = 3 -10 %: the launch plan picks this kernel from k = 6.
 // Cold record (uint4):
 //   x = rolls | farkles << 16
 //   y = highest_turn / 50 [10:0] | banked total / 50 [22:11] | has_scored [23] | hot_dice [31:24]
 //   z = smart_five_uses | n_smart_five_dice << 16        w = smart_one_uses | n_smart_one_dice << 16
 // The 12-bit total needs target / 50 + one turn (<= 1310) < 4096, the 8-bit hot-dice count a guard band at 250 (a seat
 // rolls hot dice in ~3 % of its turns); the launch plan keeps other tables on fk_play_kernel, and a count that leaves the
-// band is FK_ERR_COUNTER_OVERFLOW like every other guarded counter (the host then replays the chunk on fk_play_kernel).
+// band is FK_ERR_COUNTER_OVERFLOW like every other guarded counter (the host then replays the call on fk_play_kernel).
 #pragma once
 
 constexpr uint32_t HC_MAX_K = 8;
 
-template <int HC_BLOCK_I, uint32_t MIXED, bool LT>
-__global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(HC_BLOCK_I == 256 ? 5 : HC_BLOCK_I / 256))) void fk_play_hc_kernel(PlayArgs a) {
+// KI: seats whose PCG increments (and, up to KI = 6, packed strategies) stay in registers for the whole game (0: both are
+// loaded at every turn start); LT: tables from the LDS image.  See the file comment.
+template <int HC_BLOCK_I, uint32_t MIXED, bool LT, int KI = 0>
+__global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(KI == 4 ? 4 : KI ? 3 : (HC_BLOCK_I == 256 ? 5 : HC_BLOCK_I / 256)))) void fk_play_hc_kernel(PlayArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t HC_BLOCK = (uint32_t)HC_BLOCK_I;
     const uint32_t tid = threadIdx.x;
@@ -63,6 +77,9 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(HC_B
     int32_t own_thr = 0;
     uint32_t own_bits = 0;
     uint32_t cA = 0, cB = 0, cC = 0, cD = 0;      // the owner's cold record
+    uint32_t inc_r[KI ? KI : 1][4] = {};          // KI: every seat's increment (constant indices only: registers)
+    constexpr bool PKR = KI != 0 && KI <= 6;      // ... and packed strategy, while 168 registers hold both without spilling
+    uint32_t pk_r[PKR ? KI : 1][2] = {};
 
     auto seat_index = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t {
         const uint32_t lo = (s & 2u) ? ix23 : ix01, hi = (s & 2u) ? ix67 : ix45;
@@ -76,8 +93,42 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(HC_B
     // turn owner := seat s (engine.py:236-240).  Three loads, none of them read before the next roll: the increment at
     // its first generator step, the strategy and the cold record behind the score-table gather.
     auto begin_turn = [&](uint32_t s) __attribute__((always_inline)) {
-        const uint4 inc = a.inc[(size_t)seed_slot * K + s];
-        const uint2 pk = a.strat[seat_index(s)];
+        uint4 inc;
+        if (KI) { // select tree on the bits of s (entries beyond k are never selected)
+            uint32_t v[8][4];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[t][j] = inc_r[t < KI ? t : 0][j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t a0 = (s & 1u) ? v[1][j] : v[0][j], a1 = (s & 1u) ? v[3][j] : v[2][j];
+                const uint32_t a2 = (s & 1u) ? v[5][j] : v[4][j], a3 = (s & 1u) ? v[7][j] : v[6][j];
+                const uint32_t b0 = (s & 2u) ? a1 : a0, b1 = (s & 2u) ? a3 : a2;
+                v[0][j] = (s & 4u) ? b1 : b0;
+            }
+            inc = make_uint4(v[0][0], v[0][1], v[0][2], v[0][3]);
+        } else {
+            inc = a.inc[(size_t)seed_slot * K + s];
+        }
+        uint2 pk;
+        if (PKR) {
+            uint32_t w[8][2];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) w[t][j] = pk_r[t < (PKR ? KI : 1) ? t : 0][j];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t a0 = (s & 1u) ? w[1][j] : w[0][j], a1 = (s & 1u) ? w[3][j] : w[2][j];
+                const uint32_t a2 = (s & 1u) ? w[5][j] : w[4][j], a3 = (s & 1u) ? w[7][j] : w[6][j];
+                const uint32_t b0 = (s & 2u) ? a1 : a0, b1 = (s & 2u) ? a3 : a2;
+                w[0][j] = (s & 4u) ? b1 : b0;
+            }
+            pk = make_uint2(w[0][0], w[0][1]);
+        } else {
+            pk = a.strat[seat_index(s)];
+        }
         const uint4 c = cold[s];
         own_inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
         own_inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
@@ -161,6 +212,15 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(HC_B
                 cold[s] = make_uint4(0u, 0u, 0u, 0u); // the previous game's record of this lane
                 const uint32_t idx = (a.state_dw == STATE_DW) ? src[R_IDX] : (uint32_t)a.seat_idx[(size_t)slot * K + s];
                 iw[s >> 1] |= idx << (16u * (s & 1u));
+                if (KI && s < (uint32_t)(KI ? KI : 1)) {
+                    const uint4 q = a.inc[(size_t)slot * K + s];
+                    inc_r[s < (uint32_t)(KI ? KI : 1) ? s : 0][0] = q.x, inc_r[s < (uint32_t)(KI ? KI : 1) ? s : 0][1] = q.y;
+                    inc_r[s < (uint32_t)(KI ? KI : 1) ? s : 0][2] = q.z, inc_r[s < (uint32_t)(KI ? KI : 1) ? s : 0][3] = q.w;
+                    if (PKR) {
+                        const uint2 pk = a.strat[idx];
+                        pk_r[s < (uint32_t)(PKR ? KI : 1) ? s : 0][0] = pk.x, pk_r[s < (uint32_t)(PKR ? KI : 1) ? s : 0][1] = pk.y;
+                    }
+                }
             }
         }
         ix01 = iw[0], ix23 = iw[1], ix45 = iw[2], ix67 = iw[3];

@@ -58,6 +58,25 @@ def test_hot_cold_blocks_and_lds_tables_agree_with_oracle(eng, po, k, block, tab
         eng.set_option("hot_cold_tables", 1)
 
 
+@pytest.mark.parametrize("k", [5, 6, 7, 8])
+def test_hot_cold_with_and_without_increments_in_registers(eng, po, k):
+    """k >= 5 with LDS tables on 256-thread blocks keeps every seat's PCG increment in registers (select tree on the seat);
+    option hot_cold_inc_regs = 0 loads it at each turn start instead: same rows either way."""
+    S = {5: 100, 6: 96, 7: 98, 8: 96}[k]
+    table = _random_valid_table(S, 1300 + k)
+    ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 21, 0, 25, shuffles_per_batch=9, want_rows=True, n_threads=8)
+    try:
+        eng.set_option("hot_cold", 1)
+        for regs in (1, 0):
+            eng.set_option("hot_cold_inc_regs", regs)
+            got = eng.tournament(table, k, 21, 0, 25, shuffles_per_batch=9, want_rows=True)
+            assert _ran_hot_cold(eng, k), eng.timing()
+            assert np.array_equal(got["tally"], ref["tally"]) and got["rows"].tobytes() == ref["rows"].tobytes(), (k, regs)
+    finally:
+        eng.set_option("hot_cold", -1)
+        eng.set_option("hot_cold_inc_regs", 1)
+
+
 @pytest.mark.parametrize("k", [3, 4, 5, 6, 7, 8])
 def test_hot_cold_kernel_agrees_with_oracle(eng, po, k):
     """Per-batch tallies, rows and all-seat statistics of the same shuffles: hot / cold kernel, LDS-record kernel, oracle."""
