@@ -46,6 +46,7 @@ struct ChunkDesc {
 
 struct ChunkSet {
     DevBuf perm, draws, state, inc, seat_idx, order, classes, misc, pools;
+    DevBuf blocks, game_block, game_row; // batched H2H: the pass's block table and game -> block / table-row maps
     hipEvent_t ready = nullptr;                       // recorded behind the preparation kernels
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; // permutation begin / end, seeding begin / end (timing)
     bool prepared = false;
@@ -75,7 +76,7 @@ struct fk_ctx {
         hipEvent_t a, b;
     };
     std::vector<PendingTimer> pending; // kernel timers recorded on the stream, read after the chunk's one sync
-    DevBuf strat, recs, rec0, tally, rows, ov, seatlist, coords, inv, slow, score_lut, discard_lut, blocks, game_block, block_out, stats, digest,
+    DevBuf strat, recs, rec0, tally, rows, ov, seatlist, coords, inv, slow, score_lut, discard_lut, block_out, stats, digest,
         dbg[6];
     std::vector<uint2> strat_host;   // the packed table currently resident in `strat` (uploaded once per table)
     int32_t longest_first = 1;
@@ -593,7 +594,7 @@ int seed_stage(fk_ctx *c, int si, hipStream_t st, SeedArgs &sa, bool full_state,
     }
     if (sa.blocks) { // batched H2H: game -> block map first (the schedule classes and the seed kernel read it)
         hipLaunchKernelGGL(fk_block_map_kernel, dim3((sa.n_games + 255u) / 256u), dim3(256), 0, st, sa.blocks, sa.n_blocks,
-                           sa.n_games, const_cast<uint32_t *>(sa.game_block));
+                           sa.n_games, const_cast<uint32_t *>(sa.game_block), const_cast<uint32_t *>(sa.game_row));
         HIPCHK(c, hipGetLastError());
     }
     if ((sa.perm_T || sa.blocks) && c->longest_first) {
@@ -622,7 +623,7 @@ int seed_stage(fk_ctx *c, int si, hipStream_t st, SeedArgs &sa, bool full_state,
     if (sa.sched) // class sizes first: a game's ticket is class offset + rank
         hipLaunchKernelGGL(fk_class_count_kernel, dim3(std::min<uint32_t>((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK, 1024u)), dim3(SEED_BLOCK), 0,
                            st, sa.perm_T, sa.perm_slots, sa.S, sa.k, sa.n_sh, sa.n_games, sa.patience,
-                           sa.blocks ? sa.game_block : nullptr, static_cast<uint32_t *>(cs.classes.p));
+                           sa.blocks ? sa.game_row : nullptr, static_cast<uint32_t *>(cs.classes.p));
     hipLaunchKernelGGL(fk_seed_kernel, dim3((sa.n_games + SEED_BLOCK - 1u) / SEED_BLOCK), dim3(SEED_BLOCK), 0, st, sa);
     if (timed) (void)hipEventRecord(cs.ev[3], st);
     HIPCHK(c, hipGetLastError());
@@ -973,10 +974,10 @@ void fk_destroy(fk_ctx *c) {
     release(c->comm_buf);
     if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     for (DevBuf *b : {&c->strat, &c->recs, &c->rec0, &c->tally, &c->rows, &c->ov, &c->seatlist, &c->coords, &c->inv, &c->slow, &c->digest, &c->score_lut,
-                      &c->discard_lut, &c->blocks, &c->game_block, &c->block_out, &c->stats, &c->cold, &c->lds_tables, &c->acc, &c->rows_alt})
+                      &c->discard_lut, &c->block_out, &c->stats, &c->cold, &c->lds_tables, &c->acc, &c->rows_alt})
         release(*b);
     for (auto &cs : c->sets) {
-        for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc, &cs.pools}) release(*b);
+        for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc, &cs.pools, &cs.blocks, &cs.game_block, &cs.game_row}) release(*b);
         if (cs.ready) (void)hipEventDestroy(cs.ready);
         for (auto &e : cs.ev)
             if (e) (void)hipEventDestroy(e);
@@ -1495,7 +1496,6 @@ int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_
     int rc = upload_strategies(c, table.data(), n_blocks * 2);
     if (rc) return rc;
     const SeedPool seat_prefix = seed_prefix(203u /* H2H_PLAYER */, root_seed, 2u);
-    constexpr size_t MAX_BLOCKS_PER_PASS = (size_t)1 << 22; // rec0 holds the winner's table row in 24 bits
     const LaunchPlan plan = plan_play(c, 2, n_blocks * 2, false, target_score, true);
     if (plan.block == 0)
         return fail(c, FK_ERR_ARG, "target_score %d: batched head-to-head plays with lean records (totals up to %d points)", target_score,
@@ -1504,111 +1504,168 @@ int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_
     rc = ensure(c, c->block_out, (size_t)n_blocks * 4 * 8);
     if (rc) return rc;
 
-    std::vector<DevBlock> pass;
-    std::vector<int64_t> pass_block;
-    std::vector<unsigned long long> out;
-    int64_t cursor = 0; // round-robin start so that an over-full pass does not starve the later blocks
+    // A GENERATION plays, for every block that still needs games, exactly min(stop - attempted, target - completed) attempts —
+    // all of them planned up front from the blocks' current states and cut into passes (launches) of at most max_launch games.
+    // The passes of a generation do not depend on each other's results, so pass i + 1 is prepared (block table, game -> block
+    // map, pools, schedule classes, seat seeding) into the other chunk set on the low-priority stream while pass i plays, as
+    // tournament chunks are (15.5 ms of seeding per 6 x 10^8-attempt launch of BASELINE config 5 used to sit between the game
+    // kernels); the strategy table (two rows per block of the CALL) and the per-block counts are per call, the error records
+    // are read once per generation.  Blocks with safety-limit games need further (geometrically smaller) generations.
+    struct Pass {
+        std::vector<DevBlock> blocks;
+        uint32_t n_games = 0;
+    };
+    constexpr size_t MAX_PASS_BLOCKS = (size_t)1 << 22;
+    std::vector<unsigned long long> out((size_t)n_blocks * 4);
+    std::vector<uint64_t> planned((size_t)n_blocks);
+    const bool pipelined = c->pipeline != 0 && n_ov == 0; // per-pass override lists live in one device buffer
     while (true) {
-        pass.clear();
-        pass_block.clear();
-        uint64_t total = 0;
-        for (int64_t i = 0; i < n_blocks; ++i) {
-            const int64_t b = (cursor + i) % n_blocks;
-            fk_h2h_block &blk = blocks[b];
+        std::vector<Pass> passes;
+        std::fill(planned.begin(), planned.end(), 0);
+        for (int64_t b = 0; b < n_blocks; ++b) {
+            const fk_h2h_block &blk = blocks[b];
             if (blk.state[0] >= stop[(size_t)b] || blk.state[1] >= blk.target) continue;
             uint64_t n = std::min<uint64_t>(stop[(size_t)b] - blk.state[0], blk.target - blk.state[1]);
-            n = std::min<uint64_t>(n, max_launch - total);
-            if (n == 0) break;
-            pass.push_back(DevBlock{blk.pair_id, blk.state[0], blk.order, (uint32_t)total});
-            pass_block.push_back(b);
-            total += n;
-            if (total >= max_launch || pass.size() >= MAX_BLOCKS_PER_PASS) {
-                cursor = b; // this block may need the rest of its range in the next pass
-                break;
+            planned[(size_t)b] = n;
+            uint64_t attempt0 = blk.state[0];
+            while (n) { // a block may straddle passes
+                if (passes.empty() || passes.back().n_games >= max_launch || passes.back().blocks.size() >= MAX_PASS_BLOCKS) passes.emplace_back();
+                Pass &p = passes.back();
+                const uint64_t take = std::min<uint64_t>(n, max_launch - p.n_games);
+                p.blocks.push_back(DevBlock{blk.pair_id, attempt0, blk.order, p.n_games, (uint32_t)b, 0u});
+                p.n_games += (uint32_t)take;
+                attempt0 += take;
+                n -= take;
             }
         }
-        if (pass.empty()) break;
-        const uint32_t n_games = (uint32_t)total, nb = (uint32_t)pass.size();
-        // overrides -> pass-local game ids
-        std::vector<DevOverride> dov;
-        for (int32_t i = 0; i < n_ov && nb; ++i) {
-            if (ov[i].root_seed != root_seed) continue;
-            if (ov[i].max_rounds > 65535u) return fail(c, FK_ERR_ARG, "override max_rounds must be <= 65535");
-            for (uint32_t p = 0; p < nb; ++p) {
-                const uint32_t n_p = (p + 1 < nb ? pass[p + 1].start : n_games) - pass[p].start;
-                if (ov[i].a != pass[p].pair || ov[i].k_or_order != pass[p].order) continue;
-                if (ov[i].b < pass[p].attempt0 || ov[i].b >= pass[p].attempt0 + n_p) continue;
-                const uint32_t game = pass[p].start + (uint32_t)(ov[i].b - pass[p].attempt0);
-                bool replaced = false;
-                for (auto &d : dov)
-                    if (d.game == game) {
-                        d.max_rounds = ov[i].max_rounds;
-                        replaced = true;
-                    }
-                if (!replaced) dov.push_back(DevOverride{game, ov[i].max_rounds});
+        if (passes.empty()) break;
+        HIPCHK(c, hipMemsetAsync(c->block_out.p, 0, (size_t)n_blocks * 4 * 8, c->stream));
+
+        // preparation of pass `i` into chunk set `si` on stream `st`
+        auto prepare = [&](size_t i, int si, hipStream_t st, SeedArgs &sa) -> int {
+            const Pass &p = passes[i];
+            ChunkSet &cs = c->sets[si];
+            const uint32_t nb = (uint32_t)p.blocks.size();
+            cs.prepared = false;
+            int rc2 = ensure(c, cs.blocks, (size_t)nb * sizeof(DevBlock));
+            if (!rc2) rc2 = ensure(c, cs.game_block, (size_t)p.n_games * 4);
+            if (!rc2) rc2 = ensure(c, cs.game_row, (size_t)p.n_games * 4);
+            if (rc2) return rc2;
+            HIPCHK(c, hipMemcpyAsync(cs.blocks.p, p.blocks.data(), (size_t)nb * sizeof(DevBlock), hipMemcpyHostToDevice, st));
+            sa = SeedArgs{};
+            sa.prefix = seat_prefix;
+            sa.gps = 0;
+            sa.k = 2;
+            sa.n_games = p.n_games;
+            sa.blocks = static_cast<const DevBlock *>(cs.blocks.p);
+            sa.n_blocks = nb;
+            sa.game_block = static_cast<const uint32_t *>(cs.game_block.p);
+            sa.game_row = static_cast<const uint32_t *>(cs.game_row.p);
+            rc2 = seed_stage(c, si, st, sa, false, true);
+            if (rc2) return rc2;
+            HIPCHK(c, hipEventRecord(cs.ready, st));
+            cs.side = (st == c->prep_stream);
+            return FK_OK;
+        };
+
+        std::vector<SeedArgs> sas(passes.size());
+        std::vector<int> set_of(passes.size());
+        set_of[0] = c->cur;
+        HIPCHK(c, hipStreamWaitEvent(c->stream, CSET(c).ready, 0)); // an unused side-stream preparation may still own the set
+        (void)hipEventRecord(CSET(c).ev[0], c->stream);             // no permutations here: an empty interval
+        (void)hipEventRecord(CSET(c).ev[1], c->stream);
+        rc = prepare(0, c->cur, c->stream, sas[0]);
+        if (rc) return rc;
+        for (size_t i = 0; i < passes.size(); ++i) {
+            const Pass &p = passes[i];
+            c->cur = set_of[i];
+            // overrides -> pass-local game ids (not pipelined: one device list)
+            std::vector<DevOverride> dov;
+            for (int32_t o = 0; o < n_ov; ++o) {
+                if (ov[o].root_seed != root_seed) continue;
+                if (ov[o].max_rounds > 65535u) return fail(c, FK_ERR_ARG, "override max_rounds must be <= 65535");
+                for (size_t q = 0; q < p.blocks.size(); ++q) {
+                    const DevBlock &db = p.blocks[q];
+                    const uint32_t n_q = (q + 1 < p.blocks.size() ? p.blocks[q + 1].start : p.n_games) - db.start;
+                    if (ov[o].a != db.pair || ov[o].k_or_order != db.order) continue;
+                    if (ov[o].b < db.attempt0 || ov[o].b >= db.attempt0 + n_q) continue;
+                    const uint32_t game = db.start + (uint32_t)(ov[o].b - db.attempt0);
+                    bool replaced = false;
+                    for (auto &d : dov)
+                        if (d.game == game) {
+                            d.max_rounds = ov[o].max_rounds;
+                            replaced = true;
+                        }
+                    if (!replaced) dov.push_back(DevOverride{game, ov[o].max_rounds});
+                }
+            }
+            rc = upload_overrides(c, dov);
+            if (rc) return rc;
+            HIPCHK(c, hipEventRecord(c->main_idle, c->stream)); // everything that used the other chunk set is in front of this point
+            if (i + 1 < passes.size()) {
+                set_of[i + 1] = c->cur ^ 1;
+                if (pipelined) {
+                    HIPCHK(c, hipStreamWaitEvent(c->prep_stream, c->main_idle, 0));
+                    (void)hipEventRecord(c->sets[c->cur ^ 1].ev[0], c->prep_stream);
+                    (void)hipEventRecord(c->sets[c->cur ^ 1].ev[1], c->prep_stream);
+                    rc = prepare(i + 1, c->cur ^ 1, c->prep_stream, sas[i + 1]);
+                    if (rc) return rc;
+                }
+            }
+            PlayArgs pa{};
+            pa.strat = static_cast<const uint2 *>(c->strat.p);
+            pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
+            pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
+            pa.lds_tables = static_cast<const uint8_t *>(c->lds_tables.p);
+            pa.game_block = sas[i].game_row; // the kernel wants table rows: seat s of a game plays strategy 2 * row + s
+            pa.ov = static_cast<const DevOverride *>(c->ov.p);
+            pa.n_ov = (uint32_t)dov.size();
+            pa.mode = MODE_BLOCKS;
+            pa.n_games = p.n_games;
+            pa.gps = 1;
+            pa.n_sh = 1;
+            pa.k = 2;
+            pa.S = (uint32_t)n_blocks * 2u;
+            pa.target50 = ceil_div50(target_score);
+            pa.beat50 = floor_div50(target_score);
+            pa.max_rounds = (uint32_t)max_rounds;
+            HIPCHK(c, hipStreamWaitEvent(c->stream, CSET(c).ready, 0));
+            rc = launch_play_stage(c, sas[i], pa, plan, false, true, false);
+            if (rc) return rc;
+            hipLaunchKernelGGL(fk_h2h_reduce_kernel, dim3((p.n_games + 256u * H2H_RUN - 1u) / (256u * H2H_RUN)), dim3(256), 0, c->stream,
+                               static_cast<const uint32_t *>(c->rec0.p), p.n_games, (uint32_t)n_blocks, static_cast<unsigned long long *>(c->block_out.p));
+            HIPCHK(c, hipGetLastError());
+            if (!pipelined || n_ov) { // the next pass re-uses the one override buffer: finish this pass first
+                rc = finish_play(c, pa, 0, "h2h attempt (pass-local index)");
+                if (rc) return rc;
+                if (i + 1 < passes.size()) {
+                    (void)hipEventRecord(c->sets[c->cur ^ 1].ev[0], c->stream);
+                    (void)hipEventRecord(c->sets[c->cur ^ 1].ev[1], c->stream);
+                    rc = prepare(i + 1, c->cur ^ 1, c->stream, sas[i + 1]);
+                    if (rc) return rc;
+                }
+            } else {
+                // the pass's error record and timers are read at the end of the generation; its kernel timer events must not
+                // be reused by the next launch
+                HIPCHK(c, hipMemcpyAsync(c->err_host, pa.err, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                rc = report_device_error(c, c->err_host, 0, "h2h attempt (pass-local index)");
+                const int rc_t = finish_timers(c);
+                if (rc) return rc;
+                if (rc_t) return rc_t;
             }
         }
-        rc = upload_overrides(c, dov);
-        if (rc) return rc;
-        // the pass's strategy table rows: seats of pass block p sit at 2p, 2p + 1 -> re-pack when the pass is a subset
-        if (nb != (uint32_t)n_blocks || pass_block[0] != 0) {
-            std::vector<fk_strategy> sub((size_t)nb * 2);
-            for (uint32_t p = 0; p < nb; ++p) {
-                sub[(size_t)p * 2] = blocks[pass_block[p]].seats[0];
-                sub[(size_t)p * 2 + 1] = blocks[pass_block[p]].seats[1];
-            }
-            rc = upload_strategies(c, sub.data(), (int64_t)nb * 2);
-        } else {
-            rc = upload_strategies(c, table.data(), n_blocks * 2);
-        }
-        if (rc) return rc;
-        rc = ensure(c, c->blocks, (size_t)nb * sizeof(DevBlock));
-        if (rc) return rc;
-        rc = ensure(c, c->game_block, (size_t)n_games * 4);
-        if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->blocks.p, pass.data(), (size_t)nb * sizeof(DevBlock), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->block_out.p, 0, (size_t)nb * 4 * 8, c->stream));
-        SeedArgs sa{};
-        sa.prefix = seat_prefix;
-        sa.gps = 0;
-        sa.k = 2;
-        sa.n_games = n_games;
-        sa.blocks = static_cast<const DevBlock *>(c->blocks.p);
-        sa.n_blocks = nb;
-        sa.game_block = static_cast<const uint32_t *>(c->game_block.p);
-        PlayArgs pa{};
-        pa.strat = static_cast<const uint2 *>(c->strat.p);
-        pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
-        pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
-        pa.lds_tables = static_cast<const uint8_t *>(c->lds_tables.p);
-        pa.game_block = sa.game_block;
-        pa.ov = static_cast<const DevOverride *>(c->ov.p);
-        pa.n_ov = (uint32_t)dov.size();
-        pa.mode = MODE_BLOCKS;
-        pa.n_games = n_games;
-        pa.gps = 1;
-        pa.n_sh = 1;
-        pa.k = 2;
-        pa.S = nb * 2;
-        pa.target50 = ceil_div50(target_score);
-        pa.beat50 = floor_div50(target_score);
-        pa.max_rounds = (uint32_t)max_rounds;
-        rc = run_chunk(c, sa, pa, plan, false, true, false, 0, "h2h attempt (pass-local index)");
-        if (rc) return rc;
-        hipLaunchKernelGGL(fk_h2h_reduce_kernel, dim3((n_games + 256u * H2H_RUN - 1u) / (256u * H2H_RUN)), dim3(256), 0, c->stream,
-                           static_cast<const uint32_t *>(c->rec0.p), n_games, nb, static_cast<unsigned long long *>(c->block_out.p));
-        HIPCHK(c, hipGetLastError());
-        out.resize((size_t)nb * 4);
-        HIPCHK(c, hipMemcpyAsync(out.data(), c->block_out.p, (size_t)nb * 4 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(out.data(), c->block_out.p, (size_t)n_blocks * 4 * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (uint32_t p = 0; p < nb; ++p) {
-            const uint64_t n_p = (uint64_t)((p + 1 < nb ? pass[p + 1].start : n_games) - pass[p].start);
-            const uint64_t comp = out[(size_t)p * 4], saf = out[(size_t)p * 4 + 1], a1 = out[(size_t)p * 4 + 2], a2 = out[(size_t)p * 4 + 3];
-            if (comp + saf != n_p || a1 + a2 != comp)
-                return fail(c, FK_ERR_HIP, "h2h block conservation failed (block %lld: %llu + %llu != %llu)", (long long)pass_block[p],
-                            (unsigned long long)comp, (unsigned long long)saf, (unsigned long long)n_p);
-            fk_h2h_block &blk = blocks[pass_block[p]];
-            blk.state[0] += n_p;
+        for (int64_t b = 0; b < n_blocks; ++b) {
+            const uint64_t n_b = planned[(size_t)b];
+            if (!n_b) continue;
+            const uint64_t comp = out[(size_t)b * 4], saf = out[(size_t)b * 4 + 1], a1 = out[(size_t)b * 4 + 2], a2 = out[(size_t)b * 4 + 3];
+            if (comp + saf != n_b || a1 + a2 != comp)
+                return fail(c, FK_ERR_HIP, "h2h block conservation failed (block %lld: %llu + %llu != %llu)", (long long)b,
+                            (unsigned long long)comp, (unsigned long long)saf, (unsigned long long)n_b);
+            fk_h2h_block &blk = blocks[b];
+            blk.state[0] += n_b;
             blk.state[1] += comp;
             blk.state[2] += saf;
             blk.state[3] += a1;

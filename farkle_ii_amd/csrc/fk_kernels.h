@@ -84,10 +84,13 @@ struct DevOverride {
     uint32_t max_rounds;
 };
 
-// One H2H block of a batched launch: games [start, next block's start) are its attempts attempt0, attempt0 + 1, ...
+// One H2H block of a batched launch (pass): games [start, next block's start) are its attempts attempt0, attempt0 + 1, ...;
+// `row` = the block's index in the CALL's block list: its seats are rows 2 row, 2 row + 1 of the strategy table, and its
+// counts go to out[row] of the reduce pass — the table and the counts are per call, so that the passes of a call share them
+// (and the next pass can be prepared while this one plays).
 struct DevBlock {
     uint64_t pair, attempt0;
-    uint32_t order, start;
+    uint32_t order, start, row, pad;
 };
 
 struct SeedArgs {
@@ -118,7 +121,8 @@ struct SeedArgs {
     // batched H2H blocks (MODE_BLOCKS): game -> (block, attempt)
     const DevBlock *blocks;
     uint32_t n_blocks;
-    const uint32_t *game_block; // [n_games] block index of every game (fk_block_map_kernel)
+    const uint32_t *game_block; // [n_games] pass-local block index of every game (fk_block_map_kernel)
+    const uint32_t *game_row;   // [n_games] the block's row in the call's block list (strategy rows 2 row, 2 row + 1)
     // SeedSequence pool after entropy words 0..11 (…, shuffle, pair, order), shared by every game of a shuffle (tournament) or
     // of a block (batched H2H): [n_sh] / [n_blocks], written by fk_pool_kernel
     const uint4 *pools;
@@ -131,7 +135,7 @@ struct PlayArgs {
     const uint16_t *perm_T;      // blocked permutations (MODE_PERM), see perm_at()
     uint32_t perm_slots;
     const int32_t *seat_strategy; // [n_games][k] (MODE_LIST)
-    const uint32_t *game_block;  // [n_games] (MODE_BLOCKS): strategy index of seat s = 2 * block + s
+    const uint32_t *game_block;  // [n_games] (MODE_BLOCKS): SeedArgs::game_row — strategy index of seat s = 2 * row + s
     uint32_t *state;             // seat state records, see SeedArgs (GS instances update them in place)
     uint32_t state_dw;
     const uint4 *inc;
@@ -517,7 +521,7 @@ __device__ inline uint32_t schedule_class_block(const uint8_t *patience, uint32_
 }
 
 // batched H2H: game -> block (the block with the largest start <= game), one lane per game
-__global__ void fk_block_map_kernel(const DevBlock *blocks, uint32_t n_blocks, uint32_t n_games, uint32_t *game_block) {
+__global__ void fk_block_map_kernel(const DevBlock *blocks, uint32_t n_blocks, uint32_t n_games, uint32_t *game_block, uint32_t *game_row) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_games) return;
     uint32_t lo = 0, hi = n_blocks;
@@ -527,6 +531,7 @@ __global__ void fk_block_map_kernel(const DevBlock *blocks, uint32_t n_blocks, u
         else hi = mid;
     }
     game_block[t] = lo;
+    game_row[t] = blocks[lo].row;
 }
 
 // Entropy words 6..11 (shuffle_index, pair_id, order: random.py:106-111) are the same for every game of a shuffle (tournament)
@@ -609,7 +614,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
     uint32_t slot = t;
     if (a.sched) {
         uint32_t cls = SCHED_CLASSES;
-        if (valid) cls = a.blocks ? schedule_class_block(a.patience, a.game_block[t])
+        if (valid) cls = a.blocks ? schedule_class_block(a.patience, a.game_row[t])
                                   : schedule_class(a.perm_T, a.perm_slots, a.S, a.k, a.patience, sh_local, g_local);
         const uint32_t wave = threadIdx.x >> 6;
         uint64_t mine_m = 0;
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(SEED_BLOCK) void fk_seed_kernel(SeedArgs a) {
             uint32_t idx = s;
             if (a.perm_T) idx = perm_at(a.perm_T, a.S, a.perm_slots, p_sh, p_g * a.k + s);
             else if (a.seat_strategy) idx = (uint32_t)a.seat_strategy[(size_t)p_id * a.k + s];
-            else if (a.blocks) idx = 2u * p_blk + s;
+            else if (a.blocks) idx = 2u * a.blocks[p_blk].row + s;
             dst[1] = make_uint4(0u, 0u, 0u, 0u);
             dst[2] = make_uint4(0u, 0u, 0u, idx);
         } else if (a.seat_idx && a.perm_T) {

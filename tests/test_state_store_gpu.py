@@ -180,6 +180,44 @@ def test_h2h_blocks_batched_equal_serial_blocks(eng, po):
     assert (got[:, 1] == 3).all() or (got[:, 0] == 6).any()
 
 
+def test_h2h_generations_cut_into_many_pipelined_passes(eng, po):
+    """A small workspace budget cuts each generation of a batched H2H call into many launches; blocks straddle passes, the
+    next pass is prepared on the side stream while the current one plays (and, with `pipeline` off or overrides present, in
+    front of its own game kernel): every block still equals the oracle's serial loop."""
+    from farkle_ii_amd.backend import make_overrides
+
+    rng = np.random.default_rng(19)
+    pool = _random_valid_table(40, 3)
+    pool["dice_threshold"][:3], pool["consider_dice"][:3], pool["require_both"][:3], pool["consider_score"][:3] = 0, 1, 1, 1
+    n = 240
+    seats = np.stack([pool[rng.integers(0, 40, 2)] for _ in range(n)])
+    seats[11] = pool[[0, 2]]
+    pair = rng.integers(0, 90, n).astype(np.uint64)
+    order = rng.integers(0, 2, n).astype(np.uint32)
+    target = rng.integers(40, 900, n).astype(np.uint64)
+    max_attempts = (target * 2).astype(np.uint64)
+    want = np.stack([po.h2h_block(seats[b].view(po.STRATEGY_DTYPE), 23, int(pair[b]), int(order[b]), int(target[b]), int(max_attempts[b]),
+                                  int(max_attempts[b]), max_rounds=80) for b in range(n)])
+    ovs = [(23, int(pair[3]), 1, int(order[3]), 0), (23, int(pair[200]), 17, int(order[200]), 2)]
+    want_ov = np.stack([po.h2h_block(seats[b].view(po.STRATEGY_DTYPE), 23, int(pair[b]), int(order[b]), int(target[b]), int(max_attempts[b]),
+                                     int(max_attempts[b]), max_rounds=80, overrides=po.make_overrides(ovs)) for b in range(n)])
+    try:
+        for chunk in (1 << 20, 48 << 30):           # ~ 7 000 games per launch: a dozen passes in the first generation / one pass
+            eng.set_option("chunk_bytes", chunk)
+            for pipeline in (1, 0):
+                eng.set_option("pipeline", pipeline)
+                got = eng.h2h_blocks(seats, 23, pair, order, target, max_attempts, max_rounds=80)
+                assert np.array_equal(got, want), (chunk, pipeline, np.argwhere(got != want)[:4])
+                if chunk == 1 << 20:
+                    assert eng.timing()["play_launches"] >= 1
+            eng.set_option("pipeline", 1)
+            got = eng.h2h_blocks(seats, 23, pair, order, target, max_attempts, max_rounds=80, overrides=make_overrides(ovs))
+            assert np.array_equal(got, want_ov), chunk
+    finally:
+        eng.set_option("pipeline", 1)
+        eng.set_option("chunk_bytes", 48 << 30)
+
+
 def test_h2h_production_shape_throughput_sanity(eng):
     """10 000 blocks of 2 191 completed games (the production H2H schedule's block size) in a few launches: every block
     reaches its target, conservation holds, wins are order-symmetric in distribution (not checked bit-wise here)."""
