@@ -472,7 +472,9 @@ def main() -> None:
     # FK_DIST_BACKEND=gloo rehearses the multi-rank path on a one-GPU box (ranks share GPU 0, tallies reduced on CPU);
     # the real runs use nccl = RCCL over xGMI with one GPU per rank.
     backend = os.environ.get("FK_DIST_BACKEND", "nccl")
-    if backend == "gloo":
+    if backend == "gloo" or os.environ.get("FK_BENCH_SHARE_GPU"):
+        # rehearsals on a box with fewer GPUs than ranks: ranks share the devices (FK_BENCH_SHARE_GPU with the RCCL backend makes
+        # RCCL refuse the duplicate device — which exercises the collective fallback on real hardware)
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     data_group = None  # the process group the tally reduction runs on (RCCL when it came up on EVERY rank)
     if distributed:
