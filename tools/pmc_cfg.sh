@@ -7,6 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=$1; grid=$2; k=$3; nsh=$4
 shift 4
 run="python3 tools/time_config.py $grid $k $nsh 3 $*"
+if [ -n "$PMC_RUN" ]; then run="$PMC_RUN"; fi   # another workload under the same passes (e.g. tools/time_h2h_blocks.py)
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats -- $run > gpurun_out/${tag}_stats.log 2>&1
 echo "stats done"
 timeout -k 10 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAVE_CYCLES --output-format csv -d gpurun_out/${tag}_pmc1 -- $run > gpurun_out/${tag}_pmc1.log 2>&1
