@@ -80,7 +80,7 @@ def hip_sources() -> list[Path]:
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    deps = hip_sources() + [SRC_DIR / "fk_device.h", SRC_DIR / "fk_kernels.h", PKG_DIR.parent / "include" / "farkle_hip.h"]
+    deps = hip_sources() + [SRC_DIR / "fk_device.h", SRC_DIR / "fk_kernels.h", SRC_DIR / "fk_play_hc.h", PKG_DIR.parent / "include" / "farkle_hip.h"]
     if LIB_PATH.exists() and not force and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return LIB_PATH
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(LIB_PATH),

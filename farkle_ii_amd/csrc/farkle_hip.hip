@@ -235,7 +235,7 @@ struct LaunchPlan {
     bool blk = false;  // batched-H2H instance (strategy index from the lane's block index)
     bool hc = false;   // hot / cold instance (fk_play_hc.h): 20 bytes of LDS per seat, cold records in an L2-resident plane
     bool hc_lt = false; // ... with the score / discard tables in LDS
-    bool hc_ki = false; // ... with every seat's PCG increment in registers
+    int hc_ki = 0;      // ... with every seat's PCG increment in registers (2: the four-wave instances of k = 5 .. 7)
     int wpe = 4;       // waves per SIMD the chosen instance is compiled for
     uint32_t mixed_flags = 0xff00u; // flag bits that differ between strategies of the table (selects the kernel instance)
 };
@@ -322,24 +322,31 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, i
 bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const LaunchPlan &base, LaunchPlan &out) {
     if (c->hc == 0 || c->gs == 1 || base.lds_tally) return false;
     if (k < 3 || k > (int32_t)HC_MAX_K || ceil_div50(target_score) > HC_MAX_TARGET50) return false;
-    const int block = (c->hc_block == 1024 || c->hc_block == 768) ? c->hc_block : 256;
     const bool lt = c->hc_tables != 0;
+    const int max_waves = std::max(1, std::min(c->hc_waves, c->max_waves));
+    // register instances (increments of every seat in registers, tables in LDS).  k = 5 .. 7 run FOUR waves per SIMD — 128
+    // registers hold the increments when the packed strategies are loaded per turn instead — in whatever block size lets
+    // the hot planes and the table images fit: 4 x 256 threads at k = 5, 2 x 512 at k = 6, 1 x 1 024 at k = 7; k = 8 (hot
+    // planes alone 160 KB at four waves) stays at 3 x 256, and so does everything when the option caps the waves.
+    const bool ki = c->hc_inc_regs != 0 && lt && c->hc_block != 1024 && c->hc_block != 768;
+    const bool four = ki && k >= 5 && k <= 7 && max_waves >= 4;
+    const int block = four ? (k == 5 ? 256 : k == 6 ? 512 : 1024) : ki ? 256 : (c->hc_block == 1024 || c->hc_block == 768) ? c->hc_block : 256;
     const size_t lds = (size_t)block * 20 * (size_t)k + (lt ? LT_BYTES : 0);
     if (lds > LDS_LIMIT) return false;
-    const int max_lanes = 256 * std::max(1, std::min(c->hc_waves, c->max_waves));
-    int per_cu = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)std::max(1, max_lanes / block));
+    int per_cu = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)std::max(1, 256 * max_waves / block));
+    if (four) per_cu = std::min(per_cu, 1024 / block);
+    else if (ki) per_cu = std::min(per_cu, k <= 4 ? 4 : 3); // 128 / 168 registers per lane
     if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
     per_cu = std::max(per_cu, 1);
     const int base_lanes = base.block * std::max(1, base.grid / std::max(1, base.cus));
-    // auto: k >= 6.  Measured on the 5 160-strategy grid against the LDS-record kernel in the same process (round 3,
-    // tools/exp_hc2.py; LDS tables + register-resident increments / strategies, three 256-thread blocks per CU):
-    // k = 8 +27 %, k = 7 +20 %, k = 6 +13 % games/s; k = 5 +-0, k = 4 -3 %, k = 3 -10 %.
-    if (c->hc < 0 && (k < 6 || per_cu * block <= base_lanes)) return false;
+    // auto: k >= 5.  Measured on the 5 160-strategy grid against the LDS-record kernel in the same process (round 3,
+    // tools/exp_hc2.py, tools/exp_hc3.py): k = 8 +27 %, k = 7 +25 %, k = 6 +23 %, k = 5 +10 % games/s; k = 4 +-0 (five waves,
+    // spilling) or -2 % (four), k = 3 -7 %.
+    if (c->hc < 0 && (k < 5 || per_cu * block <= base_lanes)) return false;
     out = base;
     out.hc = true;
     out.hc_lt = lt;
-    out.hc_ki = c->hc_inc_regs != 0 && lt && block == 256;
-    if (out.hc_ki) per_cu = std::min(per_cu, k <= 4 ? 4 : 3); // 128 / 168 registers per lane: room for the seats' increments and strategies
+    out.hc_ki = ki ? (four ? 2 : 1) : 0;
     out.lean = true;
     out.gs = false;
     out.blk = false;
@@ -433,12 +440,12 @@ hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) 
     return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS, BLK, KC>(p, a, s);
 }
 
-template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0>
+template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR = true>
 hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     static int configured_dev = -1; // dynamic-LDS ceiling and occupancy are per device
     static size_t occ_lds = ~(size_t)0;
     static int occ_blocks = 0;
-    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI>);
+    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR>);
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (configured_dev != dev) {
@@ -456,18 +463,24 @@ hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t 
     }
     const int grid = std::min(p.grid, occ_blocks * p.cus);
     p.launched_grid = grid;
-    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
+    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
     return hipGetLastError();
 }
 
-template <int BLOCK, bool LT, int KI = 0>
+template <int BLOCK, bool LT, int KI = 0, int WPE = 0, bool PKR = true>
 hipError_t launch_play_hc_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI>(p, a, s);
-    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI>(p, a, s);
-    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI>(p, a, s);
+    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI, WPE, PKR>(p, a, s);
+    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI, WPE, PKR>(p, a, s);
+    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI, WPE, PKR>(p, a, s);
 }
 
 hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
+    if (p.hc_ki == 2) { // four waves per SIMD: increments in registers, strategies loaded per turn
+        if (a.k == 5u && p.block == 256) return launch_play_hc_t<256, true, 6, 4, false>(p, a, s);
+        if (a.k == 6u && p.block == 512) return launch_play_hc_t<512, true, 6, 4, false>(p, a, s);
+        if (a.k == 7u && p.block == 1024) return launch_play_hc_t<1024, true, 7, 4, false>(p, a, s);
+        return hipErrorInvalidValue;
+    }
     if (p.hc_ki && p.block == 256 && p.hc_lt) { // increments + strategies in registers: 256-thread blocks with LDS tables
         if (a.k <= 4u) return launch_play_hc_t<256, true, 4>(p, a, s);
         if (a.k <= 6u) return launch_play_hc_t<256, true, 6>(p, a, s);

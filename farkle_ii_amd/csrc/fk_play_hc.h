@@ -43,8 +43,8 @@ constexpr uint32_t HC_MAX_K = 8;
 
 // KI: seats whose PCG increments (and, up to KI = 6, packed strategies) stay in registers for the whole game (0: both are
 // loaded at every turn start); LT: tables from the LDS image.  See the file comment.
-template <int HC_BLOCK_I, uint32_t MIXED, bool LT, int KI = 0>
-__global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(KI == 4 ? 4 : KI ? 3 : (HC_BLOCK_I == 256 ? 5 : HC_BLOCK_I / 256)))) void fk_play_hc_kernel(PlayArgs a) {
+template <int HC_BLOCK_I, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR_I = true>
+__global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : KI == 4 ? 4 : KI ? 3 : (HC_BLOCK_I == 256 ? 5 : HC_BLOCK_I / 256)))) void fk_play_hc_kernel(PlayArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t HC_BLOCK = (uint32_t)HC_BLOCK_I;
     const uint32_t tid = threadIdx.x;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(KI =
     uint32_t own_bits = 0;
     uint32_t cA = 0, cB = 0, cC = 0, cD = 0;      // the owner's cold record
     uint32_t inc_r[KI ? KI : 1][4] = {};          // KI: every seat's increment (constant indices only: registers)
-    constexpr bool PKR = KI != 0 && KI <= 6;      // ... and packed strategy, while 168 registers hold both without spilling
+    constexpr bool PKR = PKR_I && KI != 0 && KI <= 6;      // ... and packed strategy, while 168 registers hold both without spilling
     uint32_t pk_r[PKR ? KI : 1][2] = {};
 
     auto seat_index = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t {

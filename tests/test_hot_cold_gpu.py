@@ -32,8 +32,12 @@ def po():
 LDS_TABLE_BYTES = 10816  # LT_BYTES of csrc/fk_play_hc.h
 
 
-def _ran_hot_cold(eng, k: int, block: int = 256, tables: int = 1) -> bool:
+FOUR_WAVE_BLOCK = {5: 256, 6: 512, 7: 1024}  # the register instances of k = 5 .. 7 run four waves per SIMD in these blocks
+
+
+def _ran_hot_cold(eng, k: int, block: int | None = None, tables: int = 1) -> bool:
     t = eng.timing()
+    block = FOUR_WAVE_BLOCK.get(k, 256) if block is None else block
     return t["play_block"] == block and t["play_lds_bytes"] == block * 20 * k + (LDS_TABLE_BYTES if tables else 0)
 
 
@@ -60,21 +64,25 @@ def test_hot_cold_blocks_and_lds_tables_agree_with_oracle(eng, po, k, block, tab
 
 @pytest.mark.parametrize("k", [5, 6, 7, 8])
 def test_hot_cold_with_and_without_increments_in_registers(eng, po, k):
-    """k >= 5 with LDS tables on 256-thread blocks keeps every seat's PCG increment in registers (select tree on the seat);
-    option hot_cold_inc_regs = 0 loads it at each turn start instead: same rows either way."""
+    """k >= 5 with LDS tables keeps every seat's PCG increment in registers (select tree on the seat) — at four waves per
+    SIMD for k = 5 .. 7 (strategies loaded per turn), at three (hot_cold_waves = 3: strategies in registers too up to
+    k = 6) otherwise; option hot_cold_inc_regs = 0 loads the increment at each turn start instead: same rows every way."""
     S = {5: 100, 6: 96, 7: 98, 8: 96}[k]
     table = _random_valid_table(S, 1300 + k)
     ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 21, 0, 25, shuffles_per_batch=9, want_rows=True, n_threads=8)
     try:
         eng.set_option("hot_cold", 1)
-        for regs in (1, 0):
+        for regs, waves in ((1, 5), (1, 3), (0, 5)):
             eng.set_option("hot_cold_inc_regs", regs)
+            eng.set_option("hot_cold_waves", waves)
             got = eng.tournament(table, k, 21, 0, 25, shuffles_per_batch=9, want_rows=True)
-            assert _ran_hot_cold(eng, k), eng.timing()
-            assert np.array_equal(got["tally"], ref["tally"]) and got["rows"].tobytes() == ref["rows"].tobytes(), (k, regs)
+            assert _ran_hot_cold(eng, k, None if (regs, waves) == (1, 5) else 256), eng.timing()
+            assert eng.timing()["play_grid"] % 256 == 0
+            assert np.array_equal(got["tally"], ref["tally"]) and got["rows"].tobytes() == ref["rows"].tobytes(), (k, regs, waves)
     finally:
         eng.set_option("hot_cold", -1)
         eng.set_option("hot_cold_inc_regs", 1)
+        eng.set_option("hot_cold_waves", 5)
 
 
 @pytest.mark.parametrize("k", [3, 4, 5, 6, 7, 8])
@@ -130,6 +138,28 @@ def test_hot_cold_limits_overrides_and_safety_games(eng, po):
             assert got["rows"].tobytes() == ref["rows"].tobytes(), (target, mr)
     finally:
         eng.set_option("hot_cold", -1)
+
+
+@pytest.mark.parametrize("k", [5, 6, 7])
+def test_four_wave_instances_limits_and_overrides(eng, po, k):
+    """The four-wave register instances (k = 5 .. 7, the auto plan's choice): short targets, round limits and per-game
+    overrides, final seat records (rows) and all-seat statistics against the oracle."""
+    from farkle_ii_amd.backend import make_overrides
+    from oracle_engine_stub import seat_stats_from_rows
+
+    S = {5: 100, 6: 96, 7: 98}[k]
+    gps = S // k
+    table = _random_valid_table(S, 4100 + k)
+    ovs = [(4, 1, 0, k, 0), (4, 1, gps - 1, k, 2), (4, 3, 2, k, 9), (4, 6, 1, k, 300)]
+    for target, mr in [(10_000, 200), (1_500, 4), (50, 200), (10_000, 0), (135_000, 30)]:
+        ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 4, 0, 9, shuffles_per_batch=4, target_score=target, max_rounds=mr,
+                            overrides=po.make_overrides(ovs), want_rows=True, n_threads=8)
+        got = eng.tournament(table, k, 4, 0, 9, shuffles_per_batch=4, target_score=target, max_rounds=mr,
+                             overrides=make_overrides(ovs), want_rows=True, want_seat_stats=True)
+        assert _ran_hot_cold(eng, k), (k, target, mr, eng.timing())  # auto plan
+        assert np.array_equal(got["tally"], ref["tally"]), (k, target, mr)
+        assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, target, mr)
+        assert np.array_equal(got["seat_stats"], seat_stats_from_rows(ref["rows"], k, S, gps, 4)), (k, target, mr)
 
 
 def test_hot_cold_counter_guard_replays_on_the_lds_record_kernel(eng, po):
