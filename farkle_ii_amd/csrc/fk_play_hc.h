@@ -1,4 +1,4 @@
-// fk_play_hc.h — the hot / cold game kernel: tournament launches of six and more seats, whose k seat records do not leave
+// fk_play_hc.h — the hot / cold game kernel: tournament launches of five and more seats, whose k seat records do not leave
 // LDS room for more than two or three waves per SIMD (included by fk_kernels.h; same rules, same turn registers, same
 // hand-over as fk_play_kernel).
 //
@@ -28,8 +28,13 @@
 //         64 KiB global tables — two gathers per roll less for the texture addresser (-14 % kernel time here; in
 //         fk_play_kernel, which does not saturate it, the same change measured +1.7 % and was dropped);
 //   has_buf of all seats is one bit mask per lane; the seats' strategy indices are eight 16-bit fields in four registers.
-// Measured against fk_play_kernel in the same process on the 5 160-strategy grid (tools/exp_hc2.py): k = 8 +27 %, k = 7
-// +20 %, k = 6 +13 % games/s; k = 5 +-0, k = 4 -3 %, k = 3 -10 %: the launch plan picks this kernel from k = 6.
+//   FOUR WAVES per SIMD for k = 5 .. 7 (WPE = 4, PKR_I = false): with the packed strategies loaded per turn instead, 128
+//         registers hold the increments of six or seven seats without a spill in the roll loop, and the hot planes + table
+//         image fit as 4 x 256 threads (k = 5), 2 x 512 (k = 6) or 1 x 1 024 (k = 7) per CU.  k = 8 stays at three waves: its
+//         hot planes alone are 160 KB at four.
+// Measured against fk_play_kernel in the same process on the 5 160-strategy grid (tools/exp_hc2.py, tools/exp_hc3.py):
+// k = 8 +27 %, k = 7 +25 %, k = 6 +23 %, k = 5 +10 % games/s (three-wave instances: +27 / +20 / +13 / +-0 %); k = 4 +-0 at five
+// waves (spilling) and -2 % at four, k = 3 -7 %: the launch plan picks this kernel from k = 5.
 // Cold record (uint4):
 //   x = rolls | farkles << 16
 //   y = highest_turn / 50 [10:0] | banked total / 50 [22:11] | has_scored [23] | hot_dice [31:24]
@@ -41,8 +46,9 @@
 
 constexpr uint32_t HC_MAX_K = 8;
 
-// KI: seats whose PCG increments (and, up to KI = 6, packed strategies) stay in registers for the whole game (0: both are
-// loaded at every turn start); LT: tables from the LDS image.  See the file comment.
+// KI: seats whose PCG increments (and, up to KI = 6 and unless PKR_I is off, packed strategies) stay in registers for the
+// whole game (0: both are loaded at every turn start); LT: tables from the LDS image; WPE: waves per SIMD the register
+// budget is cut for (0: 4 for KI = 4, 3 for the other KI instances).  See the file comment.
 template <int HC_BLOCK_I, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR_I = true>
 __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : KI == 4 ? 4 : KI ? 3 : (HC_BLOCK_I == 256 ? 5 : HC_BLOCK_I / 256)))) void fk_play_hc_kernel(PlayArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];

@@ -76,6 +76,20 @@ def _write_parquet_atomic(table, path: Path) -> None:
     os.replace(tmp, path)
 
 
+_ARTIFACT_POOL = None
+
+
+def _artifact_pool():
+    """Four threads that write the per-batch parquet files of a launch group (Arrow's writer releases the GIL) while the main
+    thread builds the manifest records; the group's manifest lines are appended only after every file of the group is in place."""
+    global _ARTIFACT_POOL
+    if _ARTIFACT_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _ARTIFACT_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="fk-artifact")
+    return _ARTIFACT_POOL
+
+
 def _resolve_strategies(cfg: AppConfig, strategies: list[ThresholdStrategy] | None) -> tuple[list[ThresholdStrategy], int]:
     if strategies is None:
         strategies, _ = generate_strategy_grid(
@@ -448,7 +462,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         if rank == 0:
             if want_rows:
                 rt.append_manifest_records(row_manifest, sorted(row_records, key=lambda r: r["shuffle_index"]))
-            chunk_records, all_player_records = [], []
+            chunk_records, all_player_records, writes = [], [], []
             if metric_chunk_dir is not None:  # the shuffle fingerprints of the whole group in one vectorised pass
                 g_first, g_last = b0 * spb, min(b1 * spb, plan.required_shuffles)
                 group_seeds = _shuffle_seeds(eng, cfg.sim.seed, k, g_first, g_last)
@@ -456,15 +470,18 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 if all_player_dir is not None:
                     ap = all_player_batch_table(group_stats[n], ids, cfg.sim.seed, k, b)
                     name = f"all_player_batch_{b + 1:06d}.parquet"
-                    _write_parquet_atomic(ap, all_player_dir / name)
+                    writes.append(_artifact_pool().submit(_write_parquet_atomic, ap, all_player_dir / name))
                     all_player_records.append({"path": name, "rows": ap.num_rows, "root_seed": cfg.sim.seed, "n_players": k,
                                                "deterministic_batch_id": b, "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
                                                "absent_columns": list(ROW_ORDER_FLOAT_FIELDS)})
                 if metric_chunk_dir is not None:
                     chunk = _metric_chunk_table(group[n], ids, k)
                     name = f"metrics_{b + 1:06d}.parquet"  # chunk / process-block indices count from 1 (run_tournament.py:1603-1642)
-                    _write_parquet_atomic(chunk, metric_chunk_dir / name)
-                    sidecars.write("metric_chunk", metric_chunk_dir / name)
+                    def write_chunk(table=chunk, path=metric_chunk_dir / name):
+                        _write_parquet_atomic(table, path)
+                        sidecars.write("metric_chunk", path)
+
+                    writes.append(_artifact_pool().submit(write_chunk))
                     first_sh, last_sh = b * spb, min((b + 1) * spb, plan.required_shuffles)
                     record = {"path": name, "rows": chunk.num_rows, "chunk_index": b + 1, "process_block_index": b + 1,
                               "root_seed": cfg.sim.seed, "n_players": k, "deterministic_batch_id": b,
@@ -481,6 +498,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 if per_batch:
                     total += group[n]
                 done_batches.add(b)
+            for w in writes:
+                w.result()  # (re-raises a writer's error) every file a manifest line is about to name exists
             if chunk_records:
                 rt.append_manifest_records(metrics_manifest, chunk_records)
             if all_player_records:

@@ -137,9 +137,10 @@ int fk_host_free(fk_ctx *ctx, void *p);
  * kernel instance, 0 never), "perm_split" (-1 auto), "pipeline" (1, default: the next chunk / hinted call is prepared around the
  * current game kernel — permutations in front of it, schedule and seat seeding on a low-priority stream in its drain tail;
  * 0: every chunk is prepared on the main stream in front of its own game kernel), "hot_cold" (tournament launches of 3..8 seats on
- * the hot / cold game kernel, csrc/fk_play_hc.h: -1 auto = from six seats, 0 never, 1 whenever the table allows it) with its variants
+ * the hot / cold game kernel, csrc/fk_play_hc.h: -1 auto = from five seats, 0 never, 1 whenever the table allows it) with its variants
  * "hot_cold_tables" (1: score / discard tables in LDS), "hot_cold_inc_regs" (1: the seats' increments / strategies in registers),
- * "hot_cold_block" (256 / 768 / 1024) and "hot_cold_waves", "rows_chunk_games" (rows mode plays in chunks of about this many games,
+ * "hot_cold_block" (256 / 768 / 1024: block size of the instances without register-resident increments) and "hot_cold_waves"
+ * (waves per SIMD the plan may seat, default 5; below 4 the register instances of k = 5 .. 7 run three waves instead of four), "rows_chunk_games" (rows mode plays in chunks of about this many games,
  * default 4 000 000: chunk i's rows cross PCIe while chunk i + 1 plays), "resident_tally" (see fk_tally_resident_reduce).  All of them
  * are scheduling / layout choices: results are identical for every setting. */
 int fk_set_option(fk_ctx *ctx, const char *name, int64_t value);
