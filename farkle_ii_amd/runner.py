@@ -76,18 +76,27 @@ def _write_parquet_atomic(table, path: Path) -> None:
     os.replace(tmp, path)
 
 
-_ARTIFACT_POOL = None
+_HELPER = None
 
 
-def _artifact_pool():
-    """Four threads that write the per-batch parquet files of a launch group (Arrow's writer releases the GIL) while the main
-    thread builds the manifest records; the group's manifest lines are appended only after every file of the group is in place."""
-    global _ARTIFACT_POOL
-    if _ARTIFACT_POOL is None:
+def _helper_thread():
+    """One thread that encodes the metric manifest's per-shuffle lists (625 000 integers per 10^7 two-player games) while
+    the engine call of the same launch group is in flight (ctypes drops the GIL for its duration).  The per-batch parquet
+    files are NOT written on threads: Arrow's writer holds the GIL for most of a 704-row file (measured: four threads
+    1.6 ms per file against 1.1 ms serial)."""
+    global _HELPER
+    if _HELPER is None:
         from concurrent.futures import ThreadPoolExecutor
 
-        _ARTIFACT_POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="fk-artifact")
-    return _ARTIFACT_POOL
+        _HELPER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="fk-manifest")
+    return _HELPER
+
+
+def _shuffle_list_fragments(seeds: np.ndarray, first: int, spb: int, bounds: Sequence[tuple[int, int]]) -> list[tuple[str, str]]:
+    """JSON text of ``shuffle_indices`` / ``shuffle_seeds`` for every (first_shuffle, last_shuffle) batch: ``str`` of a list of
+    ints is exactly what ``json.dumps`` writes for it, at 60 % of the time."""
+    del spb
+    return [(str(list(range(lo, hi))), str(seeds[lo - first:hi - first].tolist())) for lo, hi in bounds]
 
 
 def _resolve_strategies(cfg: AppConfig, strategies: list[ThresholdStrategy] | None) -> tuple[list[ThresholdStrategy], int]:
@@ -158,28 +167,43 @@ def simulation_is_complete(cfg: AppConfig, n_players: int, plan: TournamentWorkl
     return meta.get("root_seed") == cfg.sim.seed and meta.get("k") == n_players
 
 
+_CHUNK_KEYS: dict = {}  # (ids, seated mask) -> the seated rows in chunk order + the two key columns (the same for every batch of a run)
+
+
 def _metric_chunk_table(batch_tally: np.ndarray, ids: Sequence[int], k: int):
     """Rows of one ``metrics_<idx>.parquet`` (run_tournament.py:1603-1642): for every metric label, one row per strategy that
     was seated in the batch, strategies in the order of their decimal strings (the reference sorts with ``key=str``).
-    Columns are built as arrays (a 5 160-strategy grid has 56 760 rows per chunk)."""
+    Columns are built as arrays (a 5 160-strategy grid has 56 760 rows per chunk); the ``metric`` / ``strategy`` key columns
+    depend only on which strategies were seated — every one, in a full shuffle — and are built once per run."""
     import pyarrow as pa
 
     del k
     t = np.asarray(batch_tally, dtype=np.int64)
-    sid = np.asarray([int(x) for x in ids], dtype=np.int64)
-    seated = np.flatnonzero((t[:, 1] > 0) | (t[:, 0] > 0))
-    seated = seated[np.argsort(sid[seated].astype(str), kind="stable")]
-    n, labels = len(seated), list(rt.METRIC_LABELS)
+    mask = (t[:, 1] > 0) | (t[:, 0] > 0)
+    key = (id(ids), len(ids), mask.tobytes())
+    cached = _CHUNK_KEYS.get(key)
+    if cached is None or cached[0] is not ids:
+        sid = np.asarray([int(x) for x in ids], dtype=np.int64)
+        seated = np.flatnonzero(mask)
+        seated = seated[np.argsort(sid[seated].astype(str), kind="stable")]
+        labels = pa.array(list(rt.METRIC_LABELS), type=pa.string())
+        metric = labels.take(pa.array(np.repeat(np.arange(len(labels), dtype=np.int32), len(seated))))
+        strategy = pa.array(np.tile(sid[seated], len(labels)), type=pa.int64())
+        _CHUNK_KEYS.clear()
+        cached = _CHUNK_KEYS[key] = (ids, seated, metric, strategy)
+    _, seated, metric, strategy = cached
+    m = len(rt.METRIC_LABELS)
     rows = t[seated]
+    outcome = np.tile(rows[:, :4].T, (1, m))  # wins / attempted / completed / safety-limit exposures repeat on every metric's rows
     return pa.table({
-        "metric": pa.array(np.repeat(np.asarray(labels, dtype=object), n), type=pa.string()),
-        "strategy": pa.array(np.tile(sid[seated], len(labels)), type=pa.int64()),
-        "sum": pa.array(rows[:, 4:4 + len(labels)].T.reshape(-1).astype(np.float64)),
-        "square_sum": pa.array(rows[:, 15:15 + len(labels)].T.reshape(-1).astype(np.float64)),
-        "wins": pa.array(np.tile(rows[:, 0], len(labels)), type=pa.int64()),
-        "attempted_exposures": pa.array(np.tile(rows[:, 1], len(labels)), type=pa.int64()),
-        "completed_exposures": pa.array(np.tile(rows[:, 2], len(labels)), type=pa.int64()),
-        "safety_limit_exposures": pa.array(np.tile(rows[:, 3], len(labels)), type=pa.int64()),
+        "metric": metric,
+        "strategy": strategy,
+        "sum": pa.array(rows[:, 4:4 + m].T.reshape(-1).astype(np.float64)),
+        "square_sum": pa.array(rows[:, 15:15 + m].T.reshape(-1).astype(np.float64)),
+        "wins": pa.array(outcome[0], type=pa.int64()),
+        "attempted_exposures": pa.array(outcome[1], type=pa.int64()),
+        "completed_exposures": pa.array(outcome[2], type=pa.int64()),
+        "safety_limit_exposures": pa.array(outcome[3], type=pa.int64()),
     })
 
 
@@ -416,7 +440,15 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         per_batch = metric_chunk_dir is not None or all_player_dir is not None
         local = np.zeros((b1 - b0 if per_batch else 1, S, 26), dtype=np.int64)
         local_stats = np.zeros((b1 - b0, S, SEAT_STAT_COLS), dtype=np.int64) if all_player_dir is not None else None
-        row_records: list[dict] = []
+        row_records: list[tuple[int, str]] = []  # (shuffle index, manifest line)
+        fragments = None
+        if metric_chunk_dir is not None and rank == 0:
+            # the shuffle fingerprints of the whole group in one vectorised pass (on the device), and their JSON text on the
+            # helper thread while the group plays
+            g_first, g_last = b0 * spb, min(b1 * spb, plan.required_shuffles)
+            group_seeds = _shuffle_seeds(eng, cfg.sim.seed, k, g_first, g_last)
+            bounds = [(b * spb, min((b + 1) * spb, plan.required_shuffles)) for b in range(b0, b1)]
+            fragments = _helper_thread().submit(_shuffle_list_fragments, group_seeds, g_first, spb, bounds)
         if hi > lo:
             if j + 1 < len(pending) and hasattr(eng, "hint_next"):
                 # the launch group after this one (same table, k, root): prepared in the drain tail of this group's kernel
@@ -445,14 +477,15 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             if local_stats is not None:
                 local_stats[first:first + len(res["seat_stats"])] = res["seat_stats"]
             if want_rows:  # every rank writes the shards of its own shuffles; rank 0 appends the manifest lines
-                tasks = rt.shuffle_tasks(cfg.sim.seed, k, lo, hi, spb)
+                sh_index = np.arange(lo, hi, dtype=np.int64)  # the ShuffleTask identities (run_tournament.py:97-105), as arrays
+                tasks = rt.ShuffleRange(cfg.sim.seed, k, sh_index, _shuffle_seeds(eng, cfg.sim.seed, k, lo, hi), sh_index // spb)
                 sha = oracle_game_profile.sha256 if oracle_game_profile else None
                 # one parquet file per shuffle is the reference's format: the host side of rows mode is Arrow encoding and
-                # file creation — one vectorised conversion per 1 024 shuffles, shards written by a small thread pool
+                # file creation — one vectorised conversion per 64 shuffles, shards and their manifest lines by writer processes
                 seeds102 = (eng.game_seeds(int(urandom.RandomPurpose.TOURNAMENT_GAME), cfg.sim.seed, k, lo, hi, gps)
                             if hasattr(eng, "game_seeds") else None)  # the rows' game_seed column, hashed on the device
                 row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
-                                                       game_seeds=seeds102,
+                                                       game_seeds=seeds102, as_lines=True,
                                                        sidecar=sidecars.template("row_shard", row_dir / "rows_template.parquet")))
         group = reduce_tally(local, dst=0)
         group_stats = reduce_tally(local_stats, dst=0) if local_stats is not None else None  # integer sums, like the tally
@@ -461,47 +494,40 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             row_records = [r for part in (gathered or []) for r in part]
         if rank == 0:
             if want_rows:
-                rt.append_manifest_records(row_manifest, sorted(row_records, key=lambda r: r["shuffle_index"]))
-            chunk_records, all_player_records, writes = [], [], []
-            if metric_chunk_dir is not None:  # the shuffle fingerprints of the whole group in one vectorised pass
-                g_first, g_last = b0 * spb, min(b1 * spb, plan.required_shuffles)
-                group_seeds = _shuffle_seeds(eng, cfg.sim.seed, k, g_first, g_last)
+                rt.append_manifest_lines(row_manifest, [line for _, line in sorted(row_records)])
+            chunk_lines, all_player_records = [], []
+            lists = fragments.result() if fragments is not None else None
             for n, b in enumerate(range(b0, b1)):
                 if all_player_dir is not None:
                     ap = all_player_batch_table(group_stats[n], ids, cfg.sim.seed, k, b)
                     name = f"all_player_batch_{b + 1:06d}.parquet"
-                    writes.append(_artifact_pool().submit(_write_parquet_atomic, ap, all_player_dir / name))
+                    _write_parquet_atomic(ap, all_player_dir / name)
                     all_player_records.append({"path": name, "rows": ap.num_rows, "root_seed": cfg.sim.seed, "n_players": k,
                                                "deterministic_batch_id": b, "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
                                                "absent_columns": list(ROW_ORDER_FLOAT_FIELDS)})
                 if metric_chunk_dir is not None:
                     chunk = _metric_chunk_table(group[n], ids, k)
                     name = f"metrics_{b + 1:06d}.parquet"  # chunk / process-block indices count from 1 (run_tournament.py:1603-1642)
-                    def write_chunk(table=chunk, path=metric_chunk_dir / name):
-                        _write_parquet_atomic(table, path)
-                        sidecars.write("metric_chunk", path)
-
-                    writes.append(_artifact_pool().submit(write_chunk))
+                    _write_parquet_atomic(chunk, metric_chunk_dir / name)
+                    sidecars.write("metric_chunk", metric_chunk_dir / name)
                     first_sh, last_sh = b * spb, min((b + 1) * spb, plan.required_shuffles)
                     record = {"path": name, "rows": chunk.num_rows, "chunk_index": b + 1, "process_block_index": b + 1,
                               "root_seed": cfg.sim.seed, "n_players": k, "deterministic_batch_id": b,
                               "shuffle_index_start": first_sh, "shuffle_index_end": last_sh - 1, "shuffle_count": last_sh - first_sh,
-                              "shuffle_indices": list(range(first_sh, last_sh)),
-                              "shuffle_seeds": group_seeds[first_sh - g_first:last_sh - g_first].tolist(),
+                              "shuffle_indices": "@indices@", "shuffle_seeds": "@seeds@",  # (spliced in below)
                               "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
                               "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
                               "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
                               "tournament_method_version": TOURNAMENT_METHOD_VERSION}
                     if oracle_game_profile is not None:  # run_tournament.py:1668
                         record["game_profile_sha256"] = oracle_game_profile.sha256
-                    chunk_records.append(record)
+                    indices, seeds = lists[n]
+                    chunk_lines.append(json.dumps(record, sort_keys=True).replace('"@indices@"', indices).replace('"@seeds@"', seeds))
                 if per_batch:
                     total += group[n]
                 done_batches.add(b)
-            for w in writes:
-                w.result()  # (re-raises a writer's error) every file a manifest line is about to name exists
-            if chunk_records:
-                rt.append_manifest_records(metrics_manifest, chunk_records)
+            if chunk_lines:
+                rt.append_manifest_lines(metrics_manifest, chunk_lines)
             if all_player_records:
                 rt.append_manifest_records(all_player_manifest, all_player_records)
             if not per_batch:
@@ -520,6 +546,17 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 sidecars.write("shard_manifest", manifest)
     barrier()
     return {"tally": total, "games": games_done, "seconds": time.perf_counter() - t_start}
+
+
+def _list_outputs(n_dir: Path, root: Path) -> list[str]:
+    """Every file below ``n_dir`` relative to the results root, sorted, without the completion marker itself (``os.walk``:
+    a rows-on run lists one shard per shuffle — pathlib's rglob / relative_to cost 60 us per file)."""
+    prefix = os.path.relpath(n_dir, root)
+    out = []
+    for d, _, files in os.walk(n_dir):
+        rel = os.path.normpath(os.path.join(prefix, os.path.relpath(d, n_dir)))
+        out.extend(os.path.join(rel, f) for f in files if f != "simulation.done.json")
+    return sorted(out)
 
 
 def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | None = None, *, force: bool = False,
@@ -632,8 +669,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
                          "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
                          "tournament_method_version": TOURNAMENT_METHOD_VERSION, "n_strategies": grid_size,
                          **({"game_profile_sha256": oracle_game_profile.sha256} if oracle_game_profile is not None else {})},
-            "outputs": sorted(str(p.relative_to(cfg.results_root)) for p in n_dir.rglob("*") if p.is_file()
-                              and p.name != "simulation.done.json"),
+            "outputs": _list_outputs(n_dir, cfg.results_root),
             "games": plan.required_games, "games_per_second_this_run": (result["games"] / result["seconds"]) if result["games"] else None}
     _atomic_write_bytes(simulation_done_path(cfg, n), (json.dumps(done, indent=2, sort_keys=True) + "\n").encode())
     return plan.required_games

@@ -278,16 +278,21 @@ def _run_chunk_metrics(shuffle_tasks: Sequence[ShuffleTask | int], *, collect_ro
     return wins_total, sums_total, sq_total
 
 
+def append_manifest_lines(manifest: Path, lines: Sequence[str]) -> None:
+    """Append already-encoded JSON lines to a manifest (one write call, flushed)."""
+    if not lines:
+        return
+    manifest.parent.mkdir(parents=True, exist_ok=True)
+    with open(manifest, "ab") as fh:
+        fh.write("".join(line + "\n" for line in lines).encode("utf-8"))
+        fh.flush()
+
+
 def append_manifest_records(manifest: Path, records: Sequence[Mapping[str, Any]]) -> None:
     """Append JSON lines to a manifest (one write call, flushed)."""
     import json
 
-    if not records:
-        return
-    manifest.parent.mkdir(parents=True, exist_ok=True)
-    with open(manifest, "a", encoding="utf-8") as fh:
-        fh.write("".join(json.dumps(r, sort_keys=True) + "\n" for r in records))
-        fh.flush()
+    append_manifest_lines(manifest, [json.dumps(r, sort_keys=True) for r in records])
 
 
 def write_row_shard(row_dir: Path, manifest_path: Path | None, task: ShuffleTask, rows: np.ndarray, ids: Sequence[int],
@@ -339,11 +344,16 @@ def _shard_record(name: str, gps: int, root_seed: int, k: int, shuffle_index: in
 
 def _write_shard_group(row_dir: str, k: int, ids: np.ndarray, gps: int, root_seed: int, rows: np.ndarray, shuffle_index: np.ndarray,
                        shuffle_seed: np.ndarray, batch_id: np.ndarray, game_seeds: np.ndarray | None,
-                       game_profile_sha256: str | None, sidecar: Mapping[str, Any] | None = None) -> list[dict]:
+                       game_profile_sha256: str | None, sidecar: Mapping[str, Any] | None = None, as_lines: bool = False,
+                       atomic: bool = True) -> list:
     """Shards of a run of shuffles (rows = their games, shuffle-major): one vectorised Arrow conversion, then one parquet
-    file per shuffle — a zero-copy slice of that table (run_tournament.py:530-558).  Runs in a writer process or inline."""
+    file per shuffle — a zero-copy slice of that table (run_tournament.py:530-558).  Runs in a writer process or inline.
+    Returns the manifest records — or, with ``as_lines``, ``(shuffle_index, JSON line)`` pairs, so that the encoding of one
+    line per shuffle happens in the writer processes too."""
+    import json
     import os
 
+    import pyarrow as pa
     import pyarrow.parquet as pq
 
     n_sh = len(shuffle_index)
@@ -363,14 +373,24 @@ def _write_shard_group(row_dir: str, k: int, ids: np.ndarray, gps: int, root_see
         name = f"rows_{root_seed}_{k}p_{int(shuffle_index[i]):012d}.parquet"
         out = os.path.join(row_dir, name)
         # a 32-row file: column statistics and dictionary pages are a third of its encoding time and nobody prunes on them
-        pq.write_table(table.slice(i * gps, gps), out + ".tmp", write_statistics=False, use_dictionary=False)
-        os.replace(out + ".tmp", out)
+        if atomic:
+            pq.write_table(table.slice(i * gps, gps), out + ".tmp", write_statistics=False, use_dictionary=False)
+            os.replace(out + ".tmp", out)
+        else:  # one directory operation per shard instead of two (see write_row_shards)
+            sink = pa.BufferOutputStream()
+            pq.write_table(table.slice(i * gps, gps), sink, write_statistics=False, use_dictionary=False)
+            fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            try:
+                os.write(fd, sink.getvalue())
+            finally:
+                os.close(fd)
         if sidecar is not None:
             from .sidecars import write_sidecar
 
             write_sidecar(out, sidecar)
-        records.append(_shard_record(name, gps, root_seed, k, int(shuffle_index[i]), int(shuffle_seed[i]), int(batch_id[i]), pid,
-                                     game_profile_sha256))
+        record = _shard_record(name, gps, root_seed, k, int(shuffle_index[i]), int(shuffle_seed[i]), int(batch_id[i]), pid,
+                               game_profile_sha256)
+        records.append((int(shuffle_index[i]), json.dumps(record, sort_keys=True)) if as_lines else record)
     return records
 
 
@@ -400,29 +420,50 @@ def _shard_pool(workers: int):
     return _SHARD_POOL[0]
 
 
-def write_row_shards(row_dir: Path, tasks: Sequence[ShuffleTask], rows: np.ndarray, ids: Sequence[int],
+@dataclass(frozen=True)
+class ShuffleRange:
+    """The ShuffleTask identities of many shuffles of one (root, k) cell as arrays (``write_row_shards`` takes either)."""
+
+    root_seed: int
+    k: int
+    shuffle_index: np.ndarray
+    shuffle_seed: np.ndarray
+    deterministic_batch_id: np.ndarray
+
+    def __len__(self) -> int:
+        return len(self.shuffle_index)
+
+
+def write_row_shards(row_dir: Path, tasks: "Sequence[ShuffleTask] | ShuffleRange", rows: np.ndarray, ids: Sequence[int],
                      game_profile_sha256: str | None = None, *, threads: int = 1, group: int = 64,
-                     game_seeds: np.ndarray | None = None, sidecar: Mapping[str, Any] | None = None) -> list[dict]:
+                     game_seeds: np.ndarray | None = None, sidecar: Mapping[str, Any] | None = None, as_lines: bool = False,
+                     atomic: bool = True) -> list:
     """Row shards of many shuffles of one (root, k) cell: the same files and manifest records as ``write_row_shard`` per
     shuffle (run_tournament.py:530-558).  The shuffles are cut into runs of ``group``; each run is converted to Arrow once and
     written shard by shard, by ``threads`` writer processes (``threads`` <= 1: inline).  ``game_seeds``: the ns-102
     fingerprints ``[n_shuffles][gps]`` when the caller has them (``Engine.game_seeds``), else they are hashed here.
-    Returns the manifest records in task order; the caller appends them."""
-    if not tasks:
+    Returns the manifest records in task order (``as_lines``: ``(shuffle_index, JSON line)`` pairs); the caller appends them."""
+    if len(tasks) == 0:
         return []
-    k, root = tasks[0].k, tasks[0].root_seed
+    if isinstance(tasks, ShuffleRange):
+        k, root = tasks.k, tasks.root_seed
+        sh = np.asarray(tasks.shuffle_index, dtype=np.int64)
+        seeds = np.asarray(tasks.shuffle_seed, dtype=np.int64)
+        batch = np.asarray(tasks.deterministic_batch_id, dtype=np.int32)
+    else:
+        k, root = tasks[0].k, tasks[0].root_seed
+        sh = np.array([t.shuffle_index for t in tasks], dtype=np.int64)
+        seeds = np.array([t.shuffle_seed for t in tasks], dtype=np.int64)
+        batch = np.array([t.deterministic_batch_id for t in tasks], dtype=np.int32)
     gps = len(rows) // len(tasks)
     row_dir.mkdir(parents=True, exist_ok=True)
     ids = np.asarray(ids, dtype=np.int32)
-    sh = np.array([t.shuffle_index for t in tasks], dtype=np.int64)
-    seeds = np.array([t.shuffle_seed for t in tasks], dtype=np.int64)
-    batch = np.array([t.deterministic_batch_id for t in tasks], dtype=np.int32)
     gs = None if game_seeds is None else np.asarray(game_seeds).reshape(len(tasks), gps)
     jobs = []
     for g0 in range(0, len(tasks), group):
         g1 = min(g0 + group, len(tasks))
         jobs.append((str(row_dir), k, ids, gps, root, rows[g0 * gps:g1 * gps], sh[g0:g1], seeds[g0:g1], batch[g0:g1],
-                     None if gs is None else gs[g0:g1], game_profile_sha256, sidecar))
+                     None if gs is None else gs[g0:g1], game_profile_sha256, sidecar, as_lines, atomic))
     if threads > 1 and len(jobs) > 1:
         parts = _shard_pool(threads).map(jobs)
     else:

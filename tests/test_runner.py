@@ -743,3 +743,39 @@ def test_farkle_run_sidecars(engine, tmp_path):
     for shard in sorted(out.glob("rows_*.parquet")):
         sc.validate_sidecar(shard, expected={"operation": "publish_simulation_row_shard"})
     assert len(list(out.glob("rows_*.parquet.sidecar.json"))) == 3
+
+
+def test_row_shard_writers_agree_across_their_calling_conventions(tmp_path):
+    """``write_row_shards``: ShuffleTask list / ShuffleRange arrays, records / pre-encoded manifest lines, tmp + rename /
+    direct writes, inline / writer processes — the same shard files (read back) and the same manifest records, which are the
+    per-shuffle ``write_row_shard``'s (run_tournament.py:530-558)."""
+    import pyarrow.parquet as pq
+
+    import pyoracle as po
+    from farkle_ii_amd import tournament as rt
+    from test_state_store_gpu import _strats
+
+    table = _strats(gu.load("grid_vectors.json")["g64"])[:8].copy()
+    table["strategy_id"] = np.arange(8) * 3 + 1
+    k, lo, hi, spb = 2, 5, 12, 3
+    rows = po.tournament(table.view(po.STRATEGY_DTYPE), k, 7, lo, hi, want_rows=True)["rows"]
+    ids = [int(x) for x in table["strategy_id"]]
+    tasks = rt.shuffle_tasks(7, k, lo, hi, spb)
+    gps = len(rows) // len(tasks)
+    base = tmp_path / "per_shuffle"
+    want = [rt.write_row_shard(base, None, t, rows[i * gps:(i + 1) * gps], ids, append_manifest=False, return_record=True)[1]
+            for i, t in enumerate(tasks)]
+    arrays = rt.ShuffleRange(7, k, np.array([t.shuffle_index for t in tasks]), np.array([t.shuffle_seed for t in tasks]),
+                             np.array([t.deterministic_batch_id for t in tasks]))
+    strip = lambda r: {key: v for key, v in r.items() if key != "pid"}  # noqa: E731
+    for name, who, kw in [("list", tasks, {}), ("arrays", arrays, {}), ("lines", arrays, {"as_lines": True}),
+                          ("direct", arrays, {"as_lines": True, "atomic": False}), ("procs", arrays, {"threads": 2, "group": 2, "as_lines": True})]:
+        d = tmp_path / name
+        got = rt.write_row_shards(d, who, rows, ids, **kw)
+        if kw.get("as_lines"):
+            assert [i for i, _ in got] == [t.shuffle_index for t in tasks]
+            got = [json.loads(line) for _, line in got]
+        assert [strip(r) for r in got] == [strip(r) for r in want], name
+        assert not list(d.glob("*.tmp"))
+        for r in want:
+            assert pq.read_table(d / r["path"]).equals(pq.read_table(base / r["path"])), (name, r["path"])
