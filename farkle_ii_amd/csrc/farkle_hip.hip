@@ -96,6 +96,7 @@ struct fk_ctx {
     int32_t hc_block = 256;    // its block size: 256, 768 or 1024
     int32_t hc_tables = 1;     // 1: score / discard tables in LDS (LT instances)
     int32_t hc_inc_regs = 1;   // 1: the seats' PCG increments in registers (k >= 5, 256-thread blocks, LDS tables)
+    int32_t hc_cl = 0;         // 1: cold records in LDS beside the hot part (k = 3 .. 5; an option only, see plan_play_hc)
     DevBuf lds_tables;         // their LDS image (fk_play_hc.h)
     DevBuf cold;
     bool ran_hc = false;       // the current tournament call launched the hot / cold kernel
@@ -236,6 +237,7 @@ struct LaunchPlan {
     bool hc = false;   // hot / cold instance (fk_play_hc.h): 20 bytes of LDS per seat, cold records in an L2-resident plane
     bool hc_lt = false; // ... with the score / discard tables in LDS
     int hc_ki = 0;      // ... with every seat's PCG increment in registers (2: the four-wave instances of k = 5 .. 7)
+    bool hc_cl = false; // ... with the cold records in LDS (32 bytes per seat and lane, no plane)
     int wpe = 4;       // waves per SIMD the chosen instance is compiled for
     uint32_t mixed_flags = 0xff00u; // flag bits that differ between strategies of the table (selects the kernel instance)
 };
@@ -322,8 +324,34 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, i
 bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const LaunchPlan &base, LaunchPlan &out) {
     if (c->hc == 0 || c->gs == 1 || base.lds_tally) return false;
     if (k < 3 || k > (int32_t)HC_MAX_K || ceil_div50(target_score) > HC_MAX_TARGET50) return false;
-    const bool lt = c->hc_tables != 0;
     const int max_waves = std::max(1, std::min(c->hc_waves, c->max_waves));
+    if (k <= 5 && c->hc_cl > 0) {
+        // cold records in LDS (option only: measured +-0 against ten-dword records at k = 3, 4 and against the register instance
+        // at k = 5): 32 k bytes per lane in 256-thread blocks, five / five / four waves per SIMD at k = 3 / 4 / 5
+        const int waves = std::min(k == 3 ? 6 : k == 4 ? 5 : 4, max_waves);
+        const size_t lds_cl = (size_t)256 * 32 * (size_t)k;
+        int per_cu = (int)std::min<size_t>(LDS_LIMIT / lds_cl, (size_t)waves);
+        if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
+        per_cu = std::max(per_cu, 1);
+        const int lanes = base.block * std::max(1, base.grid / std::max(1, base.cus));
+        if (c->hc > 0 || per_cu * 256 > lanes) {
+            out = base;
+            out.hc = true;
+            out.hc_lt = false;
+            out.hc_ki = 0;
+            out.hc_cl = true;
+            out.lean = true;
+            out.gs = false;
+            out.blk = false;
+            out.block = 256;
+            out.lds = lds_cl;
+            out.wpe = per_cu;
+            out.grid = c->prop.multiProcessorCount * per_cu;
+            out.cus = c->prop.multiProcessorCount;
+            return true;
+        }
+    }
+    const bool lt = c->hc_tables != 0;
     // register instances (increments of every seat in registers, tables in LDS).  k = 5 .. 7 run FOUR waves per SIMD — 128
     // registers hold the increments when the packed strategies are loaded per turn instead — in whatever block size lets
     // the hot planes and the table images fit: 4 x 256 threads at k = 5, 2 x 512 at k = 6, 1 x 1 024 at k = 7; k = 8 (hot
@@ -440,12 +468,12 @@ hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) 
     return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS, BLK, KC>(p, a, s);
 }
 
-template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR = true>
+template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false>
 hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     static int configured_dev = -1; // dynamic-LDS ceiling and occupancy are per device
     static size_t occ_lds = ~(size_t)0;
     static int occ_blocks = 0;
-    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR>);
+    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL>);
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (configured_dev != dev) {
@@ -463,18 +491,22 @@ hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t 
     }
     const int grid = std::min(p.grid, occ_blocks * p.cus);
     p.launched_grid = grid;
-    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
+    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
     return hipGetLastError();
 }
 
-template <int BLOCK, bool LT, int KI = 0, int WPE = 0, bool PKR = true>
+template <int BLOCK, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false>
 hipError_t launch_play_hc_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI, WPE, PKR>(p, a, s);
-    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI, WPE, PKR>(p, a, s);
-    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI, WPE, PKR>(p, a, s);
+    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI, WPE, PKR, CL>(p, a, s);
+    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI, WPE, PKR, CL>(p, a, s);
+    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI, WPE, PKR, CL>(p, a, s);
 }
 
 hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
+    if (p.hc_cl) { // cold records in LDS: six / five / four waves per SIMD at k = 3 / 4 / 5
+        if (a.k > 5u) return hipErrorInvalidValue;
+        return launch_play_hc_t<256, false, 0, 6, false, true>(p, a, s); // 79 registers: one instance for every k
+    }
     if (p.hc_ki == 2) { // four waves per SIMD: increments in registers, strategies loaded per turn
         if (a.k == 5u && p.block == 256) return launch_play_hc_t<256, true, 6, 4, false>(p, a, s);
         if (a.k == 6u && p.block == 512) return launch_play_hc_t<512, true, 6, 4, false>(p, a, s);
@@ -1068,6 +1100,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "hot_cold_block") c->hc_block = (int32_t)value;
     else if (n == "hot_cold_tables") c->hc_tables = (int32_t)value;
     else if (n == "hot_cold_inc_regs") c->hc_inc_regs = (int32_t)value;
+    else if (n == "hot_cold_lds") c->hc_cl = (int32_t)value;
     else if (n == "perm_split") c->perm_split = (int32_t)value;
     else if (n == "pipeline") c->pipeline = (int32_t)value;
     else if (n == "uniform_flags") c->uniform_flags_opt = (int32_t)value;
@@ -1102,6 +1135,7 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
     if (rc == FK_ERR_COUNTER_OVERFLOW && c->ran_hc) {
         // the hot / cold kernel's narrower counter fields (fk_play_hc.h) left their guard bands: the call is replayed on
         // fk_play_kernel, whose 16-bit fields are the ABI's stated limits
+        if (getenv("FK_DEBUG_REPLAY")) fprintf(stderr, "hot / cold kernel replayed: %s\n", c->err.c_str());
         const int32_t saved = c->hc;
         c->hc = 0;
         for (auto &cs : c->sets) cs.prepared = false;
@@ -1147,8 +1181,8 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
         LaunchPlan hc_plan;
         if (plan_play_hc(c, k, target_score, plan, hc_plan)) plan = hc_plan;
     }
-    if (plan.hc) { // cold seat records of every lane the grid can seat
-        c->ran_hc = true;
+    if (plan.hc) c->ran_hc = true;
+    if (plan.hc && !plan.hc_cl) { // cold seat records of every lane the grid can seat
         rc = ensure(c, c->cold, (size_t)plan.grid * (size_t)plan.block * (size_t)k * 16);
         if (rc) return rc;
     }

@@ -647,9 +647,20 @@ __device__ inline Roll50 default_score_lds50(const uint8_t *img, uint32_t key, i
     }
     return apply_discards50(e, choice);
 }
-constexpr uint32_t HC_HI_MASK = 0x7ffu, HC_SCORE_SHIFT = 11, HC_SCORE_MASK = 0xfffu, HC_HAS_SCORED = 1u << 23, HC_HOT_SHIFT = 24;
+// Cold seat record of the hot / cold game kernel (fk_play_hc.h), three dwords.  The top bit of every counter field is a
+// guard bit: a count that reaches it raises FK_ERR_COUNTER_OVERFLOW (the host replays the call on fk_play_kernel, whose
+// fields are 16 bits wide) before the field can carry into its neighbour.
+//   x = rolls [11:0] | farkles [20:12] | smart_five_uses [30:21] | has_scored [31]
+//   y = n_smart_five_dice [10:0] | n_smart_one_dice [21:11] | smart_one_uses [31:22]
+//   z = highest_turn / 50 [10:0] | banked total / 50 [22:11] | hot_dice [31:23]
+// (highest turn and banked total are bounded by the turn-score guard and the launch plan: no guard bits.  The widths come from
+// the reference's default grid: four never-banking strategies seated together play 200 rounds with up to 940 rolls, 200 farkles,
+// 228 smart-five uses and 142 hot-dice turns of one seat.)
+constexpr uint32_t HC_ROLLS_MASK = 0x7ffu, HC_FARKLE_SHIFT = 12, HC_FARKLE_MASK = 0xffu, HC_S5U_SHIFT = 21, HC_S1U_SHIFT = 22, HC_USES_MASK = 0x1ffu;
+constexpr uint32_t HC_D1_SHIFT = 11, HC_DICE_MASK = 0x3ffu;
+constexpr uint32_t HC_HI_MASK = 0x7ffu, HC_SCORE_SHIFT = 11, HC_SCORE_MASK = 0xfffu, HC_HOT_SHIFT = 23, HC_HOT_MASK = 0xffu, HC_HAS_SCORED = 1u << 31 /* in x */;
+constexpr uint32_t HC_X_GUARD = (1u << 11) | (1u << 20) | (1u << 30), HC_Y_GUARD = (1u << 10) | (1u << 21) | (1u << 31), HC_Z_GUARD = 1u << 31;
 constexpr int32_t HC_MAX_TARGET50 = 2700; // 2700 + 1310 < 4096
-constexpr uint32_t HC_HOT_GUARD = 250;
 
 // should_continue in units of 50; stb50 = floor(score_to_beat / 50)
 __host__ __device__ inline bool should_continue50(const Strat50 &s, int32_t turn50, int32_t dice_left, bool has_scored, bool final_round,

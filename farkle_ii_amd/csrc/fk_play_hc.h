@@ -16,11 +16,16 @@
 // So the seat record is split by how often it is touched, and each part goes where there is room:
 //   HOT   per roll: generator state (16 B) + buffered half word (4 B) = 20 bytes per seat, in LDS for every seat
 //         (k = 8: 160 B per lane; three 256-thread blocks per CU with the tables below);
-//   COLD  per turn: the eight behaviour counters, the banked total and has_scored = 16 bytes per seat.  The turn owner's
-//         live in four registers; at a turn hand-over they go to a PLANE indexed by (resident lane, seat) — 16 k bytes per
-//         lane, 25 MB for the whole chip at k = 8, L2-resident once the increments no longer compete for it — and the next
-//         owner's come in.  One store + one load per turn; the load is issued at the hand-over and first read in the middle
-//         of the next roll, so its latency is not on the roll's dependency chain;
+//   COLD  per turn: the eight behaviour counters, the banked total and has_scored, packed into three dwords per seat
+//         (fk_device.h: every counter field ends in a guard bit).  The turn owner's live in three registers; at a turn
+//         hand-over they go to a PLANE indexed by (resident lane, seat) — 16 k bytes per lane, 25 MB for the whole chip at
+//         k = 8, L2-resident once the increments no longer compete for it — and the next owner's come in.  One store + one
+//         load per turn; the load is issued at the hand-over and first read in the middle of the next roll, so its latency
+//         is not on the roll's dependency chain;
+//   COLD IN LDS (CL instances, k = 3 .. 5): with three dwords the cold record fits LDS beside the hot part — 32 bytes per
+//         seat instead of fk_play_kernel's 40: five waves per SIMD at k = 4 where ten-dword records
+//         seat four, six at k = 3, four at k = 5 — with no plane, no select trees and the global tables (the texture
+//         addresser is not saturated there);
 //   READ-ONLY per seat (KI instances, k <= 8): the PCG increment (4 dwords) and the packed strategy (2 dwords, k <= 6) of
 //         EVERY seat stay in registers for the whole game and are picked by a select tree on the seat index at a turn start
 //         (7 v_cndmask per dword at k = 8): no increment / strategy request per turn, no increment lines in L2;
@@ -35,28 +40,30 @@
 // Measured against fk_play_kernel in the same process on the 5 160-strategy grid (tools/exp_hc2.py, tools/exp_hc3.py):
 // k = 8 +27 %, k = 7 +25 %, k = 6 +23 %, k = 5 +10 % games/s (three-wave instances: +27 / +20 / +13 / +-0 %); k = 4 +-0 at five
 // waves (spilling) and -2 % at four, k = 3 -7 %: the launch plan picks this kernel from k = 5.
-// Cold record (uint4):
-//   x = rolls | farkles << 16
-//   y = highest_turn / 50 [10:0] | banked total / 50 [22:11] | has_scored [23] | hot_dice [31:24]
-//   z = smart_five_uses | n_smart_five_dice << 16        w = smart_one_uses | n_smart_one_dice << 16
-// The 12-bit total needs target / 50 + one turn (<= 1310) < 4096, the 8-bit hot-dice count a guard band at 250 (a seat
-// rolls hot dice in ~3 % of its turns); the launch plan keeps other tables on fk_play_kernel, and a count that leaves the
-// band is FK_ERR_COUNTER_OVERFLOW like every other guarded counter (the host then replays the call on fk_play_kernel).
+// Cold record: fk_device.h (HC_*).  The 12-bit total needs target / 50 + one turn (<= 1310) < 4096; the launch plan keeps other
+// tables on fk_play_kernel, and a count that reaches its guard bit (2 048 rolls, 256 farkles, 512 smart-discard uses, 1 024
+// discarded dice, 256 hot-dice turns of one seat in one game) is FK_ERR_COUNTER_OVERFLOW like every other guarded counter
+// (the host then replays the call on fk_play_kernel).
 #pragma once
 
 constexpr uint32_t HC_MAX_K = 8;
 
 // KI: seats whose PCG increments (and, up to KI = 6 and unless PKR_I is off, packed strategies) stay in registers for the
 // whole game (0: both are loaded at every turn start); LT: tables from the LDS image; WPE: waves per SIMD the register
-// budget is cut for (0: 4 for KI = 4, 3 for the other KI instances).  See the file comment.
-template <int HC_BLOCK_I, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR_I = true>
+// budget is cut for (0: 4 for KI = 4, 3 for the other KI instances); CL: cold records in LDS beside the buffered half words
+// (no plane).  See the file comment.
+template <int HC_BLOCK_I, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR_I = true, bool CL = false>
 __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : KI == 4 ? 4 : KI ? 3 : (HC_BLOCK_I == 256 ? 5 : HC_BLOCK_I / 256)))) void fk_play_hc_kernel(PlayArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t HC_BLOCK = (uint32_t)HC_BLOCK_I;
     const uint32_t tid = threadIdx.x;
     const uint32_t K = a.k;
+    static_assert(!CL || (KI == 0 && !LT), "cold-in-LDS instances load increments / strategies per turn and gather from the global tables");
     uint4 *const lds_state = reinterpret_cast<uint4 *>(lds) + tid;   // [seat][lane] generator state
     uint32_t *const lds_buf = lds + 4u * K * HC_BLOCK + tid;          // [seat][lane] buffered half word
+    // CL: [seat][lane] cold x, y (one 8-byte plane) and z — planes of the access width, so that a wave's lanes fall on distinct banks
+    uint2 *const lds_xy = reinterpret_cast<uint2 *>(lds + 5u * K * HC_BLOCK) + tid;
+    uint32_t *const lds_z = lds + 7u * K * HC_BLOCK + tid;
     const uint8_t *const lt_img = reinterpret_cast<const uint8_t *>(lds + 5u * K * HC_BLOCK); // LT: the two tables
     if (LT) {
         uint4 *dst = reinterpret_cast<uint4 *>(lds + 5u * K * HC_BLOCK);
@@ -64,7 +71,15 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         for (uint32_t i = tid; i < LT_BYTES / 16u; i += HC_BLOCK) dst[i] = src[i];
         __syncthreads();
     }
-    uint4 *const cold = a.cold + (size_t)(blockIdx.x * HC_BLOCK + tid) * K; // [resident lane][seat]
+    uint4 *const cold = CL ? nullptr : a.cold + (size_t)(blockIdx.x * HC_BLOCK + tid) * K; // [resident lane][seat] (w unused)
+    auto cold_load = [&](uint32_t s) __attribute__((always_inline)) -> uint4 {
+        if (CL) {
+            const uint2 xy = lds_xy[s * HC_BLOCK];
+            return make_uint4(0u, xy.x, xy.y, lds_z[s * HC_BLOCK]);
+        }
+        const uint4 c = cold[s];
+        return make_uint4(0u, c.x, c.y, c.z);
+    };
 
     enum : uint32_t { ST_FRESH = 0, ST_ACTIVE = 1, ST_ENDED = 2, ST_DONE = 3 };
     uint32_t st = ST_FRESH;
@@ -82,7 +97,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     uint64_t own_inc_lo = 0, own_inc_hi = 0;
     int32_t own_thr = 0;
     uint32_t own_bits = 0;
-    uint32_t cA = 0, cB = 0, cC = 0, cD = 0;      // the owner's cold record
+    uint32_t cX = 0, cY = 0, cZ = 0;              // the owner's cold record
     uint32_t inc_r[KI ? KI : 1][4] = {};          // KI: every seat's increment (constant indices only: registers)
     constexpr bool PKR = PKR_I && KI != 0 && KI <= 6;      // ... and packed strategy, while 168 registers hold both without spilling
     uint32_t pk_r[PKR ? KI : 1][2] = {};
@@ -135,12 +150,12 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         } else {
             pk = a.strat[seat_index(s)];
         }
-        const uint4 c = cold[s];
+        const uint4 c = cold_load(s);
         own_inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
         own_inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
         own_thr = (int32_t)pk.x;
         own_bits = pk.y;
-        cA = c.x, cB = c.y, cC = c.z, cD = c.w;
+        cX = c.y, cY = c.z, cZ = c.w;
         dice = 6;
         turn_score = 0;
         rolls_this_turn = 0;
@@ -156,13 +171,13 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     // ---- finished game -> one result record (run_tournament.py:375-391), final seat records on request ----
     auto finish_game = [&]() {
         const bool completed = (safety == 0u);
-        // the owner's cold record is in registers (its store may still be on its way), the others come from the plane
+        // the owner's cold record is in registers (its store may still be on its way), the others come from the plane / LDS
         uint32_t w = 0;
         int32_t best = -1;
         uint4 wrec = make_uint4(0u, 0u, 0u, 0u);
         for (uint32_t s = 0; s < K; ++s) { // stable sort on score desc: first maximum wins (engine.py:477)
-            const uint4 c = (s == seat) ? make_uint4(cA, cB, cC, cD) : cold[s];
-            const int32_t sc = (int32_t)((c.y >> HC_SCORE_SHIFT) & HC_SCORE_MASK);
+            const uint4 c = (s == seat) ? make_uint4(0u, cX, cY, cZ) : cold_load(s);
+            const int32_t sc = (int32_t)((c.w >> HC_SCORE_SHIFT) & HC_SCORE_MASK);
             if (sc > best) {
                 best = sc;
                 w = s;
@@ -171,9 +186,11 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
             if (a.gs_out) { // the state store's format (R_*): score, n_turns and hot dice spelled out
                 uint4 *g = reinterpret_cast<uint4 *>(G(s));
                 g[0] = lds_state[s * HC_BLOCK];
-                g[1] = make_uint4(lds_buf[s * HC_BLOCK], (uint32_t)sc, c.x, (c.y & HC_HI_MASK) | (seat_turns(s) << 16));
-                g[2] = make_uint4(c.z, c.w,
-                                  (c.y >> HC_HOT_SHIFT) | ((c.y & HC_HAS_SCORED) ? CE_HAS_SCORED : 0u) | (((hasbuf >> s) & 1u) ? CE_HAS_BUF : 0u),
+                g[1] = make_uint4(lds_buf[s * HC_BLOCK], (uint32_t)sc,
+                                  (c.y & HC_ROLLS_MASK) | (((c.y >> HC_FARKLE_SHIFT) & HC_FARKLE_MASK) << 16), (c.w & HC_HI_MASK) | (seat_turns(s) << 16));
+                g[2] = make_uint4(((c.y >> HC_S5U_SHIFT) & HC_USES_MASK) | ((c.z & HC_DICE_MASK) << 16),
+                                  ((c.z >> HC_S1U_SHIFT) & HC_USES_MASK) | (((c.z >> HC_D1_SHIFT) & HC_DICE_MASK) << 16),
+                                  ((c.w >> HC_HOT_SHIFT) & HC_HOT_MASK) | ((c.y & HC_HAS_SCORED) ? CE_HAS_SCORED : 0u) | (((hasbuf >> s) & 1u) ? CE_HAS_BUF : 0u),
                                   seat_index(s));
             }
         }
@@ -182,10 +199,13 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         const uint32_t d0 = widx | (completed ? (w << 24) : REC_SAFETY);
         a.rec0[game_id] = d0;
         if (a.recs) {
-            const uint32_t wa = completed ? wrec.x : 0u, wh = completed ? (wrec.y & HC_HI_MASK) : 0u;
+            if (!completed) wrec = make_uint4(0u, 0u, 0u, 0u);
             uint4 *r = reinterpret_cast<uint4 *>(a.recs + (size_t)game_id * REC_DW);
-            r[0] = make_uint4(d0, completed ? (uint32_t)best * 50u : 0u, rounds | (wa & 0xffff0000u), (wa & 0xffffu) | ((wh * 50u) << 16));
-            r[1] = make_uint4(completed ? wrec.z : 0u, completed ? wrec.w : 0u, completed ? (wrec.y >> HC_HOT_SHIFT) : 0u, 0u);
+            r[0] = make_uint4(d0, completed ? (uint32_t)best * 50u : 0u, rounds | (((wrec.y >> HC_FARKLE_SHIFT) & HC_FARKLE_MASK) << 16),
+                              (wrec.y & HC_ROLLS_MASK) | (((wrec.w & HC_HI_MASK) * 50u) << 16));
+            r[1] = make_uint4(((wrec.y >> HC_S5U_SHIFT) & HC_USES_MASK) | ((wrec.z & HC_DICE_MASK) << 16),
+                              ((wrec.z >> HC_S1U_SHIFT) & HC_USES_MASK) | (((wrec.z >> HC_D1_SHIFT) & HC_DICE_MASK) << 16),
+                              (wrec.w >> HC_HOT_SHIFT) & HC_HOT_MASK, 0u);
         }
     };
 
@@ -215,7 +235,12 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
                 const uint32_t *src = G(s);
                 lds_state[s * HC_BLOCK] = *reinterpret_cast<const uint4 *>(src);
                 lds_buf[s * HC_BLOCK] = 0u;
-                cold[s] = make_uint4(0u, 0u, 0u, 0u); // the previous game's record of this lane
+                if (CL) {
+                    lds_xy[s * HC_BLOCK] = make_uint2(0u, 0u);
+                    lds_z[s * HC_BLOCK] = 0u;
+                } else {
+                    cold[s] = make_uint4(0u, 0u, 0u, 0u); // the previous game's record of this lane
+                }
                 const uint32_t idx = (a.state_dw == STATE_DW) ? src[R_IDX] : (uint32_t)a.seat_idx[(size_t)slot * K + s];
                 iw[s >> 1] |= idx << (16u * (s & 1u));
                 if (KI && s < (uint32_t)(KI ? KI : 1)) {
@@ -231,7 +256,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         }
         ix01 = iw[0], ix23 = iw[1], ix45 = iw[2], ix67 = iw[3];
         hasbuf = 0;
-        cA = cB = cC = cD = 0u;
+        cX = cY = cZ = 0u;
         seat = 0;
         trigger = 0;
         final_round = 0;
@@ -290,32 +315,35 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         const Roll50 rr = LT ? default_score_lds50(lt_img, key, (int32_t)n, turn_score, sp)
                              : default_score_lut50(a.score_lut, a.discard_lut, key, (int32_t)n, turn_score, sp);
         const bool farkle = rr.score50 == 0;
-        const int32_t score = (int32_t)((cB >> HC_SCORE_SHIFT) & HC_SCORE_MASK);
-        cA += 1u + (farkle ? 0x10000u : 0u);
-        cC += (rr.d5 > 0) ? (1u + ((uint32_t)rr.d5 << 16)) : 0u;
-        cD += (rr.d1 > 0) ? (1u + ((uint32_t)rr.d1 << 16)) : 0u;
+        const int32_t score = (int32_t)((cZ >> HC_SCORE_SHIFT) & HC_SCORE_MASK);
+        cX += 1u + (farkle ? (1u << HC_FARKLE_SHIFT) : 0u) + ((rr.d5 > 0) ? (1u << HC_S5U_SHIFT) : 0u);
+        cY += (uint32_t)rr.d5 + ((uint32_t)rr.d1 << HC_D1_SHIFT) + ((rr.d1 > 0) ? (1u << HC_S1U_SHIFT) : 0u);
         dice = (rr.used == (int32_t)n) ? 6u : (n - (uint32_t)rr.used);
         turn_score = farkle ? 0 : (turn_score + rr.score50);
         const bool hot = !farkle & sp.has(SF_AUTO_HOT) & (dice == 6u);
-        cB += hot ? (1u << HC_HOT_SHIFT) : 0u;
-        const bool keep = should_continue50(sp, turn_score, (int32_t)dice, (cB & HC_HAS_SCORED) != 0u, final_round != 0u, score_to_beat, score);
+        cZ += hot ? (1u << HC_HOT_SHIFT) : 0u;
+        const bool keep = should_continue50(sp, turn_score, (int32_t)dice, (cX & HC_HAS_SCORED) != 0u, final_round != 0u, score_to_beat, score);
         const bool over = farkle | (!hot & !keep);
         const uint32_t ts = over ? (uint32_t)turn_score : 0u;
-        cB |= (ts >= 10u) ? HC_HAS_SCORED : 0u; // 500 points
-        const uint32_t banked = (cB & HC_HAS_SCORED) ? ts : 0u;
-        cB += banked << HC_SCORE_SHIFT;
-        cB = (banked > (cB & HC_HI_MASK)) ? ((cB & ~HC_HI_MASK) | banked) : cB;
-        const bool overflow = (turn_score > 1310) | ((cA & 0xffffu) > 64000u) | ((cC >> 16) > 63000u) | ((cD >> 16) > 63000u) |
-                              ((cB >> HC_HOT_SHIFT) > HC_HOT_GUARD);
+        cX |= (ts >= 10u) ? HC_HAS_SCORED : 0u; // 500 points
+        const uint32_t banked = (cX & HC_HAS_SCORED) ? ts : 0u;
+        cZ += banked << HC_SCORE_SHIFT;
+        cZ = (banked > (cZ & HC_HI_MASK)) ? ((cZ & ~HC_HI_MASK) | banked) : cZ;
+        const bool overflow = (turn_score > 1310) | (((cX & HC_X_GUARD) | (cY & HC_Y_GUARD) | (cZ & HC_Z_GUARD)) != 0u);
         if (roll_limit | overflow) {
             raise(roll_limit ? FK_ERR_ROLL_LIMIT : FK_ERR_COUNTER_OVERFLOW);
             return;
         }
         lds_state[s * HC_BLOCK] = make_uint4((uint32_t)rng.lo, (uint32_t)(rng.lo >> 32), (uint32_t)rng.hi, (uint32_t)(rng.hi >> 32));
-        lds_buf[s * HC_BLOCK] = rng.buf;
         hasbuf = (hasbuf & ~(1u << s)) | (rng.has_buf << s);
+        lds_buf[s * HC_BLOCK] = rng.buf;
         if (over) {
-            cold[s] = make_uint4(cA, cB, cC, cD);
+            if (CL) {
+                lds_xy[s * HC_BLOCK] = make_uint2(cX, cY);
+                lds_z[s * HC_BLOCK] = cZ;
+            } else {
+                cold[s] = make_uint4(cX, cY, cZ, 0u);
+            }
             advance(score + (int32_t)banked);
         }
     };

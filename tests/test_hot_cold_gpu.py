@@ -150,7 +150,7 @@ def test_four_wave_instances_limits_and_overrides(eng, po, k):
     S = {5: 100, 6: 96, 7: 98}[k]
     gps = S // k
     table = _random_valid_table(S, 4100 + k)
-    ovs = [(4, 1, 0, k, 0), (4, 1, gps - 1, k, 2), (4, 3, 2, k, 9), (4, 6, 1, k, 300)]
+    ovs = [(4, 1, 0, k, 0), (4, 1, gps - 1, k, 2), (4, 3, 2, k, 9), (4, 6, 1, k, 240)]  # (<= 255 rounds: the farkle field)
     for target, mr in [(10_000, 200), (1_500, 4), (50, 200), (10_000, 0), (135_000, 30)]:
         ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 4, 0, 9, shuffles_per_batch=4, target_score=target, max_rounds=mr,
                             overrides=po.make_overrides(ovs), want_rows=True, n_threads=8)
@@ -162,9 +162,44 @@ def test_four_wave_instances_limits_and_overrides(eng, po, k):
         assert np.array_equal(got["seat_stats"], seat_stats_from_rows(ref["rows"], k, S, gps, 4)), (k, target, mr)
 
 
+@pytest.mark.parametrize("k", [3, 4, 5])
+def test_cold_records_in_lds_instance(eng, po, k):
+    """Option hot_cold_lds: the cold records sit in LDS beside the hot part (32 bytes per seat and lane, no plane, global tables).
+    Tallies, rows (final seat records), all-seat statistics, short targets, round limits and overrides against the oracle."""
+    from farkle_ii_amd.backend import make_overrides
+    from oracle_engine_stub import seat_stats_from_rows
+
+    S = {3: 96, 4: 96, 5: 100}[k]
+    gps = S // k
+    table = _random_valid_table(S, 5200 + k)
+    ovs = [(11, 0, 1, k, 0), (11, 2, gps - 1, k, 3), (11, 5, 0, k, 120)]
+    try:
+        eng.set_option("hot_cold", 1)
+        eng.set_option("hot_cold_lds", 1)
+        for target, mr in [(10_000, 200), (2_000, 6), (50, 200), (10_000, 0), (135_000, 25)]:
+            ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 11, 0, 8, shuffles_per_batch=3, target_score=target, max_rounds=mr,
+                                overrides=po.make_overrides(ovs), want_rows=True, n_threads=8)
+            got = eng.tournament(table, k, 11, 0, 8, shuffles_per_batch=3, target_score=target, max_rounds=mr,
+                                 overrides=make_overrides(ovs), want_rows=True, want_seat_stats=True)
+            t = eng.timing()
+            assert t["play_block"] == 256 and t["play_lds_bytes"] == 256 * 32 * k, t
+            assert np.array_equal(got["tally"], ref["tally"]), (k, target, mr)
+            assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, target, mr)
+            assert np.array_equal(got["seat_stats"], seat_stats_from_rows(ref["rows"], k, S, gps, 3)), (k, target, mr)
+            eng.set_option("use_lds_tally", 0)  # counts only, through result records
+            rec = eng.tournament(table, k, 11, 0, 8, target_score=target, max_rounds=mr, overrides=make_overrides(ovs))
+            eng.set_option("use_lds_tally", -1)
+            assert np.array_equal(rec["tally"][0], ref["tally"].sum(axis=0)), (k, target, mr)
+    finally:
+        eng.set_option("hot_cold", -1)
+        eng.set_option("hot_cold_lds", 0)
+        eng.set_option("use_lds_tally", -1)
+
+
 def test_hot_cold_counter_guard_replays_on_the_lds_record_kernel(eng, po):
-    """A seat that rolls hot dice more than 250 times in one game leaves the hot / cold kernel's 8-bit field: the call is
-    replayed on the LDS-record kernel (16-bit fields) and still equals the oracle."""
+    """A seat that rolls hot dice more than 255 times (or rolls more than 2 047 times) in one game reaches a guard bit of the
+    hot / cold kernel's packed cold record: the call is replayed on the LDS-record kernel (16-bit fields) and still equals
+    the oracle — with the cold records in the plane and in LDS."""
     table = _strats(gu.load("grid_vectors.json")["g64"])[:8].copy()
     table["dice_threshold"], table["require_both"], table["auto_hot_dice"] = 0, 1, 1   # nobody banks: games run to the round limit
     table["strategy_id"] = np.arange(8)
@@ -172,12 +207,26 @@ def test_hot_cold_counter_guard_replays_on_the_lds_record_kernel(eng, po):
     assert int(ref["rows"]["seats"]["hot_dice"].max()) > 250
     try:
         eng.set_option("hot_cold", 1)
-        got = eng.tournament(table, 4, 3, 0, 2, max_rounds=6000, want_rows=True)
-        assert not _ran_hot_cold(eng, 4)  # the replay's kernel is the one the timing record describes
-        assert np.array_equal(got["tally"], ref["tally"])
-        assert got["rows"].tobytes() == ref["rows"].tobytes()
+        for in_lds in (0, 1):
+            eng.set_option("hot_cold_lds", in_lds)
+            got = eng.tournament(table, 4, 3, 0, 2, max_rounds=6000, want_rows=True)
+            t = eng.timing()  # the replay's kernel is the one the timing record describes
+            assert not _ran_hot_cold(eng, 4) and t["play_lds_bytes"] != 256 * 32 * 4, t
+            assert np.array_equal(got["tally"], ref["tally"])
+            assert got["rows"].tobytes() == ref["rows"].tobytes()
+        # the reference's default grid seats four never-banking strategies together now and then: 200 rounds, 940 rolls, 200
+        # farkles, 142 hot-dice turns of one seat — inside the packed fields, no replay
+        never = table.copy()
+        never["strategy_id"] = np.arange(8)
+        want = po.tournament(never.view(po.STRATEGY_DTYPE), 4, 3, 0, 3, max_rounds=200, want_rows=True)
+        assert int(want["rows"]["seats"]["farkles"].max()) >= 190
+        eng.set_option("hot_cold_lds", 0)
+        got = eng.tournament(never, 4, 3, 0, 3, max_rounds=200, want_rows=True)
+        assert _ran_hot_cold(eng, 4)
+        assert got["rows"].tobytes() == want["rows"].tobytes()
     finally:
         eng.set_option("hot_cold", -1)
+        eng.set_option("hot_cold_lds", 0)
 
 
 def test_hot_cold_is_the_default_for_wide_tables(eng, po):
