@@ -96,7 +96,7 @@ struct fk_ctx {
     int32_t hc_block = 256;    // its block size: 256, 768 or 1024
     int32_t hc_tables = 1;     // 1: score / discard tables in LDS (LT instances)
     int32_t hc_inc_regs = 1;   // 1: the seats' PCG increments in registers (k >= 5, 256-thread blocks, LDS tables)
-    int32_t hc_cl = 0;         // 1: cold records in LDS beside the hot part (k = 3 .. 5; an option only, see plan_play_hc)
+    int32_t hc_cl = -1;        // cold records in LDS beside the hot part (k = 3 .. 5): -1 auto (k = 4), 0 never, 1 always
     DevBuf lds_tables;         // their LDS image (fk_play_hc.h)
     DevBuf cold;
     bool ran_hc = false;       // the current tournament call launched the hot / cold kernel
@@ -325,31 +325,31 @@ bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const Launch
     if (c->hc == 0 || c->gs == 1 || base.lds_tally) return false;
     if (k < 3 || k > (int32_t)HC_MAX_K || ceil_div50(target_score) > HC_MAX_TARGET50) return false;
     const int max_waves = std::max(1, std::min(c->hc_waves, c->max_waves));
-    if (k <= 5 && c->hc_cl > 0) {
-        // cold records in LDS (option only: measured +-0 against ten-dword records at k = 3, 4 and against the register instance
-        // at k = 5): 32 k bytes per lane in 256-thread blocks, five / five / four waves per SIMD at k = 3 / 4 / 5
-        const int waves = std::min(k == 3 ? 6 : k == 4 ? 5 : 4, max_waves);
-        const size_t lds_cl = (size_t)256 * 32 * (size_t)k;
-        int per_cu = (int)std::min<size_t>(LDS_LIMIT / lds_cl, (size_t)waves);
+    if (k <= 5 && (c->hc_cl > 0 || (c->hc_cl < 0 && k == 4))) {
+        // cold records in LDS: 32 k bytes per lane; six / five / four waves per SIMD at k = 3 / 4 / 5.  Auto at k = 4 only (+5 %
+        // over ten-dword records; k = 3 and k = 5 measured +-0 against ten-dword records / the register instance).  k = 4 runs four
+        // 320-thread blocks: five 256-thread blocks of 32 768 bytes do NOT fit the 160 KB once each is rounded up to the LDS
+        // allocation granule (measured: the fifth block never became resident, tools/exp_occupancy.py).
+        const int block_cl = (k == 4 && c->hc_cl != 2) ? 320 : 256; // (2: the 5 x 256 launch, for the record)
+        const int waves = k == 3 ? 6 : k == 4 ? 5 : 4;
+        const size_t lds_cl = (size_t)block_cl * 32 * (size_t)k;
+        int per_cu = (int)std::min<size_t>(LDS_LIMIT / lds_cl, (size_t)(waves * 256 / block_cl));
         if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
         per_cu = std::max(per_cu, 1);
-        const int lanes = base.block * std::max(1, base.grid / std::max(1, base.cus));
-        if (c->hc > 0 || per_cu * 256 > lanes) {
-            out = base;
-            out.hc = true;
-            out.hc_lt = false;
-            out.hc_ki = 0;
-            out.hc_cl = true;
-            out.lean = true;
-            out.gs = false;
-            out.blk = false;
-            out.block = 256;
-            out.lds = lds_cl;
-            out.wpe = per_cu;
-            out.grid = c->prop.multiProcessorCount * per_cu;
-            out.cus = c->prop.multiProcessorCount;
-            return true;
-        }
+        out = base;
+        out.hc = true;
+        out.hc_lt = false;
+        out.hc_ki = 0;
+        out.hc_cl = true;
+        out.lean = true;
+        out.gs = false;
+        out.blk = false;
+        out.block = block_cl;
+        out.lds = lds_cl;
+        out.wpe = per_cu * block_cl / 256;
+        out.grid = c->prop.multiProcessorCount * per_cu;
+        out.cus = c->prop.multiProcessorCount;
+        return true;
     }
     const bool lt = c->hc_tables != 0;
     // register instances (increments of every seat in registers, tables in LDS).  k = 5 .. 7 run FOUR waves per SIMD — 128
@@ -468,12 +468,12 @@ hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) 
     return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS, BLK, KC>(p, a, s);
 }
 
-template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false>
+template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8>
 hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     static int configured_dev = -1; // dynamic-LDS ceiling and occupancy are per device
     static size_t occ_lds = ~(size_t)0;
     static int occ_blocks = 0;
-    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL>);
+    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS>);
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (configured_dev != dev) {
@@ -491,21 +491,25 @@ hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t 
     }
     const int grid = std::min(p.grid, occ_blocks * p.cus);
     p.launched_grid = grid;
-    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
+    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
     return hipGetLastError();
 }
 
-template <int BLOCK, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false>
+template <int BLOCK, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8>
 hipError_t launch_play_hc_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI, WPE, PKR, CL>(p, a, s);
-    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI, WPE, PKR, CL>(p, a, s);
-    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI, WPE, PKR, CL>(p, a, s);
+    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI, WPE, PKR, CL, NS>(p, a, s);
+    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI, WPE, PKR, CL, NS>(p, a, s);
+    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI, WPE, PKR, CL, NS>(p, a, s);
 }
 
 hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     if (p.hc_cl) { // cold records in LDS: six / five / four waves per SIMD at k = 3 / 4 / 5
         if (a.k > 5u) return hipErrorInvalidValue;
-        return launch_play_hc_t<256, false, 0, 6, false, true>(p, a, s); // 79 registers: one instance for every k
+        // (77 VGPRs: a SIMD must be able to take six waves, or the 2 + 1 + 1 + 1 waves of four 320-thread blocks do not all find a
+        // slot — a 96-register build seated three blocks.  Strategies in registers as well: 26.7 against 26.5 ms, not kept)
+        if (p.block == 320) return a.k <= 4u ? launch_play_hc_t<320, false, 0, 6, false, true, 4>(p, a, s) : hipErrorInvalidValue;
+        if (a.k <= 4u) return launch_play_hc_t<256, false, 0, 6, false, true, 4>(p, a, s);
+        return launch_play_hc_t<256, false, 0, 6, false, true>(p, a, s); // 77 - 79 registers whatever the player count
     }
     if (p.hc_ki == 2) { // four waves per SIMD: increments in registers, strategies loaded per turn
         if (a.k == 5u && p.block == 256) return launch_play_hc_t<256, true, 6, 4, false>(p, a, s);

@@ -1,4 +1,4 @@
-// fk_play_hc.h — the hot / cold game kernel: tournament launches of five and more seats, whose k seat records do not leave
+// fk_play_hc.h — the hot / cold game kernel: tournament launches of four and more seats, whose k seat records do not leave
 // LDS room for more than two or three waves per SIMD (included by fk_kernels.h; same rules, same turn registers, same
 // hand-over as fk_play_kernel).
 //
@@ -22,10 +22,11 @@
 //         k = 8, L2-resident once the increments no longer compete for it — and the next owner's come in.  One store + one
 //         load per turn; the load is issued at the hand-over and first read in the middle of the next roll, so its latency
 //         is not on the roll's dependency chain;
-//   COLD IN LDS (CL instances, k = 3 .. 5): with three dwords the cold record fits LDS beside the hot part — 32 bytes per
-//         seat instead of fk_play_kernel's 40: five waves per SIMD at k = 4 where ten-dword records
-//         seat four, six at k = 3, four at k = 5 — with no plane, no select trees and the global tables (the texture
-//         addresser is not saturated there);
+//   COLD IN LDS (CL instances; the launch plan's choice at k = 4, an option at k = 3 and 5): with three dwords the cold record
+//         fits LDS beside the hot part — 32 bytes per seat instead of fk_play_kernel's 40: five waves per SIMD at k = 4 where
+//         ten-dword records seat four (+5 % games/s), six at k = 3 and four at k = 5 (both +-0) — with no plane, no select trees
+//         and the global tables (the texture addresser is not saturated there).  k = 4 launches four 320-thread blocks per CU:
+//         five 256-thread blocks of exactly 32 KB do not fit 160 KB of LDS once each is rounded up to the allocation granule;
 //   READ-ONLY per seat (KI instances, k <= 8): the PCG increment (4 dwords) and the packed strategy (2 dwords, k <= 6) of
 //         EVERY seat stay in registers for the whole game and are picked by a select tree on the seat index at a turn start
 //         (7 v_cndmask per dword at k = 8): no increment / strategy request per turn, no increment lines in L2;
@@ -39,7 +40,8 @@
 //         hot planes alone are 160 KB at four.
 // Measured against fk_play_kernel in the same process on the 5 160-strategy grid (tools/exp_hc2.py, tools/exp_hc3.py):
 // k = 8 +27 %, k = 7 +25 %, k = 6 +23 %, k = 5 +10 % games/s (three-wave instances: +27 / +20 / +13 / +-0 %); k = 4 +-0 at five
-// waves (spilling) and -2 % at four, k = 3 -7 %: the launch plan picks this kernel from k = 5.
+// waves (spilling) and -2 % at four, k = 3 -7 %: the launch plan picks the register instances from k = 5 and the cold-in-LDS
+// instance at k = 4.
 // Cold record: fk_device.h (HC_*).  The 12-bit total needs target / 50 + one turn (<= 1310) < 4096; the launch plan keeps other
 // tables on fk_play_kernel, and a count that reaches its guard bit (2 048 rolls, 256 farkles, 512 smart-discard uses, 1 024
 // discarded dice, 256 hot-dice turns of one seat in one game) is FK_ERR_COUNTER_OVERFLOW like every other guarded counter
@@ -51,8 +53,8 @@ constexpr uint32_t HC_MAX_K = 8;
 // KI: seats whose PCG increments (and, up to KI = 6 and unless PKR_I is off, packed strategies) stay in registers for the
 // whole game (0: both are loaded at every turn start); LT: tables from the LDS image; WPE: waves per SIMD the register
 // budget is cut for (0: 4 for KI = 4, 3 for the other KI instances); CL: cold records in LDS beside the buffered half words
-// (no plane).  See the file comment.
-template <int HC_BLOCK_I, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR_I = true, bool CL = false>
+// (no plane); NS: the most seats a launch of the instance has (strategy-index select).  See the file comment.
+template <int HC_BLOCK_I, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR_I = true, bool CL = false, int NS = 8>
 __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : KI == 4 ? 4 : KI ? 3 : (HC_BLOCK_I == 256 ? 5 : HC_BLOCK_I / 256)))) void fk_play_hc_kernel(PlayArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t HC_BLOCK = (uint32_t)HC_BLOCK_I;
@@ -64,6 +66,10 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     // CL: [seat][lane] cold x, y (one 8-byte plane) and z — planes of the access width, so that a wave's lanes fall on distinct banks
     uint2 *const lds_xy = reinterpret_cast<uint2 *>(lds + 5u * K * HC_BLOCK) + tid;
     uint32_t *const lds_z = lds + 7u * K * HC_BLOCK + tid;
+    // seat s's offset in a [seat][lane] plane (a 24-bit multiply where the block size is not a power of two)
+    auto SB = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t {
+        return (HC_BLOCK & (HC_BLOCK - 1u)) ? __umul24(s, HC_BLOCK) : s * HC_BLOCK;
+    };
     const uint8_t *const lt_img = reinterpret_cast<const uint8_t *>(lds + 5u * K * HC_BLOCK); // LT: the two tables
     if (LT) {
         uint4 *dst = reinterpret_cast<uint4 *>(lds + 5u * K * HC_BLOCK);
@@ -74,8 +80,8 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     uint4 *const cold = CL ? nullptr : a.cold + (size_t)(blockIdx.x * HC_BLOCK + tid) * K; // [resident lane][seat] (w unused)
     auto cold_load = [&](uint32_t s) __attribute__((always_inline)) -> uint4 {
         if (CL) {
-            const uint2 xy = lds_xy[s * HC_BLOCK];
-            return make_uint4(0u, xy.x, xy.y, lds_z[s * HC_BLOCK]);
+            const uint2 xy = lds_xy[SB(s)];
+            return make_uint4(0u, xy.x, xy.y, lds_z[SB(s)]);
         }
         const uint4 c = cold[s];
         return make_uint4(0u, c.x, c.y, c.z);
@@ -104,9 +110,10 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
 
     auto seat_index = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t {
         const uint32_t lo = (s & 2u) ? ix23 : ix01, hi = (s & 2u) ? ix67 : ix45;
-        const uint32_t w = (s & 4u) ? hi : lo;
+        const uint32_t w = (NS > 4 && (s & 4u)) ? hi : lo; // (NS <= 4: the launch has at most four seats)
         return (s & 1u) ? (w >> 16) : (w & 0xffffu);
     };
+
     auto G = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t * {
         return a.state + ((size_t)seed_slot * K + s) * a.state_dw;
     };
@@ -185,8 +192,8 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
             }
             if (a.gs_out) { // the state store's format (R_*): score, n_turns and hot dice spelled out
                 uint4 *g = reinterpret_cast<uint4 *>(G(s));
-                g[0] = lds_state[s * HC_BLOCK];
-                g[1] = make_uint4(lds_buf[s * HC_BLOCK], (uint32_t)sc,
+                g[0] = lds_state[SB(s)];
+                g[1] = make_uint4(lds_buf[SB(s)], (uint32_t)sc,
                                   (c.y & HC_ROLLS_MASK) | (((c.y >> HC_FARKLE_SHIFT) & HC_FARKLE_MASK) << 16), (c.w & HC_HI_MASK) | (seat_turns(s) << 16));
                 g[2] = make_uint4(((c.y >> HC_S5U_SHIFT) & HC_USES_MASK) | ((c.z & HC_DICE_MASK) << 16),
                                   ((c.z >> HC_S1U_SHIFT) & HC_USES_MASK) | (((c.z >> HC_D1_SHIFT) & HC_DICE_MASK) << 16),
@@ -233,11 +240,11 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         for (uint32_t s = 0; s < HC_MAX_K; ++s) {
             if (s < K) {
                 const uint32_t *src = G(s);
-                lds_state[s * HC_BLOCK] = *reinterpret_cast<const uint4 *>(src);
-                lds_buf[s * HC_BLOCK] = 0u;
+                lds_state[SB(s)] = *reinterpret_cast<const uint4 *>(src);
+                lds_buf[SB(s)] = 0u;
                 if (CL) {
-                    lds_xy[s * HC_BLOCK] = make_uint2(0u, 0u);
-                    lds_z[s * HC_BLOCK] = 0u;
+                    lds_xy[SB(s)] = make_uint2(0u, 0u);
+                    lds_z[SB(s)] = 0u;
                 } else {
                     cold[s] = make_uint4(0u, 0u, 0u, 0u); // the previous game's record of this lane
                 }
@@ -303,8 +310,8 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     auto roll_step = [&]() __attribute__((always_inline)) {
         const bool roll_limit = rolls_this_turn >= 1000u; // ROLL_LIMIT, engine.py:36,242
         const uint32_t s = seat;
-        const uint4 sv = lds_state[s * HC_BLOCK];
-        const uint32_t buf0 = lds_buf[s * HC_BLOCK];
+        const uint4 sv = lds_state[SB(s)];
+        const uint32_t buf0 = lds_buf[SB(s)];
         Rng rng{(uint64_t)sv.z | ((uint64_t)sv.w << 32), (uint64_t)sv.x | ((uint64_t)sv.y << 32), own_inc_hi, own_inc_lo, buf0, (hasbuf >> s) & 1u};
         const uint32_t n = dice;
         const uint32_t key = roll_counts<3>(rng, n);
@@ -334,13 +341,13 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
             raise(roll_limit ? FK_ERR_ROLL_LIMIT : FK_ERR_COUNTER_OVERFLOW);
             return;
         }
-        lds_state[s * HC_BLOCK] = make_uint4((uint32_t)rng.lo, (uint32_t)(rng.lo >> 32), (uint32_t)rng.hi, (uint32_t)(rng.hi >> 32));
+        lds_state[SB(s)] = make_uint4((uint32_t)rng.lo, (uint32_t)(rng.lo >> 32), (uint32_t)rng.hi, (uint32_t)(rng.hi >> 32));
         hasbuf = (hasbuf & ~(1u << s)) | (rng.has_buf << s);
-        lds_buf[s * HC_BLOCK] = rng.buf;
+        lds_buf[SB(s)] = rng.buf;
         if (over) {
             if (CL) {
-                lds_xy[s * HC_BLOCK] = make_uint2(cX, cY);
-                lds_z[s * HC_BLOCK] = cZ;
+                lds_xy[SB(s)] = make_uint2(cX, cY);
+                lds_z[SB(s)] = cZ;
             } else {
                 cold[s] = make_uint4(cX, cY, cZ, 0u);
             }

@@ -137,9 +137,9 @@ int fk_host_free(fk_ctx *ctx, void *p);
  * kernel instance, 0 never), "perm_split" (-1 auto), "pipeline" (1, default: the next chunk / hinted call is prepared around the
  * current game kernel — permutations in front of it, schedule and seat seeding on a low-priority stream in its drain tail;
  * 0: every chunk is prepared on the main stream in front of its own game kernel), "hot_cold" (tournament launches of 3..8 seats on
- * the hot / cold game kernel, csrc/fk_play_hc.h: -1 auto = from five seats, 0 never, 1 whenever the table allows it) with its variants
- * "hot_cold_tables" (1: score / discard tables in LDS), "hot_cold_inc_regs" (1: the seats' increments / strategies in registers), "hot_cold_lds" (1: k = 3 .. 5 keep the cold records in
- * LDS, 32 bytes per seat and lane; default 0),
+ * the hot / cold game kernel, csrc/fk_play_hc.h: -1 auto = from four seats, 0 never, 1 whenever the table allows it) with its variants
+ * "hot_cold_tables" (1: score / discard tables in LDS), "hot_cold_inc_regs" (1: the seats' increments / strategies in registers), "hot_cold_lds" (k = 3 .. 5 keep the cold records in
+ * LDS, 32 bytes per seat and lane: -1 auto = at k = 4, 0 never, 1 always),
  * "hot_cold_block" (256 / 768 / 1024: block size of the instances without register-resident increments) and "hot_cold_waves"
  * (waves per SIMD the plan may seat, default 5; below 4 the register instances of k = 5 .. 7 run three waves instead of four), "rows_chunk_games" (rows mode plays in chunks of about this many games,
  * default 4 000 000: chunk i's rows cross PCIe while chunk i + 1 plays), "resident_tally" (see fk_tally_resident_reduce).  All of them

@@ -1,7 +1,8 @@
 """GPU parity tests of the hot / cold game kernel (``fk_play_hc_kernel``, csrc/fk_play_hc.h) through the C-ABI, bit-exact
 against the CPU oracle: generator state of every seat in LDS, the behaviour counters / banked totals in a per-lane plane.
 
-The kernel is chosen by the launch plan for k >= 5 (option ``hot_cold`` = -1) and forced here for every k it supports."""
+The kernel is chosen by the launch plan for k >= 4 (option ``hot_cold`` = -1; k = 4: the cold-in-LDS instance) and forced here
+for every k it supports."""
 from __future__ import annotations
 
 import numpy as np
@@ -33,10 +34,18 @@ LDS_TABLE_BYTES = 10816  # LT_BYTES of csrc/fk_play_hc.h
 
 
 FOUR_WAVE_BLOCK = {5: 256, 6: 512, 7: 1024}  # the register instances of k = 5 .. 7 run four waves per SIMD in these blocks
+COLD_IN_LDS_BLOCK = {3: 256, 4: 320, 5: 256}  # cold records in LDS: 32 bytes per seat and lane (the auto plan at k = 4)
+
+
+def _ran_cold_in_lds(eng, k: int) -> bool:
+    t = eng.timing()
+    return t["play_block"] == COLD_IN_LDS_BLOCK[k] and t["play_lds_bytes"] == COLD_IN_LDS_BLOCK[k] * 32 * k
 
 
 def _ran_hot_cold(eng, k: int, block: int | None = None, tables: int = 1) -> bool:
     t = eng.timing()
+    if block is None and k == 4:
+        return _ran_cold_in_lds(eng, 4)
     block = FOUR_WAVE_BLOCK.get(k, 256) if block is None else block
     return t["play_block"] == block and t["play_lds_bytes"] == block * 20 * k + (LDS_TABLE_BYTES if tables else 0)
 
@@ -48,6 +57,7 @@ def test_hot_cold_blocks_and_lds_tables_agree_with_oracle(eng, po, k, block, tab
     S = {3: 96, 4: 96, 5: 100, 6: 96, 7: 98, 8: 96}[k]
     try:
         eng.set_option("hot_cold", 1)
+        eng.set_option("hot_cold_lds", 0)
         eng.set_option("hot_cold_block", block)
         eng.set_option("hot_cold_tables", tables)
         for table, root in [(_random_valid_table(S, 500 + k), 8), (_random_valid_table(S, 900 + 7 * k), 1234567)]:
@@ -58,6 +68,7 @@ def test_hot_cold_blocks_and_lds_tables_agree_with_oracle(eng, po, k, block, tab
             assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, block, tables)
     finally:
         eng.set_option("hot_cold", -1)
+        eng.set_option("hot_cold_lds", -1)
         eng.set_option("hot_cold_block", 256)
         eng.set_option("hot_cold_tables", 1)
 
@@ -181,8 +192,7 @@ def test_cold_records_in_lds_instance(eng, po, k):
                                 overrides=po.make_overrides(ovs), want_rows=True, n_threads=8)
             got = eng.tournament(table, k, 11, 0, 8, shuffles_per_batch=3, target_score=target, max_rounds=mr,
                                  overrides=make_overrides(ovs), want_rows=True, want_seat_stats=True)
-            t = eng.timing()
-            assert t["play_block"] == 256 and t["play_lds_bytes"] == 256 * 32 * k, t
+            assert _ran_cold_in_lds(eng, k), eng.timing()
             assert np.array_equal(got["tally"], ref["tally"]), (k, target, mr)
             assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, target, mr)
             assert np.array_equal(got["seat_stats"], seat_stats_from_rows(ref["rows"], k, S, gps, 3)), (k, target, mr)
@@ -192,7 +202,7 @@ def test_cold_records_in_lds_instance(eng, po, k):
             assert np.array_equal(rec["tally"][0], ref["tally"].sum(axis=0)), (k, target, mr)
     finally:
         eng.set_option("hot_cold", -1)
-        eng.set_option("hot_cold_lds", 0)
+        eng.set_option("hot_cold_lds", -1)
         eng.set_option("use_lds_tally", -1)
 
 
@@ -211,7 +221,7 @@ def test_hot_cold_counter_guard_replays_on_the_lds_record_kernel(eng, po):
             eng.set_option("hot_cold_lds", in_lds)
             got = eng.tournament(table, 4, 3, 0, 2, max_rounds=6000, want_rows=True)
             t = eng.timing()  # the replay's kernel is the one the timing record describes
-            assert not _ran_hot_cold(eng, 4) and t["play_lds_bytes"] != 256 * 32 * 4, t
+            assert not _ran_hot_cold(eng, 4, 256) and not _ran_cold_in_lds(eng, 4), t
             assert np.array_equal(got["tally"], ref["tally"])
             assert got["rows"].tobytes() == ref["rows"].tobytes()
         # the reference's default grid seats four never-banking strategies together now and then: 200 rounds, 940 rolls, 200
@@ -220,13 +230,14 @@ def test_hot_cold_counter_guard_replays_on_the_lds_record_kernel(eng, po):
         never["strategy_id"] = np.arange(8)
         want = po.tournament(never.view(po.STRATEGY_DTYPE), 4, 3, 0, 3, max_rounds=200, want_rows=True)
         assert int(want["rows"]["seats"]["farkles"].max()) >= 190
-        eng.set_option("hot_cold_lds", 0)
-        got = eng.tournament(never, 4, 3, 0, 3, max_rounds=200, want_rows=True)
-        assert _ran_hot_cold(eng, 4)
-        assert got["rows"].tobytes() == want["rows"].tobytes()
+        for in_lds in (0, 1):
+            eng.set_option("hot_cold_lds", in_lds)
+            got = eng.tournament(never, 4, 3, 0, 3, max_rounds=200, want_rows=True)
+            assert _ran_cold_in_lds(eng, 4) if in_lds else _ran_hot_cold(eng, 4, 256)
+            assert got["rows"].tobytes() == want["rows"].tobytes()
     finally:
         eng.set_option("hot_cold", -1)
-        eng.set_option("hot_cold_lds", 0)
+        eng.set_option("hot_cold_lds", -1)
 
 
 def test_hot_cold_is_the_default_for_wide_tables(eng, po):

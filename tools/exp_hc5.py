@@ -27,4 +27,4 @@ for k, n_sh in ((5, 15000), (4, 12000), (3, 9000)):
         assert np.array_equal(ref, r["tally"]), (k, label)
         print(f"k={k} {label:30s} play {best:8.3f} ms  {games / best / 1e3:8.1f} M games/s  block {t['play_block']} grid {t['play_grid']} lds {t['play_lds_bytes']}", flush=True)
     eng.set_option("hot_cold", -1)
-    eng.set_option("hot_cold_lds", 0)
+    eng.set_option("hot_cold_lds", -1)
