@@ -626,14 +626,22 @@ def main() -> None:
         hbm_bpg = wl.hbm_bytes_per_game()
         # HBM bytes per launch from the PMC passes of the same launch shape (rocprofv3 cannot run inside this process):
         # profiles/r*_hbm_traffic.json carries the commit it was taken at; dropped when that is not an ancestor's kernel
+        def kernel_of(shape: dict, k_seats: int) -> str:
+            """fk_play_hc_kernel launches are recognisable by their LDS size: 20 bytes per seat and lane (+ the 10 816-byte table
+            image), or 32 with the cold records in LDS (csrc/fk_play_hc.h); everything else is fk_play_kernel."""
+            block, lds = shape.get("play_block"), shape.get("play_lds_bytes")
+            hc = bool(block) and lds in (block * 20 * k_seats, block * 20 * k_seats + 10816, block * 32 * k_seats)
+            return "fk_play_hc_kernel" if hc else "fk_play_kernel"
+
+        dominant = kernel_of(t, int(wl.k)) if isinstance(getattr(wl, "k", None), int) else "fk_play_kernel"  # (sweep / H2H lines: per_k / k = 2)
         traffic = None
         for tpath in sorted((ROOT / "profiles").glob(f"r*_hbm_traffic_config{wl.config}.json"), reverse=True):
             rec = json.loads(tpath.read_text())
             if rec.get("kernel_source_sha256") == kernel_source_sha():
-                traffic = rec["kernels"]["fk_play_kernel"]["hbm_bytes_corrected"]
+                traffic = rec["kernels"].get(dominant, {}).get("hbm_bytes_corrected")
             break
         roofline = {
-            "bound": "valu", "kernel": "fk_play_kernel",
+            "bound": "valu", "kernel": dominant,
             "achieved": achieved_ops / 1e12, "peak": peak_ops / 1e12, "unit": "Tlane-op/s (int32)", "frac": achieved_ops / peak_ops,
             "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, separate pass; null when the kernel sources changed since)",
             "kernel_ms": kernel_ms, "games_per_launch": games_per_launch, "kernel_games_per_s": kernel_games_per_s, **wpg,
@@ -654,8 +662,7 @@ def main() -> None:
                 ms = tk.get("play_ms", 0.0) / n_l
                 gpl = tk.get("games", 0) / n_l
                 rate = gpl / max(ms * 1e-3, 1e-12)
-                hc = tk.get("play_block") and tk.get("play_lds_bytes") in (tk["play_block"] * 20 * int(k2), tk["play_block"] * 20 * int(k2) + 10816)
-                per_k.append({"k": int(k2), "kernel": "fk_play_hc_kernel" if hc else "fk_play_kernel", "kernel_ms": ms,
+                per_k.append({"k": int(k2), "kernel": kernel_of(tk, int(k2)), "kernel_ms": ms,
                               "games_per_launch": gpl, "kernel_games_per_s": rate, **w2,
                               "frac": rate * w2["ops_per_game"] / peak_ops,
                               "launch": {k3: tk.get(k3) for k3 in ("play_block", "play_grid", "play_lds_bytes")}})

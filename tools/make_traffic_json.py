@@ -37,7 +37,9 @@ for name, c in agg.items():
         rec["hbm_bytes_raw"] = (c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024
         rec["hbm_bytes_corrected"] = (2 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024
     kernels[name] = rec
-kernels.setdefault("fk_play_kernel", {})["algorithmic_bytes"] = algo
+game_kernel = max((n for n in ("fk_play_hc_kernel", "fk_play_kernel") if n in kernels), key=lambda n: kernels[n].get("hbm_bytes_corrected", 0.0),
+                  default="fk_play_kernel")  # the game kernel the launch plan chose for this configuration
+kernels.setdefault(game_kernel, {})["algorithmic_bytes"] = algo
 head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
 out = {"source": source, "round": rnd, "config": config, "commit": head, "kernel_source_sha256": kernel_source_sha(),
        "units": "FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; hbm_bytes_corrected = 2 x FETCH_SIZE + WRITE_SIZE "
@@ -46,4 +48,4 @@ out = {"source": source, "round": rnd, "config": config, "commit": head, "kernel
        "kernels": kernels}
 path = ROOT / "profiles" / f"r{rnd:02d}_hbm_traffic_config{config}.json"
 path.write_text(json.dumps(out, indent=1) + "\n")
-print(path, json.dumps(kernels.get("fk_play_kernel"), indent=0)[:400])
+print(path, game_kernel, json.dumps(kernels.get(game_kernel), indent=0)[:400])
