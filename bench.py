@@ -701,9 +701,9 @@ def main() -> None:
                     "tournament_loop_games_per_s_1_process": ref["tournament_loop_1_process"]["games_per_s"],
                     "tournament_loop_games_per_s_8_processes": ref["tournament_loop_8_processes"]["games_per_s"],
                     "where": ref["host"]["note"]}
-            e2e = ROOT / "profiles" / "r02_farkle_run_end_to_end.json"
-            if e2e.exists():  # committed measurement of `farkle run` end to end (rows off / on), not of this run
-                line["farkle_run_end_to_end_fixture"] = json.loads(e2e.read_text())
+            e2e = sorted((ROOT / "profiles").glob("r*_farkle_run_end_to_end.json"))
+            if e2e:  # the latest committed measurement of `farkle run` end to end (rows off / on), not of this run
+                line["farkle_run_end_to_end_fixture"] = {"file": f"profiles/{e2e[-1].name}", **json.loads(e2e[-1].read_text())}
         print(json.dumps(line), flush=True)
     eng.close()
     if distributed:
