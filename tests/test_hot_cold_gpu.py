@@ -249,3 +249,33 @@ def test_hot_cold_is_the_default_for_wide_tables(eng, po):
     got = eng.tournament(table, 8, 0, 0, 6, shuffles_per_batch=4)
     assert _ran_hot_cold(eng, 8)
     assert np.array_equal(got["tally"], ref["tally"])
+
+
+@pytest.mark.parametrize("k", [4, 6])
+def test_hot_cold_kernels_in_chunked_hinted_and_unpipelined_calls(eng, po, k):
+    """The auto plan's hot / cold instances (k = 4: cold records in LDS; k = 6: registers + plane) under the host-side machinery:
+    about ten chunks per call (1 MiB of workspace each), a hinted next call prepared behind this call's kernel, the pipeline
+    off, rows and per-batch tallies."""
+    S = 96
+    table = _random_valid_table(S, 6100 + k)
+    ranges = [(0, 1500), (1500, 2600)]
+    ref = {rng: po.tournament(table.view(po.STRATEGY_DTYPE), k, 13, rng[0], rng[1], shuffles_per_batch=250, want_rows=True, n_threads=8)
+           for rng in ranges}
+    try:
+        for pipeline in (1, 0):
+            eng.set_option("pipeline", pipeline)
+            for chunk in (48 << 30, 1 << 20):  # one chunk / roughly ten chunks per call
+                eng.set_option("chunk_bytes", chunk)
+                eng.hint_next(*ranges[1], need_state=True)
+                for rng in ranges:
+                    got = eng.tournament(table, k, 13, rng[0], rng[1], shuffles_per_batch=250, want_rows=True)
+                    assert _ran_hot_cold(eng, k), eng.timing()
+                    if chunk == 1 << 20:
+                        assert eng.timing()["play_launches"] >= 5, eng.timing()
+                    assert np.array_equal(got["tally"], ref[rng]["tally"]), (k, pipeline, chunk, rng)
+                    assert got["rows"].tobytes() == ref[rng]["rows"].tobytes(), (k, pipeline, chunk, rng)
+                counts = eng.tournament(table, k, 13, 0, 1500, shuffles_per_batch=250)
+                assert np.array_equal(counts["tally"], ref[ranges[0]]["tally"]), (k, pipeline, chunk)
+    finally:
+        eng.set_option("pipeline", 1)
+        eng.set_option("chunk_bytes", 48 << 30)
