@@ -110,12 +110,23 @@ def init_engine_comm(engine, rank: int | None = None, world: int | None = None) 
         world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
     if world == 1:
         return False
-    comm_id = engine.comm_unique_id() if rank == 0 else None
+    # rank 0 makes the id; a failure there travels with the broadcast, so that every rank raises it instead of waiting for an id
+    comm_id = error = None
+    if rank == 0:
+        try:
+            comm_id = engine.comm_unique_id()
+        except Exception as exc:  # noqa: BLE001 - re-raised on every rank below
+            error = f"{type(exc).__name__}: {exc}"
     if group:
-        comm_id = gather_objects(comm_id, broadcast_from=0)
+        comm_id, error = gather_objects((comm_id, error), broadcast_from=0)
     else:
         port = int(os.environ.get("FK_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 17))
-        comm_id = tcp_broadcast(comm_id, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port)
+        import pickle
+
+        blob = tcp_broadcast(pickle.dumps((comm_id, error)) if rank == 0 else None, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"), port)
+        comm_id, error = pickle.loads(blob)
+    if error is not None:
+        raise RuntimeError(f"fk_comm_unique_id failed on rank 0: {error}")
     engine.comm_init(comm_id, rank, world)
     _ENGINE_COMM = engine
     return True

@@ -129,3 +129,40 @@ def test_engine_comm_is_skipped_for_engines_without_it_and_single_rank():
         pass
 
     assert init_engine_comm(NoComm()) is False
+
+
+def test_engine_comm_id_failure_on_rank_0_reaches_every_rank():
+    """`fk_comm_unique_id` failing on rank 0 must not leave the other ranks waiting for an id: the error travels with the
+    rendezvous and every rank raises it (stdlib TCP rendezvous, two threads standing in for two ranks)."""
+    import socket
+    import threading
+
+    from farkle_ii_amd.distributed import init_engine_comm
+
+    class Broken:
+        def comm_unique_id(self):
+            raise RuntimeError("no RCCL here")
+
+        def comm_init(self, *a):  # pragma: no cover - must not be reached
+            raise AssertionError("comm_init called without an id")
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    errors = [None, None]
+
+    def run(rank):
+        import os
+
+        os.environ["FK_COMM_PORT"] = str(port)
+        try:
+            init_engine_comm(Broken(), rank=rank, world=2)
+        except RuntimeError as exc:
+            errors[rank] = str(exc)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+    assert all(e and "no RCCL here" in e for e in errors), errors
