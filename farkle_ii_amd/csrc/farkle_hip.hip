@@ -113,6 +113,7 @@ struct fk_ctx {
     hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
     int64_t rows_chunk_games = 4000000; // rows mode plays in chunks of about this many games (overlap granularity)
     int32_t resident = 0;
+    size_t last_tally_bytes = 0; // bytes of the last successful tournament call's tally in `tally`
     DevBuf acc;
     size_t acc_n = 0;
 };
@@ -1134,6 +1135,7 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
                             int64_t *seat_stats) {
     if (!c) return FK_ERR_ARG;
     c->ran_hc = false;
+    c->last_tally_bytes = 0;
     int rc = tournament_run_impl(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds,
                                  ov, n_ov, tally, rows, perms, seat_stats);
     if (rc == FK_ERR_COUNTER_OVERFLOW && c->ran_hc) {
@@ -1146,6 +1148,20 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
         rc = tournament_run_impl(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds,
                                  ov, n_ov, tally, rows, perms, seat_stats);
         c->hc = saved;
+    }
+    if (rc == 0 && c->resident && c->last_tally_bytes) {
+        // the call's tally (still in c->tally) joins the resident accumulator — only now: a call that raised a device error,
+        // the overflow that is replayed above included, must not have added anything (shape changes start a new accumulator)
+        const size_t tally_bytes = c->last_tally_bytes, n_el = tally_bytes / sizeof(int64_t);
+        if (c->acc_n != n_el) {
+            rc = ensure(c, c->acc, tally_bytes);
+            if (rc) return rc;
+            HIPCHK(c, hipMemsetAsync(c->acc.p, 0, tally_bytes, c->stream));
+            c->acc_n = n_el;
+        }
+        hipLaunchKernelGGL(fk_add_i64_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, c->stream,
+                           static_cast<unsigned long long *>(c->acc.p), static_cast<const unsigned long long *>(c->tally.p), n_el);
+        HIPCHK(c, hipGetLastError());
     }
     return rc;
 }
@@ -1424,18 +1440,7 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
     hipLaunchKernelGGL(fk_finalize_tally, dim3((n_rows + 255u) / 256u), dim3(256), 0, c->stream,
                        static_cast<unsigned long long *>(c->tally.p), n_rows, (uint32_t)S, shuffles_per_batch, n_sh_total, 1u);
     HIPCHK(c, hipGetLastError());
-    if (c->resident) { // the call's tally joins the resident accumulator (shape changes start a new one)
-        const size_t n_el = tally_bytes / sizeof(int64_t);
-        if (c->acc_n != n_el) {
-            rc = ensure(c, c->acc, tally_bytes);
-            if (rc) return rc;
-            HIPCHK(c, hipMemsetAsync(c->acc.p, 0, tally_bytes, c->stream));
-            c->acc_n = n_el;
-        }
-        hipLaunchKernelGGL(fk_add_i64_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, c->stream,
-                           static_cast<unsigned long long *>(c->acc.p), static_cast<const unsigned long long *>(c->tally.p), n_el);
-        HIPCHK(c, hipGetLastError());
-    }
+    c->last_tally_bytes = tally_bytes; // (fk_tournament_run_stats adds it to the resident accumulator once the call has succeeded)
     HIPCHK(c, hipEventRecord(t1, c->stream));
     HIPCHK(c, hipMemcpyAsync(tally, c->tally.p, tally_bytes, hipMemcpyDeviceToHost, c->stream));
     if (seat_stats) HIPCHK(c, hipMemcpyAsync(seat_stats, c->stats.p, stats_bytes, hipMemcpyDeviceToHost, c->stream));

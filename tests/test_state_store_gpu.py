@@ -332,8 +332,19 @@ def test_resident_tally_accumulates_on_the_device_and_reduces_through_rccl(eng):
                 eng.reduce_resident_tally((5, 5))
         finally:
             eng.comm_destroy()
+        # a call that the hot / cold kernel hands back (a counter reaches its guard bit) and the C-ABI replays on the LDS-record
+        # kernel joins the accumulator ONCE; a call that fails (1000-roll fuse cannot be provoked here: a bad argument) not at all
+        never = table[:8].copy()
+        never["dice_threshold"], never["require_both"], never["auto_hot_dice"], never["strategy_id"] = 0, 1, 1, np.arange(8)
+        eng.set_option("hot_cold", 1)
+        f = eng.tournament(never, 4, 3, 0, 2, max_rounds=6000)["tally"]        # replayed (tests/test_hot_cold_gpu.py)
+        g = eng.tournament(never, 4, 3, 2, 5, max_rounds=40)["tally"]
+        with pytest.raises(Exception):
+            eng.tournament(never, 4, 3, 5, 4)                                 # empty / inverted range
+        assert np.array_equal(eng.reduce_resident_tally(f.shape), f + g)
     finally:
         eng.set_option("resident_tally", 0)
+        eng.set_option("hot_cold", -1)
 
 
 @pytest.mark.parametrize("S,k", [(8, 2), (64, 2), (96, 3), (1290, 2), (5160, 4), (7140, 5)])
