@@ -429,7 +429,7 @@ def test_strategy_table_size_limits(eng, po):
     (strategy index in 14 bits: S <= 16 384) and one strategy too many."""
     from farkle_ii_amd.backend import FarkleHipError
 
-    for S, k, n_sh in ((65_534, 2, 2), (16_384, 2, 3), (16_386, 2, 3), (16_386, 6, 4)):
+    for S, k, n_sh in ((65_534, 2, 2), (16_384, 2, 3), (16_386, 2, 3), (16_386, 6, 4), (65_532, 4, 2)):  # (k = 4, 6: 16-bit indices of fk_play_hc_kernel)
         table = _random_valid_table(S, S + k)
         ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 5, 0, n_sh, want_rows=True, n_threads=8)
         got = eng.tournament(table, k, 5, 0, n_sh, want_rows=True)
