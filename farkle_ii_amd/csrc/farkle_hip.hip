@@ -96,6 +96,7 @@ struct fk_ctx {
     int32_t hc_block = 256;    // its block size: 256, 768 or 1024
     int32_t hc_tables = 1;     // 1: score / discard tables in LDS (LT instances)
     int32_t hc_inc_regs = 1;   // 1: the seats' PCG increments in registers (k >= 5, 256-thread blocks, LDS tables)
+    int32_t hc_cr = 0;         // EXPERIMENT: cold records in registers (1: with the increments, 2: increments loaded per turn)
     int32_t hc_cl = -1;        // cold records in LDS beside the hot part (k = 3 .. 5): -1 auto (k = 4), 0 never, 1 always
     DevBuf lds_tables;         // their LDS image (fk_play_hc.h)
     DevBuf cold;
@@ -239,6 +240,7 @@ struct LaunchPlan {
     bool hc_lt = false; // ... with the score / discard tables in LDS
     int hc_ki = 0;      // ... with every seat's PCG increment in registers (2: the four-wave instances of k = 5 .. 7)
     bool hc_cl = false; // ... with the cold records in LDS (32 bytes per seat and lane, no plane)
+    int hc_cr = 0;      // ... with the cold records in registers (experiment)
     int wpe = 4;       // waves per SIMD the chosen instance is compiled for
     uint32_t mixed_flags = 0xff00u; // flag bits that differ between strategies of the table (selects the kernel instance)
 };
@@ -376,6 +378,7 @@ bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const Launch
     out.hc = true;
     out.hc_lt = lt;
     out.hc_ki = ki ? (four ? 2 : 1) : 0;
+    out.hc_cr = (ki && k >= 5) ? c->hc_cr : 0;
     out.lean = true;
     out.gs = false;
     out.blk = false;
@@ -469,12 +472,12 @@ hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) 
     return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS, BLK, KC>(p, a, s);
 }
 
-template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8>
+template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8, bool CR = false, bool IL = false>
 hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     static int configured_dev = -1; // dynamic-LDS ceiling and occupancy are per device
     static size_t occ_lds = ~(size_t)0;
     static int occ_blocks = 0;
-    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS>);
+    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS, CR, IL>);
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (configured_dev != dev) {
@@ -492,15 +495,15 @@ hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t 
     }
     const int grid = std::min(p.grid, occ_blocks * p.cus);
     p.launched_grid = grid;
-    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
+    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS, CR, IL>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
     return hipGetLastError();
 }
 
-template <int BLOCK, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8>
+template <int BLOCK, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8, bool CR = false, bool IL = false>
 hipError_t launch_play_hc_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI, WPE, PKR, CL, NS>(p, a, s);
-    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI, WPE, PKR, CL, NS>(p, a, s);
-    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI, WPE, PKR, CL, NS>(p, a, s);
+    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI, WPE, PKR, CL, NS, CR, IL>(p, a, s);
+    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI, WPE, PKR, CL, NS, CR, IL>(p, a, s);
+    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI, WPE, PKR, CL, NS, CR, IL>(p, a, s);
 }
 
 hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
@@ -511,6 +514,16 @@ hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s)
         if (p.block == 320) return a.k <= 4u ? launch_play_hc_t<320, false, 0, 6, false, true, 4>(p, a, s) : hipErrorInvalidValue;
         if (a.k <= 4u) return launch_play_hc_t<256, false, 0, 6, false, true, 4>(p, a, s);
         return launch_play_hc_t<256, false, 0, 6, false, true>(p, a, s); // 77 - 79 registers whatever the player count
+    }
+    if (p.hc_cr && p.hc_ki == 2) { // EXPERIMENT: cold records in registers, four waves (increments loaded per turn)
+        if (a.k == 5u && p.block == 256) return launch_play_hc_t<256, true, 6, 4, false, false, 8, true, true>(p, a, s);
+        if (a.k == 6u && p.block == 512) return launch_play_hc_t<512, true, 6, 4, false, false, 8, true, true>(p, a, s);
+        if (a.k == 7u && p.block == 1024) return launch_play_hc_t<1024, true, 7, 4, false, false, 8, true, true>(p, a, s);
+        return hipErrorInvalidValue;
+    }
+    if (p.hc_cr && p.hc_ki && p.block == 256 && p.hc_lt && a.k > 6u) { // EXPERIMENT, three waves
+        if (p.hc_cr == 1) return launch_play_hc_t<256, true, 8, 0, false, false, 8, true, false>(p, a, s);
+        return launch_play_hc_t<256, true, 8, 0, false, false, 8, true, true>(p, a, s);
     }
     if (p.hc_ki == 2) { // four waves per SIMD: increments in registers, strategies loaded per turn
         if (a.k == 5u && p.block == 256) return launch_play_hc_t<256, true, 6, 4, false>(p, a, s);
@@ -1106,6 +1119,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "hot_cold_tables") c->hc_tables = (int32_t)value;
     else if (n == "hot_cold_inc_regs") c->hc_inc_regs = (int32_t)value;
     else if (n == "hot_cold_lds") c->hc_cl = (int32_t)value;
+    else if (n == "hot_cold_cold_regs") c->hc_cr = (int32_t)value;
     else if (n == "perm_split") c->perm_split = (int32_t)value;
     else if (n == "pipeline") c->pipeline = (int32_t)value;
     else if (n == "uniform_flags") c->uniform_flags_opt = (int32_t)value;
@@ -1202,7 +1216,7 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
         if (plan_play_hc(c, k, target_score, plan, hc_plan)) plan = hc_plan;
     }
     if (plan.hc) c->ran_hc = true;
-    if (plan.hc && !plan.hc_cl) { // cold seat records of every lane the grid can seat
+    if (plan.hc && !plan.hc_cl && !plan.hc_cr) { // cold seat records of every lane the grid can seat
         rc = ensure(c, c->cold, (size_t)plan.grid * (size_t)plan.block * (size_t)k * 16);
         if (rc) return rc;
     }

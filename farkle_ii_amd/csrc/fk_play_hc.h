@@ -54,13 +54,17 @@ constexpr uint32_t HC_MAX_K = 8;
 // whole game (0: both are loaded at every turn start); LT: tables from the LDS image; WPE: waves per SIMD the register
 // budget is cut for (0: 4 for KI = 4, 3 for the other KI instances); CL: cold records in LDS beside the buffered half words
 // (no plane); NS: the most seats a launch of the instance has (strategy-index select).  See the file comment.
-template <int HC_BLOCK_I, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR_I = true, bool CL = false, int NS = 8>
+// CR: the cold records of the KI seats in REGISTERS as well (no plane, no store + load per turn: every store to the plane leaves
+// L2 as a 64-byte fabric write on this chip); IL: increments loaded per turn although KI sizes the register arrays.
+template <int HC_BLOCK_I, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR_I = true, bool CL = false, int NS = 8, bool CR = false, bool IL = false>
 __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : KI == 4 ? 4 : KI ? 3 : (HC_BLOCK_I == 256 ? 5 : HC_BLOCK_I / 256)))) void fk_play_hc_kernel(PlayArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t HC_BLOCK = (uint32_t)HC_BLOCK_I;
     const uint32_t tid = threadIdx.x;
     const uint32_t K = a.k;
     static_assert(!CL || (KI == 0 && !LT), "cold-in-LDS instances load increments / strategies per turn and gather from the global tables");
+    static_assert(!CR || (KI != 0 && !CL), "cold-in-register instances size their arrays by KI");
+    static_assert(!IL || CR, "IL only makes sense when KI is there for the cold records");
     uint4 *const lds_state = reinterpret_cast<uint4 *>(lds) + tid;   // [seat][lane] generator state
     uint32_t *const lds_buf = lds + 4u * K * HC_BLOCK + tid;          // [seat][lane] buffered half word
     // CL: [seat][lane] cold x, y (one 8-byte plane) and z — planes of the access width, so that a wave's lanes fall on distinct banks
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         for (uint32_t i = tid; i < LT_BYTES / 16u; i += HC_BLOCK) dst[i] = src[i];
         __syncthreads();
     }
-    uint4 *const cold = CL ? nullptr : a.cold + (size_t)(blockIdx.x * HC_BLOCK + tid) * K; // [resident lane][seat] (w unused)
+    uint4 *const cold = (CL || CR) ? nullptr : a.cold + (size_t)(blockIdx.x * HC_BLOCK + tid) * K; // [resident lane][seat] (w unused)
     auto cold_load = [&](uint32_t s) __attribute__((always_inline)) -> uint4 {
         if (CL) {
             const uint2 xy = lds_xy[SB(s)];
@@ -104,10 +108,28 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     int32_t own_thr = 0;
     uint32_t own_bits = 0;
     uint32_t cX = 0, cY = 0, cZ = 0;              // the owner's cold record
-    uint32_t inc_r[KI ? KI : 1][4] = {};          // KI: every seat's increment (constant indices only: registers)
-    constexpr bool PKR = PKR_I && KI != 0 && KI <= 6;      // ... and packed strategy, while 168 registers hold both without spilling
+    constexpr bool IR = KI != 0 && !IL;          // increments in registers
+    uint32_t inc_r[IR ? KI : 1][4] = {};          // KI: every seat's increment (constant indices only: registers)
+    uint32_t cold_r[CR ? KI : 1][3] = {};         // CR: every seat's cold record
+    constexpr bool PKR = PKR_I && IR && KI <= 6;      // ... and packed strategy, while 168 registers hold both without spilling
     uint32_t pk_r[PKR ? KI : 1][2] = {};
 
+    // CR: seat s's cold record out of the register array (select tree on the bits of s; entries beyond k are never selected)
+    auto cold_pick = [&](uint32_t s) __attribute__((always_inline)) -> uint4 {
+        uint32_t v[8][3];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[t][j] = cold_r[t < (CR ? KI : 1) ? t : 0][j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t a0 = (s & 1u) ? v[1][j] : v[0][j], a1 = (s & 1u) ? v[3][j] : v[2][j];
+            const uint32_t a2 = (s & 1u) ? v[5][j] : v[4][j], a3 = (s & 1u) ? v[7][j] : v[6][j];
+            const uint32_t b0 = (s & 2u) ? a1 : a0, b1 = (s & 2u) ? a3 : a2;
+            v[0][j] = (KI > 4 && (s & 4u)) ? b1 : b0;
+        }
+        return make_uint4(0u, v[0][0], v[0][1], v[0][2]);
+    };
     auto seat_index = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t {
         const uint32_t lo = (s & 2u) ? ix23 : ix01, hi = (s & 2u) ? ix67 : ix45;
         const uint32_t w = (NS > 4 && (s & 4u)) ? hi : lo; // (NS <= 4: the launch has at most four seats)
@@ -122,12 +144,12 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     // its first generator step, the strategy and the cold record behind the score-table gather.
     auto begin_turn = [&](uint32_t s) __attribute__((always_inline)) {
         uint4 inc;
-        if (KI) { // select tree on the bits of s (entries beyond k are never selected)
+        if (IR) { // select tree on the bits of s (entries beyond k are never selected)
             uint32_t v[8][4];
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[t][j] = inc_r[t < KI ? t : 0][j];
+                for (int j = 0; j < 4; ++j) v[t][j] = inc_r[t < (IR ? KI : 1) ? t : 0][j];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t a0 = (s & 1u) ? v[1][j] : v[0][j], a1 = (s & 1u) ? v[3][j] : v[2][j];
@@ -157,7 +179,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         } else {
             pk = a.strat[seat_index(s)];
         }
-        const uint4 c = cold_load(s);
+        const uint4 c = CR ? cold_pick(s) : cold_load(s);
         own_inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
         own_inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
         own_thr = (int32_t)pk.x;
@@ -183,7 +205,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         int32_t best = -1;
         uint4 wrec = make_uint4(0u, 0u, 0u, 0u);
         for (uint32_t s = 0; s < K; ++s) { // stable sort on score desc: first maximum wins (engine.py:477)
-            const uint4 c = (s == seat) ? make_uint4(0u, cX, cY, cZ) : cold_load(s);
+            const uint4 c = (s == seat) ? make_uint4(0u, cX, cY, cZ) : CR ? cold_pick(s) : cold_load(s);
             const int32_t sc = (int32_t)((c.w >> HC_SCORE_SHIFT) & HC_SCORE_MASK);
             if (sc > best) {
                 best = sc;
@@ -245,15 +267,17 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
                 if (CL) {
                     lds_xy[SB(s)] = make_uint2(0u, 0u);
                     lds_z[SB(s)] = 0u;
+                } else if (CR) {
+                    if (s < (uint32_t)(CR ? KI : 1)) cold_r[s < (uint32_t)(CR ? KI : 1) ? s : 0][0] = cold_r[s < (uint32_t)(CR ? KI : 1) ? s : 0][1] = cold_r[s < (uint32_t)(CR ? KI : 1) ? s : 0][2] = 0u;
                 } else {
                     cold[s] = make_uint4(0u, 0u, 0u, 0u); // the previous game's record of this lane
                 }
                 const uint32_t idx = (a.state_dw == STATE_DW) ? src[R_IDX] : (uint32_t)a.seat_idx[(size_t)slot * K + s];
                 iw[s >> 1] |= idx << (16u * (s & 1u));
-                if (KI && s < (uint32_t)(KI ? KI : 1)) {
+                if (IR && s < (uint32_t)(IR ? KI : 1)) {
                     const uint4 q = a.inc[(size_t)slot * K + s];
-                    inc_r[s < (uint32_t)(KI ? KI : 1) ? s : 0][0] = q.x, inc_r[s < (uint32_t)(KI ? KI : 1) ? s : 0][1] = q.y;
-                    inc_r[s < (uint32_t)(KI ? KI : 1) ? s : 0][2] = q.z, inc_r[s < (uint32_t)(KI ? KI : 1) ? s : 0][3] = q.w;
+                    inc_r[s < (uint32_t)(IR ? KI : 1) ? s : 0][0] = q.x, inc_r[s < (uint32_t)(IR ? KI : 1) ? s : 0][1] = q.y;
+                    inc_r[s < (uint32_t)(IR ? KI : 1) ? s : 0][2] = q.z, inc_r[s < (uint32_t)(IR ? KI : 1) ? s : 0][3] = q.w;
                     if (PKR) {
                         const uint2 pk = a.strat[idx];
                         pk_r[s < (uint32_t)(PKR ? KI : 1) ? s : 0][0] = pk.x, pk_r[s < (uint32_t)(PKR ? KI : 1) ? s : 0][1] = pk.y;
@@ -348,6 +372,14 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
             if (CL) {
                 lds_xy[SB(s)] = make_uint2(cX, cY);
                 lds_z[SB(s)] = cZ;
+            } else if (CR) { // the owner's record back into its slot of the register array
+#pragma unroll
+                for (int t = 0; t < (CR ? KI : 1); ++t) {
+                    const bool here = s == (uint32_t)t;
+                    cold_r[t][0] = here ? cX : cold_r[t][0];
+                    cold_r[t][1] = here ? cY : cold_r[t][1];
+                    cold_r[t][2] = here ? cZ : cold_r[t][2];
+                }
             } else {
                 cold[s] = make_uint4(cX, cY, cZ, 0u);
             }

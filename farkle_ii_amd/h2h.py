@@ -232,7 +232,7 @@ class PrefetchingBlockRunner:
                               strategy_from_manifest(block["seat2_strategy"], manifest), attempt_count, self._profile, self._engine)
 
 
-def gpu_block_runner(oracle_game_profile: GameProfile | None = None) -> Callable[[dict, Any, int], dict]:
+def gpu_block_runner(oracle_game_profile: GameProfile | None = None, engine=None) -> Callable[[dict, Any, int], dict]:
     """A ``BlockRunner`` (h2h_schedule.py:1521): ``runner(block, strategy_manifest_path, attempt_count) -> block``."""
     cache: dict[str, Any] = {}
 
@@ -242,6 +242,6 @@ def gpu_block_runner(oracle_game_profile: GameProfile | None = None) -> Callable
             cache[key] = _load_manifest(strategy_manifest_path)
         manifest = cache[key]
         return simulate_block(block, strategy_from_manifest(block["seat1_strategy"], manifest),
-                              strategy_from_manifest(block["seat2_strategy"], manifest), attempt_count, oracle_game_profile)
+                              strategy_from_manifest(block["seat2_strategy"], manifest), attempt_count, oracle_game_profile, engine)
 
     return runner

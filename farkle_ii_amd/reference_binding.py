@@ -1,0 +1,201 @@
+"""The engine behind the reference's OWN seams — the drop-in a reference maintainer installs.
+
+The reference (Isaac-McPadden/Farkle_II) is pure Python; its seams for this path are in-process callables:
+
+* tournament: ``farkle.simulation.run_tournament`` looks ``_play_one_shuffle`` / ``_play_shuffle`` / ``_run_chunk`` /
+  ``_run_chunk_metrics`` up in its module globals at call time (``run_tournament.py:301-585``; the reference's own tests
+  swap ``_play_shuffle`` there, ``tests/unit/simulation/test_run_tournament.py:45-60``).  :class:`TournamentBinding`
+  replaces those four names; everything above them — ``run_tournament.run_tournament`` (:1050), ``runner.run_single_n``,
+  checkpoints, row shards (``run_streaming_shard``), metric chunks, sidecars of whatever contract version the run is
+  configured for, ``simulation.done.json`` — stays the reference's code, fed with objects of the reference's own types.
+* H2H: ``execute_h2h_schedule(cfg, block_runner=...)`` (``analysis/h2h_schedule.py:1597``) takes a ``BlockRunner``
+  (:1521); :func:`block_runner` / :func:`prefetching_block_runner` build one.  Every result goes through the reference's
+  ``_normalize_runner_result`` (:1422) and is published by its ``_write_block`` (:1471).
+
+This module never imports the reference: the caller hands over the module object it has already imported.  It has no
+CPU path either — without an engine (``farkle_ii_amd.engine.get_engine``, i.e. a MI355X) every call raises.
+
+    from farkle.simulation import run_tournament as rt, runner
+    from farkle_ii_amd.reference_binding import TournamentBinding
+    with TournamentBinding(rt):
+        runner.run_single_n(cfg, k)          # sim.n_jobs = 1: the GPU is the worker pool
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Any, Callable, Dict, Mapping, Sequence
+
+import numpy as np
+
+from . import h2h as _h2h
+from .backend import FarkleHipError, FK_ERR_ROLL_LIMIT, make_overrides
+from .engine import get_engine
+from .game_profile import GameProfile, H2HMaxRoundsOverride, TournamentMaxRoundsOverride
+from .strategies import STRATEGY_DTYPE
+from .tournament import METRIC_LABELS, _shuffle_rows, tally_to_counters
+
+
+def coerce_game_profile(profile: Any) -> GameProfile | None:
+    """Any object with the field names of ``simulation/game_profile.py:24-191`` (the reference's ``GameProfile`` is one)
+    -> this package's :class:`GameProfile` (same canonical payload, so the same ``sha256``)."""
+    if profile is None or isinstance(profile, GameProfile):
+        return profile
+    return GameProfile(
+        default_target_score=int(profile.default_target_score), default_max_rounds=int(profile.default_max_rounds),
+        tournament_max_rounds_overrides=tuple(
+            TournamentMaxRoundsOverride(int(o.root_seed), int(o.k), int(o.shuffle_index), int(o.game_index), int(o.max_rounds))
+            for o in profile.tournament_max_rounds_overrides),
+        h2h_max_rounds_overrides=tuple(
+            H2HMaxRoundsOverride(int(o.root_seed), int(o.pair_id), int(o.order), int(o.attempt_index), int(o.max_rounds))
+            for o in profile.h2h_max_rounds_overrides))
+
+
+def pack_reference_strategies(strategies: Sequence[Any]) -> np.ndarray:
+    """``ThresholdStrategy`` objects of the reference (``simulation/strategies.py:165-194``) -> ``fk_strategy[S]``.
+    ``favor_dice_or_score`` is the reference's enum: its member name is compared, not its identity."""
+    out = np.zeros(len(strategies), dtype=STRATEGY_DTYPE)
+    for i, s in enumerate(strategies):
+        favor = s.favor_dice_or_score
+        favor_score = str(getattr(favor, "name", favor)).upper().endswith("SCORE")
+        sid = s.strategy_id if getattr(s, "strategy_id", None) is not None else i
+        out[i] = (int(s.score_threshold), int(s.dice_threshold), int(s.smart_five), int(s.smart_one), int(s.consider_score),
+                  int(s.consider_dice), int(s.require_both), int(s.auto_hot_dice), int(s.run_up_score), int(favor_score), int(sid))
+    return out
+
+
+class TournamentBinding:
+    """Installs the engine behind ``farkle.simulation.run_tournament``'s four shuffle / chunk callables.
+
+    ``rt`` is the imported reference module.  A chunk (the contiguous shuffles of one deterministic batch,
+    ``run_tournament.py:974``) is ONE ``fk_tournament_run`` launch with a tally per shuffle; the reference's own
+    ``_run_chunk`` / ``_run_chunk_metrics`` bodies then run unchanged — their per-shuffle ``_play_shuffle`` /
+    ``_play_one_shuffle`` calls are served from that launch — so the shard writer, the manifest records and the sidecars
+    are the reference's.  A shuffle asked for outside a chunk is played alone.  The returned objects are the reference's
+    types: its ``OutcomeCounter`` (``rt.OutcomeCounter``), ``defaultdict(float)`` sums keyed by strategy id, row dicts in
+    the shape ``_play_game`` returns (``simulation.py:576-655``)."""
+
+    _NAMES = ("_play_one_shuffle", "_play_shuffle", "_run_chunk", "_run_chunk_metrics")
+
+    def __init__(self, rt: Any, engine: Any = None):
+        self.rt = rt
+        self._engine = engine
+        self._orig: dict[str, Callable] = {}
+        self._served: dict[tuple, tuple] = {}   # (root, k, shuffle, rows?) -> (wins, sums, sqs, rows) of a chunk launch
+        self._table_of: tuple[int, np.ndarray, list[int]] | None = None
+        self.launches = 0
+
+    # ---- install / uninstall -------------------------------------------------------------------------------------
+    def install(self) -> "TournamentBinding":
+        if self._orig:
+            return self
+        for name in self._NAMES:
+            self._orig[name] = getattr(self.rt, name)
+            setattr(self.rt, name, getattr(self, name))
+        return self
+
+    def uninstall(self) -> None:
+        for name, fn in self._orig.items():
+            setattr(self.rt, name, fn)
+        self._orig.clear()
+        self._served.clear()
+
+    __enter__ = install
+
+    def __exit__(self, *exc) -> None:
+        self.uninstall()
+
+    # ---- state of the reference's worker (run_tournament.py:253-277) ----------------------------------------------
+    def _state(self):
+        state = self.rt._STATE
+        if state is None:
+            raise RuntimeError("farkle.simulation.run_tournament._STATE is not initialised (_init_worker)")
+        if self._table_of is None or self._table_of[0] != id(state.strats):
+            table = pack_reference_strategies(state.strats)
+            self._table_of = (id(state.strats), table, [int(v) for v in table["strategy_id"]])
+        return state, self._table_of[1], self._table_of[2]
+
+    def _launch(self, tasks: Sequence[Any], want_rows: bool) -> None:
+        """One launch per contiguous shuffle range of ``tasks``; the per-shuffle results go to the serving table."""
+        state, table, ids = self._state()
+        profile = coerce_game_profile(state.game_profile)
+        target, max_rounds, ov = 10_000, 200, None
+        if profile is not None:
+            target, max_rounds, ov = profile.default_target_score, profile.default_max_rounds, profile.tournament_overrides()
+        eng = self._engine or get_engine()
+        i = 0
+        while i < len(tasks):
+            j = i
+            while (j + 1 < len(tasks) and tasks[j + 1].shuffle_index == tasks[j].shuffle_index + 1
+                   and tasks[j + 1].root_seed == tasks[i].root_seed and tasks[j + 1].k == tasks[i].k):
+                j += 1
+            first, last = tasks[i], tasks[j]
+            try:
+                res = eng.tournament(table, int(first.k), int(first.root_seed), int(first.shuffle_index), int(last.shuffle_index) + 1,
+                                     shuffles_per_batch=1, target_score=target, max_rounds=max_rounds, overrides=ov,
+                                     want_rows=want_rows)
+            except FarkleHipError as exc:
+                if exc.code == FK_ERR_ROLL_LIMIT:  # engine.py:242-243 raises RuntimeError for a 1000-roll turn
+                    raise RuntimeError(str(exc)) from exc
+                raise
+            self.launches += 1
+            gps = len(table) // int(first.k)
+            for n, task in enumerate(tasks[i:j + 1]):
+                wins, sums, sqs = tally_to_counters(res["tally"][n], ids, int(task.k), counter_cls=self.rt.OutcomeCounter)
+                rows = _shuffle_rows(task, res["rows"][n * gps:(n + 1) * gps], ids) if want_rows else []
+                self._served[(int(task.root_seed), int(task.k), int(task.shuffle_index), bool(want_rows))] = (wins, sums, sqs, rows)
+            i = j + 1
+
+    # ---- the four callables (same names, arguments and return shapes as the reference's) ---------------------------
+    def _play_one_shuffle(self, task, *, collect_rows: bool = False):
+        work = self.rt._coerce_shuffle_task(task)
+        key = (int(work.root_seed), int(work.k), int(work.shuffle_index), bool(collect_rows))
+        if key not in self._served:
+            self._launch([work], bool(collect_rows))
+        return self._served.pop(key)
+
+    def _play_shuffle(self, task):
+        wins, _, _, _ = self._play_one_shuffle(task, collect_rows=False)
+        return wins
+
+    def _run_chunk(self, shuffle_tasks):
+        tasks = [self.rt._coerce_shuffle_task(t) for t in shuffle_tasks]
+        self._launch(tasks, False)
+        try:
+            return self._orig["_run_chunk"](tasks)
+        finally:
+            self._served.clear()
+
+    def _run_chunk_metrics(self, shuffle_tasks, *, collect_rows: bool = False, **kwargs):
+        tasks = [self.rt._coerce_shuffle_task(t) for t in shuffle_tasks]
+        self._launch(tasks, bool(collect_rows))
+        try:
+            return self._orig["_run_chunk_metrics"](tasks, collect_rows=collect_rows, **kwargs)
+        finally:
+            self._served.clear()
+
+
+def chunk_counters(rt: Any, tally: np.ndarray, strategy_ids: Sequence[int], k: int):
+    """``int64[S][26]`` of one chunk -> the ``(wins, sums, square_sums)`` triple ``rt._run_chunk_metrics`` returns, built
+    from the reference's own ``OutcomeCounter`` class (for callers that bind ``fk_tournament_run`` per chunk themselves)."""
+    wins, sums, sqs = tally_to_counters(tally, strategy_ids, k, counter_cls=rt.OutcomeCounter)
+    full: Dict[str, Dict[int, float]] = {m: defaultdict(float, sums[m]) for m in METRIC_LABELS}
+    return wins, full, {m: defaultdict(float, sqs[m]) for m in METRIC_LABELS}
+
+
+# ---- H2H: BlockRunner objects for execute_h2h_schedule(cfg, block_runner=...) -------------------------------------------
+
+def block_runner(oracle_game_profile: Any = None, engine: Any = None) -> Callable[[dict, Any, int], dict]:
+    """One block per call (``BlockRunner``, h2h_schedule.py:1521): ``runner(block, strategy_manifest_path, attempt_count)``."""
+    return _h2h.gpu_block_runner(coerce_game_profile(oracle_game_profile), engine=engine)
+
+
+def prefetching_block_runner(schedule_blocks: Sequence[Mapping[str, Any]], oracle_game_profile: Any = None, engine: Any = None,
+                             chunk_games: int | None = None) -> "_h2h.PrefetchingBlockRunner":
+    """The whole schedule in shared launches, served to the reference's serial loop (h2h_schedule.py:2038-2093) block by
+    block.  ``schedule_blocks``: the records of the block manifest (``cfg.h2h_block_manifest_path()``) as dicts."""
+    return _h2h.PrefetchingBlockRunner([dict(b) for b in schedule_blocks], coerce_game_profile(oracle_game_profile), engine,
+                                       chunk_games=chunk_games)
+
+
+__all__ = ["TournamentBinding", "block_runner", "prefetching_block_runner", "chunk_counters", "coerce_game_profile",
+           "pack_reference_strategies", "make_overrides"]

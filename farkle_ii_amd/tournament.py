@@ -135,14 +135,15 @@ def _coerce_shuffle_task(task: ShuffleTask | int) -> ShuffleTask:
     return ShuffleTask(root_seed=int(task), k=k, shuffle_index=0, shuffle_seed=int(task), deterministic_batch_id=0)
 
 
-def tally_to_counters(tally: np.ndarray, ids: Sequence[int], k: int, *, dense: bool = False):
+def tally_to_counters(tally: np.ndarray, ids: Sequence[int], k: int, *, dense: bool = False, counter_cls=None):
     """``int64[S][26]`` -> (OutcomeCounter, sums, square sums) with the reference's dict shapes.
 
     ``dense``: every strategy that was seated gets explicit zero entries, which is what the reference's totals look
     like when they are rebuilt from metric chunk files (``_reduce_metric_chunk_payloads``, run_tournament.py:905-922:
     each chunk row is added with ``+=``, zeros included); worker-side counters (``dense=False``) only hold what was
-    incremented."""
-    wins = OutcomeCounter()
+    incremented.  ``counter_cls``: the counter class to build (``reference_binding`` passes the reference's own
+    ``OutcomeCounter`` so that its ``absorb`` / pickling see their own type)."""
+    wins = (counter_cls or OutcomeCounter)()
     sums: Dict[str, Dict[int, float]] = {m: defaultdict(float) for m in METRIC_LABELS}
     sqs: Dict[str, Dict[int, float]] = {m: defaultdict(float) for m in METRIC_LABELS}
     for i, sid in enumerate(ids):

@@ -89,3 +89,42 @@ def assert_tally_matches(tally: np.ndarray, ids, golden: dict, ctx: str = "") ->
     games = golden["games"]
     k_att = sum(golden["attempted"].values())
     assert int(tally[:, 1].sum()) == k_att and int(tally[:, 0].sum()) == games[1]
+
+
+def replay_binding_calls(engine, calls, strategy_dtype, override_dtype) -> int:
+    """Replay the engine calls recorded while the binding ran INSIDE the reference (tests/golden/binding_vectors.json,
+    oracle/gen_binding.py) on ``engine`` and compare every result with the recorded one.  Returns the number of calls."""
+    import base64
+
+    def table_of(rows):
+        return np.array([tuple(int(v) for v in r) for r in rows], dtype=strategy_dtype)
+
+    def overrides_of(rows):
+        return np.array([tuple(int(v) for v in r) for r in rows], dtype=override_dtype) if rows else None
+
+    for n, c in enumerate(calls):
+        ctx = f"recorded call {n} ({c['method']})"
+        if c["method"] == "tournament":
+            res = engine.tournament(table_of(c["table"]), c["k"], c["root_seed"], c["shuffle_begin"], c["shuffle_end"],
+                                    shuffles_per_batch=c["shuffles_per_batch"], target_score=c["target_score"], max_rounds=c["max_rounds"],
+                                    overrides=overrides_of(c["overrides"]), want_rows=c["want_rows"])
+            assert np.array_equal(np.asarray(res["tally"]), np.array(c["tally"], dtype=np.int64)), ctx
+            if c["want_rows"]:
+                assert res["rows"].tobytes() == base64.b64decode(c["rows_b64"]), ctx
+        elif c["method"] == "h2h":
+            seats = np.array([tuple(int(v) for v in r) for r in c["seats"]], dtype=strategy_dtype)
+            state = None if c["state_in"] is None else np.array(c["state_in"], dtype=np.uint64)
+            out = engine.h2h(seats, c["root_seed"], c["pair_id"], c["order"], c["target"], c["max_attempts"], c["chunk_games"],
+                             target_score=c["target_score"], max_rounds=c["max_rounds"], overrides=overrides_of(c["overrides"]), state=state)
+            assert [int(v) for v in out] == c["state_out"], ctx
+        elif c["method"] == "h2h_blocks":
+            seats = np.array([[tuple(int(v) for v in s) for s in pair] for pair in c["seats"]], dtype=strategy_dtype)
+            states = None if c["states_in"] is None else np.array(c["states_in"], dtype=np.uint64)
+            out = engine.h2h_blocks(seats, c["root_seed"], c["pair_ids"], c["orders"], np.array(c["target"], dtype=np.uint64),
+                                    np.array(c["max_attempts"], dtype=np.uint64), chunk_games=c["chunk_games"],
+                                    target_score=c["target_score"], max_rounds=c["max_rounds"], overrides=overrides_of(c["overrides"]),
+                                    states=states)
+            assert np.asarray(out).astype(np.int64).tolist() == c["states_out"], ctx
+        else:
+            raise AssertionError(f"unknown recorded method {c['method']}")
+    return len(calls)

@@ -255,3 +255,88 @@ def test_prefetching_block_runner_equals_the_per_block_runner_on_10000_blocks():
     got, _ = serial_schedule_loop(blocks, told, manifest, 64)
     assert got == want and told.single_block_calls == 0 and told.generations <= 3  # 180 attempts at most = three chunks
     assert run_blocks(blocks, manifest, None) == want  # and in one call, to the terminal states
+
+
+def test_reference_binding_calls_replay_on_the_hip_engine():
+    """The engine calls recorded while the binding ran INSIDE the reference (its own run_single_n / execute_h2h_schedule writing
+    artifacts equal to an unpatched run, oracle/gen_binding.py) — same arguments, same results from the HIP kernels."""
+    from farkle_ii_amd.backend import OVERRIDE_DTYPE
+    from farkle_ii_amd.engine import get_engine
+    from farkle_ii_amd.strategies import STRATEGY_DTYPE
+
+    doc = gu.load("binding_vectors.json")
+    eng = get_engine()
+    n = gu.replay_binding_calls(eng, doc["tournament"]["calls"], STRATEGY_DTYPE, OVERRIDE_DTYPE)
+    for mode in ("block_runner", "prefetching_block_runner"):
+        n += gu.replay_binding_calls(eng, doc["h2h"]["calls"][mode], STRATEGY_DTYPE, OVERRIDE_DTYPE)
+    assert n == 20
+
+
+def test_reference_binding_on_a_stand_in_module_runs_the_hip_engine():
+    """TournamentBinding with the process's HIP engine (engine=None), on the stand-in module of tests/test_binding_cpu.py."""
+    import pyoracle as po
+    from test_binding_cpu import _stand_in_module
+
+    from farkle_ii_amd import reference_binding as rb
+    from farkle_ii_amd import tournament as tn
+    from farkle_ii_amd.strategies import generate_strategy_grid, pack_strategies
+
+    strategies, _ = generate_strategy_grid(score_thresholds=[300, 500], dice_thresholds=[1, 2], smart_five_opts=[False, True],
+                                           smart_one_opts=[False], consider_score_opts=[True], consider_dice_opts=[True],
+                                           auto_hot_dice_opts=[True], run_up_score_opts=[False])
+    rt = _stand_in_module(strategies, 4)
+    tasks = tn.shuffle_tasks(5, 4, 0, 7, 7)
+    with rb.TournamentBinding(rt) as binding:
+        wins, sums, sqs = rt._run_chunk_metrics(tasks, collect_rows=False)
+    assert binding.launches == 1
+    ref = po.tournament(pack_strategies(strategies).view(po.STRATEGY_DTYPE), 4, 5, 0, 7)
+    want, want_sums, want_sqs = tn.tally_to_counters(ref["tally"][0], [int(s.strategy_id) for s in strategies], 4)
+    assert dict(wins) == dict(want) and wins.outcome_payload() == want.outcome_payload()
+    assert {m: dict(v) for m, v in sums.items()} == {m: dict(v) for m, v in want_sums.items()}
+    assert {m: dict(v) for m, v in sqs.items()} == {m: dict(v) for m, v in want_sqs.items()}
+
+
+def test_integration_md_ctypes_blocks_run():
+    """INTEGRATION.md §1-§4a as ONE program on the MI355X: the ctypes stub a reference maintainer would add, checked against the oracle."""
+    import re
+    from pathlib import Path
+
+    import pyoracle as po
+
+    from farkle_ii_amd.backend import LIB_PATH
+    from farkle_ii_amd.strategies import generate_strategy_grid, pack_strategies
+
+    root = Path(__file__).resolve().parent.parent
+    blocks = re.findall(r"<!-- ctypes:([a-z0-9_]+) -->\s*```python\n(.*?)```", (root / "INTEGRATION.md").read_text(encoding="utf-8"), flags=re.S)
+    ns: dict = {"LIB_PATH": str(LIB_PATH)}
+    for name, code in blocks:
+        exec(compile(code, f"INTEGRATION.md[ctypes:{name}]", "exec"), ns)
+    try:
+        strategies, _ = generate_strategy_grid(score_thresholds=[250, 300, 350, 400], dice_thresholds=[0, 1, 2, 3], smart_five_opts=[True],
+                                               smart_one_opts=[True], consider_score_opts=[True], consider_dice_opts=[True],
+                                               auto_hot_dice_opts=[True], run_up_score_opts=[True])
+        table = ns["pack"](strategies)
+        assert table.tobytes() == pack_strategies(strategies).tobytes()
+        otable = table.view(po.STRATEGY_DTYPE)
+        tally, rows = ns["tournament_chunk"](table, 4, 42, 3, 11, shuffles_per_batch=3, collect_rows=True)
+        ref = po.tournament(otable, 4, 42, 3, 11, shuffles_per_batch=3, want_rows=True)
+        assert np.array_equal(tally, ref["tally"]) and rows.tobytes() == ref["rows"].tobytes()
+        seat_strategy = np.tile(np.array([5, 40, 17], dtype=np.int32), (50, 1))
+        got = ns["play_games"](table, seat_strategy, 3, 123, 50, target_score=5000)
+        coords = np.zeros(50, po.COORD_DTYPE)
+        coords["purpose"], coords["root_seed"], coords["k"], coords["game_index"] = 10, 123, 3, np.arange(50)
+        assert got.tobytes() == po.play_games(coords, otable, seat_strategy, 3, target_score=5000).tobytes()
+        block = {"root_seed": 42, "pair_id": 5, "order": 0, "n_completed_required": 200, "max_attempts": 400}
+        out = ns["h2h_block"](table[[3, 40]], block, 10**6)
+        want = po.h2h_block(otable[[3, 40]], 42, 5, 0, 200, 400, 10**6)
+        assert [out[key] for key in ns["STATE_KEYS"]] == [int(v) for v in want]
+        pending = [dict(block, pair_id=5 + i, order=i & 1) for i in range(3)]
+        pairs = [table[[3, 40]], table[[0, 2]], table[[17, 9]]]
+        outs = ns["h2h_blocks"](pairs, pending, 42, 300)
+        for i, o in enumerate(outs):
+            w = po.h2h_block(pairs[i].view(po.STRATEGY_DTYPE), 42, 5 + i, i & 1, 200, 400, 300)
+            assert [o[key] for key in ns["STATE_KEYS"]] == [int(v) for v in w], i
+    finally:
+        ns["lib"].fk_destroy.restype = None
+        ns["lib"].fk_destroy.argtypes = [ns["C"].c_void_p]
+        ns["lib"].fk_destroy(ns["ctx"])
