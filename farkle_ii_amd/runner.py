@@ -158,8 +158,10 @@ def simulation_is_complete(cfg: AppConfig, n_players: int, plan: TournamentWorkl
     if not path.exists() or not cfg.checkpoint_path(n_players).exists():
         return False
     try:
-        meta = json.loads(path.read_text(encoding="utf-8"))["metadata"]
-    except (OSError, KeyError, json.JSONDecodeError):
+        meta = json.loads(path.read_text(encoding="utf-8"))  # the contract sits at the top level (stage_completion.py:505-512)
+    except (OSError, json.JSONDecodeError):
+        return False
+    if not isinstance(meta, dict) or meta.get("status") != "success" or meta.get("completion_state") != "complete_valid":
         return False
     if plan is not None and (meta.get("num_shuffles") != plan.required_shuffles or meta.get("n_strategies") != plan.strategy_count
                              or meta.get("shuffles_per_batch") != plan.shuffles_per_batch):
@@ -548,17 +550,6 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
     return {"tally": total, "games": games_done, "seconds": time.perf_counter() - t_start}
 
 
-def _list_outputs(n_dir: Path, root: Path) -> list[str]:
-    """Every file below ``n_dir`` relative to the results root, sorted, without the completion marker itself (``os.walk``:
-    a rows-on run lists one shard per shuffle — pathlib's rglob / relative_to cost 60 us per file)."""
-    prefix = os.path.relpath(n_dir, root)
-    out = []
-    for d, _, files in os.walk(n_dir):
-        rel = os.path.normpath(os.path.join(prefix, os.path.relpath(d, n_dir)))
-        out.extend(os.path.join(rel, f) for f in files if f != "simulation.done.json")
-    return sorted(out)
-
-
 def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | None = None, *, force: bool = False,
                  oracle_game_profile: GameProfile | None = None) -> int:
     """Run a Farkle tournament for a single player count ``n``; returns the number of games of the plan."""
@@ -660,18 +651,35 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
     if metrics_rows:
         _write_parquet_atomic(pa.Table.from_pylist(metrics_rows), cfg.metrics_path(n))
         sidecars.write("metrics_summary", cfg.metrics_path(n), sources=[ckpt_path])
-    done = {"stage": "simulation", "status": "success", "engine": "farkle_ii_amd/hip-gfx950",
-            "metadata": {"n_players": n, "seed": cfg.sim.seed, "root_seed": cfg.sim.seed, "k": n,
-                         "num_shuffles": plan.required_shuffles, "shuffle_index_start": 0,
-                         "shuffle_index_end": plan.required_shuffles - 1, "deterministic_batch_count": plan.batch_count,
-                         "shuffles_per_batch": plan.shuffles_per_batch, "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
-                         "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
-                         "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
-                         "tournament_method_version": TOURNAMENT_METHOD_VERSION, "n_strategies": grid_size,
-                         **({"game_profile_sha256": oracle_game_profile.sha256} if oracle_game_profile is not None else {})},
-            "outputs": _list_outputs(n_dir, cfg.results_root),
-            "games": plan.required_games, "games_per_second_this_run": (result["games"] / result["seconds"]) if result["games"] else None}
-    _atomic_write_bytes(simulation_done_path(cfg, n), (json.dumps(done, indent=2, sort_keys=True) + "\n").encode())
+    # the completion stamp, in the reference's shape (write_simulation_done, simulation/runner.py:685-743 -> write_stage_done,
+    # utils/stage_completion.py:391-512): the simulation contract at the TOP level, where ingest reads it (ingest.py:191-215)
+    from . import stage_completion as sc
+    from .sidecars import config_hash, engine_code_revision
+
+    profile_sha = oracle_game_profile.sha256 if oracle_game_profile is not None else None
+    metadata: dict[str, Any] = {
+        "n_players": n, "seed": cfg.sim.seed, "root_seed": cfg.sim.seed, "k": n, "num_shuffles": plan.required_shuffles,
+        "shuffle_index_start": 0, "shuffle_index_end": plan.required_shuffles - 1, "deterministic_batch_count": plan.batch_count,
+        "shuffles_per_batch": plan.shuffles_per_batch, "rng_scheme_version": urandom.RNG_SCHEME_VERSION,
+        "rng_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE), "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
+        "tournament_method_version": TOURNAMENT_METHOD_VERSION, "n_strategies": grid_size}
+    if profile_sha is not None:
+        metadata["game_profile_sha256"] = profile_sha
+    done_path = simulation_done_path(cfg, n)
+    outputs: list[Path] = [ckpt_path, n_dir / "simulation_workload_plan.json"]  # the order of simulation/runner.py:1714-1727
+    for extra in (n_dir / f"{n}p_checkpoint.parquet", cfg.metrics_path(n), cfg.strategy_manifest_root_path(),
+                  cfg.simulation_row_dir(n), cfg.metric_chunk_dir(n), cfg.all_player_batch_dir(n)):
+        if extra is not None and Path(extra).exists():
+            outputs.append(Path(extra))
+    engine_config_sha = config_hash(cfg)
+    sc.write_stage_done(
+        done_path, inputs=[cfg.strategy_manifest_root_path(), n_dir / "simulation_workload_plan.json"],
+        outputs=sc.completion_output_files(outputs, done_path), stage="simulation", config_sha=engine_config_sha,
+        stage_config_sha=sc.simulation_stage_config_sha(engine_config_sha, cfg.sim.seed, n, profile_sha),
+        cache_key_version=sc.SIMULATION_CACHE_KEY_VERSION, freshness_key=sc.freshness_key(cfg, profile_sha),
+        code_identity={"state": "supplied_by_caller", "commit": None, "dirty_fingerprint_sha256": None,
+                       "revision": engine_code_revision(), "engine": "farkle_ii_amd/hip-gfx950"},
+        metadata=metadata)
     return plan.required_games
 
 

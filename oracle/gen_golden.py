@@ -610,7 +610,10 @@ def _jsonable(obj):
 def gen_artifacts():
     """Run the reference's ``run_single_n`` (runner.py:1326) on a tiny config and freeze every artifact it writes:
     parquet schemas + records, manifest records, workload plan, checkpoint payload.  The authenticated v3 sidecars
-    and the stage-done stamp need the reference's Git identity and are not produced here (the run stops there)."""
+    are not produced here (artifact-contract version 2: the plain write path).  The stage-done stamp IS: ``write_stage_done``
+    (utils/stage_completion.py:391-512) takes the code identity from ``cfg._code_identity`` when one is supplied
+    (``_code_identity_payload`` :190-211), so the reference writes its own ``simulation.done.json`` without a Git checkout; it is
+    frozen with the per-run path prefix replaced by ``<root>``."""
     import dataclasses
     import pickle
     import shutil
@@ -631,8 +634,11 @@ def gen_artifacts():
         cfg = load_app_config(cfg_path, seed_list_len=1)
         # plain (pre-v3) write path: same bytes minus the authenticated sidecars
         cfg.artifact_contract = dataclasses.replace(cfg.artifact_contract, artifact_contract_version=2)
+        cfg._code_identity = {"state": "supplied_by_caller", "commit": None, "dirty_fingerprint_sha256": None,
+                              "revision": "reference imported from /root/reference (not a Git checkout)"}
         gp = GameProfile(default_target_score=100, default_max_rounds=200,
                          tournament_max_rounds_overrides=(TournamentMaxRoundsOverride(11, 2, 0, 0, 0),))
+        cfg._game_profile_sha256 = gp.sha256  # what the run context binds when a profile is in use (orchestration/run_contexts.py)
         out = {"config": ARTIFACT_CONFIG, "game_profile": {"target": 100, "max_rounds": 200, "overrides": [[11, 2, 0, 0, 0]]},
                "runs": {}}
         volatile = {"ts", "pid"}
@@ -656,6 +662,9 @@ def gen_artifacts():
                 run["jsonl"][str(f.relative_to(root))] = [
                     {kk: vv for kk, vv in json.loads(line).items() if kk not in volatile} for line in f.read_text().splitlines()]
             run["workload_plan"] = json.loads((n_dir / "simulation_workload_plan.json").read_text())
+            done_file = n_dir / "simulation.done.json"
+            if done_file.exists():  # the reference's own stamp; absolute paths -> <root>/...
+                run["stage_done"] = json.loads(done_file.read_text().replace(str(root), "<root>"))
             ck = pickle.loads((n_dir / f"{k}p_checkpoint.pkl").read_bytes())
             run["checkpoint"] = {"win_totals": _jsonable(dict(ck["win_totals"])), "outcome_counts": _jsonable(ck["outcome_counts"]),
                                  "metric_sums": _jsonable({m: dict(v) for m, v in ck["metric_sums"].items()}),

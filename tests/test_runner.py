@@ -7,6 +7,7 @@
 """
 from __future__ import annotations
 
+import hashlib
 import json
 import os
 import pickle
@@ -122,7 +123,7 @@ batching:
         rows = sorted((n_dir / f"{k}p_rows").glob("rows_*.parquet"))
         assert len(rows) == n_sh and sum(pq.read_table(r).num_rows for r in rows) == n_sh * (8 // k)
         done = json.loads((n_dir / "simulation.done.json").read_text())
-        assert done["metadata"]["num_shuffles"] == n_sh and done["status"] == "success"
+        assert done["num_shuffles"] == n_sh and done["status"] == "success" and done["completion_state"] == "complete_valid"
     # second invocation: complete -> preserved untouched
     before = (root / "2_players" / "2p_checkpoint.pkl").stat().st_mtime_ns
     main(["--config", str(cfg_path), "run"])
@@ -204,8 +205,7 @@ def test_farkle_run_artifacts_match_reference_run(engine, tmp_path):
         root = cfg.results_root
         n_dir = root / f"{k}_players"
         files = sorted(str(f.relative_to(root)) for f in root.rglob("*") if f.is_file() and (f.parent == root or n_dir in f.parents))
-        # the reference's stage-done stamp needs its Git identity and is absent from the frozen run
-        mine = [f for f in files if f not in ours_extra_ok and not f.endswith("simulation.done.json")]
+        mine = [f for f in files if f not in ours_extra_ok]
         if mine != ref["files"]:
             diffs.append(f"k={k} file set: only ours {sorted(set(mine) - set(ref['files']))} only reference {sorted(set(ref['files']) - set(mine))}")
         for name, want in ref["parquet"].items():
@@ -237,6 +237,27 @@ def test_farkle_run_artifacts_match_reference_run(engine, tmp_path):
                 if not same(a, b):
                     diffs.append(f"k={k} {name} {b['path']}: {({c: (a.get(c), b.get(c)) for c in set(a) | set(b) if not same(a.get(c), b.get(c))})}")
                     break
+        # the completion stamp against the one the REFERENCE wrote for this run (write_stage_done, utils/stage_completion.py:391-512):
+        # same keys, same values — except the producer's own identities (digests of ITS config serialisation and code, and the
+        # stage identity derived from them) and the byte identities of files whose bytes legitimately differ (pids, writer metadata)
+        done = json.loads((n_dir / "simulation.done.json").read_text().replace(str(root), "<root>"))
+        want_done = ref["stage_done"]
+        producer_identity = {"config_sha", "stage_config_sha", "code_identity", "stage_identity_sha256", "input_identities", "output_identities"}
+        if sorted(done) != sorted(want_done):
+            diffs.append(f"k={k} simulation.done.json keys: only ours {sorted(set(done) - set(want_done))} only reference {sorted(set(want_done) - set(done))}")
+        for key, val in want_done.items():
+            if key not in producer_identity and not same(done.get(key), val):
+                diffs.append(f"k={k} simulation.done.json {key}: ours {done.get(key)!r} reference {val!r}")
+        for key in ("input_identities", "output_identities"):
+            shape = lambda ids: [(i["logical_role"], i["kind"], sorted(i)) for i in ids]  # noqa: E731
+            if shape(done[key]) != shape(want_done[key]):
+                diffs.append(f"k={k} simulation.done.json {key}: ours {shape(done[key])} reference {shape(want_done[key])}")
+        for ident, path_text in zip(done["output_identities"], done["outputs"]):  # the identities are the files' bytes
+            data = Path(path_text.replace("<root>", str(root))).read_bytes()
+            if ident["byte_length"] != len(data) or ident["content_sha256"] != hashlib.sha256(data).hexdigest():
+                diffs.append(f"k={k} simulation.done.json identity of {path_text} is not the file's")
+        if len(done["stage_identity_sha256"]) != 64 or len(done["stage_config_sha"]) != 64 or not done["code_identity"].get("revision"):
+            diffs.append(f"k={k} simulation.done.json producer identity is incomplete: {done['code_identity']}")
         plan = json.loads((n_dir / "simulation_workload_plan.json").read_text())
         for key, val in ref["workload_plan"].items():
             if key in ("projected_games_per_second", "projected_runtime_seconds"):  # throughput of the backend, not of the plan
