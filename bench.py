@@ -634,12 +634,18 @@ def main() -> None:
             return "fk_play_hc_kernel" if hc else "fk_play_kernel"
 
         dominant = kernel_of(t, int(wl.k)) if isinstance(getattr(wl, "k", None), int) else "fk_play_kernel"  # (sweep / H2H lines: per_k / k = 2)
-        traffic = None
-        for tpath in sorted((ROOT / "profiles").glob(f"r*_hbm_traffic_config{wl.config}.json"), reverse=True):
-            rec = json.loads(tpath.read_text())
-            if rec.get("kernel_source_sha256") == kernel_source_sha():
-                traffic = rec["kernels"].get(dominant, {}).get("hbm_bytes_corrected")
-            break
+        def traffic_for(kernel: str, k_seats: int | None = None):
+            """HBM bytes per launch of `kernel` from the newest PMC stamp of this workload (per player count for the sweep), or None
+            when the kernel sources have changed since it was taken."""
+            suffix = f"config{wl.config}" + (f"_k{k_seats}" if k_seats is not None else "")
+            for tpath in sorted((ROOT / "profiles").glob(f"r*_hbm_traffic_{suffix}.json"), reverse=True):
+                rec = json.loads(tpath.read_text())
+                if rec.get("kernel_source_sha256") == kernel_source_sha():
+                    return rec["kernels"].get(kernel, {}).get("hbm_bytes_corrected")
+                break
+            return None
+
+        traffic = traffic_for(dominant)
         roofline = {
             "bound": "valu", "kernel": dominant,
             "achieved": achieved_ops / 1e12, "peak": peak_ops / 1e12, "unit": "Tlane-op/s (int32)", "frac": achieved_ops / peak_ops,
@@ -664,10 +670,17 @@ def main() -> None:
                 rate = gpl / max(ms * 1e-3, 1e-12)
                 per_k.append({"k": int(k2), "kernel": kernel_of(tk, int(k2)), "kernel_ms": ms,
                               "games_per_launch": gpl, "kernel_games_per_s": rate, **w2,
-                              "frac": rate * w2["ops_per_game"] / peak_ops,
+                              "frac": rate * w2["ops_per_game"] / peak_ops, "traffic": traffic_for(kernel_of(tk, int(k2)), int(k2)),
                               "launch": {k3: tk.get(k3) for k3 in ("play_block", "play_grid", "play_lds_bytes")}})
             roofline["per_k"] = per_k
+            # the line's headline figures are the sweep's: the mean fraction over the player counts, and — as the dominant kernel —
+            # the one of the player count furthest below its roofline (round 3 printed the k = 2 launches' kernel and fraction here)
+            worst = min(per_k, key=lambda r: r["frac"])
             roofline["frac_mean_over_k"] = float(np.mean([r["frac"] for r in per_k]))
+            roofline.update({"frac": roofline["frac_mean_over_k"], "achieved": roofline["frac_mean_over_k"] * peak_ops / 1e12,
+                             "kernel": worst["kernel"], "kernel_note": f"slowest player count of the sweep: k = {worst['k']} at frac {worst['frac']:.3f}",
+                             "kernel_ms": worst["kernel_ms"], "games_per_launch": worst["games_per_launch"],
+                             "kernel_games_per_s": worst["kernel_games_per_s"], "traffic": worst["traffic"], "launch": worst["launch"]})
         cpu = None
         if not args.no_cpu_baseline and n_gpus == 1:  # the CPU leg runs on rank 0 of the single-GPU run only
             cpu = wl.cpu_baseline(eng)

@@ -37,6 +37,7 @@ H2H_BLOCK_DTYPE = np.dtype(
      ("max_attempts", "<u8"), ("state", "<u8", (5,))]
 )
 TALLY_COLS = 26
+LAG_COLS = 11  # FK_LAG_COLS: pairs | win: sx sy sxx syy sxy | n_rounds: sx sy sxx syy sxy
 SEAT_STAT_COLS = 31
 SEAT_STAT_NAMES = ("exposures", "completed_exposures", "safety_limit_exposures", "wins", "final_score_sum", "final_score_square_sum",
                    "n_turns_sum", "n_turns_square_sum", "turn_round_mismatch_count", "turn_minus_rounds_sum",
@@ -95,7 +96,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
 
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
-            "fk_tournament_run", "fk_tournament_run_stats", "fk_tournament_hint_next", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
+            "fk_tournament_run", "fk_tournament_run_stats", "fk_tournament_run_lags", "fk_tournament_hint_next", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
             "fk_debug_dice", "fk_debug_dice_state", "fk_debug_dice_keys", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy", "fk_tally_resident_reduce", "fk_comm_ranks", "fk_host_alloc", "fk_host_free", "fk_game_seeds"]
 _lib = None
 
@@ -230,6 +231,30 @@ class Engine:
             C.c_int32(len(ov)), _p(tally), _p(rows), _p(perms), _p(stats)))
         return {"tally": tally[:n_batches], "rows": rows, "perms": perms,
                 "seat_stats": None if stats is None else stats[:n_batches]}
+
+    def tournament_lags(self, table: np.ndarray, k: int, root_seed: int, shuffle_begin: int, shuffle_end: int, lags,
+                        shuffles_per_batch: int | None = None, target_score: int = 10_000, max_rounds: int = 200,
+                        overrides: np.ndarray | None = None) -> dict:
+        """``tournament`` + the lag sufficient statistics of the strategy family (``fk_tournament_run_lags``):
+        ``lag_sums [S][n_lags][LAG_COLS]`` int64 and the first / last ``min(max lag, n_shuffles)`` series rows
+        (``lag_head`` / ``lag_tail``, uint16 ``n_rounds | won << 15``, ``[m][S]``) that ``rng_lags.LagSummary`` merges ranges with."""
+        table = np.ascontiguousarray(table, dtype=STRATEGY_DTYPE)
+        lags = np.ascontiguousarray(list(lags), dtype=np.int32)
+        S = len(table)
+        n_sh = max(int(shuffle_end) - int(shuffle_begin), 0)
+        spb = max(n_sh if not shuffles_per_batch else int(shuffles_per_batch), 1)
+        n_batches = (n_sh + spb - 1) // spb
+        tally = np.zeros((max(n_batches, 1), S, TALLY_COLS), dtype=np.int64)
+        m = min(int(lags.max()) if len(lags) else 0, n_sh)
+        sums = np.zeros((S, len(lags), LAG_COLS), dtype=np.int64)
+        head = np.zeros((max(m, 1), S), dtype=np.uint16)
+        tail = np.zeros((max(m, 1), S), dtype=np.uint16)
+        ov = np.ascontiguousarray(overrides if overrides is not None else np.zeros(0, dtype=OVERRIDE_DTYPE), dtype=OVERRIDE_DTYPE)
+        self._check(self._lib.fk_tournament_run_lags(
+            self._ctx, _p(table), C.c_int32(S), C.c_int32(k), C.c_uint64(root_seed), C.c_uint64(shuffle_begin),
+            C.c_uint64(shuffle_end), C.c_uint32(spb), C.c_int32(target_score), C.c_int32(max_rounds), _p(ov), C.c_int32(len(ov)),
+            _p(tally), _p(lags), C.c_int32(len(lags)), _p(sums), _p(head), _p(tail)))
+        return {"tally": tally[:n_batches], "lag_sums": sums, "lag_head": head[:m], "lag_tail": tail[:m], "n_shuffles": n_sh}
 
     def pinned_empty(self, n: int, dtype) -> np.ndarray:
         """``n`` elements of ``dtype`` in page-locked host memory (``fk_host_alloc``), freed when the array is collected — the

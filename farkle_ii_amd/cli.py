@@ -33,6 +33,10 @@ def build_parser() -> argparse.ArgumentParser:
     run.add_argument("--all-player-batches", nargs="?", const=Path("all_player_batches"), type=Path, default=None, metavar="DIR",
                      help="Write the unconditional all-player batch metrics (integer columns of the reference's "
                           "all_player_batch_schema) per deterministic batch, from device accumulators, without rows")
+    run.add_argument("--rng-lag-sums", action="store_true",
+                     help="Write the lag sufficient statistics of the RNG diagnostics' strategy family (per strategy and "
+                          "analysis.rng_diagnostic_lags: pairs, sums, square sums and cross sums of the win indicator and of n_rounds) "
+                          "and the autocorrelation rows computed from them, from device accumulators, without rows")
     run.add_argument("--sidecars", action="store_true",
                      help="Write <artifact>.sidecar.json (producer contract + SHA-256 / size of the artifact) beside every output")
     run.add_argument("--force", action="store_true", help="Recompute even when existing run artifacts are available")
@@ -88,6 +92,8 @@ def main(argv: Sequence[str] | None = None) -> None:
         cfg.sim.sidecars = True
     if args.all_player_batches is not None:
         cfg.sim.all_player_batch_dir = args.all_player_batches
+    if args.rng_lag_sums:
+        cfg.sim.rng_lag_sums = True
     _maybe_init_distributed()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("FK_TALLY_REDUCE", "rccl") == "rccl":
         # The per-group tally reduction through the C-ABI's own RCCL communicator (fk_comm_init / fk_reduce_tally): the default

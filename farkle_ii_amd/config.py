@@ -62,6 +62,7 @@ class SimConfig:
     metric_chunk_dir: Path | None = None
     sidecars: bool = False  # this engine's option: per-artifact <name>.sidecar.json (sidecars.py; contract version 2)
     all_player_batch_dir: Path | None = None  # this engine's option: all-player batch metrics without rows (all_player.py)
+    rng_lag_sums: bool = False  # this engine's option: lag sufficient statistics of the RNG diagnostics' strategy family (rng_lags.py)
     per_n: dict = field(default_factory=dict)
     n_jobs: int | None = None
     mp_start_method: str | None = None
@@ -141,6 +142,20 @@ class AppConfig:
 
     def all_player_batch_dir(self, n: int) -> Path | None:
         return self._per_n_dir(self.sim.all_player_batch_dir, n, "all-player-batch-dir")
+
+    def rng_diagnostic_lags(self) -> tuple[int, ...]:
+        """``analysis.rng_diagnostic_lags`` (config.py:335, validated like :1933-1939); the analysis section is carried opaquely."""
+        raw = (self.opaque.get("analysis") or {}).get("rng_diagnostic_lags", (1,))
+        lags = tuple(int(v) for v in raw)
+        if not lags or any(v < 1 for v in lags) or tuple(sorted(set(lags))) != lags:
+            raise ValueError("analysis.rng_diagnostic_lags must be unique increasing positive integers")
+        return lags
+
+    def rng_lag_sums_path(self, n: int) -> Path:
+        return self.n_dir(n) / f"{n}p_rng_lag_sums.parquet"
+
+    def rng_lag_stats_path(self, n: int) -> Path:
+        return self.n_dir(n) / f"{n}p_rng_lag_stats.parquet"
 
     def checkpoint_path(self, n: int) -> Path:
         return self.n_dir(n) / f"{n}p_checkpoint.pkl"

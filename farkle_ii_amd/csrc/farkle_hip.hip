@@ -7,8 +7,14 @@
 #include "fk_kernels.h" // device side: every kernel of the engine (pulls in farkle_hip.h, fk_device.h, hip_runtime.h)
 
 #include <dlfcn.h>
+#include <rccl/rccl.h> // TYPES ONLY (ncclConfig_t, result codes): the library itself is bound with dlopen on first use
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <memory>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -96,14 +102,18 @@ struct fk_ctx {
     int32_t hc_block = 256;    // its block size: 256, 768 or 1024
     int32_t hc_tables = 1;     // 1: score / discard tables in LDS (LT instances)
     int32_t hc_inc_regs = 1;   // 1: the seats' PCG increments in registers (k >= 5, 256-thread blocks, LDS tables)
-    int32_t hc_cr = 0;         // EXPERIMENT: cold records in registers (1: with the increments, 2: increments loaded per turn)
+    int32_t hc_cr = 0;         // FK_EXPERIMENTS builds: cold records in registers (1: with the increments, 2: increments loaded per turn)
     int32_t hc_cl = -1;        // cold records in LDS beside the hot part (k = 3 .. 5): -1 auto (k = 4), 0 never, 1 always
     DevBuf lds_tables;         // their LDS image (fk_play_hc.h)
     DevBuf cold;
+    DevBuf lag_v, lag_out, lag_lags, lag_edge, lag_tmp; // fk_tournament_run_lags: value matrix, sums, lag list, head / tail rows
     bool ran_hc = false;       // the current tournament call launched the hot / cold kernel
     int32_t perm_split = -1;   // -1 auto, 0 one-kernel Fisher-Yates, 1 draws + serial swap chains, 2 draws + chain-free kernel
     void *comm = nullptr;      // RCCL communicator (fk_comm_init), one per context / GPU
     int comm_rank = 0, comm_world = 1;
+    bool comm_async = false;   // (non-blocking communicators: every RCCL call settled by polling; not used — see fk_comm_init)
+    int32_t comm_timeout_ms = 120000; // option "comm_timeout_ms" (FK_COMM_TIMEOUT_MS): deadline of communicator creation and of each
+                                      // collective; 0 = the blocking calls of round 3 (no deadline)
     DevBuf comm_buf;
     // resident tally (option "resident_tally"): every tournament call adds its [n_batches][S][26] tally to this device
     // accumulator; fk_tally_resident_reduce sums it over the communicator on the device (the tally never leaves HBM before
@@ -288,8 +298,13 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, i
             if (!gs && c->lean >= 0 && lean != c->lean) continue;
             if (!gs && lean && !blocks_mode && S > (1 << (32 - CE_IDX_SHIFT))) continue; // strategy index must fit cE[31:18]
             for (int block : {1024, 768, 512, 256, 128, 64}) {
+#ifdef FK_EXPERIMENTS
                 if (gs && block != 768 && block != 256 && block != 64) continue;
                 if (c->block != 0 && block != c->block && !(gs && block == (c->block >= 768 ? 768 : c->block >= 256 ? 256 : 64))) continue;
+#else
+                if (gs && block != 768) continue; // (one record per lane: 768-thread blocks seat six waves per SIMD whatever k is)
+                if (c->block != 0 && block != c->block && !gs) continue;
+#endif
                 if (block == 768 && !lean) continue;
                 const int wpe = (block == 768) ? 6 : 4;
                 bool tally = want_tally && play_lds_bytes(k, block, lean != 0, gs != 0, true, (int32_t)S) <= LDS_LIMIT / (gs ? 2 : 1);
@@ -506,53 +521,71 @@ hipError_t launch_play_hc_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t 
     return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI, WPE, PKR, CL, NS, CR, IL>(p, a, s);
 }
 
+// The instances the launch plan can reach (plan_play_hc): k = 4 cold records in LDS (four 320-thread blocks, five waves per
+// SIMD), k = 5 .. 7 four waves per SIMD with the increments in registers, k = 8 three.  Every other variant that was built and
+// measured (global tables, increments / strategies loaded or held, three-wave forms, other block sizes, cold
+// records in LDS at k = 3 / 5, cold records in registers) lost or tied; they are compiled only with -DFK_EXPERIMENTS
+// (tools/build_experiments.sh), where the tools/exp_*.py scripts that produced the log still run.
 hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    if (p.hc_cl) { // cold records in LDS: six / five / four waves per SIMD at k = 3 / 4 / 5
-        if (a.k > 5u) return hipErrorInvalidValue;
+    if (p.hc_cl) { // cold records in LDS
         // (77 VGPRs: a SIMD must be able to take six waves, or the 2 + 1 + 1 + 1 waves of four 320-thread blocks do not all find a
         // slot — a 96-register build seated three blocks.  Strategies in registers as well: 26.7 against 26.5 ms, not kept)
-        if (p.block == 320) return a.k <= 4u ? launch_play_hc_t<320, false, 0, 6, false, true, 4>(p, a, s) : hipErrorInvalidValue;
-        if (a.k <= 4u) return launch_play_hc_t<256, false, 0, 6, false, true, 4>(p, a, s);
-        return launch_play_hc_t<256, false, 0, 6, false, true>(p, a, s); // 77 - 79 registers whatever the player count
+        if (p.block == 320 && a.k <= 4u) return launch_play_hc_t<320, false, 0, 6, false, true, 4>(p, a, s);
+#ifdef FK_EXPERIMENTS
+        if (a.k > 5u) return hipErrorInvalidValue;
+        if (p.block == 256 && a.k <= 4u) return launch_play_hc_t<256, false, 0, 6, false, true, 4>(p, a, s);
+        if (p.block == 256) return launch_play_hc_t<256, false, 0, 6, false, true>(p, a, s); // 77 - 79 registers whatever the player count
+#endif
+        return hipErrorInvalidValue;
     }
-    if (p.hc_cr && p.hc_ki == 2) { // EXPERIMENT: cold records in registers, four waves (increments loaded per turn)
+#ifdef FK_EXPERIMENTS
+    if (p.hc_cr && p.hc_ki == 2) { // cold records in registers, four waves (increments loaded per turn)
         if (a.k == 5u && p.block == 256) return launch_play_hc_t<256, true, 6, 4, false, false, 8, true, true>(p, a, s);
         if (a.k == 6u && p.block == 512) return launch_play_hc_t<512, true, 6, 4, false, false, 8, true, true>(p, a, s);
         if (a.k == 7u && p.block == 1024) return launch_play_hc_t<1024, true, 7, 4, false, false, 8, true, true>(p, a, s);
         return hipErrorInvalidValue;
     }
-    if (p.hc_cr && p.hc_ki && p.block == 256 && p.hc_lt && a.k > 6u) { // EXPERIMENT, three waves
+    if (p.hc_cr && p.hc_ki && p.block == 256 && p.hc_lt && a.k > 6u) { // cold records in registers, three waves
         if (p.hc_cr == 1) return launch_play_hc_t<256, true, 8, 0, false, false, 8, true, false>(p, a, s);
         return launch_play_hc_t<256, true, 8, 0, false, false, 8, true, true>(p, a, s);
     }
+#endif
     if (p.hc_ki == 2) { // four waves per SIMD: increments in registers, strategies loaded per turn
         if (a.k == 5u && p.block == 256) return launch_play_hc_t<256, true, 6, 4, false>(p, a, s);
         if (a.k == 6u && p.block == 512) return launch_play_hc_t<512, true, 6, 4, false>(p, a, s);
         if (a.k == 7u && p.block == 1024) return launch_play_hc_t<1024, true, 7, 4, false>(p, a, s);
         return hipErrorInvalidValue;
     }
-    if (p.hc_ki && p.block == 256 && p.hc_lt) { // increments + strategies in registers: 256-thread blocks with LDS tables
+    if (p.hc_ki && p.block == 256 && p.hc_lt) { // three waves: increments in registers, 256-thread blocks with LDS tables
+        if (a.k == 8u) return launch_play_hc_t<256, true, 8>(p, a, s);
+#ifdef FK_EXPERIMENTS
         if (a.k <= 4u) return launch_play_hc_t<256, true, 4>(p, a, s);
         if (a.k <= 6u) return launch_play_hc_t<256, true, 6>(p, a, s);
         return launch_play_hc_t<256, true, 8>(p, a, s);
+#endif
     }
+#ifdef FK_EXPERIMENTS
     switch (p.block) {
     case 1024: return p.hc_lt ? launch_play_hc_t<1024, true>(p, a, s) : launch_play_hc_t<1024, false>(p, a, s);
     case 768: return p.hc_lt ? launch_play_hc_t<768, true>(p, a, s) : launch_play_hc_t<768, false>(p, a, s);
     default: return p.hc_lt ? launch_play_hc_t<256, true>(p, a, s) : launch_play_hc_t<256, false>(p, a, s);
     }
+#else
+    return hipErrorInvalidValue;
+#endif
 }
 
 hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     if (p.lds > LDS_LIMIT) return hipErrorInvalidValue;
     if (p.hc) return launch_play_hc(p, a, s);
     if (p.blk) return launch_play_t<768, true, 6, false, true, 2>(p, a, s); // batched H2H: k = 2, lean LDS records
-    if (p.gs) {
-        switch (p.block) {
-        case 768: return launch_play_t<768, true, 6, true>(p, a, s);
-        case 256: return launch_play_t<256, true, 4, true>(p, a, s);
-        default: return launch_play_t<64, true, 4, true>(p, a, s);
-        }
+    if (p.gs) { // state-store instances: the path of tables too wide for LDS records (k > 64); 2 x 768 threads per CU
+        if (p.block == 768) return launch_play_t<768, true, 6, true>(p, a, s);
+#ifdef FK_EXPERIMENTS
+        if (p.block == 256) return launch_play_t<256, true, 4, true>(p, a, s);
+        if (p.block == 64) return launch_play_t<64, true, 4, true>(p, a, s);
+#endif
+        return hipErrorInvalidValue;
     }
     if (p.lean) {
         switch (p.block) {
@@ -904,6 +937,10 @@ struct Rccl {
     void *lib = nullptr;
     int (*GetUniqueId)(void *) = nullptr;
     int (*CommInitRank)(void **, int, fk_comm_id, int) = nullptr; // ncclUniqueId is a 128-byte struct passed by value
+    // non-blocking initialisation (a rank that never joins must not park its peers inside RCCL): optional symbols
+    int (*CommInitRankConfig)(void **, int, fk_comm_id, int, ncclConfig_t *) = nullptr;
+    int (*CommGetAsyncError)(void *, int *) = nullptr;
+    int (*CommAbort)(void *) = nullptr;
     int (*Reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -941,6 +978,9 @@ Rccl &rccl() {
     r.Reduce = reinterpret_cast<decltype(r.Reduce)>(dlsym(r.lib, "ncclReduce"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    r.CommInitRankConfig = reinterpret_cast<decltype(r.CommInitRankConfig)>(dlsym(r.lib, "ncclCommInitRankConfig"));
+    r.CommGetAsyncError = reinterpret_cast<decltype(r.CommGetAsyncError)>(dlsym(r.lib, "ncclCommGetAsyncError"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
     if (!r.GetUniqueId || !r.CommInitRank || !r.Reduce || !r.CommDestroy) {
         r.why = "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclReduce / ncclCommDestroy";
         dlclose(r.lib);
@@ -952,6 +992,74 @@ Rccl &rccl() {
 int rccl_fail(fk_ctx *c, const char *what, int code) {
     Rccl &r = rccl();
     return fail(c, FK_ERR_COMM, "%s failed: %s", what, r.GetErrorString ? r.GetErrorString(code) : "RCCL error");
+}
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// Give the communicator up: abort it (ncclCommAbort ends a collective kernel that waits for a peer) and forget it.
+void comm_abandon(fk_ctx *c) {
+    Rccl &r = rccl();
+    const bool dbg = getenv("FK_DEBUG_COMM") != nullptr;
+    if (c->comm) {
+        if (dbg) fprintf(stderr, "[fk comm] abandoning the communicator (%s)\n", r.CommAbort ? "ncclCommAbort" : "ncclCommDestroy");
+        if (r.CommAbort) (void)r.CommAbort(c->comm);
+        else (void)r.CommDestroy(c->comm);
+        if (dbg) fprintf(stderr, "[fk comm] abandoned\n");
+    }
+    c->comm = nullptr;
+    c->comm_world = 1;
+    c->comm_rank = 0;
+    c->comm_async = false;
+}
+
+// A non-blocking communicator reports ncclInProgress from every call until the operation has been issued: poll its state
+// under the context's deadline ("comm_timeout_ms").  On expiry or error the communicator is aborted -> FK_ERR_COMM.
+int comm_settle(fk_ctx *c, const char *what, int rc, double t0) {
+    Rccl &r = rccl();
+    if (rc != ncclSuccess && rc != ncclInProgress) {
+        const int out = rccl_fail(c, what, rc);
+        comm_abandon(c);
+        return out;
+    }
+    if (!c->comm_async) return FK_OK;
+    for (;;) {
+        int st = ncclSuccess;
+        const int q = r.CommGetAsyncError(c->comm, &st);
+        if (q != ncclSuccess || (st != ncclSuccess && st != ncclInProgress)) {
+            const int out = rccl_fail(c, what, q != ncclSuccess ? q : st);
+            comm_abandon(c);
+            return out;
+        }
+        if (st == ncclSuccess) return FK_OK;
+        if (now_ms() - t0 > (double)c->comm_timeout_ms) {
+            comm_abandon(c);
+            return fail(c, FK_ERR_COMM, "%s did not complete within %d ms (comm_timeout_ms): a peer rank never joined; communicator aborted", what,
+                        c->comm_timeout_ms);
+        }
+        usleep(500);
+    }
+}
+
+// Wait for the context's stream behind a collective, under the same deadline: a peer that never enters the collective leaves
+// the RCCL kernel spinning, and hipStreamSynchronize would wait with it.
+int comm_wait_stream(fk_ctx *c, const char *what, double t0) {
+    hipEvent_t ev = c->ev[SLOT_CALL + 1];
+    HIPCHK(c, hipEventRecord(ev, c->stream));
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return FK_OK;
+        if (q != hipErrorNotReady) return fail(c, FK_ERR_HIP, "%s: %s", what, hipGetErrorString(q));
+        if (c->comm_timeout_ms > 0 && now_ms() - t0 > (double)c->comm_timeout_ms) {
+            comm_abandon(c);
+            (void)hipStreamSynchronize(c->stream); // the aborted collective returns
+            return fail(c, FK_ERR_COMM, "%s did not complete within %d ms (comm_timeout_ms): a peer rank never entered the collective; communicator aborted",
+                        what, c->comm_timeout_ms);
+        }
+        usleep(200);
+    }
 }
 
 } // namespace
@@ -1037,7 +1145,7 @@ void fk_destroy(fk_ctx *c) {
     release(c->comm_buf);
     if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     for (DevBuf *b : {&c->strat, &c->recs, &c->rec0, &c->tally, &c->rows, &c->ov, &c->seatlist, &c->coords, &c->inv, &c->slow, &c->digest, &c->score_lut,
-                      &c->discard_lut, &c->block_out, &c->stats, &c->cold, &c->lds_tables, &c->acc, &c->rows_alt})
+                      &c->discard_lut, &c->block_out, &c->stats, &c->cold, &c->lds_tables, &c->acc, &c->rows_alt, &c->lag_v, &c->lag_out, &c->lag_lags, &c->lag_edge, &c->lag_tmp})
         release(*b);
     for (auto &cs : c->sets) {
         for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc, &cs.pools, &cs.blocks, &cs.game_block, &cs.game_row}) release(*b);
@@ -1102,6 +1210,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return FK_ERR_ARG;
     std::string n(name);
     if (n == "chunk_bytes") c->chunk_bytes = std::max<int64_t>(value, 1 << 20);
+    else if (n == "comm_timeout_ms") c->comm_timeout_ms = (int32_t)std::max<int64_t>(value, 0);
     else if (n == "batch_threshold") c->batch_threshold = (int32_t)value;
     else if (n == "use_lds_tally") c->use_lds_tally = (int32_t)value;
     else if (n == "longest_first") c->longest_first = (int32_t)value;
@@ -1113,13 +1222,20 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "resident_tally") {
         c->resident = value != 0;
         c->acc_n = 0; // the next tournament call starts a fresh accumulator
-    } else if (n == "hot_cold") c->hc = (int32_t)value;
+    } else if (n == "hot_cold") {
+#ifndef FK_EXPERIMENTS
+        if (value != -1 && value != 0) return fail(c, FK_ERR_ARG, "hot_cold is -1 (auto: four and more seats) or 0 (never); forcing it at three seats is an FK_EXPERIMENTS build's option");
+#endif
+        c->hc = (int32_t)value;
+    }
+#ifdef FK_EXPERIMENTS
     else if (n == "hot_cold_waves") c->hc_waves = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8);
     else if (n == "hot_cold_block") c->hc_block = (int32_t)value;
     else if (n == "hot_cold_tables") c->hc_tables = (int32_t)value;
     else if (n == "hot_cold_inc_regs") c->hc_inc_regs = (int32_t)value;
     else if (n == "hot_cold_lds") c->hc_cl = (int32_t)value;
     else if (n == "hot_cold_cold_regs") c->hc_cr = (int32_t)value;
+#endif
     else if (n == "perm_split") c->perm_split = (int32_t)value;
     else if (n == "pipeline") c->pipeline = (int32_t)value;
     else if (n == "uniform_flags") c->uniform_flags_opt = (int32_t)value;
@@ -1138,20 +1254,58 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
                                    max_rounds, ov, n_ov, tally, rows, perms, nullptr);
 }
 
+struct LagReq { // fk_tournament_run_lags: host pointers of the request
+    const int32_t *lags;
+    int32_t n_lags, max_lag;
+    int64_t *sums;
+    uint16_t *head, *tail;
+};
+
 static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
                                uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
                                int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
-                               int64_t *seat_stats);
+                               int64_t *seat_stats, const LagReq *lag);
+
+static int tournament_call(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                           uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
+                           int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
+                           int64_t *seat_stats, const LagReq *lag);
 
 int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
                             uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
                             int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
                             int64_t *seat_stats) {
+    return tournament_call(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds, ov, n_ov,
+                           tally, rows, perms, seat_stats, nullptr);
+}
+
+int fk_tournament_run_lags(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed, uint64_t shuffle_begin,
+                           uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score, int32_t max_rounds,
+                           const fk_override *ov, int32_t n_ov, int64_t *tally, const int32_t *lags, int32_t n_lags, int64_t *lag_sums,
+                           uint16_t *edge_head, uint16_t *edge_tail) {
+    if (!c) return FK_ERR_ARG;
+    if (!lags || !lag_sums || !edge_head || !edge_tail || n_lags < 1 || n_lags > FK_MAX_LAGS)
+        return fail(c, FK_ERR_ARG, "lags, lag_sums, edge_head, edge_tail are required; 1 <= n_lags <= %d", FK_MAX_LAGS);
+    for (int32_t i = 0; i < n_lags; ++i)
+        if (lags[i] < 1 || lags[i] > 65535 || (i > 0 && lags[i] <= lags[i - 1]))
+            return fail(c, FK_ERR_ARG, "lags must be strictly increasing positive integers (rng_diagnostic_lags, config.py:1933-1939)");
+    if (max_rounds > 32767) return fail(c, FK_ERR_ARG, "lag statistics carry n_rounds in 15 bits: max_rounds must be <= 32767");
+    for (int32_t i = 0; i < n_ov; ++i)
+        if (ov && ov[i].max_rounds > 32767u) return fail(c, FK_ERR_ARG, "lag statistics carry n_rounds in 15 bits: override max_rounds must be <= 32767");
+    const LagReq req{lags, n_lags, lags[n_lags - 1], lag_sums, edge_head, edge_tail};
+    return tournament_call(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds, ov, n_ov,
+                           tally, nullptr, nullptr, nullptr, &req);
+}
+
+static int tournament_call(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                           uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
+                           int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
+                           int64_t *seat_stats, const LagReq *lag) {
     if (!c) return FK_ERR_ARG;
     c->ran_hc = false;
     c->last_tally_bytes = 0;
     int rc = tournament_run_impl(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds,
-                                 ov, n_ov, tally, rows, perms, seat_stats);
+                                 ov, n_ov, tally, rows, perms, seat_stats, lag);
     if (rc == FK_ERR_COUNTER_OVERFLOW && c->ran_hc) {
         // the hot / cold kernel's narrower counter fields (fk_play_hc.h) left their guard bands: the call is replayed on
         // fk_play_kernel, whose 16-bit fields are the ABI's stated limits
@@ -1160,7 +1314,7 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
         c->hc = 0;
         for (auto &cs : c->sets) cs.prepared = false;
         rc = tournament_run_impl(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds,
-                                 ov, n_ov, tally, rows, perms, seat_stats);
+                                 ov, n_ov, tally, rows, perms, seat_stats, lag);
         c->hc = saved;
     }
     if (rc == 0 && c->resident && c->last_tally_bytes) {
@@ -1183,7 +1337,7 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
 static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
                                uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
                                int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
-                               int64_t *seat_stats) {
+                               int64_t *seat_stats, const LagReq *lag) {
     if (!strategies || !tally) return fail(c, FK_ERR_ARG, "strategies and tally are required");
     if (k < 1 || S < k || S % k != 0) return fail(c, FK_ERR_ARG, "n_players must divide %d", S); // run_tournament.py:274
     if (S > 65535) return fail(c, FK_ERR_ARG, "S=%d exceeds 65535 strategies", S);
@@ -1221,7 +1375,7 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
         if (rc) return rc;
     }
     const bool want_state = rows != nullptr || seat_stats != nullptr;
-    const bool want_recs = !plan.lds_tally || want_state;
+    const bool want_recs = !plan.lds_tally || want_state || lag != nullptr;
     const size_t stats_bytes = sizeof(int64_t) * (size_t)n_batches * (size_t)S * FK_SEAT_STAT_COLS;
     if (seat_stats) {
         rc = ensure(c, c->stats, stats_bytes);
@@ -1231,7 +1385,8 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
 
     // chunk planning: whole shuffles per chunk inside the workspace budget
     const size_t bytes_per_shuffle = (size_t)S * 2 + (size_t)gps * (game_workspace_bytes(k, plan.gs || want_state, want_recs, rows != nullptr) +
-                                                                    (seat_stats ? (size_t)k * 32 : 0)); // + the exposure digests
+                                                                    (seat_stats ? (size_t)k * 32 : 0)) // + the exposure digests
+                                     + (lag ? (size_t)S * 2 : 0);                                        // + the lag value matrix row
     uint64_t chunk_sh = std::max<uint64_t>(1, (uint64_t)c->chunk_bytes / bytes_per_shuffle);
     chunk_sh = std::min<uint64_t>(chunk_sh, (uint64_t)0x7fffffff / gps);
     if (rows) // rows mode: several chunks per call, so that the rows of chunk i cross PCIe while chunk i + 1 plays
@@ -1240,6 +1395,21 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
 
     const hipEvent_t t0 = c->ev[SLOT_CALL], t1 = c->ev[SLOT_CALL + 1];
     HIPCHK(c, hipEventRecord(t0, c->stream));
+
+    // lag statistics (fk_tournament_run_lags): V = [max_lag carry rows][chunk rows] x S values, sums [S][n_lags][11]
+    const uint32_t L = lag ? (uint32_t)lag->max_lag : 0u;
+    const uint32_t edge_rows = lag ? (uint32_t)std::min<uint64_t>(L, n_sh_total) : 0u;
+    const size_t lag_sum_bytes = lag ? sizeof(int64_t) * (size_t)S * (size_t)lag->n_lags * FK_LAG_COLS : 0;
+    uint32_t head_filled = 0;
+    if (lag) {
+        if ((rc = ensure(c, c->lag_v, ((size_t)L + chunk_sh) * (size_t)S * 2))) return rc;
+        if ((rc = ensure(c, c->lag_out, lag_sum_bytes))) return rc;
+        if ((rc = ensure(c, c->lag_lags, sizeof(int32_t) * (size_t)lag->n_lags))) return rc;
+        if ((rc = ensure(c, c->lag_edge, 2 * (size_t)std::max<uint32_t>(edge_rows, 1) * (size_t)S * 2))) return rc;
+        if ((rc = ensure(c, c->lag_tmp, (size_t)std::max<uint32_t>(L, 1) * (size_t)S * 2))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->lag_out.p, 0, lag_sum_bytes, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->lag_lags.p, lag->lags, sizeof(int32_t) * (size_t)lag->n_lags, hipMemcpyHostToDevice, c->stream));
+    }
 
     const uint32_t slots = (uint32_t)std::max<size_t>(1, std::min<size_t>(PERM_BLOCK, LDS_LIMIT / ((size_t)S * 2)));
     const uint32_t state_dw = (plan.gs || want_state) ? STATE_DW : 4u;
@@ -1406,6 +1576,36 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
                                static_cast<long long *>(c->stats.p));
             HIPCHK(c, hipGetLastError());
         }
+        if (lag) {
+            uint16_t *V = static_cast<uint16_t *>(c->lag_v.p);
+            const size_t row = (size_t)S; // values per row
+            const uint32_t carry = (uint32_t)std::min<uint64_t>(done, L);
+            hipLaunchKernelGGL(fk_lag_values_kernel, dim3((unsigned)(((size_t)n_games * k + 255u) / 256u)), dim3(256), 0, c->stream,
+                               static_cast<const uint32_t *>(c->recs.p), static_cast<const uint16_t *>(CSET(c).perm.p), slots, (uint32_t)S,
+                               (uint32_t)k, gps, n_games, V + (size_t)L * row);
+            const uint32_t s_blocks = ((uint32_t)S + 255u) / 256u;
+            // enough (strategy block, segment) workgroups to fill the chip, at least 64 rows per segment
+            const uint32_t want_seg = std::max<uint32_t>(1u, (2048u + s_blocks - 1u) / s_blocks);
+            const uint32_t rows_per_seg = std::max<uint32_t>(64u, (n_sh + want_seg - 1u) / want_seg);
+            const uint32_t n_seg = (n_sh + rows_per_seg - 1u) / rows_per_seg;
+            hipLaunchKernelGGL(fk_lag_sums_kernel, dim3(s_blocks, n_seg), dim3(256), 0, c->stream, V, (uint32_t)S, L - carry, L, L + n_sh,
+                               rows_per_seg, static_cast<const int32_t *>(c->lag_lags.p), (uint32_t)lag->n_lags,
+                               static_cast<long long *>(c->lag_out.p));
+            HIPCHK(c, hipGetLastError());
+            uint16_t *edge = static_cast<uint16_t *>(c->lag_edge.p);
+            if (head_filled < edge_rows) { // the first rows of the call's range (they may span chunks shorter than the largest lag)
+                const uint32_t take = std::min<uint32_t>(edge_rows - head_filled, n_sh);
+                HIPCHK(c, hipMemcpyAsync(edge + (size_t)head_filled * row, V + (size_t)L * row, (size_t)take * row * 2, hipMemcpyDeviceToDevice, c->stream));
+                head_filled += take;
+            }
+            if (done + chunk_sh >= n_sh_total) { // last chunk: the last rows of the range (carry rows + this chunk's)
+                HIPCHK(c, hipMemcpyAsync(edge + (size_t)edge_rows * row, V + ((size_t)L + n_sh - edge_rows) * row, (size_t)edge_rows * row * 2,
+                                         hipMemcpyDeviceToDevice, c->stream));
+            } else { // the next chunk's carry = the last L rows of [carry | chunk] (through a scratch copy: the ranges may overlap)
+                HIPCHK(c, hipMemcpyAsync(c->lag_tmp.p, V + (size_t)n_sh * row, (size_t)L * row * 2, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(V, c->lag_tmp.p, (size_t)L * row * 2, hipMemcpyDeviceToDevice, c->stream));
+            }
+        }
         if (!plan.lds_tally) { // result records -> per-batch tallies
             const uint64_t games_per_batch = (uint64_t)shuffles_per_batch * gps;
             unsigned long long *d_tally = static_cast<unsigned long long *>(c->tally.p);
@@ -1458,6 +1658,12 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
     HIPCHK(c, hipEventRecord(t1, c->stream));
     HIPCHK(c, hipMemcpyAsync(tally, c->tally.p, tally_bytes, hipMemcpyDeviceToHost, c->stream));
     if (seat_stats) HIPCHK(c, hipMemcpyAsync(seat_stats, c->stats.p, stats_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (lag) {
+        const size_t edge_bytes = (size_t)edge_rows * (size_t)S * 2;
+        HIPCHK(c, hipMemcpyAsync(lag->sums, c->lag_out.p, lag_sum_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(lag->head, c->lag_edge.p, edge_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(lag->tail, static_cast<uint8_t *>(c->lag_edge.p) + edge_bytes, edge_bytes, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (deferred) {
         rc = report_device_error(c, c->err_host, deferred_base, "tournament");
@@ -1797,6 +2003,44 @@ int fk_comm_init(fk_ctx *c, const fk_comm_id *id, int32_t rank, int32_t world_si
         (void)r.CommDestroy(c->comm);
         c->comm = nullptr;
     }
+    if (const char *env = getenv("FK_COMM_TIMEOUT_MS")) c->comm_timeout_ms = atoi(env);
+    c->comm_async = false;
+    const bool dbg = getenv("FK_DEBUG_COMM") != nullptr;
+    if (c->comm_timeout_ms > 0) {
+        // ncclCommInitRank blocks until every rank has joined (measured on RCCL 2.27.7: so does ncclCommInitRankConfig with
+        // blocking = 0 when it is called outside a group).  A rank that died between the rendezvous and this call must not park its
+        // peers here until the job's time limit: the call runs on a helper thread and this thread waits for it under the deadline.
+        // On expiry the helper stays parked in RCCL's bootstrap (a socket wait; it owns nothing of this context and is never
+        // joined), the context has no communicator, and the caller gets FK_ERR_COMM — bench.py / farkle run then agree on gloo.
+        struct Pending {
+            std::atomic<int> done{0};
+            int rc = 0;
+            void *comm = nullptr;
+        };
+        auto pending = std::make_shared<Pending>();
+        const fk_comm_id id_copy = *id;
+        const int device = c->device;
+        const double t0 = now_ms();
+        std::thread([pending, id_copy, device, world_size, rank, &r]() {
+            (void)hipSetDevice(device);
+            pending->rc = r.CommInitRank(&pending->comm, world_size, id_copy, rank);
+            pending->done.store(1, std::memory_order_release);
+        }).detach();
+        while (!pending->done.load(std::memory_order_acquire)) {
+            if (now_ms() - t0 > (double)c->comm_timeout_ms) {
+                if (dbg) fprintf(stderr, "[fk comm] ncclCommInitRank still waiting after %.0f ms: giving up\n", now_ms() - t0);
+                return fail(c, FK_ERR_COMM, "ncclCommInitRank did not complete within %d ms (comm_timeout_ms): a peer rank never joined",
+                            c->comm_timeout_ms);
+            }
+            usleep(500);
+        }
+        if (dbg) fprintf(stderr, "[fk comm] ncclCommInitRank returned %d after %.1f ms\n", pending->rc, now_ms() - t0);
+        if (pending->rc != 0) return rccl_fail(c, "ncclCommInitRank", pending->rc);
+        c->comm = pending->comm;
+        c->comm_rank = rank;
+        c->comm_world = world_size;
+        return FK_OK;
+    }
     const int rc = r.CommInitRank(&c->comm, world_size, *id, rank);
     if (rc != 0) {
         c->comm = nullptr;
@@ -1818,11 +2062,12 @@ int fk_reduce_tally(fk_ctx *c, int64_t *tally, int64_t n, int32_t root_rank) {
     int rc = ensure(c, c->comm_buf, bytes);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->comm_buf.p, tally, bytes, hipMemcpyHostToDevice, c->stream));
+    const double t0 = now_ms();
+    const bool is_root = c->comm_rank == root_rank;
     const int nrc = rccl().Reduce(c->comm_buf.p, c->comm_buf.p, (size_t)n, 4 /* ncclInt64 */, 0 /* ncclSum */, root_rank, c->comm, c->stream);
-    if (nrc != 0) return rccl_fail(c, "ncclReduce", nrc);
-    if (c->comm_rank == root_rank) HIPCHK(c, hipMemcpyAsync(tally, c->comm_buf.p, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return FK_OK;
+    if ((rc = comm_settle(c, "ncclReduce", nrc, t0))) return rc;
+    if (is_root) HIPCHK(c, hipMemcpyAsync(tally, c->comm_buf.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    return comm_wait_stream(c, "ncclReduce", t0);
 }
 
 // The resident accumulator summed over the communicator ON THE DEVICE (ncclReduce on the engine's stream) and copied to the
@@ -1835,9 +2080,12 @@ int fk_tally_resident_reduce(fk_ctx *c, int64_t *out, int64_t n, int32_t root_ra
     bool root = true;
     if (c->comm && c->comm_world > 1) {
         if (root_rank < 0 || root_rank >= c->comm_world) return fail(c, FK_ERR_ARG, "root rank outside the communicator");
-        const int nrc = rccl().Reduce(c->acc.p, c->acc.p, (size_t)n, 4 /* ncclInt64 */, 0 /* ncclSum */, root_rank, c->comm, c->stream);
-        if (nrc != 0) return rccl_fail(c, "ncclReduce", nrc);
+        const double t0 = now_ms();
         root = c->comm_rank == root_rank;
+        const int nrc = rccl().Reduce(c->acc.p, c->acc.p, (size_t)n, 4 /* ncclInt64 */, 0 /* ncclSum */, root_rank, c->comm, c->stream);
+        int rc = comm_settle(c, "ncclReduce", nrc, t0);
+        if (!rc) rc = comm_wait_stream(c, "ncclReduce", t0);
+        if (rc) return rc;
     }
     if (root) {
         if (!out) return fail(c, FK_ERR_ARG, "the root rank needs an output buffer");
@@ -1867,6 +2115,7 @@ int fk_comm_destroy(fk_ctx *c) {
     }
     c->comm_world = 1;
     c->comm_rank = 0;
+    c->comm_async = false;
     return FK_OK;
 }
 

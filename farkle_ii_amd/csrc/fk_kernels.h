@@ -1269,6 +1269,57 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
 #include "fk_play_hc.h" // the hot / cold variant of the game kernel (k >= 3 seats)
 
 // ---------------------------------------------------------------------------------------
+// Lag sufficient statistics of the RNG diagnostics, strategy family (analysis/rng_diagnostics.py:1870-1905 observation
+// records, :2031-2076 _OnlineMetric): a strategy is seated exactly once per shuffle, so its series (win indicator, n_rounds)
+// is indexed by the shuffle index; for every lag L the six sums (pairs, sum x, sum y, sum x^2, sum y^2, sum xy; x = the
+// EARLIER value) are shifted element-wise products over a [shuffle][strategy] matrix.
+//   fk_lag_values_kernel: one lane per (game, seat): V[row0 + shuffle][strategy] = n_rounds | won << 15 (u16; coalesced
+//                         reads of the result records, scattered 2-byte stores inside one S-wide row)
+//   fk_lag_sums_kernel:   thread = (strategy, segment of rows); consecutive threads read consecutive strategies of a row
+//                         (coalesced); the earlier value of a pair is re-read `lag` rows up (L2); per-lag accumulators in
+//                         registers, one set of int64 atomics per (thread, lag)
+// Rows [0, carry) of V hold the last shuffles of the previous chunk of the call, so pairs across chunks are counted here;
+// pairs across CALLS (ranks, launch groups) are the host's: every call returns the first and last max_lag rows of its range.
+constexpr uint32_t LAG_WIN_BIT = 0x8000u;
+
+__global__ __launch_bounds__(256) void fk_lag_values_kernel(const uint32_t *recs, const uint16_t *perm_T, uint32_t perm_slots, uint32_t S,
+                                                            uint32_t k, uint32_t gps, uint32_t n_games, uint16_t *V) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)n_games * k) return;
+    const uint32_t id = (uint32_t)(t / k), seat = (uint32_t)(t - (size_t)id * k);
+    const uint32_t sh = id / gps, g = id - sh * gps;
+    const uint4 q0 = *reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
+    const bool won = !(q0.x & REC_SAFETY) && ((q0.x >> 24) & 0x7fu) == seat; // safety-limit rows have no winner (:1129-1147)
+    const uint32_t idx = perm_at(perm_T, S, perm_slots, sh, g * k + seat);
+    V[(size_t)sh * S + idx] = (uint16_t)((q0.z & 0x7fffu) | (won ? LAG_WIN_BIT : 0u));
+}
+
+// rows [first_row, n_rows) are this chunk's shuffles (later elements of the pairs), rows [valid_from, first_row) the carry
+__global__ __launch_bounds__(256) void fk_lag_sums_kernel(const uint16_t *V, uint32_t S, uint32_t valid_from, uint32_t first_row, uint32_t n_rows,
+                                                          uint32_t rows_per_seg, const int32_t *lags, uint32_t n_lags, long long *out) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const uint32_t r0 = first_row + blockIdx.y * rows_per_seg, r1 = min(r0 + rows_per_seg, n_rows);
+    for (uint32_t li = 0; li < n_lags; ++li) {
+        const uint32_t lag = (uint32_t)lags[li];
+        long long n = 0, wx = 0, wy = 0, wxy = 0, rx = 0, ry = 0, rxx = 0, ryy = 0, rxy = 0;
+        for (uint32_t r = max(r0, valid_from + lag); r < r1; ++r) {
+            const uint32_t later = V[(size_t)r * S + s], earlier = V[(size_t)(r - lag) * S + s];
+            const long long a = earlier & 0x7fffu, b = later & 0x7fffu, wa = earlier >> 15, wb = later >> 15;
+            n += 1;
+            wx += wa, wy += wb, wxy += wa & wb;
+            rx += a, ry += b, rxx += a * a, ryy += b * b, rxy += a * b;
+        }
+        if (n == 0) continue;
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(out) + ((size_t)s * n_lags + li) * FK_LAG_COLS;
+        const long long v[FK_LAG_COLS] = {n, wx, wy, wx, wy, wxy, rx, ry, rxx, ryy, rxy}; // (an indicator is its own square)
+#pragma unroll
+        for (int c = 0; c < FK_LAG_COLS; ++c)
+            if (v[c]) atomicAdd(&o[c], (unsigned long long)v[c]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Post-passes over the result records / the state store (streaming kernels, one thread per game).
 // ---------------------------------------------------------------------------------------
 

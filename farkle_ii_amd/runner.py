@@ -329,8 +329,11 @@ def _check_ownership(total: np.ndarray, done_batches: set[int], spb: int, requir
 def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[ThresholdStrategy], plan: TournamentWorkloadPlan,
                    checkpoint_path: Path, collect_metrics: bool, row_dir: Path | None, metric_chunk_dir: Path | None,
                    resume: bool, checkpoint_metadata: Mapping[str, Any], oracle_game_profile: GameProfile | None = None,
-                   all_player_dir: Path | None = None, sidecars: "_Sidecars | None" = None) -> dict:
-    """Play every deterministic batch not yet owned by the checkpoint and persist the aggregates."""
+                   all_player_dir: Path | None = None, sidecars: "_Sidecars | None" = None,
+                   rng_lags: Sequence[int] | None = None) -> dict:
+    """Play every deterministic batch not yet owned by the checkpoint and persist the aggregates.  ``rng_lags``: also accumulate the lag
+    sufficient statistics of the RNG diagnostics' strategy family over the WHOLE shuffle range (``fk_tournament_run_lags``; launch
+    groups and ranks are contiguous ranges that merge in order, rng_lags.LagSummary) — returned as ``result["lag_summary"]``."""
     rank, world = _rank_world()
     eng = get_engine()
     k = n_players
@@ -406,6 +409,12 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             raise ValueError(f"resume failed on rank 0: {resume_error}")
         done_batches = set(shared)
     pending = [b for b in range(n_batches) if b not in done_batches]
+    lag_total = None
+    if rng_lags:
+        if done_batches:  # a strategy's series runs over every shuffle of the root: a partial replay cannot rebuild it
+            raise ValueError("lag statistics need the whole shuffle range of the run; this checkpoint already owns batches: use --force")
+        if row_dir is not None or all_player_dir is not None:
+            raise ValueError("--rng-lag-sums runs without rows / all-player batches (one post-pass per launch): run them separately")
     target = oracle_game_profile.default_target_score if oracle_game_profile else 10_000
     max_rounds = oracle_game_profile.default_max_rounds if oracle_game_profile else 200
     ov = oracle_game_profile.tournament_overrides() if oracle_game_profile else None
@@ -472,8 +481,12 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                     pinned_rows = None
                     pinned_rows = eng.pinned_empty(need, row_dtype(k))
                 extra["rows_out"] = pinned_rows
-            res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=spb if per_batch else hi - lo,
-                                 target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows, **extra)
+            if rng_lags:
+                res = eng.tournament_lags(table, k, cfg.sim.seed, lo, hi, rng_lags, shuffles_per_batch=spb if per_batch else hi - lo,
+                                          target_score=target, max_rounds=max_rounds, overrides=ov)
+            else:
+                res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=spb if per_batch else hi - lo,
+                                     target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows, **extra)
             first = lo // spb - b0 if per_batch else 0
             local[first:first + len(res["tally"])] = res["tally"]
             if local_stats is not None:
@@ -489,6 +502,15 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
                                                        game_seeds=seeds102, as_lines=True,
                                                        sidecar=sidecars.template("row_shard", row_dir / "rows_template.parquet")))
+        if rng_lags:  # this group's ranges in rank order (contiguous whole batches per rank), appended to the run's summary
+            from .rng_lags import LagSummary
+
+            part = LagSummary.from_engine(res, rng_lags) if hi > lo else None
+            parts = gather_objects(part, dst=0) if world > 1 else [part]
+            if rank == 0:
+                for piece in parts:
+                    if piece is not None:
+                        lag_total = piece if lag_total is None else lag_total.merge(piece)
         group = reduce_tally(local, dst=0)
         group_stats = reduce_tally(local_stats, dst=0) if local_stats is not None else None  # integer sums, like the tally
         if want_rows and world > 1:
@@ -547,7 +569,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             if manifest is not None:
                 sidecars.write("shard_manifest", manifest)
     barrier()
-    return {"tally": total, "games": games_done, "seconds": time.perf_counter() - t_start}
+    return {"tally": total, "games": games_done, "seconds": time.perf_counter() - t_start, "lag_summary": lag_total}
 
 
 def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | None = None, *, force: bool = False,
@@ -578,7 +600,8 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
     manifest_sha = hashlib.sha256(manifest.to_csv(index=False).encode("utf-8")).hexdigest()  # runner.py:790-800
     if rank == 0:
         if force:
-            for path in (ckpt_path, n_dir / f"{n}p_checkpoint.parquet", cfg.metrics_path(n), simulation_done_path(cfg, n)):
+            for path in (ckpt_path, n_dir / f"{n}p_checkpoint.parquet", cfg.metrics_path(n), simulation_done_path(cfg, n),
+                         cfg.rng_lag_sums_path(n), cfg.rng_lag_stats_path(n)):
                 path.unlink(missing_ok=True)
                 path.with_name(path.name + ".sidecar.json").unlink(missing_ok=True)
             for d in (row_dir, metric_chunk_dir, all_player_dir):
@@ -608,10 +631,18 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
     result = run_tournament(cfg=cfg, n_players=n, strategies=strategies, plan=plan, checkpoint_path=ckpt_path,
                             collect_metrics=cfg.sim.expanded_metrics, row_dir=row_dir, metric_chunk_dir=metric_chunk_dir,
                             resume=not force, checkpoint_metadata={"strategy_manifest_sha": manifest_sha},
-                            oracle_game_profile=oracle_game_profile, all_player_dir=all_player_dir, sidecars=sidecars)
+                            oracle_game_profile=oracle_game_profile, all_player_dir=all_player_dir, sidecars=sidecars,
+                            rng_lags=cfg.rng_diagnostic_lags() if cfg.sim.rng_lag_sums else None)
     if rank != 0:
         return plan.required_games
     ids = [int(s.strategy_id) for s in strategies]
+    if cfg.sim.rng_lag_sums and result.get("lag_summary") is not None:
+        # the strategy family of the reference's RNG diagnostics without rows: the sufficient statistics, and the stats rows
+        # (_rows_for_online_group, analysis/rng_diagnostics.py:2110-2160) computed from them
+        from .rng_lags import lag_sums_table, lag_stats_table
+
+        _write_parquet_atomic(lag_sums_table(result["lag_summary"], ids, cfg.sim.seed, n), cfg.rng_lag_sums_path(n))
+        _write_parquet_atomic(lag_stats_table(result["lag_summary"], ids, n), cfg.rng_lag_stats_path(n))
     wins, sums, sqs = rt.tally_to_counters(result["tally"], ids, n)
     # (A) summary parquet, (B) expanded metrics parquet — column order as in runner.py:1612-1712
     summary, metrics_rows = [], []
@@ -668,7 +699,8 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
     done_path = simulation_done_path(cfg, n)
     outputs: list[Path] = [ckpt_path, n_dir / "simulation_workload_plan.json"]  # the order of simulation/runner.py:1714-1727
     for extra in (n_dir / f"{n}p_checkpoint.parquet", cfg.metrics_path(n), cfg.strategy_manifest_root_path(),
-                  cfg.simulation_row_dir(n), cfg.metric_chunk_dir(n), cfg.all_player_batch_dir(n)):
+                  cfg.simulation_row_dir(n), cfg.metric_chunk_dir(n), cfg.all_player_batch_dir(n),
+                  cfg.rng_lag_sums_path(n) if cfg.sim.rng_lag_sums else None, cfg.rng_lag_stats_path(n) if cfg.sim.rng_lag_sums else None):
         if extra is not None and Path(extra).exists():
             outputs.append(Path(extra))
     engine_config_sha = config_hash(cfg)

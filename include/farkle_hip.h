@@ -89,6 +89,8 @@ typedef struct {
 } fk_coord;
 
 #define FK_SEAT_STAT_COLS 31 /* all-seat integer statistics per strategy, see fk_tournament_run_stats */
+#define FK_LAG_COLS 11 /* lag sufficient statistics per (strategy, lag), see fk_tournament_run_lags */
+#define FK_MAX_LAGS 16
 #define FK_TALLY_COLS 26 /* wins, attempted, completed, safety, 11 metric sums, 11 square sums (run_tournament.py:109-121) */
 
 typedef struct {
@@ -131,17 +133,14 @@ int fk_host_free(fk_ctx *ctx, void *p);
 /* Tunables: "chunk_bytes" (device workspace budget per chunk), "batch_threshold" (lanes that must be waiting
  * before a wave runs its game hand-over), "use_lds_tally" (0/1/-1 auto), "block" (0 auto), "lean" (seat-record layout:
  * -1 auto, 0 full, 1 lean), "state_store" (-1 auto: seat records live in the HBM state store, with only the turn owner's staged in LDS, when
- * k of them do not fit LDS; 0 the same; 1 always), "blocks_per_cu", "max_waves" (resident waves per SIMD the launch plan counts
+ * k of them do not fit LDS (k > 64); 0 the same; 1 always), "blocks_per_cu", "max_waves" (resident waves per SIMD the launch plan counts
  * on, default 6), "longest_first" (1 = deal
  * never-banking pairings first), "uniform_flags" (-1 auto: tables whose strategies share all flag bits run the scalar-flag
  * kernel instance, 0 never), "perm_split" (-1 auto), "pipeline" (1, default: the next chunk / hinted call is prepared around the
  * current game kernel — permutations in front of it, schedule and seat seeding on a low-priority stream in its drain tail;
- * 0: every chunk is prepared on the main stream in front of its own game kernel), "hot_cold" (tournament launches of 3..8 seats on
- * the hot / cold game kernel, csrc/fk_play_hc.h: -1 auto = from four seats, 0 never, 1 whenever the table allows it) with its variants
- * "hot_cold_tables" (1: score / discard tables in LDS), "hot_cold_inc_regs" (1: the seats' increments / strategies in registers), "hot_cold_lds" (k = 3 .. 5 keep the cold records in
- * LDS, 32 bytes per seat and lane: -1 auto = at k = 4, 0 never, 1 always),
- * "hot_cold_block" (256 / 768 / 1024: block size of the instances without register-resident increments) and "hot_cold_waves"
- * (waves per SIMD the plan may seat, default 5; below 4 the register instances of k = 5 .. 7 run three waves instead of four), "rows_chunk_games" (rows mode plays in chunks of about this many games,
+ * 0: every chunk is prepared on the main stream in front of its own game kernel), "hot_cold" (tournament launches of 4..8 seats on
+ * the hot / cold game kernel, csrc/fk_play_hc.h: -1 auto, 0 never — the LDS-record kernel plays them), "comm_timeout_ms" (deadline of
+ * fk_comm_init and of each collective, default 120 000; 0 = no deadline), "rows_chunk_games" (rows mode plays in chunks of about this many games,
  * default 4 000 000: chunk i's rows cross PCIe while chunk i + 1 plays), "resident_tally" (see fk_tally_resident_reduce).  All of them
  * are scheduling / layout choices: results are identical for every setting. */
 int fk_set_option(fk_ctx *ctx, const char *name, int64_t value);
@@ -181,6 +180,25 @@ int fk_tournament_run_stats(fk_ctx *ctx, const fk_strategy *strategies, int32_t 
  * ignores hints).  Results never depend on hints; a hint that turns out wrong only wastes the preparation.  (The reference's process pool keeps `window = 4 * n_jobs` chunks in flight
  * for the same reason, run_tournament.py:1576-1586.) */
 int fk_tournament_hint_next(fk_ctx *ctx, uint64_t shuffle_begin, uint64_t shuffle_end, int32_t need_state);
+
+/* fk_tournament_run + the lag sufficient statistics of the reference's RNG diagnostics for the STRATEGY family
+ * (analysis/rng_diagnostics.py: observation records :1870-1905, _OnlineMetric :2031-2076, stats rows :2110-2160).  A strategy is
+ * seated exactly once per shuffle, so its observation series — win indicator and n_rounds of the game it sat in, ordered by
+ * (root_seed, shuffle_index) — is indexed by the shuffle; for every lag the pairs (earlier x, later y) = (series[t - lag], series[t]).
+ *   lags        n_lags (1 .. FK_MAX_LAGS) strictly increasing positive shuffle distances (analysis.rng_diagnostic_lags)
+ *   lag_sums    int64 [S][n_lags][FK_LAG_COLS], overwritten: 0 pair_count; win indicator: 1 sum x, 2 sum y, 3 sum x^2, 4 sum y^2,
+ *               5 sum xy; n_rounds: 6 sum x, 7 sum y, 8 sum x^2, 9 sum y^2, 10 sum xy — over the pairs whose BOTH shuffles lie in
+ *               [shuffle_begin, shuffle_end).  Exact integers (the reference accumulates the same integers in float64).
+ *   edge_head / edge_tail   uint16 [m][S], m = min(max lag, n_shuffles): the series values (n_rounds | won << 15) of the first / last m
+ *               shuffles of the range, strategy-minor.  Two ranges that follow each other (launch groups, ranks: contiguous whole
+ *               batches per rank) combine on the host: sums add, plus the pairs that straddle the cut, which need exactly the
+ *               tail of the earlier and the head of the later range (farkle_ii_amd/rng_lags.py: LagSummary.merge).
+ * The matchup family of the same module (one group per seat TUPLE, O(games) groups) has no pre-aggregation and keeps reading rows.
+ * Requires max_rounds (and every override) <= 32767. */
+int fk_tournament_run_lags(fk_ctx *ctx, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                           uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
+                           int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, const int32_t *lags, int32_t n_lags,
+                           int64_t *lag_sums, uint16_t *edge_head, uint16_t *edge_tail);
 
 /* Explicit game list: game g seats strategies table[seat_strategy[g*k+i]] with streams coords[g](seat i).
  * rows: n_games * (4+28k) bytes (required). */

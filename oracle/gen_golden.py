@@ -505,6 +505,66 @@ def gen_all_player():
     _dump({"cases": cases}, open(OUT / "all_player_vectors.json", "w"))
 
 
+def gen_rng_lags():
+    """The strategy-family rows of the reference's RNG diagnostics, by the reference's OWN code over rows it simulated: rows of
+    ``_play_one_shuffle`` -> ``simulation_rows_to_table`` -> ``_extract_batch_arrays`` -> ``_observation_records``
+    (analysis/rng_diagnostics.py:1092-1150, 1870-1905), the strategy records sorted by ``_observation_sort_order`` (:1964) and pushed
+    through ``_OnlineMetric`` / ``_rows_for_online_group`` exactly as ``_write_stats_partition`` does (:2162-2206).  Frozen: the rows,
+    the metric states' six sums per lag, and the value series per strategy (so that range merges can be checked at every cut)."""
+    from farkle.analysis import rng_diagnostics as rd
+    from farkle.simulation.simulation import simulation_rows_to_table
+
+    lags = (1, 2, 5)
+    out = {"lags": list(lags), "cases": []}
+    strategies = grid(score_thresholds=[300, 500], dice_thresholds=[1, 2], smart_five_opts=[False, True], smart_one_opts=[False],
+                      consider_score_opts=[True], consider_dice_opts=[True], auto_hot_dice_opts=[True], run_up_score_opts=[False])
+    for k, root, n_sh, target, overrides in ((2, 7, 40, 1500, ((7, 2, 3, 1, 2), (7, 2, 17, 0, 0))), (4, 9, 24, 1000, ())):
+        gp = GameProfile(default_target_score=target, default_max_rounds=200,
+                         tournament_max_rounds_overrides=tuple(TournamentMaxRoundsOverride(*o) for o in overrides))
+        cfg = rt.TournamentConfig(n_players=k, num_shuffles=n_sh, n_strategies=len(strategies))
+        rt._init_worker(strategies, cfg, gp)
+        rows = []
+        for sh in range(n_sh):
+            seed = ur.coordinate_seed(RandomPurpose.TOURNAMENT_SHUFFLE, root_seed=root, k=k, shuffle_index=sh, dtype=np.uint32)
+            task = rt.ShuffleTask(root_seed=root, k=k, shuffle_index=sh, shuffle_seed=int(seed), deterministic_batch_id=sh // 8)
+            rows.extend(rt._play_one_shuffle(task, collect_rows=True)[3])
+        table = simulation_rows_to_table(rows, k)
+        names = table.schema.names
+        records = []
+        for batch in table.to_batches(max_chunksize=37):  # several batches, as the stage streams them
+            arrays = rd._extract_batch_arrays(batch, winner_col=rd._winner_column(set(names)),
+                                              strat_cols=rd._seat_strategy_columns(None, names), expected_root_seed=root)
+            records.append(rd._observation_records(arrays))
+        records = np.concatenate(records)
+        records = records[records["group_type"] == rd._GROUP_STRATEGY]
+        records = records[rd._observation_sort_order(records)]
+        dtype = records.dtype
+        stats_rows, states, series = [], {}, {}
+        current, rounds, wins = None, None, None
+
+        def flush():
+            stats_rows.extend(rd._rows_for_online_group(current, lags=lags, rounds=rounds, wins=wins))
+            states[str(current[2])] = {name: {"n_obs": int(m.n_obs), "pair_count": m.pair_count.tolist(), "sum_x": m.sum_x.tolist(),
+                                              "sum_y": m.sum_y.tolist(), "sum_x2": m.sum_x2.tolist(), "sum_y2": m.sum_y2.tolist(),
+                                              "sum_xy": m.sum_xy.tolist()} for name, m in (("win_indicator", wins), ("n_rounds", rounds))}
+
+        for record in records:
+            identity = rd._group_identity(record, dtype)
+            if identity != current:
+                if current is not None:
+                    flush()
+                current, rounds, wins = identity, rd._OnlineMetric(lags), rd._OnlineMetric(lags)
+            rounds.push(float(record["n_rounds"]))
+            wins.push(float(record["win_indicator"]))
+            series.setdefault(str(identity[2]), []).append([int(record["shuffle_index"]), int(record["n_rounds"]), int(record["win_indicator"])])
+        flush()
+        out["cases"].append({"k": k, "root_seed": root, "n_shuffles": n_sh, "target_score": target, "max_rounds": 200,
+                             "overrides": [list(o) for o in overrides], "strategies": [strat_tuple(s) for s in strategies],
+                             "rows": stats_rows, "states": states, "series": series,
+                             "safety_limit_games": sum(1 for r in rows if r["termination_status"] != "completed")})
+    _dump(out, open(OUT / "rng_lag_vectors.json", "w"))
+
+
 def gen_sidecars():
     """The reference's simulation sidecar payloads (`_simulation_output_sidecar`, runner.py:338-376, canonical JSON) for every
     operation it publishes, and — the acceptance check — sidecars written by THIS engine's farkle_ii_amd/sidecars.py run through
@@ -763,6 +823,7 @@ if __name__ == "__main__":
     gen_runner()
     gen_wilson()
     gen_all_player()
+    gen_rng_lags()
     gen_sidecars()
     gen_fuzz()
     gen_rng()

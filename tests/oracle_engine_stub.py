@@ -90,6 +90,28 @@ class Engine:
             stats = seat_stats_from_rows(res["rows"], k, len(t), len(t) // k, spb)
         return {"tally": res["tally"], "rows": res["rows"] if want_rows else None, "perms": res["perms"], "seat_stats": stats}
 
+    def tournament_lags(self, table, k, root_seed, shuffle_begin, shuffle_end, lags, shuffles_per_batch=None, target_score=10_000,
+                        max_rounds=200, overrides=None) -> dict:
+        """fk_tournament_run_lags from ROWS: the value matrix (n_rounds | won << 15) per (shuffle, strategy), then the host
+        statement of the rule (rng_lags.LagSummary.from_series)."""
+        from farkle_ii_amd.rng_lags import LagSummary
+
+        res = self.tournament(table, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=shuffles_per_batch,
+                              target_score=target_score, max_rounds=max_rounds, overrides=overrides, want_rows=True)
+        rows, S = res["rows"], len(table)
+        n_sh, gps = shuffle_end - shuffle_begin, len(table) // k
+        values = np.zeros((max(n_sh, 0), S), dtype=np.uint16)
+        if n_sh > 0:
+            sh = np.arange(len(rows)) // gps
+            completed = rows["status"] == 0
+            for seat in range(k):
+                won = completed & (rows["winner_seat"] == seat)
+                values[sh, rows["seats"][:, seat]["strategy"]] = (rows["n_rounds"] & 0x7FFF) | (won.astype(np.uint16) << 15)
+        summ = LagSummary.from_series(values, lags) if n_sh > 0 else None
+        m = min(max(lags), max(n_sh, 0))
+        return {"tally": res["tally"], "lag_sums": summ.sums if summ else np.zeros((S, len(lags), 11), dtype=np.int64),
+                "lag_head": values[:m], "lag_tail": values[n_sh - m:] if n_sh > 0 else values[:0], "n_shuffles": max(n_sh, 0)}
+
     def play_games(self, coords, table, seat_strategy, k, target_score=10_000, max_rounds=200):
         return po.play_games(np.ascontiguousarray(coords).view(po.COORD_DTYPE), np.ascontiguousarray(table).view(po.STRATEGY_DTYPE),
                              seat_strategy, k, target_score=target_score, max_rounds=max_rounds, n_threads=2)

@@ -340,3 +340,40 @@ def test_integration_md_ctypes_blocks_run():
         ns["lib"].fk_destroy.restype = None
         ns["lib"].fk_destroy.argtypes = [ns["C"].c_void_p]
         ns["lib"].fk_destroy(ns["ctx"])
+
+
+def test_baseline_config0_fast_config_file_through_farkle_run_on_the_hip_engine(tmp_path):
+    """BASELINE configs[0] as a FILE: configs/fast_config.yaml with the YAML overlay {sim: {n_players_list: [2], seed_list: [42]}}
+    (lists do not go through the reference's --set) through `farkle run` on the HIP engine; the checkpoint's totals against the
+    oracle over every game of the plan."""
+    import pickle
+    from pathlib import Path
+
+    import pyoracle as po
+    import yaml
+
+    from farkle_ii_amd import checkpoint as ckpt
+    from farkle_ii_amd import engine as eng_mod
+    from farkle_ii_amd import runner
+    from farkle_ii_amd import tournament as tn
+    from farkle_ii_amd.cli import main
+    from farkle_ii_amd.config import load_app_config
+    from farkle_ii_amd.strategies import pack_strategies
+
+    root = Path(__file__).resolve().parent.parent
+    base = yaml.safe_load((root / "configs" / "fast_config.yaml").read_text())
+    base["sim"].update({"n_players_list": [2], "seed_list": [42]})          # the overlay
+    base["io"] = {"results_dir_prefix": str(tmp_path / "fast")}
+    cfg_path = tmp_path / "fast_config_overlaid.yaml"
+    cfg_path.write_text(yaml.safe_dump(base))
+    eng_mod.set_engine(None)
+    main(["--config", str(cfg_path), "run", "--metrics"])
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    payload = pickle.loads(cfg.checkpoint_path(2).read_bytes())
+    n_sh = payload["meta"]["num_shuffles"]
+    strategies, grid = runner._resolve_strategies(cfg, None)
+    assert grid == 80 and n_sh * 40 >= 100_000 and payload["meta"]["complete"]
+    got = ckpt.payload_to_tally(payload, [int(s.strategy_id) for s in strategies], tn.METRIC_LABELS)
+    want = po.tournament(pack_strategies(strategies).view(po.STRATEGY_DTYPE), 2, 42, 0, n_sh, n_threads=8)["tally"][0]
+    assert np.array_equal(got, want)
+    assert eng_mod.get_engine().device_info()["arch"].startswith("gfx")  # the HIP engine played them

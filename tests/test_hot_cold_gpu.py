@@ -1,8 +1,9 @@
 """GPU parity tests of the hot / cold game kernel (``fk_play_hc_kernel``, csrc/fk_play_hc.h) through the C-ABI, bit-exact
 against the CPU oracle: generator state of every seat in LDS, the behaviour counters / banked totals in a per-lane plane.
 
-The kernel is chosen by the launch plan for k >= 4 (option ``hot_cold`` = -1; k = 4: the cold-in-LDS instance) and forced here
-for every k it supports."""
+The kernel is chosen by the launch plan for k >= 4 (option ``hot_cold`` = -1; k = 4: the cold-in-LDS instance; k = 5 .. 7: four
+waves per SIMD with the increments in registers; k = 8: three) — the instances the shipped library holds.  The variants that lost
+or tied against them are compiled only with -DFK_EXPERIMENTS and are not part of this suite."""
 from __future__ import annotations
 
 import numpy as np
@@ -50,52 +51,6 @@ def _ran_hot_cold(eng, k: int, block: int | None = None, tables: int = 1) -> boo
     return t["play_block"] == block and t["play_lds_bytes"] == block * 20 * k + (LDS_TABLE_BYTES if tables else 0)
 
 
-@pytest.mark.parametrize("k,block,tables", [(4, 256, 1), (3, 768, 1), (6, 1024, 1), (8, 768, 1), (5, 1024, 0), (7, 768, 0), (6, 256, 0)])
-def test_hot_cold_blocks_and_lds_tables_agree_with_oracle(eng, po, k, block, tables):
-    """The kernel's block sizes, and its LT instances (score / discard tables in LDS, dense multiset index): per-batch
-    tallies and rows against the oracle on a random table (every flag combination) and on the reference's grid slice."""
-    S = {3: 96, 4: 96, 5: 100, 6: 96, 7: 98, 8: 96}[k]
-    try:
-        eng.set_option("hot_cold", 1)
-        eng.set_option("hot_cold_lds", 0)
-        eng.set_option("hot_cold_block", block)
-        eng.set_option("hot_cold_tables", tables)
-        for table, root in [(_random_valid_table(S, 500 + k), 8), (_random_valid_table(S, 900 + 7 * k), 1234567)]:
-            ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, root, 0, 30, shuffles_per_batch=11, want_rows=True, n_threads=8)
-            got = eng.tournament(table, k, root, 0, 30, shuffles_per_batch=11, want_rows=True)
-            assert _ran_hot_cold(eng, k, block, tables), eng.timing()
-            assert np.array_equal(got["tally"], ref["tally"]), (k, block, tables)
-            assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, block, tables)
-    finally:
-        eng.set_option("hot_cold", -1)
-        eng.set_option("hot_cold_lds", -1)
-        eng.set_option("hot_cold_block", 256)
-        eng.set_option("hot_cold_tables", 1)
-
-
-@pytest.mark.parametrize("k", [5, 6, 7, 8])
-def test_hot_cold_with_and_without_increments_in_registers(eng, po, k):
-    """k >= 5 with LDS tables keeps every seat's PCG increment in registers (select tree on the seat) — at four waves per
-    SIMD for k = 5 .. 7 (strategies loaded per turn), at three (hot_cold_waves = 3: strategies in registers too up to
-    k = 6) otherwise; option hot_cold_inc_regs = 0 loads the increment at each turn start instead: same rows every way."""
-    S = {5: 100, 6: 96, 7: 98, 8: 96}[k]
-    table = _random_valid_table(S, 1300 + k)
-    ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 21, 0, 25, shuffles_per_batch=9, want_rows=True, n_threads=8)
-    try:
-        eng.set_option("hot_cold", 1)
-        for regs, waves in ((1, 5), (1, 3), (0, 5)):
-            eng.set_option("hot_cold_inc_regs", regs)
-            eng.set_option("hot_cold_waves", waves)
-            got = eng.tournament(table, k, 21, 0, 25, shuffles_per_batch=9, want_rows=True)
-            assert _ran_hot_cold(eng, k, None if (regs, waves) == (1, 5) else 256), eng.timing()
-            assert eng.timing()["play_grid"] % 256 == 0
-            assert np.array_equal(got["tally"], ref["tally"]) and got["rows"].tobytes() == ref["rows"].tobytes(), (k, regs, waves)
-    finally:
-        eng.set_option("hot_cold", -1)
-        eng.set_option("hot_cold_inc_regs", 1)
-        eng.set_option("hot_cold_waves", 5)
-
-
 @pytest.mark.parametrize("k", [3, 4, 5, 6, 7, 8])
 def test_hot_cold_kernel_agrees_with_oracle(eng, po, k):
     """Per-batch tallies, rows and all-seat statistics of the same shuffles: hot / cold kernel, LDS-record kernel, oracle."""
@@ -104,20 +59,21 @@ def test_hot_cold_kernel_agrees_with_oracle(eng, po, k):
     n_sh = 36
     ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 6, 2, 2 + n_sh, shuffles_per_batch=16, want_rows=True, n_threads=8)
     try:
-        for hc in (1, 0):
+        for hc in (-1, 0):  # the launch plan's choice (hot / cold from four seats), then the LDS-record kernel on the same shuffles
             eng.set_option("hot_cold", hc)
+            expect = hc == -1 and k >= 4
             got = eng.tournament(table, k, 6, 2, 2 + n_sh, shuffles_per_batch=16, want_rows=True, want_seat_stats=True)
-            assert _ran_hot_cold(eng, k) == bool(hc), (k, hc, eng.timing())
+            assert (k >= 4 and _ran_hot_cold(eng, k)) == expect, (k, hc, eng.timing())
             assert np.array_equal(got["tally"], ref["tally"]), (k, hc)
             assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, hc)
-            if hc:
+            if hc == -1:
                 stats = got["seat_stats"]
             else:
                 assert np.array_equal(got["seat_stats"], stats), k
             eng.set_option("use_lds_tally", 0)  # one batch through result records, no final state records wanted
             rec = eng.tournament(table, k, 6, 2, 2 + n_sh)
             eng.set_option("use_lds_tally", -1)
-            assert _ran_hot_cold(eng, k) == bool(hc)
+            assert (k >= 4 and _ran_hot_cold(eng, k)) == expect
             assert np.array_equal(rec["tally"][0], ref["tally"].sum(axis=0)), (k, hc)
     finally:
         eng.set_option("hot_cold", -1)
@@ -135,7 +91,6 @@ def test_hot_cold_limits_overrides_and_safety_games(eng, po):
     k, gps = 4, 16
     ovs = [(9, 2, 1, k, 0), (9, 2, 3, k, 7), (9, 5, gps - 1, k, 1), (9, 0, 0, k, 3), (9, 7, 2, k, 250), (9, 2, 5, k, 5)]
     try:
-        eng.set_option("hot_cold", 1)
         for tbl, target, mr, expect_hc in [(table, 10_000, 200, True), (table, 2_000, 5, True), (never, 10_000, 12, True),
                                            (table, 50, 200, True), (table, 10_000, 0, True), (table, 10_025, 200, True),
                                            (table, 1_030, 60, True), (table, 75, 200, True), (table, 1, 200, True),
@@ -173,9 +128,9 @@ def test_four_wave_instances_limits_and_overrides(eng, po, k):
         assert np.array_equal(got["seat_stats"], seat_stats_from_rows(ref["rows"], k, S, gps, 4)), (k, target, mr)
 
 
-@pytest.mark.parametrize("k", [3, 4, 5])
+@pytest.mark.parametrize("k", [4])
 def test_cold_records_in_lds_instance(eng, po, k):
-    """Option hot_cold_lds: the cold records sit in LDS beside the hot part (32 bytes per seat and lane, no plane, global tables).
+    """Four seats: the cold records sit in LDS beside the hot part (32 bytes per seat and lane, no plane, global tables).
     Tallies, rows (final seat records), all-seat statistics, short targets, round limits and overrides against the oracle."""
     from farkle_ii_amd.backend import make_overrides
     from oracle_engine_stub import seat_stats_from_rows
@@ -185,8 +140,6 @@ def test_cold_records_in_lds_instance(eng, po, k):
     table = _random_valid_table(S, 5200 + k)
     ovs = [(11, 0, 1, k, 0), (11, 2, gps - 1, k, 3), (11, 5, 0, k, 120)]
     try:
-        eng.set_option("hot_cold", 1)
-        eng.set_option("hot_cold_lds", 1)
         for target, mr in [(10_000, 200), (2_000, 6), (50, 200), (10_000, 0), (135_000, 25)]:
             ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 11, 0, 8, shuffles_per_batch=3, target_score=target, max_rounds=mr,
                                 overrides=po.make_overrides(ovs), want_rows=True, n_threads=8)
@@ -201,43 +154,40 @@ def test_cold_records_in_lds_instance(eng, po, k):
             eng.set_option("use_lds_tally", -1)
             assert np.array_equal(rec["tally"][0], ref["tally"].sum(axis=0)), (k, target, mr)
     finally:
-        eng.set_option("hot_cold", -1)
-        eng.set_option("hot_cold_lds", -1)
         eng.set_option("use_lds_tally", -1)
 
 
 def test_hot_cold_counter_guard_replays_on_the_lds_record_kernel(eng, po):
     """A seat that rolls hot dice more than 255 times (or rolls more than 2 047 times) in one game reaches a guard bit of the
     hot / cold kernel's packed cold record: the call is replayed on the LDS-record kernel (16-bit fields) and still equals
-    the oracle — with the cold records in the plane and in LDS."""
+    the oracle — with the cold records in LDS (four seats) and in the plane (eight)."""
     table = _strats(gu.load("grid_vectors.json")["g64"])[:8].copy()
     table["dice_threshold"], table["require_both"], table["auto_hot_dice"] = 0, 1, 1   # nobody banks: games run to the round limit
     table["strategy_id"] = np.arange(8)
     ref = po.tournament(table.view(po.STRATEGY_DTYPE), 4, 3, 0, 2, max_rounds=6000, want_rows=True)
     assert int(ref["rows"]["seats"]["hot_dice"].max()) > 250
-    try:
-        eng.set_option("hot_cold", 1)
-        for in_lds in (0, 1):
-            eng.set_option("hot_cold_lds", in_lds)
-            got = eng.tournament(table, 4, 3, 0, 2, max_rounds=6000, want_rows=True)
-            t = eng.timing()  # the replay's kernel is the one the timing record describes
-            assert not _ran_hot_cold(eng, 4, 256) and not _ran_cold_in_lds(eng, 4), t
-            assert np.array_equal(got["tally"], ref["tally"])
-            assert got["rows"].tobytes() == ref["rows"].tobytes()
-        # the reference's default grid seats four never-banking strategies together now and then: 200 rounds, 940 rolls, 200
-        # farkles, 142 hot-dice turns of one seat — inside the packed fields, no replay
-        never = table.copy()
-        never["strategy_id"] = np.arange(8)
-        want = po.tournament(never.view(po.STRATEGY_DTYPE), 4, 3, 0, 3, max_rounds=200, want_rows=True)
-        assert int(want["rows"]["seats"]["farkles"].max()) >= 190
-        for in_lds in (0, 1):
-            eng.set_option("hot_cold_lds", in_lds)
-            got = eng.tournament(never, 4, 3, 0, 3, max_rounds=200, want_rows=True)
-            assert _ran_cold_in_lds(eng, 4) if in_lds else _ran_hot_cold(eng, 4, 256)
-            assert got["rows"].tobytes() == want["rows"].tobytes()
-    finally:
-        eng.set_option("hot_cold", -1)
-        eng.set_option("hot_cold_lds", -1)
+    got = eng.tournament(table, 4, 3, 0, 2, max_rounds=6000, want_rows=True)
+    t = eng.timing()  # the replay's kernel is the one the timing record describes
+    assert not _ran_cold_in_lds(eng, 4), t
+    assert np.array_equal(got["tally"], ref["tally"])
+    assert got["rows"].tobytes() == ref["rows"].tobytes()
+    # the same with eight seats (cold records in the per-lane plane)
+    table8 = np.concatenate([table, table])
+    table8["strategy_id"] = np.arange(16)
+    ref8 = po.tournament(table8.view(po.STRATEGY_DTYPE), 8, 3, 0, 1, max_rounds=3000, want_rows=True)
+    assert int(ref8["rows"]["seats"]["hot_dice"].max()) > 250
+    got8 = eng.tournament(table8, 8, 3, 0, 1, max_rounds=3000, want_rows=True)
+    assert not _ran_hot_cold(eng, 8), eng.timing()
+    assert np.array_equal(got8["tally"], ref8["tally"]) and got8["rows"].tobytes() == ref8["rows"].tobytes()
+    # the reference's default grid seats four never-banking strategies together now and then: 200 rounds, 940 rolls, 200
+    # farkles, 142 hot-dice turns of one seat — inside the packed fields, no replay
+    never = table.copy()
+    never["strategy_id"] = np.arange(8)
+    want = po.tournament(never.view(po.STRATEGY_DTYPE), 4, 3, 0, 3, max_rounds=200, want_rows=True)
+    assert int(want["rows"]["seats"]["farkles"].max()) >= 190
+    got = eng.tournament(never, 4, 3, 0, 3, max_rounds=200, want_rows=True)
+    assert _ran_cold_in_lds(eng, 4)
+    assert got["rows"].tobytes() == want["rows"].tobytes()
 
 
 def test_hot_cold_is_the_default_for_wide_tables(eng, po):

@@ -800,3 +800,86 @@ def test_row_shard_writers_agree_across_their_calling_conventions(tmp_path):
         assert not list(d.glob("*.tmp"))
         for r in want:
             assert pq.read_table(d / r["path"]).equals(pq.read_table(base / r["path"])), (name, r["path"])
+
+
+def _run_rank_lags(rank: int, world: int, port: int, cfg_path: str, k: int) -> None:
+    for p in (ROOT, ROOT / "oracle", ROOT / "tests"):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    import oracle_engine_stub
+    from farkle_ii_amd import engine as eng_mod
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.config import load_app_config
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng_mod.set_engine(oracle_engine_stub.Engine(0))
+    runner.MAX_GAMES_PER_LAUNCH = 40  # several launch groups, each cut over the two ranks
+    cfg = load_app_config(Path(cfg_path), seed_list_len=1)
+    cfg.sim.rng_lag_sums = True
+    runner.run_single_n(cfg, k)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_farkle_run_rng_lag_sums(engine, tmp_path, monkeypatch):
+    """`farkle run --rng-lag-sums`: the lag sufficient statistics of the RNG diagnostics' strategy family over the whole shuffle
+    range of the run — several launch groups merged in order — and the stats rows computed from them, against one pass over
+    the oracle's rows; a resumed partial run is refused (the series needs every shuffle)."""
+    import pyarrow.parquet as pq
+    import oracle_engine_stub
+
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.cli import main
+    from farkle_ii_amd.config import load_app_config
+    from farkle_ii_amd.rng_lags import LagSummary, lag_stats_table, lag_sums_table
+    from farkle_ii_amd.strategies import pack_strategies
+
+    cfg_path = _tiny_config(tmp_path)
+    cfg_path.write_text(cfg_path.read_text() + "analysis:\n  rng_diagnostic_lags: [1, 3]\n")
+    monkeypatch.setattr(runner, "MAX_GAMES_PER_LAUNCH", 40)  # a launch group = one deterministic batch of this tiny plan
+    main(["--config", str(cfg_path), "run", "--rng-lag-sums"])
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    n_dir = cfg.n_dir(2)
+    payload = pickle.loads((n_dir / "2p_checkpoint.pkl").read_bytes())
+    n_sh = payload["meta"]["num_shuffles"]
+    strategies, _ = runner._resolve_strategies(cfg, None)
+    table = pack_strategies(strategies)
+    want = LagSummary.from_engine(oracle_engine_stub.Engine(0).tournament_lags(table, 2, 7, 0, n_sh, (1, 3)), (1, 3))
+    ids = list(range(len(table)))
+    assert pq.read_table(n_dir / "2p_rng_lag_sums.parquet").equals(lag_sums_table(want, ids, 7, 2))
+    stats = pq.read_table(n_dir / "2p_rng_lag_stats.parquet")
+    assert stats.equals(lag_stats_table(want, ids, 2)) and stats.num_rows == len(table) * 2 * 2
+    assert set(stats.column("observations").to_pylist()) == {n_sh} and set(stats.column("summary_level").to_pylist()) == {"strategy"}
+    done = json.loads((n_dir / "simulation.done.json").read_text())
+    assert any(p.endswith("2p_rng_lag_sums.parquet") for p in done["outputs"])
+    # a checkpoint that already owns batches cannot rebuild a strategy's series
+    (n_dir / "simulation.done.json").unlink()
+    ck_meta = {**payload["meta"], "completed_process_block_indices": [1], "complete": False}
+    spb = payload["meta"]["shuffles_per_batch"]
+    part = oracle_engine_stub.Engine(0).tournament(table, 2, 7, 0, spb)["tally"][0]
+    _write_partial_checkpoint(n_dir / "2p_checkpoint.pkl", part, ids, 2, ck_meta, [1], spb)
+    with pytest.raises(ValueError, match="whole shuffle range"):
+        main(["--config", str(cfg_path), "run", "--rng-lag-sums"])
+
+
+def test_two_gloo_ranks_merge_their_lag_ranges_in_order(tmp_path):
+    import pyarrow.parquet as pq
+    import torch.multiprocessing as mp
+
+    import oracle_engine_stub
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.config import load_app_config
+    from farkle_ii_amd.rng_lags import LagSummary, lag_sums_table
+    from farkle_ii_amd.strategies import pack_strategies
+
+    cfg_path = _tiny_config(tmp_path)
+    cfg_path.write_text(cfg_path.read_text() + "analysis:\n  rng_diagnostic_lags: [1, 2, 5]\n")
+    mp.spawn(_run_rank_lags, args=(2, 35500 + os.getpid() % 2000, str(cfg_path), 2), nprocs=2, join=True)
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    n_sh = pickle.loads((cfg.n_dir(2) / "2p_checkpoint.pkl").read_bytes())["meta"]["num_shuffles"]
+    strategies, _ = runner._resolve_strategies(cfg, None)
+    table = pack_strategies(strategies)
+    want = LagSummary.from_engine(oracle_engine_stub.Engine(0).tournament_lags(table, 2, 7, 0, n_sh, (1, 2, 5)), (1, 2, 5))
+    assert pq.read_table(cfg.n_dir(2) / "2p_rng_lag_sums.parquet").equals(lag_sums_table(want, list(range(len(table))), 7, 2))

@@ -62,12 +62,13 @@ def _random_valid_table(n: int, seed: int) -> np.ndarray:
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 6, 8, 12])
 def test_state_store_and_lds_record_instances_agree_with_oracle(eng, po, k):
     """Same shuffles through the state-store instance, the LDS-record instance (when k records fit) and the oracle:
-    tallies per batch, rows, and the three GS block sizes."""
+    tallies per batch, rows.  (The state-store instance is the 768-thread one: the path of tables wider than LDS, k > 64;
+    `state_store = 1` selects it at any k.  Its 256- and 64-thread forms are FK_EXPERIMENTS builds only.)"""
     table = _random_valid_table(96, 100 + k)
     n_sh = 40
     ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 5, 3, 3 + n_sh, shuffles_per_batch=16, want_rows=True, n_threads=8)
     try:
-        for store, block in [(1, 0), (1, 256), (1, 64), (0, 0), (-1, 0)]:
+        for store, block in [(1, 0), (0, 0), (-1, 0)]:
             eng.set_option("state_store", store)
             eng.set_option("block", block)
             got = eng.tournament(table, k, 5, 3, 3 + n_sh, shuffles_per_batch=16, want_rows=True)
@@ -336,7 +337,6 @@ def test_resident_tally_accumulates_on_the_device_and_reduces_through_rccl(eng):
         # kernel joins the accumulator ONCE; a call that fails (1000-roll fuse cannot be provoked here: a bad argument) not at all
         never = table[:8].copy()
         never["dice_threshold"], never["require_both"], never["auto_hot_dice"], never["strategy_id"] = 0, 1, 1, np.arange(8)
-        eng.set_option("hot_cold", 1)
         f = eng.tournament(never, 4, 3, 0, 2, max_rounds=6000)["tally"]        # replayed (tests/test_hot_cold_gpu.py)
         g = eng.tournament(never, 4, 3, 2, 5, max_rounds=40)["tally"]
         with pytest.raises(Exception):
@@ -344,7 +344,6 @@ def test_resident_tally_accumulates_on_the_device_and_reduces_through_rccl(eng):
         assert np.array_equal(eng.reduce_resident_tally(f.shape), f + g)
     finally:
         eng.set_option("resident_tally", 0)
-        eng.set_option("hot_cold", -1)
 
 
 @pytest.mark.parametrize("S,k", [(8, 2), (64, 2), (96, 3), (1290, 2), (5160, 4), (7140, 5)])
@@ -414,3 +413,42 @@ def test_pipelined_preparation_never_changes_results(eng, po):
     finally:
         eng.set_option("pipeline", 1)
         eng.set_option("chunk_bytes", 48 << 30)
+
+
+def test_comm_init_with_a_peer_that_never_joins_returns_fk_err_comm_within_the_deadline():
+    """A world of two whose second rank never calls in: `fk_comm_init` (non-blocking ncclCommInitRankConfig polled under
+    `comm_timeout_ms`) must come back with FK_ERR_COMM, abort the half-made communicator and leave the engine usable — in a child
+    process, which then exits.  (Round 3's blocking ncclCommInitRank would sit there until the job's time limit.)"""
+    import subprocess
+    import sys
+    import time
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    child = f"""
+import sys, time
+sys.path.insert(0, {str(root)!r})
+import numpy as np
+from farkle_ii_amd.backend import Engine, FarkleHipError, FK_ERR_COMM
+from bench import grid64
+eng = Engine(0)
+eng.set_option("comm_timeout_ms", 4000)
+t0 = time.time()
+try:
+    eng.comm_init(eng.comm_unique_id(), 0, 2)
+except FarkleHipError as exc:
+    assert exc.code == FK_ERR_COMM, exc
+    assert "comm_timeout_ms" in str(exc) or "ncclCommInitRank" in str(exc), exc
+    print("refused after %.1f s: %s" % (time.time() - t0, exc))
+else:
+    raise SystemExit("fk_comm_init returned success for a world of two with one rank")
+assert time.time() - t0 < 60
+assert eng.comm_ranks() == 1
+assert eng.tournament(grid64(), 2, 42, 0, 4)["tally"].sum() > 0   # the context still plays
+eng.close()
+print("child ok")
+"""
+    t0 = time.time()
+    res = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=150, cwd=str(root))
+    assert res.returncode == 0 and "child ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+    assert time.time() - t0 < 120

@@ -1,5 +1,6 @@
 """HBM-traffic record of one PMC run of tools/pmc_cfg.sh, stamped with the kernel sources it was taken on.
-usage: python tools/make_traffic_json.py <tag> <config> <algorithmic_bytes_per_launch> "<source command>" [round=3]
+usage: python tools/make_traffic_json.py <tag> <config> <algorithmic_bytes_per_launch> "<source command>" [round=3] [k]
+(with k: profiles/r<round>_hbm_traffic_config<config>_k<k>.json, one stamp per player count of the sweep)
 Writes profiles/r<round>_hbm_traffic_config<config>.json; bench.py attaches `hbm_bytes_corrected` as roofline.traffic only while
 the sha256 of the kernel sources still matches."""
 import collections, csv, glob, os, json, subprocess, sys
@@ -10,6 +11,7 @@ from bench import kernel_source_sha
 
 tag, config, algo, source = sys.argv[1], int(sys.argv[2]), float(sys.argv[3]), sys.argv[4]
 rnd = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+k_suffix = f"_k{int(sys.argv[6])}" if len(sys.argv) > 6 else ""
 agg = collections.defaultdict(dict)
 def newest(paths):
     """one file per directory: the most recent run (gpurun merges every run's files into the same directory)"""
@@ -46,6 +48,6 @@ out = {"source": source, "round": rnd, "config": config, "commit": head, "kernel
                 "(the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md applied to the whole read side: an upper bound for this "
                 "access mix); per launch, mean over the launches of the run",
        "kernels": kernels}
-path = ROOT / "profiles" / f"r{rnd:02d}_hbm_traffic_config{config}.json"
+path = ROOT / "profiles" / f"r{rnd:02d}_hbm_traffic_config{config}{k_suffix}.json"
 path.write_text(json.dumps(out, indent=1) + "\n")
 print(path, game_kernel, json.dumps(kernels.get(game_kernel), indent=0)[:400])
