@@ -550,6 +550,23 @@ def test_config4_player_count_sweep_properties(eng):
         assert t[:, 0].sum() * k == t[:, 2].sum(), k
 
 
+def test_config4_full_size_launches_are_additive_over_a_split(eng):
+    """BASELINE config 4 at FULL size for its two extreme player counts: 2.5 x 10^8 games of one call (k = 2: one launch of
+    2.5 x 10^8 tickets; k = 8: two chunks of 1.25 x 10^8) — the 32-bit ticket / game-id arithmetic at that size.  Exposure
+    conservation, and the whole range against the sum of an uneven three-way split of it (a lost, duplicated or misaddressed
+    game changes a tally)."""
+    table = _default_table()
+    for k in (2, 8):
+        n_sh = 250_000_000 // (5160 // k)
+        whole = eng.tournament(table, k, 0, 0, n_sh)["tally"][0]
+        assert eng.timing()["games"] == n_sh * (5160 // k)
+        assert np.all(whole[:, 1] == n_sh) and np.array_equal(whole[:, 1], whole[:, 2] + whole[:, 3]), k
+        assert whole[:, 0].sum() * k == whole[:, 2].sum(), k
+        cuts = [0, n_sh // 3 + 1, n_sh - 12_345, n_sh]
+        parts = sum(eng.tournament(table, k, 0, a, b)["tally"][0] for a, b in zip(cuts[:-1], cuts[1:]))
+        assert np.array_equal(parts, whole), k
+
+
 def test_config5_h2h_full_size_block(eng):
     """BASELINE config 5 shape: one pairing at 10^8 completed games; chunked execution reaches the same state."""
     g64 = _strats(gu.load("grid_vectors.json")["g64"])
