@@ -112,6 +112,7 @@ struct fk_ctx {
     void *comm = nullptr;      // RCCL communicator (fk_comm_init), one per context / GPU
     int comm_rank = 0, comm_world = 1;
     bool comm_async = false;   // (non-blocking communicators: every RCCL call settled by polling; not used — see fk_comm_init)
+    bool comm_lost = false;    // a collective failed or timed out and the communicator was aborted: reductions fail until fk_comm_init
     int32_t comm_timeout_ms = 120000; // option "comm_timeout_ms" (FK_COMM_TIMEOUT_MS): deadline of communicator creation and of each
                                       // collective; 0 = the blocking calls of round 3 (no deadline)
     DevBuf comm_buf;
@@ -1013,6 +1014,7 @@ void comm_abandon(fk_ctx *c) {
     c->comm_world = 1;
     c->comm_rank = 0;
     c->comm_async = false;
+    c->comm_lost = true; // (never silently fall back to a one-rank "reduction" of a multi-rank job)
 }
 
 // A non-blocking communicator reports ncclInProgress from every call until the operation has been issued: poll its state
@@ -2039,6 +2041,7 @@ int fk_comm_init(fk_ctx *c, const fk_comm_id *id, int32_t rank, int32_t world_si
         c->comm = pending->comm;
         c->comm_rank = rank;
         c->comm_world = world_size;
+        c->comm_lost = false;
         return FK_OK;
     }
     const int rc = r.CommInitRank(&c->comm, world_size, *id, rank);
@@ -2048,12 +2051,14 @@ int fk_comm_init(fk_ctx *c, const fk_comm_id *id, int32_t rank, int32_t world_si
     }
     c->comm_rank = rank;
     c->comm_world = world_size;
+    c->comm_lost = false;
     return FK_OK;
 }
 
 int fk_reduce_tally(fk_ctx *c, int64_t *tally, int64_t n, int32_t root_rank) {
     if (!c) return FK_ERR_ARG;
     if (!tally || n < 0) return fail(c, FK_ERR_ARG, "tally is required");
+    if (c->comm_lost) return fail(c, FK_ERR_COMM, "the communicator was aborted after a failed or timed-out collective: call fk_comm_init again");
     if (!c->comm) return fail(c, FK_ERR_COMM, "no communicator: call fk_comm_init first");
     if (root_rank < 0 || root_rank >= c->comm_world) return fail(c, FK_ERR_ARG, "root rank outside the communicator");
     if (n == 0) return FK_OK;
@@ -2075,6 +2080,7 @@ int fk_reduce_tally(fk_ctx *c, int64_t *tally, int64_t n, int32_t root_rank) {
 int fk_tally_resident_reduce(fk_ctx *c, int64_t *out, int64_t n, int32_t root_rank) {
     if (!c) return FK_ERR_ARG;
     if (n < 0 || (size_t)n != c->acc_n || !c->acc.p) return fail(c, FK_ERR_ARG, "resident tally holds %lld elements, %lld asked for", (long long)c->acc_n, (long long)n);
+    if (c->comm_lost) return fail(c, FK_ERR_COMM, "the communicator was aborted after a failed or timed-out collective: call fk_comm_init again");
     HIPCHK(c, hipSetDevice(c->device));
     const size_t bytes = (size_t)n * sizeof(int64_t);
     bool root = true;
@@ -2116,6 +2122,7 @@ int fk_comm_destroy(fk_ctx *c) {
     c->comm_world = 1;
     c->comm_rank = 0;
     c->comm_async = false;
+    c->comm_lost = false;
     return FK_OK;
 }
 
