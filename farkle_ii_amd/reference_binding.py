@@ -28,7 +28,7 @@ from typing import Any, Callable, Dict, Mapping, Sequence
 import numpy as np
 
 from . import h2h as _h2h
-from .backend import FarkleHipError, FK_ERR_ROLL_LIMIT, make_overrides
+from .backend import FarkleHipError, FK_ERR_ROLL_LIMIT
 from .engine import get_engine
 from .game_profile import GameProfile, H2HMaxRoundsOverride, TournamentMaxRoundsOverride
 from .strategies import STRATEGY_DTYPE
@@ -81,7 +81,7 @@ class TournamentBinding:
         self._engine = engine
         self._orig: dict[str, Callable] = {}
         self._served: dict[tuple, tuple] = {}   # (root, k, shuffle, rows?) -> (wins, sums, sqs, rows) of a chunk launch
-        self._table_of: tuple[int, np.ndarray, list[int]] | None = None
+        self._table_of: tuple[tuple[int, int], np.ndarray, list[int]] | None = None
         self.launches = 0
 
     # ---- install / uninstall -------------------------------------------------------------------------------------
@@ -109,9 +109,10 @@ class TournamentBinding:
         state = self.rt._STATE
         if state is None:
             raise RuntimeError("farkle.simulation.run_tournament._STATE is not initialised (_init_worker)")
-        if self._table_of is None or self._table_of[0] != id(state.strats):
+        key = (id(state.strats), len(state.strats))
+        if self._table_of is None or self._table_of[0] != key:
             table = pack_reference_strategies(state.strats)
-            self._table_of = (id(state.strats), table, [int(v) for v in table["strategy_id"]])
+            self._table_of = (key, table, [int(v) for v in table["strategy_id"]])
         return state, self._table_of[1], self._table_of[2]
 
     def _launch(self, tasks: Sequence[Any], want_rows: bool) -> None:
@@ -198,4 +199,4 @@ def prefetching_block_runner(schedule_blocks: Sequence[Mapping[str, Any]], oracl
 
 
 __all__ = ["TournamentBinding", "block_runner", "prefetching_block_runner", "chunk_counters", "coerce_game_profile",
-           "pack_reference_strategies", "make_overrides"]
+           "pack_reference_strategies"]
