@@ -1449,9 +1449,13 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
         int ready_set = -1;
         for (int si : {c->cur ^ 1, c->cur})
             if (c->sets[si].prepared && c->sets[si].desc == d) ready_set = si;
+        // A chunk prepared on the side stream: its seat seeding may still be running in the previous game kernel's drain tail.
+        // The main stream waits for it only in front of THIS chunk's game kernel (below) — what is enqueued before that point,
+        // the next chunk's permutation kernels above all, runs beside the seeding's tail instead of behind it.
+        bool wait_ready = false;
         if (ready_set >= 0) {
             c->cur = ready_set;
-            HIPCHK(c, hipStreamWaitEvent(c->stream, CSET(c).ready, 0));
+            wait_ready = true;
         } else {
             if (c->sets[c->cur].prepared) c->cur ^= 1; // keep a prepared (hinted) chunk for its own call if there is room
             rc = prep_tournament_chunk(c, c->cur, c->stream, d, CSET(c).sa);
@@ -1460,6 +1464,8 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
         CSET(c).prepared = false; // consumed
         const SeedArgs sa = CSET(c).sa;
         if (perms) {
+            if (wait_ready) HIPCHK(c, hipStreamWaitEvent(c->stream, CSET(c).ready, 0));
+            wait_ready = false;
             perm_host.resize((size_t)perm_blocks * S * slots);
             HIPCHK(c, hipMemcpyAsync(perm_host.data(), CSET(c).perm.p, perm_host.size() * 2, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1533,6 +1539,7 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
                 if (rc) return rc;
             }
         }
+        if (wait_ready) HIPCHK(c, hipStreamWaitEvent(c->stream, c->sets[c->cur].ready, 0));
         rc = launch_play_stage(c, sa, pa, plan, want_state, want_recs, want_recs);
         if (rc) return rc;
         // The last chunk of a call without rows: its error record travels with the tally, behind the post-passes — one host

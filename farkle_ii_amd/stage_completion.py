@@ -64,15 +64,9 @@ def path_content_identity(path: Path, *, logical_role: str) -> dict[str, object]
 
 
 def path_identities(paths: Sequence[Path], *, prefix: str) -> list[dict[str, object]]:
-    """A rows-on run lists one shard per shuffle (51 200 files in the end-to-end measurement): the files are read and hashed by a
-    few threads (file reads and hashlib release the GIL); the result is in path order."""
-    jobs = [(p, f"{prefix}_{i:04d}") for i, p in enumerate(paths)]
-    if len(jobs) < 256:
-        return [path_content_identity(p, logical_role=role) for p, role in jobs]
-    from concurrent.futures import ThreadPoolExecutor
-
-    with ThreadPoolExecutor(max_workers=min(16, (os.cpu_count() or 4))) as pool:
-        return list(pool.map(lambda job: path_content_identity(job[0], logical_role=job[1]), jobs, chunksize=256))
+    """In path order.  One thread: a shard is read and hashed in ~25 us, and a pool of threads taking turns at the GIL for work
+    items that small measured 20x SLOWER inside a `farkle run` (11 s for 20 000 shards against 0.5 s)."""
+    return [path_content_identity(p, logical_role=f"{prefix}_{i:04d}") for i, p in enumerate(paths)]
 
 
 def stage_identity_sha256(*, stage: str | None, stage_config_sha: str | None, cache_key_version: int,
