@@ -409,6 +409,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             raise ValueError(f"resume failed on rank 0: {resume_error}")
         done_batches = set(shared)
     pending = [b for b in range(n_batches) if b not in done_batches]
+    shard_identities: dict[str, tuple[int, str]] = {}
     lag_total = None
     if rng_lags:
         if done_batches:  # a strategy's series runs over every shuffle of the root: a partial replay cannot rebuild it
@@ -451,7 +452,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         per_batch = metric_chunk_dir is not None or all_player_dir is not None
         local = np.zeros((b1 - b0 if per_batch else 1, S, 26), dtype=np.int64)
         local_stats = np.zeros((b1 - b0, S, SEAT_STAT_COLS), dtype=np.int64) if all_player_dir is not None else None
-        row_records: list[tuple[int, str]] = []  # (shuffle index, manifest line)
+        row_records: list[tuple] = []  # (shuffle index, manifest line, shard bytes, shard sha256)
         fragments = None
         if metric_chunk_dir is not None and rank == 0:
             # the shuffle fingerprints of the whole group in one vectorised pass (on the device), and their JSON text on the
@@ -518,7 +519,10 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             row_records = [r for part in (gathered or []) for r in part]
         if rank == 0:
             if want_rows:
-                rt.append_manifest_lines(row_manifest, [line for _, line in sorted(row_records)])
+                row_records.sort()
+                rt.append_manifest_lines(row_manifest, [rec[1] for rec in row_records])
+                for sh, _, size, sha in row_records:  # the shards' byte identities, for the completion stamp
+                    shard_identities[str(row_dir / f"rows_{cfg.sim.seed}_{k}p_{sh:012d}.parquet")] = (int(size), sha)
             chunk_lines, all_player_records = [], []
             lists = fragments.result() if fragments is not None else None
             for n, b in enumerate(range(b0, b1)):
@@ -569,7 +573,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             if manifest is not None:
                 sidecars.write("shard_manifest", manifest)
     barrier()
-    return {"tally": total, "games": games_done, "seconds": time.perf_counter() - t_start, "lag_summary": lag_total}
+    return {"tally": total, "games": games_done, "seconds": time.perf_counter() - t_start, "lag_summary": lag_total,
+            "shard_identities": shard_identities}
 
 
 def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | None = None, *, force: bool = False,
@@ -711,7 +716,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         cache_key_version=sc.SIMULATION_CACHE_KEY_VERSION, freshness_key=sc.freshness_key(cfg, profile_sha),
         code_identity={"state": "supplied_by_caller", "commit": None, "dirty_fingerprint_sha256": None,
                        "revision": engine_code_revision(), "engine": "farkle_ii_amd/hip-gfx950"},
-        metadata=metadata)
+        metadata=metadata, known_identities=None if cfg.sim.sidecars else result.get("shard_identities"))
     return plan.required_games
 
 

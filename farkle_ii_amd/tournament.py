@@ -349,8 +349,9 @@ def _write_shard_group(row_dir: str, k: int, ids: np.ndarray, gps: int, root_see
                        atomic: bool = True) -> list:
     """Shards of a run of shuffles (rows = their games, shuffle-major): one vectorised Arrow conversion, then one parquet
     file per shuffle — a zero-copy slice of that table (run_tournament.py:530-558).  Runs in a writer process or inline.
-    Returns the manifest records — or, with ``as_lines``, ``(shuffle_index, JSON line)`` pairs, so that the encoding of one
+    Returns the manifest records — or, with ``as_lines``, ``(shuffle_index, JSON line, bytes, sha256)`` tuples, so that the encoding of one
     line per shuffle happens in the writer processes too."""
+    import hashlib
     import json
     import os
 
@@ -374,24 +375,29 @@ def _write_shard_group(row_dir: str, k: int, ids: np.ndarray, gps: int, root_see
         name = f"rows_{root_seed}_{k}p_{int(shuffle_index[i]):012d}.parquet"
         out = os.path.join(row_dir, name)
         # a 32-row file: column statistics and dictionary pages are a third of its encoding time and nobody prunes on them
+        # encoded in memory, so that the writer can hand the shard's byte identity (size, SHA-256) back with its manifest line: the
+        # completion stamp (stage_completion.py) then does not read 51 200 files again
+        sink = pa.BufferOutputStream()
+        pq.write_table(table.slice(i * gps, gps), sink, write_statistics=False, use_dictionary=False)
+        blob = sink.getvalue()
+        fd = os.open(out + ".tmp" if atomic else out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        try:
+            os.write(fd, blob)
+        finally:
+            os.close(fd)
         if atomic:
-            pq.write_table(table.slice(i * gps, gps), out + ".tmp", write_statistics=False, use_dictionary=False)
             os.replace(out + ".tmp", out)
-        else:  # one directory operation per shard instead of two (see write_row_shards)
-            sink = pa.BufferOutputStream()
-            pq.write_table(table.slice(i * gps, gps), sink, write_statistics=False, use_dictionary=False)
-            fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-            try:
-                os.write(fd, sink.getvalue())
-            finally:
-                os.close(fd)
+        # (not atomic: one directory operation per shard instead of two, see write_row_shards)
         if sidecar is not None:
             from .sidecars import write_sidecar
 
             write_sidecar(out, sidecar)
         record = _shard_record(name, gps, root_seed, k, int(shuffle_index[i]), int(shuffle_seed[i]), int(batch_id[i]), pid,
                                game_profile_sha256)
-        records.append((int(shuffle_index[i]), json.dumps(record, sort_keys=True)) if as_lines else record)
+        if as_lines:  # (shuffle, manifest line, shard size, shard SHA-256; without a sidecar the stamp needs nothing else of the file)
+            records.append((int(shuffle_index[i]), json.dumps(record, sort_keys=True), blob.size, hashlib.sha256(blob).hexdigest()))
+        else:
+            records.append(record)
     return records
 
 
@@ -443,7 +449,7 @@ def write_row_shards(row_dir: Path, tasks: "Sequence[ShuffleTask] | ShuffleRange
     shuffle (run_tournament.py:530-558).  The shuffles are cut into runs of ``group``; each run is converted to Arrow once and
     written shard by shard, by ``threads`` writer processes (``threads`` <= 1: inline).  ``game_seeds``: the ns-102
     fingerprints ``[n_shuffles][gps]`` when the caller has them (``Engine.game_seeds``), else they are hashed here.
-    Returns the manifest records in task order (``as_lines``: ``(shuffle_index, JSON line)`` pairs); the caller appends them."""
+    Returns the manifest records in task order (``as_lines``: ``(shuffle_index, JSON line, shard bytes, shard sha256)`` tuples); the caller appends them."""
     if len(tasks) == 0:
         return []
     if isinstance(tasks, ShuffleRange):

@@ -793,9 +793,12 @@ def test_row_shard_writers_agree_across_their_calling_conventions(tmp_path):
                           ("direct", arrays, {"as_lines": True, "atomic": False}), ("procs", arrays, {"threads": 2, "group": 2, "as_lines": True})]:
         d = tmp_path / name
         got = rt.write_row_shards(d, who, rows, ids, **kw)
-        if kw.get("as_lines"):
-            assert [i for i, _ in got] == [t.shuffle_index for t in tasks]
-            got = [json.loads(line) for _, line in got]
+        if kw.get("as_lines"):  # (shuffle, manifest line, shard bytes, shard sha256): the identity is the file's
+            assert [rec[0] for rec in got] == [t.shuffle_index for t in tasks]
+            for _, line, size, sha in got:
+                data = (d / json.loads(line)["path"]).read_bytes()
+                assert size == len(data) and sha == hashlib.sha256(data).hexdigest()
+            got = [json.loads(rec[1]) for rec in got]
         assert [strip(r) for r in got] == [strip(r) for r in want], name
         assert not list(d.glob("*.tmp"))
         for r in want:
