@@ -85,18 +85,18 @@ def stage_identity_sha256(*, stage: str | None, stage_config_sha: str | None, ca
 _STAGING_PREFIXES = ("._tmp_", "._artifact_v3_", "._sidecar_v3_", "._manifest_v3_", "._manifest_sidecar_v3_")
 
 
-def completion_output_files(paths: Iterable[Path], done_path: Path) -> list[Path]:
+def completion_output_files(paths: Iterable[Path], done_path: Path) -> list[str]:
     """simulation/runner.py:434-461: directories are expanded (sorted by POSIX path) so that a stamp never authenticates itself;
     a directory whose manifest has a sidecar is represented by that manifest alone; sidecars and staging files are skipped."""
     done = os.path.realpath(done_path)
-    files: list[Path] = []
+    files: list[str] = []  # (plain strings: a rows-on run lists one shard per shuffle, and 51 200 Path objects cost 0.3 s)
     for path in paths:
         path = Path(path)
         if path.is_dir():
             sealed = [c for c in (path / "manifest.jsonl", path / "metrics_manifest.jsonl")
                       if c.is_file() and c.with_name(f"{c.name}.sidecar.json").is_file()]
             if sealed:
-                files.extend(sealed)
+                files.extend(str(c) for c in sealed)
                 continue
             found = []
             for d, _, names in os.walk(path):  # (os.walk, one realpath per DIRECTORY: a rows-on run lists one shard per shuffle)
@@ -106,9 +106,9 @@ def completion_output_files(paths: Iterable[Path], done_path: Path) -> list[Path
                         continue
                     if os.path.join(real_dir, name) != done:
                         found.append(os.path.join(d, name))
-            files.extend(Path(f) for f in sorted(found))
+            files.extend(sorted(found))
         else:
-            files.append(path)
+            files.append(str(path))
     return list(dict.fromkeys(files))
 
 
@@ -120,9 +120,9 @@ def write_stage_done(done_path: Path, *, inputs: Iterable[Path], outputs: Iterab
     """The payload of stage_completion.py:473-512 for a successful stage, written atomically.  Returns the payload.
     ``known_identities``: ``{path: (bytes, sha256)}`` of files this run wrote and hashed while it had their bytes in memory (row
     shards without sidecars); every other path is read."""
-    input_paths, output_paths = [Path(p) for p in inputs], [Path(p) for p in outputs]
+    input_paths, output_paths = [os.fspath(p) for p in inputs], [os.fspath(p) for p in outputs]
     if status == "success":
-        missing = [p for p in (*input_paths, *output_paths) if not p.exists()]
+        missing = [p for p in (*input_paths, *output_paths) if not (known_identities and p in known_identities) and not os.path.exists(p)]
         if missing:
             raise FileNotFoundError(f"cannot publish successful completion with missing paths: {missing}")
     completion_state = "complete_valid" if status == "success" else "blocked_by_cap" if status == "blocked_by_cap" else "partial_resumable"
@@ -134,8 +134,8 @@ def write_stage_done(done_path: Path, *, inputs: Iterable[Path], outputs: Iterab
         "schema_version": SCHEMA_VERSION, "lifecycle_contract_version": LIFECYCLE_CONTRACT_VERSION, "stage": stage,
         "config_sha": config_sha, "stage_config_sha": resolved_stage_sha, "cache_key_version": cache_key_version,
         "freshness_key": fresh, "freshness_sha256": None if fresh is None else freshness_sha256(fresh),
-        "completion_state": completion_state, "inputs": [str(p) for p in input_paths], "input_identities": input_ids,
-        "outputs": [str(p) for p in output_paths], "output_identities": output_ids, "code_identity": dict(code_identity),
+        "completion_state": completion_state, "inputs": input_paths, "input_identities": input_ids,
+        "outputs": output_paths, "output_identities": output_ids, "code_identity": dict(code_identity),
         "run_lineage_sha256": run_lineage_sha256,
         "stage_identity_sha256": stage_identity_sha256(stage=stage, stage_config_sha=resolved_stage_sha, cache_key_version=cache_key_version,
                                                        freshness_key=fresh, code_identity=code_identity,
