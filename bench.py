@@ -577,7 +577,30 @@ def main() -> None:
     for i in range(args.warmup):  # (the last warm-up step does not prepare the first timed step)
         tally, _, _ = wl.step(eng, i, rank, n_gpus, next_index=i + 1 if i + 1 < args.warmup else None)
         local += tally
-    reduce_to_rank0(local)
+    # The warm-up reduce is also the engine communicator's FIRST collective.  If it fails or runs into the deadline on any rank
+    # (fk_reduce_tally / fk_tally_resident_reduce return FK_ERR_COMM and abort the communicator), every rank learns of it over
+    # gloo and the job continues on torch.distributed's reduce — decided collectively, outside the timed region.
+    reduce_ok, reduce_why = 1, ""
+    try:
+        reduce_to_rank0(local)
+    except Exception as exc:
+        if not (distributed and use_fk_comm):
+            raise
+        reduce_ok, reduce_why = 0, f"{type(exc).__name__}: {str(exc)[:200]}"
+    if distributed and use_fk_comm:
+        flag = torch.tensor([reduce_ok], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            print(f"rank {rank}: the engine communicator's first reduce failed ({reduce_why or 'on another rank'}); "
+                  "torch.distributed reduce instead", file=sys.stderr)
+            use_fk_comm = resident = False
+            eng.set_option("resident_tally", 0)
+            try:
+                eng.comm_destroy()
+            except Exception:
+                pass
+            tally_reduce = f"torch.distributed.reduce ({'nccl = RCCL' if data_group is not None else 'gloo'}) after the engine communicator's first reduce failed"
+            rccl_ranks = dist.get_world_size(data_group) if data_group is not None else 0
     local[:] = 0
     my_games = 0
     t: dict = {}
