@@ -4,6 +4,7 @@ from __future__ import annotations
 import hashlib
 import json
 import pickle
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -287,3 +288,86 @@ def test_c_header_is_plain_c(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(root / "include"), str(src), "-o", str(exe)], check=True)
     assert subprocess.run([str(exe)]).returncode == 0
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", "-I", str(root / "include"), str(src)], check=True)
+
+
+def test_stage_completion_output_list_and_identities(tmp_path):
+    """`completion_output_files` / `path_identities` (simulation/runner.py:434-461, utils/stage_completion.py:150-187): directories are
+    expanded in POSIX path order without sidecars, staging files and the stamp itself; a directory whose manifest has a sidecar is
+    represented by that manifest; identities are the files' bytes unless the run hands them over."""
+    import hashlib
+    import json
+
+    from farkle_ii_amd import stage_completion as sc
+
+    n_dir = tmp_path / "2_players"
+    rows, chunks = n_dir / "2p_rows", n_dir / "2p_metric_chunks"
+    rows.mkdir(parents=True)
+    chunks.mkdir()
+    done = n_dir / "simulation.done.json"
+    done.write_text("{}")
+    for name in ("rows_7_2p_000000000001.parquet", "rows_7_2p_000000000000.parquet", "manifest.jsonl", "._tmp_x.parquet",
+                 "rows_7_2p_000000000000.parquet.sidecar.json"):
+        (rows / name).write_bytes(name.encode())
+    (chunks / "metrics_000001.parquet").write_bytes(b"m1")
+    (chunks / "metrics_manifest.jsonl").write_bytes(b"mm")
+    (chunks / "metrics_manifest.jsonl.sidecar.json").write_bytes(b"{}")  # sealed: the manifest stands for the directory
+    ckpt = n_dir / "2p_checkpoint.pkl"
+    ckpt.write_bytes(b"pickle")
+    files = sc.completion_output_files([ckpt, rows, chunks, n_dir], done)
+    rel = [str(Path(f).relative_to(n_dir)) for f in files]
+    assert rel[:5] == ["2p_checkpoint.pkl", "2p_rows/manifest.jsonl", "2p_rows/rows_7_2p_000000000000.parquet",
+                       "2p_rows/rows_7_2p_000000000001.parquet", "2p_metric_chunks/metrics_manifest.jsonl"]
+    assert "simulation.done.json" not in rel and not any(r.endswith(".sidecar.json") or "._tmp_" in r for r in rel)
+    assert len(rel) == len(set(rel))  # the n_dir walk repeats nothing that was already listed
+    known = {str(rows / "rows_7_2p_000000000001.parquet"): (123, "ab" * 32)}
+    ids = sc.path_identities(files[:4], prefix="output", known=known)
+    assert [i["logical_role"] for i in ids] == ["output_0000", "output_0001", "output_0002", "output_0003"]
+    assert ids[0]["content_sha256"] == hashlib.sha256(b"pickle").hexdigest() and ids[0]["byte_length"] == 6 and ids[0]["sidecar_sha256"] is None
+    assert ids[2]["sidecar_sha256"] == hashlib.sha256(b"rows_7_2p_000000000000.parquet.sidecar.json").hexdigest()
+    assert ids[3] == {"logical_role": "output_0003", "kind": "file", "byte_length": 123, "content_sha256": "ab" * 32, "sidecar_sha256": None}
+    assert sc.path_content_identity(n_dir / "nope", logical_role="x") == {"logical_role": "x", "kind": "missing"}
+    tree = sc.path_content_identity(chunks, logical_role="d")
+    assert tree["kind"] == "directory" and tree["entry_count"] == 3 and len(tree["tree_sha256"]) == 64
+    payload = sc.write_stage_done(done, inputs=[ckpt], outputs=files, stage="simulation", config_sha="c" * 64, stage_config_sha=None,
+                                  cache_key_version=4, freshness_key={"b": 1, "a": 2}, code_identity={"state": "supplied_by_caller"},
+                                  metadata={"num_shuffles": 3}, known_identities=known)
+    on_disk = json.loads(done.read_text())
+    assert on_disk == payload and on_disk["num_shuffles"] == 3 and on_disk["stage_config_sha"] == "c" * 64
+    assert on_disk["freshness_sha256"] == hashlib.sha256(b'{"a":2,"b":1}').hexdigest() and on_disk["completion_state"] == "complete_valid"
+    with pytest.raises(ValueError, match="collides"):
+        sc.write_stage_done(done, inputs=[], outputs=[], stage="simulation", config_sha=None, stage_config_sha=None, cache_key_version=4,
+                            freshness_key=None, code_identity={}, metadata={"status": "x"})
+    with pytest.raises(FileNotFoundError):
+        sc.write_stage_done(done, inputs=[n_dir / "missing"], outputs=[], stage="simulation", config_sha=None, stage_config_sha=None,
+                            cache_key_version=4, freshness_key=None, code_identity={})
+
+
+def test_rng_diagnostic_lags_option_and_stats_table_schema():
+    from farkle_ii_amd.config import AppConfig
+    from farkle_ii_amd.rng_lags import LagSummary, lag_stats_table, lag_sums_table
+
+    cfg = AppConfig()
+    assert cfg.rng_diagnostic_lags() == (1,)
+    cfg.opaque["analysis"] = {"rng_diagnostic_lags": [1, 4, 9]}
+    assert cfg.rng_diagnostic_lags() == (1, 4, 9)
+    for bad in ([], [0], [2, 2], [3, 1]):
+        cfg.opaque["analysis"] = {"rng_diagnostic_lags": bad}
+        with pytest.raises(ValueError, match="increasing positive"):
+            cfg.rng_diagnostic_lags()
+    rng = np.random.default_rng(3)
+    series = (rng.integers(1, 30, (50, 6)) | (rng.integers(0, 2, (50, 6)) << 15)).astype(np.uint16)
+    summ = LagSummary.from_series(series, (1, 3))
+    stats = lag_stats_table(summ, list(range(6)), 2)
+    assert stats.schema.names == ["summary_level", "strategy", "matchup_id", "matchup", "participant_strategy_ids", "n_players", "observations",
+                                  "lagged_pairs", "lag", "metric", "autocorr", "estimability_status",
+                                  "zero_centered_descriptive_reference_band_lower", "zero_centered_descriptive_reference_band_upper",
+                                  "sequence_order", "note"]  # _stats_schema, analysis/rng_diagnostics.py:2079-2098
+    assert stats.num_rows == 6 * 2 * 2 and set(stats.column("lagged_pairs").to_pylist()) == {49, 47}
+    sums = lag_sums_table(summ, list(range(6)), 11, 2)
+    assert sums.num_rows == 12 and sums.column("lagged_pairs").to_pylist()[:2] == [49, 47]
+    # a constant series has zero variance: no autocorrelation, status says why (_OnlineMetric.result :2066-2076)
+    flat = LagSummary.from_series(np.full((10, 1), 7, dtype=np.uint16), (1,))
+    row = lag_stats_table(flat, [0], 2).to_pylist()
+    assert [r["estimability_status"] for r in row] == ["zero_variance", "zero_variance"] and row[0]["autocorr"] is None
+    short = LagSummary.from_series(series[:2], (1, 3))
+    assert [r["estimability_status"] for r in lag_stats_table(short, list(range(6)), 2).to_pylist()[:2]] == ["insufficient_pairs"] * 2
