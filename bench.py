@@ -89,6 +89,12 @@ def add_timing(acc: dict, t: dict) -> dict:
         acc[key] = acc.get(key, 0) + t.get(key, 0)
     for key in ("play_block", "play_grid", "play_lds_bytes"):
         acc[key] = t.get(key)
+    if t.get("play_clock_mhz"):  # option "clock_stamps": the shader clock the call's last game kernel ran at, measured inside it
+        acc["clock_sum"] = acc.get("clock_sum", 0) + t["play_clock_mhz"]
+        acc["clock_n"] = acc.get("clock_n", 0) + 1
+    elif t.get("clock_n"):
+        acc["clock_sum"] = acc.get("clock_sum", 0) + t["clock_sum"]
+        acc["clock_n"] = acc.get("clock_n", 0) + t["clock_n"]
     for k, sub in (t.get("per_k") or {}).items():  # config 4: one record per player count
         add_timing(acc.setdefault("per_k", {}).setdefault(k, {}), sub)
     return acc
@@ -516,6 +522,10 @@ def main() -> None:
     wl = make_workload(args)
     eng = make_engine(local_rank)
     info = eng.device_info()
+    try:  # every game-kernel workgroup stamps s_memtime / s_memrealtime at its first and last instruction (two scalar reads and one
+        eng.set_option("clock_stamps", 1)  # 32-byte store per workgroup and launch): the clock the fractions below are also priced at
+    except Exception:
+        pass  # (the CPU test stub has no such option)
     dev = torch.device("cuda", local_rank) if have_gpu else torch.device("cpu")
     red_dev = dev if data_group is not None else torch.device("cpu")  # where the tally reduction runs
 
@@ -683,6 +693,17 @@ def main() -> None:
             "launches_seeded_behind_the_previous_kernel": int(t.get("prefetched_chunks", 0)),
             "launch": {k2: t.get(k2) for k2 in ("play_block", "play_grid", "play_lds_bytes")},
         }
+
+        def with_clock(rec: dict, tt: dict) -> None:
+            """`frac` stays defined against the NOMINAL clock (as every round before); next to it the clock the game kernels
+            really held (in-kernel s_memtime / s_memrealtime, median over workgroups, mean over the timed launches) and the fraction of
+            the peak at THAT clock — the chip lowers its clock under load (MI355X_MICROARCH.md, DVFS give-back)."""
+            if tt.get("clock_n"):
+                mhz = tt["clock_sum"] / tt["clock_n"]
+                rec["clock_mhz_measured"] = mhz
+                rec["frac_at_measured_clock"] = rec["frac"] * info["clock_mhz"] / mhz
+
+        with_clock(roofline, t)
         if "per_k" in wpg:  # config 4: one roofline record per player count (kernel time, W and fraction of each k's launches)
             per_k = []
             for k2, w2 in wpg.pop("per_k").items():
@@ -695,6 +716,7 @@ def main() -> None:
                               "games_per_launch": gpl, "kernel_games_per_s": rate, **w2,
                               "frac": rate * w2["ops_per_game"] / peak_ops, "traffic": traffic_for(kernel_of(tk, int(k2)), int(k2)),
                               "launch": {k3: tk.get(k3) for k3 in ("play_block", "play_grid", "play_lds_bytes")}})
+                with_clock(per_k[-1], tk)
             roofline["per_k"] = per_k
             # the line's headline figures are the sweep's: the mean fraction over the player counts, and — as the dominant kernel —
             # the one of the player count furthest below its roofline (round 3 printed the k = 2 launches' kernel and fraction here)

@@ -106,6 +106,9 @@ struct fk_ctx {
     int32_t hc_cl = -1;        // cold records in LDS beside the hot part (k = 3 .. 5): -1 auto (k = 4), 0 never, 1 always
     DevBuf lds_tables;         // their LDS image (fk_play_hc.h)
     DevBuf cold;
+    int32_t clock_stamps = 0;  // option "clock_stamps": every game-kernel block stamps s_memtime / s_memrealtime at both ends
+    DevBuf clk;                // [grid][4] stamps of the last game kernel
+    int clk_grid = 0;
     DevBuf lag_v, lag_out, lag_lags, lag_edge, lag_tmp; // fk_tournament_run_lags: value matrix, sums, lag list, head / tail rows
     bool ran_hc = false;       // the current tournament call launched the hot / cold kernel
     int32_t perm_split = -1;   // -1 auto, 0 one-kernel Fisher-Yates, 1 draws + serial swap chains, 2 draws + chain-free kernel
@@ -759,6 +762,15 @@ int launch_play_stage(fk_ctx *c, const SeedArgs &sa, PlayArgs &pa, const LaunchP
     pa.err = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(cs.misc.p) + 16);
     pa.batch_threshold = (uint32_t)std::max(1, std::min(64, c->batch_threshold));
     pa.use_lds_tally = plan.lds_tally ? 1u : 0u;
+    pa.clk = nullptr;
+    c->clk_grid = 0;
+    if (c->clock_stamps) {
+        const size_t bytes = (size_t)std::max(plan.grid, 1) * 4 * sizeof(unsigned long long);
+        rc = ensure(c, c->clk, bytes);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(c->clk.p, 0, bytes, c->stream));
+        pa.clk = static_cast<unsigned long long *>(c->clk.p);
+    }
     {
         Timer t(c, &c->timing.play_ms, SLOT_PLAY);
         LaunchPlan lp = plan;
@@ -768,6 +780,7 @@ int launch_play_stage(fk_ctx *c, const SeedArgs &sa, PlayArgs &pa, const LaunchP
         t.stop();
         HIPCHK(c, e);
         c->timing.play_grid = lp.launched_grid;
+        if (pa.clk) c->clk_grid = lp.launched_grid;
     }
     c->timing.play_launches += 1;
     c->timing.play_block = plan.block;
@@ -779,6 +792,20 @@ int launch_play_stage(fk_ctx *c, const SeedArgs &sa, PlayArgs &pa, const LaunchP
 // the kernel timers of the chunk just played (incl. those of its preparation); the main stream has been synchronised
 int finish_timers(fk_ctx *c) {
     HIPCHK(c, collect_timers(c));
+    if (c->clk_grid > 0) { // shader clock of the last game kernel: median over its blocks of d(s_memtime) / d(s_memrealtime) x 100 MHz
+        std::vector<unsigned long long> h((size_t)c->clk_grid * 4);
+        HIPCHK(c, hipMemcpy(h.data(), c->clk.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::vector<double> mhz;
+        for (int b = 0; b < c->clk_grid; ++b) {
+            const unsigned long long t0 = h[(size_t)b * 4], r0 = h[(size_t)b * 4 + 1], t1 = h[(size_t)b * 4 + 2], r1 = h[(size_t)b * 4 + 3];
+            if (r1 > r0 && t1 > t0) mhz.push_back(100.0 * (double)(t1 - t0) / (double)(r1 - r0));
+        }
+        if (!mhz.empty()) {
+            std::nth_element(mhz.begin(), mhz.begin() + (std::ptrdiff_t)(mhz.size() / 2), mhz.end());
+            c->timing.play_clock_mhz = (int32_t)(mhz[mhz.size() / 2] + 0.5);
+        }
+        c->clk_grid = 0;
+    }
     ChunkSet &cs = CSET(c);
     float ms = 0.f;
     // the permutations of a pipelined chunk ran on the main stream, in front of the previous game kernel: a clean interval
@@ -1147,7 +1174,7 @@ void fk_destroy(fk_ctx *c) {
     release(c->comm_buf);
     if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     for (DevBuf *b : {&c->strat, &c->recs, &c->rec0, &c->tally, &c->rows, &c->ov, &c->seatlist, &c->coords, &c->inv, &c->slow, &c->digest, &c->score_lut,
-                      &c->discard_lut, &c->block_out, &c->stats, &c->cold, &c->lds_tables, &c->acc, &c->rows_alt, &c->lag_v, &c->lag_out, &c->lag_lags, &c->lag_edge, &c->lag_tmp})
+                      &c->discard_lut, &c->block_out, &c->stats, &c->cold, &c->clk, &c->lds_tables, &c->acc, &c->rows_alt, &c->lag_v, &c->lag_out, &c->lag_lags, &c->lag_edge, &c->lag_tmp})
         release(*b);
     for (auto &cs : c->sets) {
         for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc, &cs.pools, &cs.blocks, &cs.game_block, &cs.game_row}) release(*b);
@@ -1238,6 +1265,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "hot_cold_lds") c->hc_cl = (int32_t)value;
     else if (n == "hot_cold_cold_regs") c->hc_cr = (int32_t)value;
 #endif
+    else if (n == "clock_stamps") c->clock_stamps = value != 0;
     else if (n == "perm_split") c->perm_split = (int32_t)value;
     else if (n == "pipeline") c->pipeline = (int32_t)value;
     else if (n == "uniform_flags") c->uniform_flags_opt = (int32_t)value;

@@ -136,7 +136,7 @@ __host__ __device__ inline void pcg_seed(Rng &r, const uint32_t (&g)[8]) {
 }
 
 // DXSM output of the current state, then the cheap-multiplier step.
-__host__ __device__ inline uint64_t pcg_next64(Rng &r) {
+__host__ __device__ inline uint64_t pcg_next64_plain(Rng &r) {
     uint64_t h = r.hi, l = r.lo | 1u;
     h ^= h >> 32;
     h *= PCG_CHEAP_MULT;
@@ -150,6 +150,14 @@ __host__ __device__ inline uint64_t pcg_next64(Rng &r) {
     r.lo = (uint64_t)st;
     return h;
 }
+
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FK_PCG_HAND)
+} // namespace fk
+#include "../../tools/pcg_hand.h" // experiment builds only: the draw as one hand-laid asm block (measured slower, see the file)
+namespace fk {
+#else
+__host__ __device__ inline uint64_t pcg_next64(Rng &r) { return pcg_next64_plain(r); }
+#endif
 
 // buffered 32-bit draw: low half first, high half on the next call (persists across rolls)
 __host__ __device__ inline uint32_t pcg_next32(Rng &r) {
@@ -206,32 +214,43 @@ __host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) {
 //                 sequential path; words that are not generated are the constant 1 (24 >= 16, never detours).
 // STRIDE = width of one face's count field in the result: 4 (nibbles, the SWAR scorer's input) or 3 (the 18-bit key
 // of the score table, SCORE_LUT below; a count is at most 6).
+// roll_counts_fast: the converged part.  `detour` = some low product word fell below the rejection bound: the caller restores the
+// generator it started from and replays the roll with roll_counts_sequential (roll_counts below does both; the game kernels
+// restore from the seat record in LDS instead of keeping a copy of the state in registers).
 template <uint32_t STRIDE = 4>
-__device__ inline uint32_t roll_counts(Rng &r, uint32_t n, uint32_t *faces_out = nullptr) {
-    const Rng saved = r;
-    const uint32_t hb = r.has_buf;
+__device__ inline uint32_t roll_counts_fast(Rng &r, uint32_t n, bool &detour, uint32_t *faces_out = nullptr) {
+    const uint32_t hb = r.has_buf, buf_in = r.buf;
     const uint32_t need = (n - hb + 1u) >> 1; // new 64-bit outputs: ceil((n - has_buf) / 2), 0..3
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FK_PCG_HAND)
+    // all draws of the roll in one hand-laid block: state as four words updated in place, nothing merged by the compiler
+    uint32_t lo0, hi0, lo1, hi1, lo2, hi2, last_hi = r.buf;
+    uint32_t s0 = (uint32_t)r.lo, s1 = (uint32_t)(r.lo >> 32), s2 = (uint32_t)r.hi, s3 = (uint32_t)(r.hi >> 32);
+    pcg_draws(s0, s1, s2, s3, r.inc_lo, r.inc_hi, need, lo0, hi0, lo1, hi1, lo2, hi2, last_hi);
+    r.lo = (uint64_t)s0 | ((uint64_t)s1 << 32);
+    r.hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
+#else
     uint32_t lo0 = 1, hi0 = 1, lo1 = 1, hi1 = 1, lo2 = 1, hi2 = 1, last_hi = r.buf;
     if (need > 0u) {
-        uint64_t o = pcg_next64(r);
+        uint64_t o = pcg_next64_plain(r);
         lo0 = (uint32_t)o;
         hi0 = (uint32_t)(o >> 32);
         last_hi = hi0;
     }
     if (need > 1u) {
-        uint64_t o = pcg_next64(r);
+        uint64_t o = pcg_next64_plain(r);
         lo1 = (uint32_t)o;
         hi1 = (uint32_t)(o >> 32);
         last_hi = hi1;
     }
     if (need > 2u) {
-        uint64_t o = pcg_next64(r);
+        uint64_t o = pcg_next64_plain(r);
         lo2 = (uint32_t)o;
         hi2 = (uint32_t)(o >> 32);
         last_hi = hi2;
     }
+#endif
     uint32_t w[6];
-    w[0] = hb ? saved.buf : lo0;
+    w[0] = hb ? buf_in : lo0;
     w[1] = hb ? lo0 : hi0;
     w[2] = hb ? hi0 : lo1;
     w[3] = hb ? lo1 : hi1;
@@ -255,7 +274,18 @@ __device__ inline uint32_t roll_counts(Rng &r, uint32_t n, uint32_t *faces_out =
     }
     r.has_buf = (n + hb) & 1u;
     r.buf = last_hi;
-    if (minleft < (STRIDE == 4u ? 16u : 4u)) { // rare (STRIDE 4: a superset of the rejections): redo this roll exactly as NumPy would
+    detour = minleft < (STRIDE == 4u ? 16u : 4u); // rare (STRIDE 4: a superset of the rejections)
+    if (faces_out) *faces_out = faces;
+    return counts;
+}
+
+template <uint32_t STRIDE = 4>
+__device__ inline uint32_t roll_counts(Rng &r, uint32_t n, uint32_t *faces_out = nullptr) {
+    const Rng saved = r;
+    bool detour;
+    uint32_t faces = 0;
+    uint32_t counts = roll_counts_fast<STRIDE>(r, n, detour, faces_out ? &faces : nullptr);
+    if (detour) { // redo this roll exactly as NumPy would
         r = saved;
         faces = 0;
         counts = roll_counts_sequential<STRIDE>(r, n, &faces);

@@ -159,7 +159,17 @@ struct PlayArgs {
     uint32_t uflags;             // the flag bits (8..15) every strategy of the table shares, see MIXED below
     uint4 *cold;                 // fk_play_hc_kernel: [resident lanes][k] cold seat records (fk_play_hc.h)
     const uint8_t *lds_tables;   // fk_play_hc_kernel, LT instances: the LDS image of the score / discard tables (LT_BYTES, fk_device.h)
+    unsigned long long *clk;     // nullable (option "clock_stamps"): [grid][4] = s_memtime, s_memrealtime at the block's first and last
+                                 // instruction — the shader clock the launch really ran at (MI355X_MICROARCH.md, DVFS give-back item 6)
 };
+
+// One pair of stamps per block and end of the kernel: shader-clock ticks and the constant 100 MHz reference counter.
+__device__ inline void clock_stamp(unsigned long long *clk, uint32_t which) {
+    if (clk && threadIdx.x == 0) {
+        clk[(size_t)blockIdx.x * 4u + 2u * which] = __builtin_amdgcn_s_memtime();
+        clk[(size_t)blockIdx.x * 4u + 2u * which + 1u] = __builtin_amdgcn_s_memrealtime();
+    }
+}
 
 __device__ inline uint32_t lane_id() { return threadIdx.x & 63u; }
 
@@ -787,6 +797,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
     // batched H2H launches (no LDS tally): one dword per lane behind the records holds the lane's block index — the strategy
     // index of seat s is 2 * block + s, whatever the number of blocks (the 14-bit index field of cE would cap it at 8 192)
     uint32_t *lane_block = lds + NFIELDS * (GS ? 1u : K) * BLOCK + tid;
+    clock_stamp(a.clk, 0u);
 
     if (a.use_lds_tally) {
         for (uint32_t i = tid; i < a.S * LT_COLS; i += BLOCK) tl[i] = 0ull;
@@ -1125,7 +1136,16 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
         }
         Rng rng{hi0, lo0, own_inc_hi, own_inc_lo, buf0, (cE & CE_HAS_BUF) ? 1u : 0u};
         const uint32_t n = dice;
-        const uint32_t key = roll_counts<3>(rng, n);
+        bool detour;
+        uint32_t key = roll_counts_fast<3>(rng, n, detour);
+        if (detour) { // a Lemire rejection (once in ~2^30 dice): the generator comes back from the seat record, which is still the roll's input
+            asm volatile("" ::: "memory"); // really re-read it: values forwarded from the loads above would stay live across the whole roll
+            rng.lo = (uint64_t)L(F_LO0, s) | ((uint64_t)L(F_LO1, s) << 32);
+            rng.hi = (uint64_t)L(F_HI0, s) | ((uint64_t)L(F_HI1, s) << 32);
+            rng.buf = L(F_BUF, s);
+            rng.has_buf = (cE & CE_HAS_BUF) ? 1u : 0u;
+            key = roll_counts_sequential<3>(rng, n, nullptr);
+        }
         rolls_this_turn += 1u;
         int32_t dthr = (int32_t)(int8_t)(own_bits & 0xffu);
         asm volatile("" : "+v"(dthr));
@@ -1264,6 +1284,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE))) vo
             atomicAdd(&a.tally[(size_t)idx * FK_TALLY_COLS + col], v);
         }
     }
+    clock_stamp(a.clk, 1u);
 }
 
 #include "fk_play_hc.h" // the hot / cold variant of the game kernel (k >= 3 seats)

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     constexpr uint32_t HC_BLOCK = (uint32_t)HC_BLOCK_I;
     const uint32_t tid = threadIdx.x;
     const uint32_t K = a.k;
+    clock_stamp(a.clk, 0u);
     static_assert(!CL || (KI == 0 && !LT), "cold-in-LDS instances load increments / strategies per turn and gather from the global tables");
     static_assert(!CR || (KI != 0 && !CL), "cold-in-register instances size their arrays by KI");
     static_assert(!IL || CR, "IL only makes sense when KI is there for the cold records");
@@ -338,7 +339,17 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         const uint32_t buf0 = lds_buf[SB(s)];
         Rng rng{(uint64_t)sv.z | ((uint64_t)sv.w << 32), (uint64_t)sv.x | ((uint64_t)sv.y << 32), own_inc_hi, own_inc_lo, buf0, (hasbuf >> s) & 1u};
         const uint32_t n = dice;
-        const uint32_t key = roll_counts<3>(rng, n);
+        bool detour;
+        uint32_t key = roll_counts_fast<3>(rng, n, detour);
+        if (detour) { // a Lemire rejection (once in ~2^30 dice): the generator comes back from the hot planes, still the roll's input
+            asm volatile("" ::: "memory"); // really re-read them: values forwarded from the loads above would stay live across the whole roll
+            const uint4 sv0 = lds_state[SB(s)];
+            rng.lo = (uint64_t)sv0.x | ((uint64_t)sv0.y << 32);
+            rng.hi = (uint64_t)sv0.z | ((uint64_t)sv0.w << 32);
+            rng.buf = lds_buf[SB(s)];
+            rng.has_buf = (hasbuf >> s) & 1u;
+            key = roll_counts_sequential<3>(rng, n, nullptr);
+        }
         rolls_this_turn += 1u;
         int32_t dthr = (int32_t)(int8_t)(own_bits & 0xffu);
         asm volatile("" : "+v"(dthr));
@@ -441,4 +452,5 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
             active = __ballot(st == ST_ACTIVE);
         } while (active && !handover_due(waiting, active));
     }
+    clock_stamp(a.clk, 1u);
 }

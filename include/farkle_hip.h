@@ -115,7 +115,8 @@ typedef struct {
     int64_t games;
     int32_t prefetched_chunks; /* chunks whose permutations / seeding ran on the side stream behind an earlier game kernel:
                                   not in perm_ms / seed_ms */
-    int32_t pad;
+    int32_t play_clock_mhz;    /* option "clock_stamps": shader clock of the call's last game kernel, measured inside it (median over
+                                  its workgroups of d(s_memtime) / d(s_memrealtime) x 100 MHz); 0 = not measured */
 } fk_timing;
 
 typedef struct fk_ctx fk_ctx;
@@ -141,7 +142,8 @@ int fk_host_free(fk_ctx *ctx, void *p);
  * 0: every chunk is prepared on the main stream in front of its own game kernel), "hot_cold" (tournament launches of 4..8 seats on
  * the hot / cold game kernel, csrc/fk_play_hc.h: -1 auto, 0 never — the LDS-record kernel plays them), "comm_timeout_ms" (deadline of
  * fk_comm_init and of each collective, default 120 000; 0 = no deadline), "rows_chunk_games" (rows mode plays in chunks of about this many games,
- * default 4 000 000: chunk i's rows cross PCIe while chunk i + 1 plays), "resident_tally" (see fk_tally_resident_reduce).  All of them
+ * default 4 000 000: chunk i's rows cross PCIe while chunk i + 1 plays), "resident_tally" (see fk_tally_resident_reduce), "clock_stamps" (1: every workgroup of a game kernel reads the
+ * shader-clock and the 100 MHz reference counters at its first and last instruction; fk_timing.play_clock_mhz).  All of them
  * are scheduling / layout choices: results are identical for every setting. */
 int fk_set_option(fk_ctx *ctx, const char *name, int64_t value);
 
