@@ -200,13 +200,14 @@ class KSweep:
 
     scaling = "strong"
 
-    def __init__(self, table: np.ndarray, games_per_k: int, ks=(2, 4, 6, 8), root: int = 0):
+    def __init__(self, table: np.ndarray, games_per_k: int, ks=(2, 4, 6, 8), root: int = 0, config: int = 4, label: str | None = None):
         self.table, self.ks, self.root = table, tuple(ks), root
         self.S = len(table)
         self.n_sh = {k: max(1, games_per_k // (self.S // k)) for k in self.ks}
         self.local_shape = (len(self.ks), self.S, 26)
-        self.config = 4
+        self.config = config
         self.k = self.ks[0]
+        self.label = label or "BASELINE configs[3]: k in {2,4,6,8}, 5 160-strategy grid, equal games per k, counts-only tallies"
 
     def games_per_step(self, world: int) -> int:
         return sum(self.n_sh[k] * (self.S // k) for k in self.ks)
@@ -249,7 +250,7 @@ class KSweep:
         games = 0
         t0 = time.perf_counter()
         for k in self.ks:  # ~1/4 of the budget per k: equal GAMES per k as in the sweep
-            n_sh = max(1, int(25_000 * seconds_target / 12.0) // (self.S // k))
+            n_sh = max(1, int(25_000 * seconds_target / 12.0 * 4 / len(self.ks)) // (self.S // k))
             ref = po.tournament(t, k, self.root, 0, n_sh, n_threads=threads)["tally"][0]
             got = eng.tournament(self.table, k, self.root, 0, n_sh)["tally"][0]
             assert np.array_equal(got, ref), f"GPU tally differs from the CPU oracle on the k={k} sample"
@@ -260,7 +261,7 @@ class KSweep:
                 "parity": "GPU tally == oracle tally on every k's sample"}
 
     def describe(self, world: int) -> dict:
-        return {"workload": "BASELINE configs[3]: k in {2,4,6,8}, 5 160-strategy grid, equal games per k, counts-only tallies",
+        return {"workload": self.label,
                 "k": list(self.ks), "n_strategies": self.S, "root_seed": self.root, "shuffles_per_k_per_step": self.n_sh,
                 "parallelism": f"every k's shuffle range split x{world}, one tally reduce per k"}
 
@@ -392,6 +393,12 @@ def make_workload(args):
                           sample_shuffles=4_000)
     if args.config == 4:
         return KSweep(grid5160(), args.games or 250_000_000)
+    if args.config == 6:
+        # the player counts the reference's production configuration runs (configs/farkle_mega_config.yaml:10 n_players_list), on its
+        # default 5 160-strategy grid (5 160 = 2^3 x 3 x 5 x 43 is divisible by every one of them)
+        return KSweep(grid5160(), args.games or 100_000_000, ks=(2, 3, 4, 5, 6, 8, 10, 12), config=6,
+                      label="the reference's production player counts (farkle_mega_config.yaml n_players_list [2,3,4,5,6,8,10,12]), 5 160-strategy "
+                            "grid, equal games per k, counts-only tallies")
     if args.config == 5:
         table = grid5160()
         # candidates: twelve ids spread over the grid (a plausible h2h_2p candidate family)
@@ -455,14 +462,14 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5))
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5, 6))
     ap.add_argument("--shuffles", type=int, default=0, help="configs 2/3: shuffles per rank per step (default: the BASELINE size)")
-    ap.add_argument("--games", type=int, default=0, help="config 4: games per k per step; config 5: completed games per pair")
+    ap.add_argument("--games", type=int, default=0, help="configs 4 / 6: games per k per step; config 5: completed games per pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-tally", type=Path, default=None, help="rank 0 saves the reduced tally here (.npy; tests)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {2: 5, 3: 2, 4: 1, 5: 1}[args.config]
+        args.steps = {2: 5, 3: 2, 4: 1, 5: 1, 6: 1}[args.config]
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -660,10 +667,10 @@ def main() -> None:
         # HBM bytes per launch from the PMC passes of the same launch shape (rocprofv3 cannot run inside this process):
         # profiles/r*_hbm_traffic.json carries the commit it was taken at; dropped when that is not an ancestor's kernel
         def kernel_of(shape: dict, k_seats: int) -> str:
-            """fk_play_hc_kernel launches are recognisable by their LDS size: 20 bytes per seat and lane (+ the 10 816-byte table
+            """fk_play_hc_kernel launches are recognisable by their LDS size: 16 bytes per seat and lane (+ the 10 816-byte table
             image), or 32 with the cold records in LDS (csrc/fk_play_hc.h); everything else is fk_play_kernel."""
             block, lds = shape.get("play_block"), shape.get("play_lds_bytes")
-            hc = bool(block) and lds in (block * 20 * k_seats, block * 20 * k_seats + 10816, block * 32 * k_seats)
+            hc = bool(block) and lds in (block * 16 * k_seats, block * 16 * k_seats + 10816, block * 32 * k_seats)
             return "fk_play_hc_kernel" if hc else "fk_play_kernel"
 
         dominant = kernel_of(t, int(wl.k)) if isinstance(getattr(wl, "k", None), int) else "fk_play_kernel"  # (sweep / H2H lines: per_k / k = 2)
@@ -718,19 +725,23 @@ def main() -> None:
                               "launch": {k3: tk.get(k3) for k3 in ("play_block", "play_grid", "play_lds_bytes")}})
                 with_clock(per_k[-1], tk)
             roofline["per_k"] = per_k
-            # the line's headline figures are the sweep's: the mean fraction over the player counts, and — as the dominant kernel —
-            # the one of the player count furthest below its roofline (round 3 printed the k = 2 launches' kernel and fraction here)
+            # The line's headline record is ONE kernel's, whole: the player count furthest below its roofline (every field — kernel, time,
+            # games, W, achieved, frac, clock, traffic, launch, hbm — from that k's launches; round 4 mixed the mean fraction with the worst
+            # k's kernel fields).  The mean over the player counts stands beside it under its own name.
             worst = min(per_k, key=lambda r: r["frac"])
             roofline["frac_mean_over_k"] = float(np.mean([r["frac"] for r in per_k]))
-            roofline.update({"frac": roofline["frac_mean_over_k"], "achieved": roofline["frac_mean_over_k"] * peak_ops / 1e12,
-                             "kernel": worst["kernel"], "kernel_note": f"slowest player count of the sweep: k = {worst['k']} at frac {worst['frac']:.3f}",
-                             "kernel_ms": worst["kernel_ms"], "games_per_launch": worst["games_per_launch"],
-                             "kernel_games_per_s": worst["kernel_games_per_s"], "traffic": worst["traffic"], "launch": worst["launch"]})
+            hbm_k = 32 * worst["k"] + 2 * worst["k"] + 4
+            roofline.update({key: worst[key] for key in worst if key != "k"})
+            roofline.update({"kernel_note": f"slowest player count of the sweep: k = {worst['k']} (every headline field is that k's; mean over k in frac_mean_over_k)",
+                             "achieved": worst["frac"] * peak_ops / 1e12,
+                             "hbm": {"achieved": worst["kernel_games_per_s"] * hbm_k / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                     "frac": worst["kernel_games_per_s"] * hbm_k / 8e12, "bytes_per_game": hbm_k}})
         cpu = None
         if not args.no_cpu_baseline and n_gpus == 1:  # the CPU leg runs on rank 0 of the single-GPU run only
             cpu = wl.cpu_baseline(eng)
         line = {
-            "metric": METRIC if wl.config in (2,) else f"{METRIC} [variant: BASELINE config {wl.config}]",
+            "metric": METRIC if wl.config in (2,) else (f"{METRIC} [variant: BASELINE config {wl.config}]" if wl.config != 6 else
+                                                          f"{METRIC} [variant: sweep over the reference's production player counts]"),
             "value": value, "unit": "games/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None,
             "dtype": "int32", "data": "synthetic", "engine": engine_name, "tally_reduce": tally_reduce,

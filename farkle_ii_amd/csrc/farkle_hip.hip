@@ -380,11 +380,25 @@ bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const Launch
     // planes alone 160 KB at four waves) stays at 3 x 256, and so does everything when the option caps the waves.
     const bool ki = c->hc_inc_regs != 0 && lt && c->hc_block != 1024 && c->hc_block != 768;
     const bool four = ki && k >= 5 && k <= 7 && max_waves >= 4;
-    const int block = four ? (k == 5 ? 256 : k == 6 ? 512 : 1024) : ki ? 256 : (c->hc_block == 1024 || c->hc_block == 768) ? c->hc_block : 256;
-    const size_t lds = (size_t)block * 20 * (size_t)k + (lt ? LT_BYTES : 0);
+    // nine to twelve seats (round 5): ONE 768-thread block per CU = three waves per SIMD, 168 registers per lane; the hot planes (16 k bytes
+    // per lane since the buffered half word moved to the cold slot: 147 456 bytes at twelve seats) fit beside the table image
+    const bool wide = ki && k >= 9 && max_waves >= 3;
+#ifndef FK_EXPERIMENTS
+    // the shipped library holds the plan's own instances only: k = 5 .. 7 at four waves, k = 8 at three, k = 9 .. 12 as above.  A cap below
+    // that (option max_waves) sends the call to the LDS-record kernel instead of to an instance that was not compiled.
+    if (k >= 5 && k <= 7 && !four) return false;
+    if (k == 8 && !(ki && max_waves >= 3)) return false;
+    if (k >= 9 && !wide) return false;
+#endif
+    const int block = wide ? 768 : four ? (k == 5 ? 256 : k == 6 ? 512 : 1024) : ki ? 256 : (c->hc_block == 1024 || c->hc_block == 768) ? c->hc_block : 256;
+    // hot part: the generator state, 16 bytes per seat and lane (the buffered half word rides in the cold-plane slot; instances with the
+    // cold records in registers — experiment builds — keep it in LDS: 20 bytes)
+    const size_t hot_bytes = (ki && k >= 5 && c->hc_cr) ? 20 : 16;
+    const size_t lds = (size_t)block * hot_bytes * (size_t)k + (lt ? LT_BYTES : 0);
     if (lds > LDS_LIMIT) return false;
     int per_cu = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)std::max(1, 256 * max_waves / block));
-    if (four) per_cu = std::min(per_cu, 1024 / block);
+    if (wide) per_cu = 1;
+    else if (four) per_cu = std::min(per_cu, 1024 / block);
     else if (ki) per_cu = std::min(per_cu, k <= 4 ? 4 : 3); // 128 / 168 registers per lane
     if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
     per_cu = std::max(per_cu, 1);
@@ -396,14 +410,14 @@ bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const Launch
     out = base;
     out.hc = true;
     out.hc_lt = lt;
-    out.hc_ki = ki ? (four ? 2 : 1) : 0;
+    out.hc_ki = ki ? (wide ? 3 : four ? 2 : 1) : 0;
     out.hc_cr = (ki && k >= 5) ? c->hc_cr : 0;
     out.lean = true;
     out.gs = false;
     out.blk = false;
     out.block = block;
     out.lds = lds;
-    out.wpe = per_cu * block / 256;
+    out.wpe = (per_cu * block + 255) / 256;
     out.grid = c->prop.multiProcessorCount * per_cu;
     out.cus = c->prop.multiProcessorCount;
     return true;
@@ -554,6 +568,11 @@ hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s)
         return launch_play_hc_t<256, true, 8, 0, false, false, 8, true, true>(p, a, s);
     }
 #endif
+    if (p.hc_ki == 3) { // nine to twelve seats: one block per CU, increments in registers, strategies loaded per turn
+        if (p.block != 768) return hipErrorInvalidValue;
+        if (a.k <= 10u) return launch_play_hc_t<768, true, 10, 3, false, false, 10>(p, a, s);
+        return launch_play_hc_t<768, true, 12, 3, false, false, 12>(p, a, s);
+    }
     if (p.hc_ki == 2) { // four waves per SIMD: increments in registers, strategies loaded per turn
         if (a.k == 5u && p.block == 256) return launch_play_hc_t<256, true, 6, 4, false>(p, a, s);
         if (a.k == 6u && p.block == 512) return launch_play_hc_t<512, true, 6, 4, false>(p, a, s);

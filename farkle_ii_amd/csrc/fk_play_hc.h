@@ -14,8 +14,8 @@
 //     version of this kernel at k = 8: 0.8 L2 misses per turn, 105 GB fetched + 107 GB written back per 1.5 x 10^7 games);
 //   * what such a launch has to spare is REGISTERS: at three waves per SIMD a lane may hold 168 VGPRs, the game needs ~85.
 // So the seat record is split by how often it is touched, and each part goes where there is room:
-//   HOT   per roll: generator state (16 B) + buffered half word (4 B) = 20 bytes per seat, in LDS for every seat
-//         (k = 8: 160 B per lane; three 256-thread blocks per CU with the tables below);
+//   HOT   per roll: generator state (16 B) per seat, in LDS for every seat (k = 8: 128 B per lane; three 256-thread blocks per CU with
+//         the tables below).  The buffered half word (4 B) was hot until round 5; it now rides in the spare dword of the cold slot (BP);
 //   COLD  per turn: the eight behaviour counters, the banked total and has_scored, packed into three dwords per seat
 //         (fk_device.h: every counter field ends in a guard bit).  The turn owner's live in three registers; at a turn
 //         hand-over they go to a PLANE indexed by (resident lane, seat) — 16 k bytes per lane, 25 MB for the whole chip at
@@ -48,7 +48,30 @@
 // (the host then replays the call on fk_play_kernel).
 #pragma once
 
-constexpr uint32_t HC_MAX_K = 8;
+constexpr uint32_t HC_MAX_K = 12; // (round 5: 9 .. 12 seats — the reference's production list is n_players_list [2, 3, 4, 5, 6, 8, 10, 12])
+
+// entry s (< N) of an N-entry register array, picked by a select tree on the bits of s: N - 1 v_cndmask.  get(t) must return the t-th entry
+// for a COMPILE-TIME t (the arrays live in registers).  Written as a recursion over scalars: a select between two elements of a local
+// ARRAY is turned by the compiler into an indexed load from scratch.
+template <int N, int LO, int CNT, typename F>
+__device__ __forceinline__ uint32_t hc_pick_r(uint32_t s, F get) {
+    if constexpr (CNT == 1) {
+        return get(LO < N ? LO : N - 1);
+    } else {
+        constexpr int H = CNT / 2;
+        if constexpr (LO + H >= N) { // s < N: the upper half cannot be meant
+            return hc_pick_r<N, LO, H>(s, get);
+        } else {
+            const uint32_t lo = hc_pick_r<N, LO, H>(s, get), hi = hc_pick_r<N, LO + H, H>(s, get);
+            return (s & (uint32_t)H) ? hi : lo;
+        }
+    }
+}
+template <int N, typename F>
+__device__ __forceinline__ uint32_t hc_pick(uint32_t s, F get) {
+    static_assert(N >= 1 && N <= 16, "select tree over at most sixteen entries");
+    return hc_pick_r<N, 0, 16>(s, get);
+}
 
 // KI: seats whose PCG increments (and, up to KI = 6 and unless PKR_I is off, packed strategies) stay in registers for the
 // whole game (0: both are loaded at every turn start); LT: tables from the LDS image; WPE: waves per SIMD the register
@@ -66,8 +89,13 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     static_assert(!CL || (KI == 0 && !LT), "cold-in-LDS instances load increments / strategies per turn and gather from the global tables");
     static_assert(!CR || (KI != 0 && !CL), "cold-in-register instances size their arrays by KI");
     static_assert(!IL || CR, "IL only makes sense when KI is there for the cold records");
+    // BP: the buffered half word of a seat that is not the turn owner rides in the fourth dword of its cold-plane slot (round 5): it is
+    // touched once per turn like the rest of the cold record, the owner's lives in a register — 16 instead of 20 bytes of LDS per seat
+    // and lane (twelve seats: 768 instead of 576 lanes per CU), two LDS instructions per roll less.  Instances without a plane keep it in LDS.
+    constexpr bool BP = !CL && !CR;
+    constexpr uint32_t HOT_DW = BP ? 4u : 5u;
     uint4 *const lds_state = reinterpret_cast<uint4 *>(lds) + tid;   // [seat][lane] generator state
-    uint32_t *const lds_buf = lds + 4u * K * HC_BLOCK + tid;          // [seat][lane] buffered half word
+    uint32_t *const lds_buf = lds + 4u * K * HC_BLOCK + tid;          // [seat][lane] buffered half word (!BP)
     // CL: [seat][lane] cold x, y (one 8-byte plane) and z — planes of the access width, so that a wave's lanes fall on distinct banks
     uint2 *const lds_xy = reinterpret_cast<uint2 *>(lds + 5u * K * HC_BLOCK) + tid;
     uint32_t *const lds_z = lds + 7u * K * HC_BLOCK + tid;
@@ -75,21 +103,22 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     auto SB = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t {
         return (HC_BLOCK & (HC_BLOCK - 1u)) ? __umul24(s, HC_BLOCK) : s * HC_BLOCK;
     };
-    const uint8_t *const lt_img = reinterpret_cast<const uint8_t *>(lds + 5u * K * HC_BLOCK); // LT: the two tables
+    const uint8_t *const lt_img = reinterpret_cast<const uint8_t *>(lds + HOT_DW * K * HC_BLOCK); // LT: the two tables
     if (LT) {
-        uint4 *dst = reinterpret_cast<uint4 *>(lds + 5u * K * HC_BLOCK);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds + HOT_DW * K * HC_BLOCK);
         const uint4 *src = reinterpret_cast<const uint4 *>(a.lds_tables);
         for (uint32_t i = tid; i < LT_BYTES / 16u; i += HC_BLOCK) dst[i] = src[i];
         __syncthreads();
     }
     uint4 *const cold = (CL || CR) ? nullptr : a.cold + (size_t)(blockIdx.x * HC_BLOCK + tid) * K; // [resident lane][seat] (w unused)
+    // (buffered half word when BP, x, y, z)
     auto cold_load = [&](uint32_t s) __attribute__((always_inline)) -> uint4 {
         if (CL) {
             const uint2 xy = lds_xy[SB(s)];
             return make_uint4(0u, xy.x, xy.y, lds_z[SB(s)]);
         }
         const uint4 c = cold[s];
-        return make_uint4(0u, c.x, c.y, c.z);
+        return make_uint4(c.w, c.x, c.y, c.z);
     };
 
     enum : uint32_t { ST_FRESH = 0, ST_ACTIVE = 1, ST_ENDED = 2, ST_DONE = 3 };
@@ -101,7 +130,9 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     uint32_t final_round = 0, safety = 0;
     int32_t score_to_beat = 0;
     uint32_t hasbuf = 0;                          // bit s: seat s holds a buffered half word
-    uint32_t ix01 = 0, ix23 = 0, ix45 = 0, ix67 = 0; // strategy indices of the seats, 16 bits each
+    constexpr int NIX = (NS + 1) / 2;
+    uint32_t ix0 = 0, ix1 = 0, ix2 = 0, ix3 = 0, ix4 = 0, ix5 = 0; // strategy indices of the seats, 16 bits each (scalars, not an array:
+                                                  // the compiler turns a select between two ARRAY elements into an indexed load from scratch)
     // turn registers
     uint32_t dice = 6, rolls_this_turn = 0;
     int32_t turn_score = 0;
@@ -109,31 +140,25 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     int32_t own_thr = 0;
     uint32_t own_bits = 0;
     uint32_t cX = 0, cY = 0, cZ = 0;              // the owner's cold record
+    uint32_t own_buf = 0;                         // BP: the owner's buffered half word
     constexpr bool IR = KI != 0 && !IL;          // increments in registers
     uint32_t inc_r[IR ? KI : 1][4] = {};          // KI: every seat's increment (constant indices only: registers)
     uint32_t cold_r[CR ? KI : 1][3] = {};         // CR: every seat's cold record
     constexpr bool PKR = PKR_I && IR && KI <= 6;      // ... and packed strategy, while 168 registers hold both without spilling
     uint32_t pk_r[PKR ? KI : 1][2] = {};
 
-    // CR: seat s's cold record out of the register array (select tree on the bits of s; entries beyond k are never selected)
+    // CR: seat s's cold record out of the register array (select tree on the bits of s)
     auto cold_pick = [&](uint32_t s) __attribute__((always_inline)) -> uint4 {
-        uint32_t v[8][3];
+        constexpr int NC = CR ? KI : 1;
+        uint32_t c[3];
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) v[t][j] = cold_r[t < (CR ? KI : 1) ? t : 0][j];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const uint32_t a0 = (s & 1u) ? v[1][j] : v[0][j], a1 = (s & 1u) ? v[3][j] : v[2][j];
-            const uint32_t a2 = (s & 1u) ? v[5][j] : v[4][j], a3 = (s & 1u) ? v[7][j] : v[6][j];
-            const uint32_t b0 = (s & 2u) ? a1 : a0, b1 = (s & 2u) ? a3 : a2;
-            v[0][j] = (KI > 4 && (s & 4u)) ? b1 : b0;
-        }
-        return make_uint4(0u, v[0][0], v[0][1], v[0][2]);
+        for (int j = 0; j < 3; ++j) c[j] = hc_pick<NC>(s, [&](int t) __attribute__((always_inline)) { return cold_r[t][j]; });
+        return make_uint4(0u, c[0], c[1], c[2]);
     };
     auto seat_index = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t {
-        const uint32_t lo = (s & 2u) ? ix23 : ix01, hi = (s & 2u) ? ix67 : ix45;
-        const uint32_t w = (NS > 4 && (s & 4u)) ? hi : lo; // (NS <= 4: the launch has at most four seats)
+        const uint32_t w = hc_pick<NIX>(s >> 1, [&](int t) __attribute__((always_inline)) {
+            return t == 0 ? ix0 : t == 1 ? ix1 : t == 2 ? ix2 : t == 3 ? ix3 : t == 4 ? ix4 : ix5;
+        });
         return (s & 1u) ? (w >> 16) : (w & 0xffffu);
     };
 
@@ -146,37 +171,18 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     auto begin_turn = [&](uint32_t s) __attribute__((always_inline)) {
         uint4 inc;
         if (IR) { // select tree on the bits of s (entries beyond k are never selected)
-            uint32_t v[8][4];
+            constexpr int NI = IR ? KI : 1;
+            uint32_t w[4];
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[t][j] = inc_r[t < (IR ? KI : 1) ? t : 0][j];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t a0 = (s & 1u) ? v[1][j] : v[0][j], a1 = (s & 1u) ? v[3][j] : v[2][j];
-                const uint32_t a2 = (s & 1u) ? v[5][j] : v[4][j], a3 = (s & 1u) ? v[7][j] : v[6][j];
-                const uint32_t b0 = (s & 2u) ? a1 : a0, b1 = (s & 2u) ? a3 : a2;
-                v[0][j] = (s & 4u) ? b1 : b0;
-            }
-            inc = make_uint4(v[0][0], v[0][1], v[0][2], v[0][3]);
+            for (int j = 0; j < 4; ++j) w[j] = hc_pick<NI>(s, [&](int t) __attribute__((always_inline)) { return inc_r[t][j]; });
+            inc = make_uint4(w[0], w[1], w[2], w[3]);
         } else {
             inc = a.inc[(size_t)seed_slot * K + s];
         }
         uint2 pk;
         if (PKR) {
-            uint32_t w[8][2];
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) w[t][j] = pk_r[t < (PKR ? KI : 1) ? t : 0][j];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const uint32_t a0 = (s & 1u) ? w[1][j] : w[0][j], a1 = (s & 1u) ? w[3][j] : w[2][j];
-                const uint32_t a2 = (s & 1u) ? w[5][j] : w[4][j], a3 = (s & 1u) ? w[7][j] : w[6][j];
-                const uint32_t b0 = (s & 2u) ? a1 : a0, b1 = (s & 2u) ? a3 : a2;
-                w[0][j] = (s & 4u) ? b1 : b0;
-            }
-            pk = make_uint2(w[0][0], w[0][1]);
+            constexpr int NP = PKR ? KI : 1;
+            pk = make_uint2(hc_pick<NP>(s, [&](int t) __attribute__((always_inline)) { return pk_r[t][0]; }), hc_pick<NP>(s, [&](int t) __attribute__((always_inline)) { return pk_r[t][1]; }));
         } else {
             pk = a.strat[seat_index(s)];
         }
@@ -186,6 +192,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         own_thr = (int32_t)pk.x;
         own_bits = pk.y;
         cX = c.y, cY = c.z, cZ = c.w;
+        if (BP) own_buf = c.x;
         dice = 6;
         turn_score = 0;
         rolls_this_turn = 0;
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         int32_t best = -1;
         uint4 wrec = make_uint4(0u, 0u, 0u, 0u);
         for (uint32_t s = 0; s < K; ++s) { // stable sort on score desc: first maximum wins (engine.py:477)
-            const uint4 c = (s == seat) ? make_uint4(0u, cX, cY, cZ) : CR ? cold_pick(s) : cold_load(s);
+            const uint4 c = (s == seat) ? make_uint4(own_buf, cX, cY, cZ) : CR ? cold_pick(s) : cold_load(s);
             const int32_t sc = (int32_t)((c.w >> HC_SCORE_SHIFT) & HC_SCORE_MASK);
             if (sc > best) {
                 best = sc;
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
             if (a.gs_out) { // the state store's format (R_*): score, n_turns and hot dice spelled out
                 uint4 *g = reinterpret_cast<uint4 *>(G(s));
                 g[0] = lds_state[SB(s)];
-                g[1] = make_uint4(lds_buf[SB(s)], (uint32_t)sc,
+                g[1] = make_uint4(BP ? c.x : lds_buf[SB(s)], (uint32_t)sc,
                                   (c.y & HC_ROLLS_MASK) | (((c.y >> HC_FARKLE_SHIFT) & HC_FARKLE_MASK) << 16), (c.w & HC_HI_MASK) | (seat_turns(s) << 16));
                 g[2] = make_uint4(((c.y >> HC_S5U_SHIFT) & HC_USES_MASK) | ((c.z & HC_DICE_MASK) << 16),
                                   ((c.z >> HC_S1U_SHIFT) & HC_USES_MASK) | (((c.z >> HC_D1_SHIFT) & HC_DICE_MASK) << 16),
@@ -258,13 +265,13 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
             slot = g * a.n_sh + sh;
         }
         seed_slot = slot;
-        uint32_t iw[4] = {0u, 0u, 0u, 0u};
+        uint32_t iw0 = 0, iw1 = 0, iw2 = 0, iw3 = 0, iw4 = 0, iw5 = 0;
 #pragma unroll
-        for (uint32_t s = 0; s < HC_MAX_K; ++s) {
+        for (uint32_t s = 0; s < (uint32_t)NS; ++s) { // (NS: the most seats a launch of the instance has)
             if (s < K) {
                 const uint32_t *src = G(s);
                 lds_state[SB(s)] = *reinterpret_cast<const uint4 *>(src);
-                lds_buf[SB(s)] = 0u;
+                if (!BP) lds_buf[SB(s)] = 0u;
                 if (CL) {
                     lds_xy[SB(s)] = make_uint2(0u, 0u);
                     lds_z[SB(s)] = 0u;
@@ -274,7 +281,13 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
                     cold[s] = make_uint4(0u, 0u, 0u, 0u); // the previous game's record of this lane
                 }
                 const uint32_t idx = (a.state_dw == STATE_DW) ? src[R_IDX] : (uint32_t)a.seat_idx[(size_t)slot * K + s];
-                iw[s >> 1] |= idx << (16u * (s & 1u));
+                const uint32_t field = idx << (16u * (s & 1u));
+                if ((s >> 1) == 0u) iw0 |= field;
+                else if ((s >> 1) == 1u) iw1 |= field;
+                else if ((s >> 1) == 2u) iw2 |= field;
+                else if ((s >> 1) == 3u) iw3 |= field;
+                else if ((s >> 1) == 4u) iw4 |= field;
+                else iw5 |= field;
                 if (IR && s < (uint32_t)(IR ? KI : 1)) {
                     const uint4 q = a.inc[(size_t)slot * K + s];
                     inc_r[s < (uint32_t)(IR ? KI : 1) ? s : 0][0] = q.x, inc_r[s < (uint32_t)(IR ? KI : 1) ? s : 0][1] = q.y;
@@ -286,9 +299,10 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
                 }
             }
         }
-        ix01 = iw[0], ix23 = iw[1], ix45 = iw[2], ix67 = iw[3];
+        ix0 = iw0, ix1 = iw1, ix2 = iw2, ix3 = iw3, ix4 = iw4, ix5 = iw5;
         hasbuf = 0;
         cX = cY = cZ = 0u;
+        own_buf = 0u;
         seat = 0;
         trigger = 0;
         final_round = 0;
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         const bool roll_limit = rolls_this_turn >= 1000u; // ROLL_LIMIT, engine.py:36,242
         const uint32_t s = seat;
         const uint4 sv = lds_state[SB(s)];
-        const uint32_t buf0 = lds_buf[SB(s)];
+        const uint32_t buf0 = BP ? own_buf : lds_buf[SB(s)];
         Rng rng{(uint64_t)sv.z | ((uint64_t)sv.w << 32), (uint64_t)sv.x | ((uint64_t)sv.y << 32), own_inc_hi, own_inc_lo, buf0, (hasbuf >> s) & 1u};
         const uint32_t n = dice;
         bool detour;
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
             const uint4 sv0 = lds_state[SB(s)];
             rng.lo = (uint64_t)sv0.x | ((uint64_t)sv0.y << 32);
             rng.hi = (uint64_t)sv0.z | ((uint64_t)sv0.w << 32);
-            rng.buf = lds_buf[SB(s)];
+            rng.buf = buf0;
             rng.has_buf = (hasbuf >> s) & 1u;
             key = roll_counts_sequential<3>(rng, n, nullptr);
         }
@@ -378,7 +392,8 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         }
         lds_state[SB(s)] = make_uint4((uint32_t)rng.lo, (uint32_t)(rng.lo >> 32), (uint32_t)rng.hi, (uint32_t)(rng.hi >> 32));
         hasbuf = (hasbuf & ~(1u << s)) | (rng.has_buf << s);
-        lds_buf[SB(s)] = rng.buf;
+        if (BP) own_buf = rng.buf;
+        else lds_buf[SB(s)] = rng.buf;
         if (over) {
             if (CL) {
                 lds_xy[SB(s)] = make_uint2(cX, cY);
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
                     cold_r[t][2] = here ? cZ : cold_r[t][2];
                 }
             } else {
-                cold[s] = make_uint4(cX, cY, cZ, 0u);
+                cold[s] = make_uint4(cX, cY, cZ, own_buf);
             }
             advance(score + (int32_t)banked);
         }

@@ -139,7 +139,7 @@ int fk_host_free(fk_ctx *ctx, void *p);
  * never-banking pairings first), "uniform_flags" (-1 auto: tables whose strategies share all flag bits run the scalar-flag
  * kernel instance, 0 never), "perm_split" (-1 auto), "pipeline" (1, default: the next chunk / hinted call is prepared around the
  * current game kernel — permutations in front of it, schedule and seat seeding on a low-priority stream in its drain tail;
- * 0: every chunk is prepared on the main stream in front of its own game kernel), "hot_cold" (tournament launches of 4..8 seats on
+ * 0: every chunk is prepared on the main stream in front of its own game kernel), "hot_cold" (tournament launches of 4..12 seats on
  * the hot / cold game kernel, csrc/fk_play_hc.h: -1 auto, 0 never — the LDS-record kernel plays them), "comm_timeout_ms" (deadline of
  * fk_comm_init and of each collective, default 120 000; 0 = no deadline), "rows_chunk_games" (rows mode plays in chunks of about this many games,
  * default 4 000 000: chunk i's rows cross PCIe while chunk i + 1 plays), "resident_tally" (see fk_tally_resident_reduce), "clock_stamps" (1: every workgroup of a game kernel reads the

@@ -55,12 +55,18 @@ def test_bench_single_process_and_rank_failure_propagates(tmp_path):
     assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
 
 
-@pytest.mark.parametrize("config,extra", [(3, ("--shuffles", "3")), (4, ("--games", "3000")), (5, ("--games", "200"))])
+@pytest.mark.parametrize("config,extra", [(3, ("--shuffles", "3")), (4, ("--games", "3000")), (5, ("--games", "200")), (6, ("--games", "1500"))])
 def test_bench_other_baseline_configs_two_ranks(config, extra):
     line = _run_bench("--gpus", "2", "--config", str(config), *extra, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", timeout=900)
-    assert line["n_gpus"] == 2 and f"config {config}" in line["metric"]
+    assert line["n_gpus"] == 2 and (f"config {config}" in line["metric"] or (config == 6 and "production player counts" in line["metric"]))
     assert line["scaling"] == ("weak" if config == 3 else "strong")
     assert line["roofline"]["ops_per_game"] > 0 and line["value"] > 0
+    if config in (4, 6):  # sweeps: one record per player count; the headline record is the slowest player count's, whole
+        per_k = line["roofline"]["per_k"]
+        assert [r["k"] for r in per_k] == ([2, 4, 6, 8] if config == 4 else [2, 3, 4, 5, 6, 8, 10, 12])
+        worst = min(per_k, key=lambda r: r["frac"])
+        assert all(line["roofline"][key] == worst[key] for key in ("frac", "kernel", "kernel_ms", "games_per_launch", "ops_per_game"))
+        assert line["roofline"]["frac_mean_over_k"] == pytest.approx(np.mean([r["frac"] for r in per_k]))
 
 
 def test_bench_under_torch_distributed_run_like_the_driver(tmp_path):

@@ -2,7 +2,8 @@
 against the CPU oracle: generator state of every seat in LDS, the behaviour counters / banked totals in a per-lane plane.
 
 The kernel is chosen by the launch plan for k >= 4 (option ``hot_cold`` = -1; k = 4: the cold-in-LDS instance; k = 5 .. 7: four
-waves per SIMD with the increments in registers; k = 8: three) — the instances the shipped library holds.  The variants that lost
+waves per SIMD with the increments in registers; k = 8: three; k = 9 .. 12 (round 5): one 768-thread block per CU) —
+the instances the shipped library holds.  The variants that lost
 or tied against them are compiled only with -DFK_EXPERIMENTS and are not part of this suite."""
 from __future__ import annotations
 
@@ -35,6 +36,7 @@ LDS_TABLE_BYTES = 10816  # LT_BYTES of csrc/fk_play_hc.h
 
 
 FOUR_WAVE_BLOCK = {5: 256, 6: 512, 7: 1024}  # the register instances of k = 5 .. 7 run four waves per SIMD in these blocks
+WIDE_BLOCK = {9: 768, 10: 768, 11: 768, 12: 768}  # nine to twelve seats: one block per CU, three waves per SIMD
 COLD_IN_LDS_BLOCK = {3: 256, 4: 320, 5: 256}  # cold records in LDS: 32 bytes per seat and lane (the auto plan at k = 4)
 
 
@@ -47,14 +49,15 @@ def _ran_hot_cold(eng, k: int, block: int | None = None, tables: int = 1) -> boo
     t = eng.timing()
     if block is None and k == 4:
         return _ran_cold_in_lds(eng, 4)
-    block = FOUR_WAVE_BLOCK.get(k, 256) if block is None else block
-    return t["play_block"] == block and t["play_lds_bytes"] == block * 20 * k + (LDS_TABLE_BYTES if tables else 0)
+    block = WIDE_BLOCK.get(k, FOUR_WAVE_BLOCK.get(k, 256)) if block is None else block
+    # hot part: 16 bytes per seat and lane (generator state; the buffered half word rides in the cold-plane slot since round 5)
+    return t["play_block"] == block and t["play_lds_bytes"] == block * 16 * k + (LDS_TABLE_BYTES if tables else 0)
 
 
-@pytest.mark.parametrize("k", [3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("k", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_hot_cold_kernel_agrees_with_oracle(eng, po, k):
     """Per-batch tallies, rows and all-seat statistics of the same shuffles: hot / cold kernel, LDS-record kernel, oracle."""
-    S = {3: 96, 4: 96, 5: 100, 6: 96, 7: 98, 8: 96}[k]
+    S = {3: 96, 4: 96, 5: 100, 6: 96, 7: 98, 8: 96, 9: 99, 10: 100, 11: 99, 12: 96}[k]
     table = _random_valid_table(S, 300 + k)
     n_sh = 36
     ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 6, 2, 2 + n_sh, shuffles_per_batch=16, want_rows=True, n_threads=8)
@@ -126,6 +129,59 @@ def test_four_wave_instances_limits_and_overrides(eng, po, k):
         assert np.array_equal(got["tally"], ref["tally"]), (k, target, mr)
         assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, target, mr)
         assert np.array_equal(got["seat_stats"], seat_stats_from_rows(ref["rows"], k, S, gps, 4)), (k, target, mr)
+
+
+@pytest.mark.parametrize("k", [9, 10, 11, 12])
+def test_wide_table_instances_limits_and_overrides(eng, po, k):
+    """Nine to twelve seats (the reference's production list holds 10 and 12, configs/farkle_mega_config.yaml:10): the one-block-per-CU
+    register instances of the hot / cold kernel — short targets, round limits, per-game overrides, never-banking tables (safety-limit
+    games), rows, per-batch tallies and all-seat statistics against the oracle; and on the reference's 5 160-strategy grid."""
+    from farkle_ii_amd.backend import make_overrides
+    from oracle_engine_stub import seat_stats_from_rows
+    from test_state_store_gpu import _default_table
+
+    S = {9: 99, 10: 100, 11: 99, 12: 96}[k]
+    gps = S // k
+    table = _random_valid_table(S, 7300 + k)
+    never = table.copy()
+    never["dice_threshold"], never["require_both"], never["consider_score"], never["consider_dice"] = 0, 1, 1, 1
+    ovs = [(5, 1, 0, k, 0), (5, 1, gps - 1, k, 2), (5, 3, 2, k, 9), (5, 6, 1, k, 240)]
+    for tbl, target, mr in [(table, 10_000, 200), (table, 1_500, 4), (table, 50, 200), (table, 10_000, 0), (table, 135_000, 30), (never, 10_000, 9)]:
+        ref = po.tournament(tbl.view(po.STRATEGY_DTYPE), k, 5, 0, 9, shuffles_per_batch=4, target_score=target, max_rounds=mr,
+                            overrides=po.make_overrides(ovs), want_rows=True, n_threads=8)
+        got = eng.tournament(tbl, k, 5, 0, 9, shuffles_per_batch=4, target_score=target, max_rounds=mr,
+                             overrides=make_overrides(ovs), want_rows=True, want_seat_stats=True)
+        assert _ran_hot_cold(eng, k), (k, target, mr, eng.timing())  # auto plan
+        assert np.array_equal(got["tally"], ref["tally"]), (k, target, mr)
+        assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, target, mr)
+        assert np.array_equal(got["seat_stats"], seat_stats_from_rows(ref["rows"], k, S, gps, 4)), (k, target, mr)
+    big = _default_table()[:5148 if k in (9, 11) else 5160].copy()  # (5 160 = 10 x 516 = 12 x 430; 5 148 = 9 x 572 = 11 x 468)
+    big["strategy_id"] = np.arange(len(big))
+    ref = po.tournament(big.view(po.STRATEGY_DTYPE), k, 0, 3, 7, shuffles_per_batch=3, n_threads=8)
+    got = eng.tournament(big, k, 0, 3, 7, shuffles_per_batch=3)
+    assert _ran_hot_cold(eng, k), eng.timing()
+    assert np.array_equal(got["tally"], ref["tally"]), k
+
+
+@pytest.mark.parametrize("k,waves", [(6, 3), (7, 3), (8, 2), (10, 2), (5, 4), (12, 3)])
+def test_max_waves_option_never_reaches_an_instance_that_was_not_compiled(eng, po, k, waves):
+    """Option ``max_waves`` below what the plan's hot / cold instance of k seats needs (round-4 advisor: max_waves = 3 at k = 6 / 7 on a wide
+    table planned the 256-thread three-wave instance the shipped library no longer holds -> hipErrorInvalidValue): the call runs on the
+    LDS-record kernel instead, results identical — on the 5 160-strategy grid, where the lane counts make the plan prefer the hot / cold kernel."""
+    from test_state_store_gpu import _default_table
+
+    big = _default_table()
+    big = big[: len(big) // k * k].copy()  # (a table's size must be a multiple of the player count)
+    big["strategy_id"] = np.arange(len(big))
+    ref = po.tournament(big.view(po.STRATEGY_DTYPE), k, 0, 0, 3, shuffles_per_batch=2, n_threads=8)
+    try:
+        eng.set_option("max_waves", waves)
+        got = eng.tournament(big, k, 0, 0, 3, shuffles_per_batch=2)
+        need = 4 if 5 <= k <= 7 else 3
+        assert _ran_hot_cold(eng, k) == (waves >= need), (k, waves, eng.timing())
+        assert np.array_equal(got["tally"], ref["tally"]), (k, waves)
+    finally:
+        eng.set_option("max_waves", 6)
 
 
 @pytest.mark.parametrize("k", [4])

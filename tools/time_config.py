@@ -1,5 +1,5 @@
 """Diagnostic: per-kernel timing of one tournament shape.
-usage: python tools/time_config.py <grid: 64|5160> <k> <n_shuffles> [reps] [root_seed] [rows: 0|1] [opt=value ...]
+usage: python tools/time_config.py <grid: 64|5160|5148> <k> <n_shuffles> [reps] [root_seed] [rows: 0|1] [opt=value ...]
 Prints one line per call; with `rows=1` also the measured R, T (rolls, turns per game) of the launch."""
 import sys, time
 from pathlib import Path
@@ -13,7 +13,7 @@ def table_for(grid: int) -> np.ndarray:
     if grid == 64:
         from bench import grid64
         return grid64()
-    tuples = default_grid_tuples()
+    tuples = default_grid_tuples()[:grid]  # (5148 = the first strategies of the default grid: divisible by 9 and 11)
     table = np.zeros(len(tuples), dtype=STRATEGY_DTYPE)
     for i, t in enumerate(tuples):
         table[i] = tuple(t)
