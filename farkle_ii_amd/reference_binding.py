@@ -19,9 +19,17 @@ CPU path either — without an engine (``farkle_ii_amd.engine.get_engine``, i.e.
     from farkle_ii_amd.reference_binding import TournamentBinding
     with TournamentBinding(rt):
         runner.run_single_n(cfg, k)          # sim.n_jobs = 1: the GPU is the worker pool
+
+The binding lives in the CALLING process.  ``run_tournament`` hands its chunks to ``parallel.process_map(..., n_jobs=resolved_n_jobs)``
+(``run_tournament.py:1576-1586``): with more than one job, spawned workers would re-import the module and silently play on the
+reference's CPU path, forked ones would inherit a parent that may hold a HIP context.  Both are refused LOUDLY (the reference
+enforces the same for custom H2H runners, ``analysis/h2h_schedule.py:1894-1895``): while the binding is installed,
+``rt.parallel`` is a guard whose ``process_map`` raises :class:`BindingWorkerPoolError` for ``n_jobs != 1``, and every patched
+callable raises it when called from another process than the one that installed it.
 """
 from __future__ import annotations
 
+import os
 from collections import defaultdict
 from typing import Any, Callable, Dict, Mapping, Sequence
 
@@ -33,6 +41,31 @@ from .engine import get_engine
 from .game_profile import GameProfile, H2HMaxRoundsOverride, TournamentMaxRoundsOverride
 from .strategies import STRATEGY_DTYPE
 from .tournament import METRIC_LABELS, _shuffle_rows, tally_to_counters
+
+
+class BindingWorkerPoolError(RuntimeError):
+    """The reference tried to play on a process pool while the engine binding was installed (sim.n_jobs must be 1)."""
+
+
+class _ParallelGuard:
+    """Stands in for ``farkle.utils.parallel`` inside ``run_tournament``'s namespace while the binding is installed: everything is
+    the real module's, except that ``process_map`` refuses a worker pool (the patched callables exist in THIS process only)."""
+
+    def __init__(self, real: Any):
+        self._real = real
+
+    def __getattr__(self, name: str) -> Any:
+        return getattr(self._real, name)
+
+    def process_map(self, *args, **kwargs):  # (utils/parallel.py:843: process_map(fn, items, *, n_jobs=None, initializer=None, ...))
+        n_jobs = kwargs.get("n_jobs")
+        normalize = getattr(self._real, "normalize_n_jobs", None)
+        resolved = normalize(n_jobs, default=1) if normalize is not None else (1 if n_jobs is None else int(n_jobs))
+        if int(resolved) != 1:
+            raise BindingWorkerPoolError(
+                f"TournamentBinding is installed and the run asks for n_jobs = {n_jobs!r} (resolved {resolved}): worker processes would not "
+                "see the binding and would play on the reference's CPU path.  Set sim.n_jobs = 1 — the GPU is the worker pool.")
+        return self._real.process_map(*args, **kwargs)
 
 
 def coerce_game_profile(profile: Any) -> GameProfile | None:
@@ -82,6 +115,8 @@ class TournamentBinding:
         self._orig: dict[str, Callable] = {}
         self._served: dict[tuple, tuple] = {}   # (root, k, shuffle, rows?) -> (wins, sums, sqs, rows) of a chunk launch
         self._table_of: tuple[tuple[int, int], np.ndarray, list[int]] | None = None
+        self._pid: int | None = None
+        self._real_parallel: Any = None
         self.launches = 0
 
     # ---- install / uninstall -------------------------------------------------------------------------------------
@@ -91,13 +126,27 @@ class TournamentBinding:
         for name in self._NAMES:
             self._orig[name] = getattr(self.rt, name)
             setattr(self.rt, name, getattr(self, name))
+        self._pid = os.getpid()
+        real = getattr(self.rt, "parallel", None)  # run_tournament.py calls parallel.process_map (:1576)
+        if real is not None and not isinstance(real, _ParallelGuard):
+            self._real_parallel = real
+            self.rt.parallel = _ParallelGuard(real)
         return self
 
     def uninstall(self) -> None:
         for name, fn in self._orig.items():
             setattr(self.rt, name, fn)
+        if self._real_parallel is not None:
+            self.rt.parallel = self._real_parallel
+            self._real_parallel = None
         self._orig.clear()
         self._served.clear()
+
+    def _check_process(self) -> None:
+        if self._pid is not None and os.getpid() != self._pid:
+            raise BindingWorkerPoolError(
+                f"TournamentBinding was installed in process {self._pid} and is being called in process {os.getpid()}: a forked worker "
+                "inherited it.  Set sim.n_jobs = 1 — the GPU is the worker pool.")
 
     __enter__ = install
 
@@ -148,6 +197,7 @@ class TournamentBinding:
 
     # ---- the four callables (same names, arguments and return shapes as the reference's) ---------------------------
     def _play_one_shuffle(self, task, *, collect_rows: bool = False):
+        self._check_process()
         work = self.rt._coerce_shuffle_task(task)
         key = (int(work.root_seed), int(work.k), int(work.shuffle_index), bool(collect_rows))
         if key not in self._served:
@@ -159,6 +209,7 @@ class TournamentBinding:
         return wins
 
     def _run_chunk(self, shuffle_tasks):
+        self._check_process()
         tasks = [self.rt._coerce_shuffle_task(t) for t in shuffle_tasks]
         self._launch(tasks, False)
         try:
@@ -167,6 +218,7 @@ class TournamentBinding:
             self._served.clear()
 
     def _run_chunk_metrics(self, shuffle_tasks, *, collect_rows: bool = False, **kwargs):
+        self._check_process()
         tasks = [self.rt._coerce_shuffle_task(t) for t in shuffle_tasks]
         self._launch(tasks, bool(collect_rows))
         try:
@@ -198,5 +250,5 @@ def prefetching_block_runner(schedule_blocks: Sequence[Mapping[str, Any]], oracl
                                        chunk_games=chunk_games)
 
 
-__all__ = ["TournamentBinding", "block_runner", "prefetching_block_runner", "chunk_counters", "coerce_game_profile",
+__all__ = ["TournamentBinding", "BindingWorkerPoolError", "block_runner", "prefetching_block_runner", "chunk_counters", "coerce_game_profile",
            "pack_reference_strategies"]

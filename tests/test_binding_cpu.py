@@ -138,6 +138,49 @@ def test_tournament_binding_serves_a_chunk_from_one_launch_and_restores_the_modu
     assert len(rows) == len(tasks) * (len(strategies) // k) and rows[0]["shuffle_index"] == 3 and rows[-1]["game_index"] == len(strategies) // k - 1
 
 
+def test_binding_refuses_a_worker_pool_and_a_forked_caller():
+    """The binding exists in the process that installed it.  While installed, `rt.parallel.process_map(..., n_jobs != 1)` raises
+    (spawned workers would re-import the module and play on the reference's CPU path: run_tournament.py:1576-1586), n_jobs = 1
+    goes through to the real function, a patched callable reached from another process (fork) raises, and uninstalling puts the
+    real module back.  The same refusal inside the REFERENCE's run_single_n is recorded in the fixture (oracle/gen_binding.py)."""
+    import os
+
+    import pytest
+
+    strategies, _ = generate_strategy_grid(score_thresholds=[300], dice_thresholds=[2], smart_five_opts=[False], smart_one_opts=[False],
+                                           consider_score_opts=[True], consider_dice_opts=[True], auto_hot_dice_opts=[True, False],
+                                           run_up_score_opts=[False])
+    rt = _stand_in_module(strategies, 2)
+    calls = []
+    real_parallel = types.SimpleNamespace(
+        normalize_n_jobs=lambda n, default=1: default if n is None else (os.cpu_count() if int(n) <= 0 else int(n)),
+        process_map=lambda fn, items, *, n_jobs=None, **kw: calls.append((n_jobs, sorted(kw))) or [fn(i) for i in items],
+        other_attribute="kept")
+    rt.parallel = real_parallel
+    binding = rb.TournamentBinding(rt, engine=StubEngine())
+    with binding:
+        assert rt.parallel is not real_parallel and rt.parallel.other_attribute == "kept"
+        for bad in (2, 8, 0, -1):  # 0 / -1: "all cores" in the reference's normalisation
+            if bad <= 0 and (os.cpu_count() or 1) == 1:
+                continue
+            with pytest.raises(rb.BindingWorkerPoolError, match="n_jobs"):
+                rt.parallel.process_map(len, [[1]], n_jobs=bad, initializer=None)
+        assert rt.parallel.process_map(len, [[1, 2], [3]], n_jobs=1, window=4) == [2, 1]
+        assert rt.parallel.process_map(len, [[1]], n_jobs=None) == [1]
+        assert calls == [(1, ["window"]), (None, [])]
+        tasks = tn.shuffle_tasks(7, 2, 0, 2, 2)
+        binding._pid = os.getpid() + 1  # as a forked worker would see it
+        for call in (lambda: rt._run_chunk(tasks), lambda: rt._run_chunk_metrics(tasks), lambda: rt._play_shuffle(tasks[0]),
+                     lambda: rt._play_one_shuffle(tasks[0])):
+            with pytest.raises(rb.BindingWorkerPoolError, match="forked worker"):
+                call()
+        binding._pid = os.getpid()
+        assert dict(rt._run_chunk(tasks))  # the installing process still plays
+    assert rt.parallel is real_parallel
+    msg = gu.load("binding_vectors.json")["tournament"]["n_jobs_2_refused"]
+    assert "n_jobs = 2" in msg and "sim.n_jobs = 1" in msg  # raised inside the reference's own run_single_n (sim.n_jobs = 2)
+
+
 def test_coerce_game_profile_keeps_the_identity_hash():
     from farkle_ii_amd.game_profile import GameProfile, H2HMaxRoundsOverride, TournamentMaxRoundsOverride
 
