@@ -39,6 +39,7 @@ H2H_BLOCK_DTYPE = np.dtype(
 TALLY_COLS = 26
 LAG_COLS = 11  # FK_LAG_COLS: pairs | win: sx sy sxx syy sxy | n_rounds: sx sy sxx syy sxy
 SEAT_STAT_COLS = 31
+SEAT_RATIO_COLS = 4  # FK_SEAT_RATIO_COLS: sum / sum of squares of score / n_turns, of score / n_rounds (float64, (shuffle, game, seat) order)
 SEAT_STAT_NAMES = ("exposures", "completed_exposures", "safety_limit_exposures", "wins", "final_score_sum", "final_score_square_sum",
                    "n_turns_sum", "n_turns_square_sum", "turn_round_mismatch_count", "turn_minus_rounds_sum",
                    "turn_minus_rounds_square_sum") + tuple(
@@ -96,7 +97,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
 
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
-            "fk_tournament_run", "fk_tournament_run_stats", "fk_tournament_run_lags", "fk_tournament_hint_next", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
+            "fk_tournament_run", "fk_tournament_run_stats", "fk_tournament_run_all_player", "fk_tournament_run_lags", "fk_tournament_hint_next", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
             "fk_debug_dice", "fk_debug_dice_state", "fk_debug_dice_keys", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy", "fk_tally_resident_reduce", "fk_comm_ranks", "fk_host_alloc", "fk_host_free", "fk_game_seeds"]
 _lib = None
 
@@ -203,7 +204,8 @@ class Engine:
                    overrides: np.ndarray | None = None, want_rows: bool = False, want_perms: bool = False,
                    want_seat_stats: bool = False, rows_out: np.ndarray | None = None) -> dict:
         """All games of shuffles ``[shuffle_begin, shuffle_end)``: per-batch tallies (+ rows / permutations / the all-seat
-        integer statistics ``[n_batches][S][SEAT_STAT_COLS]``, columns ``SEAT_STAT_NAMES``)."""
+        integer statistics ``[n_batches][S][SEAT_STAT_COLS]``, columns ``SEAT_STAT_NAMES``, with the four float64 ratio sums
+        ``seat_ratio_sums [n_batches][S][SEAT_RATIO_COLS]`` of the same table)."""
         table = np.ascontiguousarray(table, dtype=STRATEGY_DTYPE)
         S = len(table)
         n_sh = int(shuffle_end) - int(shuffle_begin)
@@ -225,12 +227,20 @@ class Engine:
         ov = overrides if overrides is not None else np.zeros(0, dtype=OVERRIDE_DTYPE)
         ov = np.ascontiguousarray(ov, dtype=OVERRIDE_DTYPE)
         stats = np.zeros((max(n_batches, 1), S, SEAT_STAT_COLS), dtype=np.int64) if want_seat_stats else None
-        self._check(self._lib.fk_tournament_run_stats(
-            self._ctx, _p(table), C.c_int32(S), C.c_int32(k), C.c_uint64(root_seed), C.c_uint64(shuffle_begin),
-            C.c_uint64(shuffle_end), C.c_uint32(spb), C.c_int32(target_score), C.c_int32(max_rounds), _p(ov),
-            C.c_int32(len(ov)), _p(tally), _p(rows), _p(perms), _p(stats)))
+        ratios = np.zeros((max(n_batches, 1), S, SEAT_RATIO_COLS), dtype=np.float64) if want_seat_stats else None
+        if want_seat_stats:  # the all-player accumulators: 31 integer sums + the four float64 sums in (shuffle, game, seat) order
+            self._check(self._lib.fk_tournament_run_all_player(
+                self._ctx, _p(table), C.c_int32(S), C.c_int32(k), C.c_uint64(root_seed), C.c_uint64(shuffle_begin),
+                C.c_uint64(shuffle_end), C.c_uint32(spb), C.c_int32(target_score), C.c_int32(max_rounds), _p(ov),
+                C.c_int32(len(ov)), _p(tally), _p(rows), _p(perms), _p(stats), _p(ratios)))
+        else:
+            self._check(self._lib.fk_tournament_run_stats(
+                self._ctx, _p(table), C.c_int32(S), C.c_int32(k), C.c_uint64(root_seed), C.c_uint64(shuffle_begin),
+                C.c_uint64(shuffle_end), C.c_uint32(spb), C.c_int32(target_score), C.c_int32(max_rounds), _p(ov),
+                C.c_int32(len(ov)), _p(tally), _p(rows), _p(perms), _p(stats)))
         return {"tally": tally[:n_batches], "rows": rows, "perms": perms,
-                "seat_stats": None if stats is None else stats[:n_batches]}
+                "seat_stats": None if stats is None else stats[:n_batches],
+                "seat_ratio_sums": None if ratios is None else ratios[:n_batches]}
 
     def tournament_lags(self, table: np.ndarray, k: int, root_seed: int, shuffle_begin: int, shuffle_end: int, lags,
                         shuffles_per_batch: int | None = None, target_score: int = 10_000, max_rounds: int = 200,

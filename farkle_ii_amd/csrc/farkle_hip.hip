@@ -82,7 +82,7 @@ struct fk_ctx {
         hipEvent_t a, b;
     };
     std::vector<PendingTimer> pending; // kernel timers recorded on the stream, read after the chunk's one sync
-    DevBuf strat, recs, rec0, tally, rows, ov, seatlist, coords, inv, slow, score_lut, discard_lut, block_out, stats, digest,
+    DevBuf strat, recs, rec0, tally, rows, ov, seatlist, coords, inv, slow, score_lut, discard_lut, block_out, stats, ratios, digest,
         dbg[6];
     std::vector<uint2> strat_host;   // the packed table currently resident in `strat` (uploaded once per table)
     int32_t longest_first = 1;
@@ -1193,7 +1193,7 @@ void fk_destroy(fk_ctx *c) {
     release(c->comm_buf);
     if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     for (DevBuf *b : {&c->strat, &c->recs, &c->rec0, &c->tally, &c->rows, &c->ov, &c->seatlist, &c->coords, &c->inv, &c->slow, &c->digest, &c->score_lut,
-                      &c->discard_lut, &c->block_out, &c->stats, &c->cold, &c->clk, &c->lds_tables, &c->acc, &c->rows_alt, &c->lag_v, &c->lag_out, &c->lag_lags, &c->lag_edge, &c->lag_tmp})
+                      &c->discard_lut, &c->block_out, &c->stats, &c->ratios, &c->cold, &c->clk, &c->lds_tables, &c->acc, &c->rows_alt, &c->lag_v, &c->lag_out, &c->lag_lags, &c->lag_edge, &c->lag_tmp})
         release(*b);
     for (auto &cs : c->sets) {
         for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc, &cs.pools, &cs.blocks, &cs.game_block, &cs.game_row}) release(*b);
@@ -1313,12 +1313,12 @@ struct LagReq { // fk_tournament_run_lags: host pointers of the request
 static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
                                uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
                                int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
-                               int64_t *seat_stats, const LagReq *lag);
+                               int64_t *seat_stats, const LagReq *lag, double *seat_ratios = nullptr);
 
 static int tournament_call(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
                            uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
                            int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
-                           int64_t *seat_stats, const LagReq *lag);
+                           int64_t *seat_stats, const LagReq *lag, double *seat_ratios = nullptr);
 
 int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
                             uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
@@ -1326,6 +1326,16 @@ int fk_tournament_run_stats(fk_ctx *c, const fk_strategy *strategies, int32_t S,
                             int64_t *seat_stats) {
     return tournament_call(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds, ov, n_ov,
                            tally, rows, perms, seat_stats, nullptr);
+}
+
+int fk_tournament_run_all_player(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                                 uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
+                                 int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
+                                 int64_t *seat_stats, double *seat_ratio_sums) {
+    if (!c) return FK_ERR_ARG;
+    if (!seat_stats || !seat_ratio_sums) return fail(c, FK_ERR_ARG, "seat_stats and seat_ratio_sums are required");
+    return tournament_call(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds, ov, n_ov,
+                           tally, rows, perms, seat_stats, nullptr, seat_ratio_sums);
 }
 
 int fk_tournament_run_lags(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed, uint64_t shuffle_begin,
@@ -1349,12 +1359,12 @@ int fk_tournament_run_lags(fk_ctx *c, const fk_strategy *strategies, int32_t S, 
 static int tournament_call(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
                            uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
                            int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
-                           int64_t *seat_stats, const LagReq *lag) {
+                           int64_t *seat_stats, const LagReq *lag, double *seat_ratios) {
     if (!c) return FK_ERR_ARG;
     c->ran_hc = false;
     c->last_tally_bytes = 0;
     int rc = tournament_run_impl(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds,
-                                 ov, n_ov, tally, rows, perms, seat_stats, lag);
+                                 ov, n_ov, tally, rows, perms, seat_stats, lag, seat_ratios);
     if (rc == FK_ERR_COUNTER_OVERFLOW && c->ran_hc) {
         // the hot / cold kernel's narrower counter fields (fk_play_hc.h) left their guard bands: the call is replayed on
         // fk_play_kernel, whose 16-bit fields are the ABI's stated limits
@@ -1363,7 +1373,7 @@ static int tournament_call(fk_ctx *c, const fk_strategy *strategies, int32_t S, 
         c->hc = 0;
         for (auto &cs : c->sets) cs.prepared = false;
         rc = tournament_run_impl(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds,
-                                 ov, n_ov, tally, rows, perms, seat_stats, lag);
+                                 ov, n_ov, tally, rows, perms, seat_stats, lag, seat_ratios);
         c->hc = saved;
     }
     if (rc == 0 && c->resident && c->last_tally_bytes) {
@@ -1386,7 +1396,7 @@ static int tournament_call(fk_ctx *c, const fk_strategy *strategies, int32_t S, 
 static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
                                uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
                                int32_t max_rounds, const fk_override *ov, int32_t n_ov, int64_t *tally, void *rows, int32_t *perms,
-                               int64_t *seat_stats, const LagReq *lag) {
+                               int64_t *seat_stats, const LagReq *lag, double *seat_ratios) {
     if (!strategies || !tally) return fail(c, FK_ERR_ARG, "strategies and tally are required");
     if (k < 1 || S < k || S % k != 0) return fail(c, FK_ERR_ARG, "n_players must divide %d", S); // run_tournament.py:274
     if (S > 65535) return fail(c, FK_ERR_ARG, "S=%d exceeds 65535 strategies", S);
@@ -1430,6 +1440,12 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
         rc = ensure(c, c->stats, stats_bytes);
         if (rc) return rc;
         HIPCHK(c, hipMemsetAsync(c->stats.p, 0, stats_bytes, c->stream));
+    }
+    const size_t ratio_bytes = sizeof(double) * (size_t)n_batches * (size_t)S * FK_SEAT_RATIO_COLS;
+    if (seat_ratios) { // running float64 sums, carried from chunk to chunk on the device (all-zero bits = 0.0)
+        rc = ensure(c, c->ratios, ratio_bytes);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(c->ratios.p, 0, ratio_bytes, c->stream));
     }
 
     // chunk planning: whole shuffles per chunk inside the workspace budget
@@ -1630,6 +1646,11 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
                                static_cast<const uint4 *>(c->digest.p), static_cast<const uint16_t *>(CSET(c).draws.p),
                                slots, (uint32_t)S, (uint32_t)k, gps, n_sh, (uint32_t)done, shuffles_per_batch, ppb, first_batch,
                                static_cast<long long *>(c->stats.p));
+            if (seat_ratios) // the four float64 sums: one thread per (strategy, batch), the batch's shuffles of this chunk in order
+                hipLaunchKernelGGL(fk_seat_ratio_kernel, dim3(s_blocks, nb), dim3(256), 0, c->stream,
+                                   static_cast<const uint4 *>(c->digest.p), static_cast<const uint16_t *>(CSET(c).draws.p),
+                                   slots, (uint32_t)S, (uint32_t)k, gps, n_sh, (uint32_t)done, shuffles_per_batch, first_batch,
+                                   static_cast<double *>(c->ratios.p));
             HIPCHK(c, hipGetLastError());
         }
         if (lag) {
@@ -1714,6 +1735,7 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
     HIPCHK(c, hipEventRecord(t1, c->stream));
     HIPCHK(c, hipMemcpyAsync(tally, c->tally.p, tally_bytes, hipMemcpyDeviceToHost, c->stream));
     if (seat_stats) HIPCHK(c, hipMemcpyAsync(seat_stats, c->stats.p, stats_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (seat_ratios) HIPCHK(c, hipMemcpyAsync(seat_ratios, c->ratios.p, ratio_bytes, hipMemcpyDeviceToHost, c->stream));
     if (lag) {
         const size_t edge_bytes = (size_t)edge_rows * (size_t)S * 2;
         HIPCHK(c, hipMemcpyAsync(lag->sums, c->lag_out.p, lag_sum_bytes, hipMemcpyDeviceToHost, c->stream));

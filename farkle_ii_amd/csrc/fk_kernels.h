@@ -1680,6 +1680,40 @@ __global__ __launch_bounds__(256) void fk_seat_stats_kernel(const uint4 *digest,
         if (acc[c]) atomicAdd(reinterpret_cast<unsigned long long *>(&out[c]), (unsigned long long)acc[c]);
 }
 
+// The four float64 sums of the all-player table that are NOT sums of integers (analysis/all_player_metrics.py:308-321): per exposure
+// exact_return = score / n_turns and proxy_return = score / n_rounds (0 where the denominator is 0), their sums and the sums of
+// their squares.  The reference accumulates them with np.add.at (:174-177: "deliberately unbuffered. It preserves source-row
+// addition order"), i.e. for every strategy ONE sequential float64 sum over its exposures in source-row order.  A strategy is
+// seated once per shuffle, so that order is the shuffle order: thread = (strategy, batch) walks the batch's shuffles of this chunk
+// in ascending order and continues the running sums the previous chunk left in `ratios` — the same additions in the same order,
+// IEEE-754 division / multiplication / addition each rounded once (no contraction into fused multiply-adds): the same bits.
+__global__ __launch_bounds__(256) void fk_seat_ratio_kernel(const uint4 *digest, const uint16_t *inv_T, uint32_t perm_slots, uint32_t S, uint32_t k,
+                                                            uint32_t gps, uint32_t n_sh, uint32_t sh_offset, uint32_t spb, uint32_t first_batch,
+                                                            double *ratios) {
+#pragma clang fp contract(off)
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t batch = first_batch + blockIdx.y;
+    const uint64_t g_lo = (uint64_t)batch * spb, g_hi = g_lo + spb;
+    const uint32_t sh_lo = g_lo > sh_offset ? (uint32_t)(g_lo - sh_offset) : 0u;
+    const uint32_t sh_hi = (uint32_t)min<uint64_t>(n_sh, g_hi > sh_offset ? g_hi - sh_offset : 0u);
+    if (s >= S || sh_hi <= sh_lo) return;
+    double *out = ratios + ((size_t)batch * S + s) * FK_SEAT_RATIO_COLS;
+    double exact_sum = out[0], exact_sq = out[1], proxy_sum = out[2], proxy_sq = out[3];
+    for (uint32_t sh = sh_lo; sh < sh_hi; ++sh) {
+        const uint32_t p = perm_at(inv_T, S, perm_slots, sh, s);
+        const uint4 *d = digest + ((size_t)sh * gps * k + p) * 2;
+        const uint4 q0 = d[0], q1 = d[1];
+        const double score = (double)((long long)(int32_t)q0.x * 50), rounds = (double)(q0.y & 0xffffu), turns = (double)(q1.w & 0xffffu);
+        const double exact = turns != 0.0 ? score / turns : 0.0, proxy = rounds != 0.0 ? score / rounds : 0.0;
+        const double exact2 = exact * exact, proxy2 = proxy * proxy;
+        exact_sum = exact_sum + exact;
+        exact_sq = exact_sq + exact2;
+        proxy_sum = proxy_sum + proxy;
+        proxy_sq = proxy_sq + proxy2;
+    }
+    out[0] = exact_sum, out[1] = exact_sq, out[2] = proxy_sum, out[3] = proxy_sq;
+}
+
 // ticket -> game id schedule inverted (rows are produced in game-id order)
 __global__ void fk_invert_sched_kernel(const uint32_t *sched, uint32_t n_games, uint32_t *inv) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

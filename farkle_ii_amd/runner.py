@@ -37,8 +37,8 @@ from .config import AppConfig
 from .distributed import barrier, gather_objects, reduce_tally, shard_shuffle_range
 from .engine import get_engine
 from .game_profile import GameProfile
-from .all_player import ROW_ORDER_FLOAT_FIELDS, all_player_batch_table
-from .backend import SEAT_STAT_COLS
+from .all_player import all_player_batch_table
+from .backend import SEAT_RATIO_COLS, SEAT_STAT_COLS
 from .rows import OUTCOME_SCHEMA_VERSION, TOURNAMENT_METHOD_VERSION
 from .strategies import (STRATEGY_TUPLE_FIELDS, FavorDiceOrScore, ThresholdStrategy, generate_strategy_grid,
                          prepare_public_helper_strategies, strategy_tuple)
@@ -452,6 +452,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         per_batch = metric_chunk_dir is not None or all_player_dir is not None
         local = np.zeros((b1 - b0 if per_batch else 1, S, 26), dtype=np.int64)
         local_stats = np.zeros((b1 - b0, S, SEAT_STAT_COLS), dtype=np.int64) if all_player_dir is not None else None
+        local_ratios = np.zeros((b1 - b0, S, SEAT_RATIO_COLS), dtype=np.float64) if all_player_dir is not None else None
         row_records: list[tuple] = []  # (shuffle index, manifest line, shard bytes, shard sha256)
         fragments = None
         if metric_chunk_dir is not None and rank == 0:
@@ -492,6 +493,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             local[first:first + len(res["tally"])] = res["tally"]
             if local_stats is not None:
                 local_stats[first:first + len(res["seat_stats"])] = res["seat_stats"]
+                local_ratios[first:first + len(res["seat_ratio_sums"])] = res["seat_ratio_sums"]
             if want_rows:  # every rank writes the shards of its own shuffles; rank 0 appends the manifest lines
                 sh_index = np.arange(lo, hi, dtype=np.int64)  # the ShuffleTask identities (run_tournament.py:97-105), as arrays
                 tasks = rt.ShuffleRange(cfg.sim.seed, k, sh_index, _shuffle_seeds(eng, cfg.sim.seed, k, lo, hi), sh_index // spb)
@@ -514,6 +516,10 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                         lag_total = piece if lag_total is None else lag_total.merge(piece)
         group = reduce_tally(local, dst=0)
         group_stats = reduce_tally(local_stats, dst=0) if local_stats is not None else None  # integer sums, like the tally
+        # the float64 sums: a deterministic batch is played whole by ONE rank (the others hold +0.0 = all-zero bits), so the int64 SUM of
+        # the bit patterns hands rank 0 every batch's sums bit for bit — no floating-point addition across ranks
+        group_ratios = (reduce_tally(np.ascontiguousarray(local_ratios).view(np.int64), dst=0).view(np.float64)
+                        if local_ratios is not None else None)
         if want_rows and world > 1:
             gathered = gather_objects(row_records, dst=0)
             row_records = [r for part in (gathered or []) for r in part]
@@ -527,12 +533,14 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             lists = fragments.result() if fragments is not None else None
             for n, b in enumerate(range(b0, b1)):
                 if all_player_dir is not None:
-                    ap = all_player_batch_table(group_stats[n], ids, cfg.sim.seed, k, b)
+                    ap = all_player_batch_table(group_stats[n], ids, cfg.sim.seed, k, b, group_ratios[n])
                     name = f"all_player_batch_{b + 1:06d}.parquet"
                     _write_parquet_atomic(ap, all_player_dir / name)
                     all_player_records.append({"path": name, "rows": ap.num_rows, "root_seed": cfg.sim.seed, "n_players": k,
                                                "deterministic_batch_id": b, "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
-                                               "absent_columns": list(ROW_ORDER_FLOAT_FIELDS)})
+                                               "absent_columns": [],
+                                               "float_sum_order": "per strategy, exposures in ascending (shuffle, game, seat) order, sequential "
+                                                                  "float64 (the order np.add.at visits curated rows, all_player_metrics.py:174-177)"})
                 if metric_chunk_dir is not None:
                     chunk = _metric_chunk_table(group[n], ids, k)
                     name = f"metrics_{b + 1:06d}.parquet"  # chunk / process-block indices count from 1 (run_tournament.py:1603-1642)

@@ -168,12 +168,26 @@ int fk_tournament_run(fk_ctx *ctx, const fk_strategy *strategies, int32_t S, int
  *     smart_one_uses, n_smart_one_dice.
  * These are the integer accumulators of the reference's unconditional all-player batch metrics
  * (src/farkle/analysis/all_player_metrics.py:257-340), produced on the device from the state store without
- * materialising rows; its two ratio statistics (score / n_turns, score / n_rounds) are float64 sums in row order and are
- * not produced here. */
+ * materialising rows; its two ratio statistics (score / n_turns, score / n_rounds) are float64 sums in row order:
+ * fk_tournament_run_all_player below. */
 int fk_tournament_run_stats(fk_ctx *ctx, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
                             uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch,
                             int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov,
                             int64_t *tally, void *rows, int32_t *perms, int64_t *seat_stats);
+
+/* fk_tournament_run_stats plus the four float64 accumulators of the same table (all_player_metrics.py:308-321), per batch and strategy:
+ *   seat_ratio_sums  double [n_batches][S][FK_SEAT_RATIO_COLS]; overwritten.  Columns: sum of score / n_turns over the strategy's
+ *     exposures (0 where n_turns is 0), sum of its squares, sum of score / n_rounds, sum of its squares.
+ * The reference adds them with np.add.at in source-row order (:174-177), i.e. one sequential float64 sum per strategy over its
+ * exposures in (shuffle, game, seat) order.  A strategy sits once per shuffle: the device runs exactly that sequence — one thread
+ * per (batch, strategy), ascending shuffles, one rounding per division, multiplication and addition — so the sums carry the bits the
+ * reference's do whenever its curated rows are in (shuffle, game) order (pinned by tests/golden/all_player_vectors.json, the reference's
+ * own _iter_batch_tables).  seat_stats is required (the digests both read are built once). */
+#define FK_SEAT_RATIO_COLS 4
+int fk_tournament_run_all_player(fk_ctx *ctx, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                                 uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch,
+                                 int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov,
+                                 int64_t *tally, void *rows, int32_t *perms, int64_t *seat_stats, double *seat_ratio_sums);
 
 /* Scheduling hint: the next fk_tournament_run / fk_tournament_run_stats call on this context — the one AFTER the call that
  * follows this hint — will play shuffles [shuffle_begin, shuffle_end) of the same table, k and root seed (need_state != 0: it

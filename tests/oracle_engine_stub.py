@@ -48,6 +48,28 @@ def seat_stats_from_rows(rows: np.ndarray, k: int, S: int, gps: int, spb: int) -
     return out
 
 
+def seat_ratio_sums_from_rows(rows: np.ndarray, k: int, S: int, gps: int, spb: int) -> np.ndarray:
+    """The four float64 accumulators of fk_tournament_run_all_player from rows, the way the reference adds them
+    (analysis/all_player_metrics.py:308-321 + np.add.at :174-177): exposures flattened in (row, seat) order, unbuffered."""
+    n = len(rows)
+    batch = (np.arange(n) // gps) // max(spb, 1)
+    out = np.zeros((int(batch.max()) + 1 if n else 1, S, 4), dtype=np.float64)
+    rounds = rows["n_rounds"].astype(np.float64)
+    strat = np.stack([rows["seats"][:, seat]["strategy"].astype(np.int64) for seat in range(k)], axis=1).reshape(-1)
+    b = np.repeat(batch, k)
+    cols = [[], [], [], []]
+    for seat in range(k):
+        x = rows["seats"][:, seat]
+        score, turns = x["score"].astype(np.float64), x["n_turns"].astype(np.float64)
+        exact = np.divide(score, turns, out=np.zeros_like(score), where=turns != 0)
+        proxy = np.divide(score, rounds, out=np.zeros_like(score), where=rounds != 0)
+        for c, v in enumerate((exact, exact * exact, proxy, proxy * proxy)):
+            cols[c].append(v)
+    for c in range(4):
+        np.add.at(out[:, :, c], (b, strat), np.stack(cols[c], axis=1).reshape(-1))
+    return out
+
+
 class Engine:
     def __init__(self, device: int = 0):
         self.device = device
@@ -84,11 +106,13 @@ class Engine:
                             target_score=target_score, max_rounds=max_rounds, overrides=ov, want_rows=want_rows or want_seat_stats,
                             want_perms=want_perms, n_threads=2)
         self._games = (shuffle_end - shuffle_begin) * (len(t) // k)
-        stats = None
+        stats = ratios = None
         if want_seat_stats:
             spb = (shuffle_end - shuffle_begin) if not shuffles_per_batch else shuffles_per_batch
             stats = seat_stats_from_rows(res["rows"], k, len(t), len(t) // k, spb)
-        return {"tally": res["tally"], "rows": res["rows"] if want_rows else None, "perms": res["perms"], "seat_stats": stats}
+            ratios = seat_ratio_sums_from_rows(res["rows"], k, len(t), len(t) // k, spb)
+        return {"tally": res["tally"], "rows": res["rows"] if want_rows else None, "perms": res["perms"], "seat_stats": stats,
+                "seat_ratio_sums": ratios}
 
     def tournament_lags(self, table, k, root_seed, shuffle_begin, shuffle_end, lags, shuffles_per_batch=None, target_score=10_000,
                         max_rounds=200, overrides=None) -> dict:

@@ -673,11 +673,11 @@ def test_resume_refuses_a_checkpoint_whose_shuffle_list_and_block_list_disagree(
 
 def test_farkle_run_all_player_batches_artifact(engine, tmp_path):
     """`farkle run --all-player-batches`: one parquet per deterministic batch in the reference's all_player_batch_schema column
-    order, integer columns from the engine's all-seat accumulators, the row-order float columns null; resume keeps the files
-    of owned batches and replays the rest."""
+    order, integer columns from the engine's all-seat accumulators, the four row-order float64 sums (and the fields derived from them)
+    from the engine's sequential sums — no null column; resume keeps the files of owned batches and replays the rest."""
     import pyarrow.parquet as pq
     import pyoracle as po
-    from oracle_engine_stub import seat_stats_from_rows
+    from oracle_engine_stub import seat_ratio_sums_from_rows, seat_stats_from_rows
 
     from farkle_ii_amd import runner
     from farkle_ii_amd.all_player import ROW_ORDER_FLOAT_FIELDS, all_player_batch_schema, all_player_batch_table
@@ -697,14 +697,17 @@ def test_farkle_run_all_player_batches_artifact(engine, tmp_path):
     S = len(table)
     rows = po.tournament(table.view(po.STRATEGY_DTYPE), 2, 7, 0, n_sh, want_rows=True)["rows"]
     stats = seat_stats_from_rows(rows, 2, S, S // 2, spb)
+    ratios = seat_ratio_sums_from_rows(rows, 2, S, S // 2, spb)
     manifest = [json.loads(line) for line in (out_dir / "all_player_manifest.jsonl").read_text().splitlines()]
-    assert [r["deterministic_batch_id"] for r in manifest] == [0, 1, 2, 3] and manifest[0]["absent_columns"] == list(ROW_ORDER_FLOAT_FIELDS)
+    assert [r["deterministic_batch_id"] for r in manifest] == [0, 1, 2, 3] and manifest[0]["absent_columns"] == []
+    assert "(shuffle, game, seat)" in manifest[0]["float_sum_order"]
     for b in range(4):
         got = pq.read_table(out_dir / f"all_player_batch_{b + 1:06d}.parquet")
         assert got.schema.names == all_player_batch_schema().names
-        assert got.equals(all_player_batch_table(stats[b], list(range(S)), 7, 2, b))
+        assert got.equals(all_player_batch_table(stats[b], list(range(S)), 7, 2, b, ratios[b]))
         assert got.column("raw_player_game_exposures").to_pylist() == [min(spb, n_sh - b * spb)] * S
-        assert all(v is None for name in ROW_ORDER_FLOAT_FIELDS for v in got.column(name).to_pylist())
+        assert all(v is not None for name in ROW_ORDER_FLOAT_FIELDS[:6] for v in got.column(name).to_pylist())
+        assert got.schema.field("raw_turn_return_round_proxy_sum").nullable is False
     # resume after losing the last batch: its file is rewritten, the others are kept, the manifest lists each batch once
     ref = po.tournament(table.view(po.STRATEGY_DTYPE), 2, 7, 0, n_sh)["tally"][0]
     last = po.tournament(table.view(po.STRATEGY_DTYPE), 2, 7, 3 * spb, n_sh)["tally"][0]

@@ -250,6 +250,10 @@ def test_all_seat_integer_statistics_match_the_rows(eng, po, k, table_kind):
     ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 3, 5, 5 + n_sh, shuffles_per_batch=spb, want_rows=True, max_rounds=40, n_threads=16)
     # the oracle numbers batches from the first shuffle of the call; shuffle 5 is local shuffle 0
     want = _seat_stats_from_rows(ref["rows"], k, S, gps, spb)
+    from oracle_engine_stub import seat_ratio_sums_from_rows
+
+    want_ratios = seat_ratio_sums_from_rows(ref["rows"], k, S, gps, spb)
+    assert want_ratios[:, :, 0].sum() > 0
     for chunk in (48 << 30, 2 << 20):
         try:
             eng.set_option("chunk_bytes", chunk)
@@ -260,6 +264,9 @@ def test_all_seat_integer_statistics_match_the_rows(eng, po, k, table_kind):
         assert got["rows"].tobytes() == ref["rows"].tobytes()
         assert got["seat_stats"].shape == want.shape
         assert np.array_equal(got["seat_stats"], want), (k, table_kind, chunk, np.argwhere(got["seat_stats"] != want)[:5])
+        # the four float64 sums (fk_tournament_run_all_player): the reference's np.add.at order — BIT equality, also when a batch
+        # straddles chunks (the running sums continue on the device)
+        assert got["seat_ratio_sums"].tobytes() == want_ratios.tobytes(), (k, table_kind, chunk, np.argwhere(got["seat_ratio_sums"] != want_ratios)[:5])
     assert want[:, :, 2].sum() > 0 or (k, table_kind) != (2, "g64")  # the 64-grid's never-banking pairings hit the 40-round limit
     only = eng.tournament(table, k, 3, 5, 5 + n_sh, shuffles_per_batch=spb, max_rounds=40, want_seat_stats=True)
     assert np.array_equal(only["seat_stats"], want)
