@@ -116,6 +116,7 @@ struct fk_ctx {
     int comm_rank = 0, comm_world = 1;
     bool comm_async = false;   // (non-blocking communicators: every RCCL call settled by polling; not used — see fk_comm_init)
     bool comm_lost = false;    // a collective failed or timed out and the communicator was aborted: reductions fail until fk_comm_init
+    bool comm_timeout_set = false;    // "comm_timeout_ms" was set explicitly: the environment default no longer applies
     int32_t comm_timeout_ms = 120000; // option "comm_timeout_ms" (FK_COMM_TIMEOUT_MS): deadline of communicator creation and of each
                                       // collective; 0 = the blocking calls of round 3 (no deadline)
     DevBuf comm_buf;
@@ -1258,7 +1259,10 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return FK_ERR_ARG;
     std::string n(name);
     if (n == "chunk_bytes") c->chunk_bytes = std::max<int64_t>(value, 1 << 20);
-    else if (n == "comm_timeout_ms") c->comm_timeout_ms = (int32_t)std::max<int64_t>(value, 0);
+    else if (n == "comm_timeout_ms") {
+        c->comm_timeout_ms = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 86400000);
+        c->comm_timeout_set = true; // from now on the FK_COMM_TIMEOUT_MS environment default is not consulted
+    }
     else if (n == "batch_threshold") c->batch_threshold = (int32_t)value;
     else if (n == "use_lds_tally") c->use_lds_tally = (int32_t)value;
     else if (n == "longest_first") c->longest_first = (int32_t)value;
@@ -2081,7 +2085,15 @@ int fk_comm_init(fk_ctx *c, const fk_comm_id *id, int32_t rank, int32_t world_si
         (void)r.CommDestroy(c->comm);
         c->comm = nullptr;
     }
-    if (const char *env = getenv("FK_COMM_TIMEOUT_MS")) c->comm_timeout_ms = atoi(env);
+    // FK_COMM_TIMEOUT_MS is the default for contexts whose "comm_timeout_ms" option was never set (an explicit fk_set_option wins);
+    // anything that is not a non-negative integer is ignored rather than silently turned into the blocking path
+    if (!c->comm_timeout_set) {
+        if (const char *env = getenv("FK_COMM_TIMEOUT_MS")) {
+            char *endp = nullptr;
+            const long v = strtol(env, &endp, 10);
+            if (endp != env && *endp == '\0' && v >= 0 && v <= 86400000L) c->comm_timeout_ms = (int32_t)v;
+        }
+    }
     c->comm_async = false;
     const bool dbg = getenv("FK_DEBUG_COMM") != nullptr;
     if (c->comm_timeout_ms > 0) {
@@ -2090,8 +2102,12 @@ int fk_comm_init(fk_ctx *c, const fk_comm_id *id, int32_t rank, int32_t world_si
         // peers here until the job's time limit: the call runs on a helper thread and this thread waits for it under the deadline.
         // On expiry the helper stays parked in RCCL's bootstrap (a socket wait; it owns nothing of this context and is never
         // joined), the context has no communicator, and the caller gets FK_ERR_COMM — bench.py / farkle run then agree on gloo.
+        // Should the peer join after all, the helper finds `abandoned` set and aborts the communicator it just made itself
+        // (ncclCommAbort: nobody else holds it), so a late join leaks nothing.  A process that has seen this error should end
+        // (exit code != 0 is the caller's call): a thread may still sit inside librccl.
         struct Pending {
             std::atomic<int> done{0};
+            std::atomic<int> abandoned{0};
             int rc = 0;
             void *comm = nullptr;
         };
@@ -2102,10 +2118,19 @@ int fk_comm_init(fk_ctx *c, const fk_comm_id *id, int32_t rank, int32_t world_si
         std::thread([pending, id_copy, device, world_size, rank, &r]() {
             (void)hipSetDevice(device);
             pending->rc = r.CommInitRank(&pending->comm, world_size, id_copy, rank);
-            pending->done.store(1, std::memory_order_release);
+            pending->done.store(1); // (sequentially consistent, like the three accesses it pairs with: a store-then-load handshake)
+            // the waiter gave up before this returned (it tests `done` once more after setting `abandoned`, so at least one side
+            // sees the other's flag): tear down what was built for nobody
+            if (pending->abandoned.load() && pending->rc == 0 && pending->comm) {
+                void *orphan = pending->comm;
+                pending->comm = nullptr;
+                (void)(r.CommAbort ? r.CommAbort(orphan) : r.CommDestroy(orphan));
+            }
         }).detach();
         while (!pending->done.load(std::memory_order_acquire)) {
             if (now_ms() - t0 > (double)c->comm_timeout_ms) {
+                pending->abandoned.store(1);
+                if (pending->done.load()) break; // it finished in this very moment (the helper may have torn it down already: checked below)
                 if (dbg) fprintf(stderr, "[fk comm] ncclCommInitRank still waiting after %.0f ms: giving up\n", now_ms() - t0);
                 return fail(c, FK_ERR_COMM, "ncclCommInitRank did not complete within %d ms (comm_timeout_ms): a peer rank never joined",
                             c->comm_timeout_ms);
@@ -2114,6 +2139,8 @@ int fk_comm_init(fk_ctx *c, const fk_comm_id *id, int32_t rank, int32_t world_si
         }
         if (dbg) fprintf(stderr, "[fk comm] ncclCommInitRank returned %d after %.1f ms\n", pending->rc, now_ms() - t0);
         if (pending->rc != 0) return rccl_fail(c, "ncclCommInitRank", pending->rc);
+        if (!pending->comm) // (both sides raced at the deadline and the helper tore the communicator down)
+            return fail(c, FK_ERR_COMM, "ncclCommInitRank completed at the deadline (%d ms) and was abandoned", c->comm_timeout_ms);
         c->comm = pending->comm;
         c->comm_rank = rank;
         c->comm_world = world_size;

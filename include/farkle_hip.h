@@ -141,7 +141,10 @@ int fk_host_free(fk_ctx *ctx, void *p);
  * current game kernel — permutations in front of it, schedule and seat seeding on a low-priority stream in its drain tail;
  * 0: every chunk is prepared on the main stream in front of its own game kernel), "hot_cold" (tournament launches of 4..12 seats on
  * the hot / cold game kernel, csrc/fk_play_hc.h: -1 auto, 0 never — the LDS-record kernel plays them), "comm_timeout_ms" (deadline of
- * fk_comm_init and of each collective, default 120 000; 0 = no deadline), "rows_chunk_games" (rows mode plays in chunks of about this many games,
+ * fk_comm_init and of each collective, default 120 000 or the environment's FK_COMM_TIMEOUT_MS — a non-negative integer, consulted only
+ * while this option has never been set; 0 = no deadline.  After a timed-out fk_comm_init the context keeps playing, a peer that joins
+ * late meets a helper that aborts the orphan communicator itself, and the process should end when its work is done: a helper thread may
+ * still sit inside librccl), "rows_chunk_games" (rows mode plays in chunks of about this many games,
  * default 4 000 000: chunk i's rows cross PCIe while chunk i + 1 plays), "resident_tally" (see fk_tally_resident_reduce), "clock_stamps" (1: every workgroup of a game kernel reads the
  * shader-clock and the 100 MHz reference counters at its first and last instruction; fk_timing.play_clock_mhz).  All of them
  * are scheduling / layout choices: results are identical for every setting. */

@@ -455,7 +455,40 @@ assert eng.tournament(grid64(), 2, 42, 0, 4)["tally"].sum() > 0   # the context 
 eng.close()
 print("child ok")
 """
+    import os
+    import re
+
+    # an explicit option wins over the environment default (round-4 advisor: FK_COMM_TIMEOUT_MS used to override it silently)
     t0 = time.time()
-    res = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=150, cwd=str(root))
+    res = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=150, cwd=str(root),
+                         env=dict(os.environ, FK_COMM_TIMEOUT_MS="1"))
     assert res.returncode == 0 and "child ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
-    assert time.time() - t0 < 120
+    assert time.time() - t0 < 120  # the timed-out process ends by itself, helper thread inside librccl and all
+    assert float(re.search(r"refused after ([0-9.]+) s", res.stdout).group(1)) >= 3.5, res.stdout
+    # the environment default alone (option never set), and a malformed value is ignored instead of selecting the blocking call
+    env_child = child.replace('eng.set_option("comm_timeout_ms", 4000)\n', "")
+    assert env_child != child
+    res = subprocess.run([sys.executable, "-c", env_child], capture_output=True, text=True, timeout=150, cwd=str(root),
+                         env=dict(os.environ, FK_COMM_TIMEOUT_MS="2500"))
+    assert res.returncode == 0 and "child ok" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+    assert 2.0 <= float(re.search(r"refused after ([0-9.]+) s", res.stdout).group(1)) < 30, res.stdout
+    probe = f"""
+import sys
+sys.path.insert(0, {str(root)!r})
+from farkle_ii_amd.backend import Engine, FarkleHipError, FK_ERR_COMM
+import time
+eng = Engine(0)
+eng.set_option("comm_timeout_ms", 1500)
+for bad in ("-5", "12x", ""):
+    import os
+    os.environ["FK_COMM_TIMEOUT_MS"] = bad
+t0 = time.time()
+try:
+    eng.comm_init(eng.comm_unique_id(), 0, 2)
+except FarkleHipError as exc:
+    assert exc.code == FK_ERR_COMM
+print("took %.1f" % (time.time() - t0))
+eng.close()
+"""
+    res = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=150, cwd=str(root))
+    assert res.returncode == 0 and 1.0 <= float(re.search(r"took ([0-9.]+)", res.stdout).group(1)) < 30, res.stdout[-1000:] + res.stderr[-1000:]
