@@ -36,7 +36,9 @@ def build_parser() -> argparse.ArgumentParser:
     run.add_argument("--rng-lag-sums", action="store_true",
                      help="Write the lag sufficient statistics of the RNG diagnostics' strategy family (per strategy and "
                           "analysis.rng_diagnostic_lags: pairs, sums, square sums and cross sums of the win indicator and of n_rounds) "
-                          "and the autocorrelation rows computed from them, from device accumulators, without rows")
+                          "and the autocorrelation rows computed from them, from device accumulators, without rows.  The series spans every "
+                          "shuffle of the run and is held in memory until the end: an interrupted --rng-lag-sums run cannot resume (the next "
+                          "invocation asks for --force), and a run completed without it must be replayed with --force")
     run.add_argument("--sidecars", action="store_true",
                      help="Write <artifact>.sidecar.json (producer contract + SHA-256 / size of the artifact) beside every output")
     run.add_argument("--force", action="store_true", help="Recompute even when existing run artifacts are available")
@@ -114,14 +116,19 @@ def main(argv: Sequence[str] | None = None) -> None:
             distributed._ENGINE_COMM = None
         LOGGER.info("tally reduce: %s", "fk_reduce_tally (RCCL through the C-ABI)" if everywhere else "torch.distributed.reduce")
     rank = int(os.environ.get("RANK", "0"))
-    if rank == 0:
-        runner.write_active_config(cfg, cfg.results_root)
+    # the resolved configuration beside the results: written on the runner's helper thread, under the first engine call (ctypes drops
+    # the GIL for its duration) — 2 ms of a 25-ms `farkle run`; any error of the write surfaces when the run has finished
+    active = runner._helper_thread().submit(runner.write_active_config, cfg, cfg.results_root) if rank == 0 else None
     LOGGER.info("Dispatching run command: seed=%s n_players_list=%s results_dir=%s", cfg.sim.seed, cfg.sim.n_players_list,
                 cfg.results_root)
-    if len(cfg.sim.n_players_list) > 1:
-        out = runner.run_multi(cfg, force=args.force)
-    else:
-        out = {cfg.sim.n_players_list[0]: runner.run_single_n(cfg, cfg.sim.n_players_list[0], force=args.force)}
+    try:
+        if len(cfg.sim.n_players_list) > 1:
+            out = runner.run_multi(cfg, force=args.force)
+        else:
+            out = {cfg.sim.n_players_list[0]: runner.run_single_n(cfg, cfg.sim.n_players_list[0], force=args.force)}
+    finally:
+        if active is not None:
+            active.result()
     if rank == 0:
         print({f"{k}p_games": v for k, v in out.items()})
 

@@ -432,8 +432,14 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         completed = sorted(done_batches)
         # process blocks are numbered from 1 (run_tournament.py:1576-1586); one block = one deterministic batch here
         shuffle_list: list[int] = []
-        for b in completed:  # (extend by ranges: 312 500 indices are a list comprehension's 20 ms otherwise)
-            shuffle_list.extend(range(b * spb, min((b + 1) * spb, plan.required_shuffles)))
+        run_first = run_last = None  # runs of consecutive batches become ONE range (a complete run: list(range(n)), 2 ms per 312 500)
+        for b in completed + [None]:
+            if run_last is not None and b is not None and b == run_last + 1:
+                run_last = b
+                continue
+            if run_first is not None:
+                shuffle_list.extend(range(run_first * spb, min((run_last + 1) * spb, plan.required_shuffles)))
+            run_first = run_last = b
         ck_meta = {**meta, "completed_shuffle_indices": shuffle_list,
                    "completed_process_block_indices": [b + 1 for b in completed], "complete": final}
         _atomic_write_bytes(checkpoint_path, ckpt.dump_checkpoint(wins, sums if collect_metrics else None,
@@ -598,6 +604,11 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
     n_dir = cfg.n_dir(n)
     n_dir.mkdir(parents=True, exist_ok=True)
     if not force and simulation_is_complete(cfg, n, plan):
+        # a completed run that is now asked for the lag statistics it was not run with: the series needs every shuffle of the root, so
+        # nothing can be added to published outputs — say so instead of returning without the files (round-4 advisor)
+        if cfg.sim.rng_lag_sums and not (cfg.rng_lag_sums_path(n).exists() and cfg.rng_lag_stats_path(n).exists()):
+            raise ValueError(f"{n}p is already complete without {cfg.rng_lag_sums_path(n).name}: --rng-lag-sums needs every shuffle of the "
+                             "run; use --force to replay it with the lag statistics")
         LOGGER.info("Simulation already complete; preserving published outputs for %sp", n)
         return plan.required_games
     plan_path = n_dir / "simulation_workload_plan.json"
@@ -629,23 +640,38 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
 
             if not pq.read_table(manifest_path).equals(table):
                 raise ValueError(f"Strategy manifest at {manifest_path} does not match the configured grid")
-        else:
-            _write_parquet_atomic(table, manifest_path)
-        write_workload_plan(plan_path, plan)
+            table = None  # (nothing to write)
     sidecars = _Sidecars(cfg, n, [cfg.strategy_manifest_root_path(), plan_path], bool(cfg.sim.sidecars))
-    if rank == 0:
+
+    def publish_inputs() -> None:
+        """The run's two input artifacts (strategy manifest, workload plan) and their sidecars.  Nothing the engine needs: a single
+        process writes them on the helper thread while the first launch plays (joined before anything reads them back)."""
+        if table is not None:
+            _write_parquet_atomic(table, cfg.strategy_manifest_root_path())
+        write_workload_plan(plan_path, plan)
         sidecars.write("strategy_manifest", cfg.strategy_manifest_root_path(), sources=(),
                        support_counts=sorted({int(v) for v in cfg.sim.n_players_list}))
         sidecars.write("workload_plan", plan_path, sources=[cfg.strategy_manifest_root_path()])
+
+    published = None
+    if rank == 0:
+        if _rank_world()[1] == 1 and not cfg.sim.sidecars:  # (sidecars of later artifacts name these files as sources: keep the order)
+            published = _helper_thread().submit(publish_inputs)
+        else:
+            publish_inputs()
     for d in (row_dir, metric_chunk_dir, all_player_dir):
         if d is not None:
             d.mkdir(parents=True, exist_ok=True)
     barrier()  # rank 0's --force cleanup and manifest write are complete before any rank plays or writes a shard
-    result = run_tournament(cfg=cfg, n_players=n, strategies=strategies, plan=plan, checkpoint_path=ckpt_path,
+    try:
+        result = run_tournament(cfg=cfg, n_players=n, strategies=strategies, plan=plan, checkpoint_path=ckpt_path,
                             collect_metrics=cfg.sim.expanded_metrics, row_dir=row_dir, metric_chunk_dir=metric_chunk_dir,
                             resume=not force, checkpoint_metadata={"strategy_manifest_sha": manifest_sha},
                             oracle_game_profile=oracle_game_profile, all_player_dir=all_player_dir, sidecars=sidecars,
                             rng_lags=cfg.rng_diagnostic_lags() if cfg.sim.rng_lag_sums else None)
+    finally:
+        if published is not None:
+            published.result()  # the inputs are on disk (or their error is raised) before the summaries and the stamp name them
     if rank != 0:
         return plan.required_games
     ids = [int(s.strategy_id) for s in strategies]
@@ -762,5 +788,5 @@ def write_active_config(cfg: AppConfig, dest_dir: Path) -> Path:
     dest_dir = Path(dest_dir)
     dest_dir.mkdir(parents=True, exist_ok=True)
     path = dest_dir / "active_config.yaml"
-    path.write_text(yaml.safe_dump(data, sort_keys=True), encoding="utf-8")
+    path.write_text(yaml.dump(data, Dumper=getattr(yaml, "CSafeDumper", yaml.SafeDumper), sort_keys=True), encoding="utf-8")
     return path

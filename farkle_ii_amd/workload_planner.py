@@ -6,6 +6,7 @@ equal contiguous batches.  Host-only arithmetic (scipy for the normal quantile, 
 from __future__ import annotations
 
 import json
+import functools
 import math
 import os
 from dataclasses import asdict, dataclass, replace
@@ -68,15 +69,22 @@ def _check_level(confidence: float) -> None:
         raise ValueError("confidence must be between 0 and 1")
 
 
+@functools.lru_cache(maxsize=64)
+def _normal_quantile(q: float) -> float:
+    """scipy.stats.norm.ppf(q) — the reference's call (workload_planner.py:86), evaluated once per level: the resolution search asks
+    for the same quantile at every candidate size (39 calls of 0.1 ms each per plan)."""
+    from scipy.stats import norm
+
+    return float(norm.ppf(q))
+
+
 def worst_case_wilson_width(n: int, *, confidence: float = 0.95) -> float:
     """Widest full Wilson score interval any success count can produce at sample size ``n``: the interval is widest at
     p = 1/2, i.e. at floor(n/2) or ceil(n/2) successes (workload_planner.py:88-108)."""
-    from scipy.stats import norm
-
     if not _is_int(n, 1):
         raise ValueError("n must be a positive integer")
     _check_level(confidence)
-    z = float(norm.ppf(0.5 + confidence / 2.0))
+    z = _normal_quantile(0.5 + confidence / 2.0)
     zz = z * z
     # The value lands in simulation_workload_plan.json (achieved_resolution) and decides minimum_shuffles_for_resolution, so
     # every operation is in the reference's order (workload_planner.py:87-93): the Wilson radicand is

@@ -860,6 +860,13 @@ def test_farkle_run_rng_lag_sums(engine, tmp_path, monkeypatch):
     assert set(stats.column("observations").to_pylist()) == {n_sh} and set(stats.column("summary_level").to_pylist()) == {"strategy"}
     done = json.loads((n_dir / "simulation.done.json").read_text())
     assert any(p.endswith("2p_rng_lag_sums.parquet") for p in done["outputs"])
+    # asking a COMPLETE run for the lag files it does not have is an error, not a silent "already complete" (round-4 advisor) ...
+    main(["--config", str(cfg_path), "run", "--rng-lag-sums"])  # (it has them: nothing to do)
+    (n_dir / "2p_rng_lag_sums.parquet").rename(n_dir / "kept.parquet")
+    with pytest.raises(ValueError, match="--force"):
+        main(["--config", str(cfg_path), "run", "--rng-lag-sums"])
+    main(["--config", str(cfg_path), "run"])  # ... while a plain run of the complete directory stays a no-op
+    (n_dir / "kept.parquet").rename(n_dir / "2p_rng_lag_sums.parquet")
     # a checkpoint that already owns batches cannot rebuild a strategy's series
     (n_dir / "simulation.done.json").unlink()
     ck_meta = {**payload["meta"], "completed_process_block_indices": [1], "complete": False}

@@ -61,6 +61,31 @@ with tempfile.TemporaryDirectory(prefix="fk_e2e_") as tmp:
     run("rows_off_metric_chunks", {"metric_chunk_dir": "metric_chunks"})
     per_batch = max(1, rows_shuffles // 100)
     run("rows_on", {"row_dir": "rows", "metric_chunk_dir": "metric_chunks"}, {"target_batches": 100, "min_shuffles_per_batch": per_batch}, {"resolution_delta": 0.5})
+    # BASELINE config 3 through the same command: k = 4, the default 5 160-strategy grid, 10^8 games (configs/bench_config3.yaml)
+    base3 = yaml.safe_load((ROOT / "configs" / "bench_config3.yaml").read_text())
+
+    def run3(name, sim_extra):
+        cfg = json.loads(json.dumps(base3))
+        cfg["io"]["results_dir_prefix"] = str(Path(tmp) / name)
+        cfg["sim"].update(sim_extra)
+        path = Path(tmp) / f"{name}.yaml"
+        path.write_text(yaml.safe_dump(cfg))
+        for key in acc: acc[key] = 0
+        t0 = time.perf_counter()
+        main(["--config", str(path), "--log-level", "WARNING", "run", "--metrics"])
+        wall = time.perf_counter() - t0
+        plan = json.loads(next((Path(tmp)).glob(f"{name}_seed_0/4_players/simulation_workload_plan.json")).read_text())
+        games = plan["required_games"]
+        out["runs"][name] = {"config": "configs/bench_config3.yaml (k=4, 5 160-strategy grid, root seed 0)", "games": games,
+                             "shuffles": plan["required_shuffles"], "wall_s": wall, "games_per_s": games / wall, "engine_s": acc["engine_s"],
+                             "engine_calls": acc["calls"], "host_s": wall - acc["engine_s"], "host_share": (wall - acc["engine_s"]) / wall}
+        print(name, json.dumps(out["runs"][name]), flush=True)
+    run3("config3_warm", {})
+    del out["runs"]["config3_warm"]
+    run3("config3_rows_off", {})
+    run3("config3_rows_off_metric_chunks", {"metric_chunk_dir": "metric_chunks"})
+for rec in out["runs"].values():
+    rec.setdefault("host_share", rec["host_s"] / rec["wall_s"])
 r = out["runs"]
 out["host_bottleneck"] = ("rows on: one parquet file + one manifest line per shuffle of 32 games (the reference's row-shard format, "
                           "run_tournament.py:530-558): %.2f ms of host wall time per shard, %.2f ms of it Arrow conversion (one per 1 024 "
