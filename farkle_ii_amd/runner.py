@@ -38,7 +38,7 @@ from .distributed import barrier, gather_objects, reduce_tally, shard_shuffle_ra
 from .engine import get_engine
 from .game_profile import GameProfile
 from .all_player import all_player_batch_table
-from .backend import SEAT_RATIO_COLS, SEAT_STAT_COLS
+from .backend import COL_ATTEMPTED, COL_COMPLETED, COL_SAFETY, COL_SQ_SUMS, COL_SUMS, COL_WINS, SEAT_RATIO_COLS, SEAT_STAT_COLS
 from .rows import OUTCOME_SCHEMA_VERSION, TOURNAMENT_METHOD_VERSION
 from .strategies import (STRATEGY_TUPLE_FIELDS, FavorDiceOrScore, ThresholdStrategy, generate_strategy_grid,
                          prepare_public_helper_strategies, strategy_tuple)
@@ -116,17 +116,22 @@ def build_strategy_manifest(strategies: Sequence[ThresholdStrategy]):
     """Manifest frame mapping strategy ids to attributes (strategies.py:725-748)."""
     import pandas as pd
 
-    rows: dict[int, dict[str, Any]] = {}
-    for s in strategies:
-        if s.strategy_id is None or int(s.strategy_id) in rows:
+    seen: set[int] = set()
+    tuples, id_col, str_col = [], [], []
+    for s in strategies:  # first occurrence of every id, columns assembled once (a dict per strategy + DataFrame(list of dicts): 25 ms per 5 160)
+        if s.strategy_id is None or int(s.strategy_id) in seen:
             continue
-        attrs = dict(zip(STRATEGY_TUPLE_FIELDS, strategy_tuple(s)))
-        attrs["strategy_id"] = int(s.strategy_id)
-        attrs["strategy_str"] = str(s)
-        if isinstance(attrs["favor_dice_or_score"], FavorDiceOrScore):
-            attrs["favor_dice_or_score"] = attrs["favor_dice_or_score"].value
-        rows[int(s.strategy_id)] = attrs
-    frame = pd.DataFrame(rows.values())
+        seen.add(int(s.strategy_id))
+        tuples.append(strategy_tuple(s))
+        id_col.append(int(s.strategy_id))
+        str_col.append(str(s))
+    columns = {name: list(col) for name, col in zip(STRATEGY_TUPLE_FIELDS, zip(*tuples))} if tuples else {}
+    if "favor_dice_or_score" in columns:
+        columns["favor_dice_or_score"] = [v.value if isinstance(v, FavorDiceOrScore) else v for v in columns["favor_dice_or_score"]]
+    if tuples:
+        columns["strategy_id"] = id_col
+        columns["strategy_str"] = str_col
+    frame = pd.DataFrame(columns)
     if not frame.empty:
         frame["strategy_id"] = frame["strategy_id"].astype("Int32")
         frame = frame.sort_values("strategy_id", kind="mergesort").reset_index(drop=True)
@@ -682,44 +687,56 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
 
         _write_parquet_atomic(lag_sums_table(result["lag_summary"], ids, cfg.sim.seed, n), cfg.rng_lag_sums_path(n))
         _write_parquet_atomic(lag_stats_table(result["lag_summary"], ids, n), cfg.rng_lag_stats_path(n))
-    wins, sums, sqs = rt.tally_to_counters(result["tally"], ids, n)
-    # (A) summary parquet, (B) expanded metrics parquet — column order as in runner.py:1612-1712
-    summary, metrics_rows = [], []
-    for strat in sorted(wins.attempted_exposures, key=str):
-        w = int(wins.get(strat, 0))
-        attempted = int(wins.attempted_exposures[strat])
-        if attempted <= 0:
-            continue
-        completed = int(wins.completed_exposures[strat])
-        safety = int(wins.safety_limit_exposures[strat])
-        row: dict[str, Any] = {"strategy": strat, "wins": float(w), "attempted_exposures": attempted, "completed_exposures": completed,
-                               "safety_limit_exposures": safety, "losses": attempted - w, "win_rate_per_attempt": w / attempted,
-                               "win_rate": w / attempted, "win_rate_given_completion": w / completed if completed else float("nan"),
-                               "safety_limit_exposure_rate": safety / attempted}
-        if cfg.sim.expanded_metrics:
-            for label in rt.METRIC_LABELS:
-                row[f"mean_{label}"] = (sums[label].get(strat, 0.0) / w) if w > 0 else 0.0
-        summary.append(row)
-        if cfg.sim.expanded_metrics:
-            base: dict[str, Any] = {"strategy": strat, "wins": w, "total_games_strat": attempted, "attempted_exposures": attempted,
-                                    "completed_exposures": completed, "safety_limit_exposures": safety, "losses": attempted - w,
-                                    "win_rate_per_attempt": w / attempted, "win_rate": w / attempted,
-                                    "win_rate_given_completion": w / completed if completed else float("nan"),
-                                    "safety_limit_exposure_rate": safety / attempted}
-            for label in rt.METRIC_LABELS:
-                s_val, q_val = sums[label].get(strat, 0.0), sqs[label].get(strat, 0.0)
-                mean = (s_val / w) if w > 0 else 0.0
-                base[f"sum_{label}"] = float(s_val)
-                base[f"sq_sum_{label}"] = float(q_val)
-                base[f"mean_{label}"] = float(mean)
-                base[f"var_{label}"] = float(max(q_val / w - mean**2, 0.0)) if w > 0 else 0.0
-            base["expected_score"] = sums["winning_score"].get(strat, 0.0) / attempted
-            metrics_rows.append(base)
+    # (A) summary parquet, (B) expanded metrics parquet — column order, types and values as in runner.py:1612-1712, built column by
+    # column from the tally (the per-strategy dict loop cost 25 us per strategy and table: 140 ms of a 330-ms config-3 run).  Rows in
+    # the reference's order: strategies sorted by the STRING of their id, those without an attempted exposure left out.
+    tally = np.asarray(result["tally"], dtype=np.int64)
+    ids_arr = np.asarray(ids, dtype=np.int64)
+    order = np.array(sorted(range(len(ids)), key=lambda i: str(ids[i])), dtype=np.int64)
+    order = order[tally[order, COL_ATTEMPTED] > 0]
+    t = tally[order]
+    strat_col = ids_arr[order]
+    w_i, attempted, completed, safety = t[:, COL_WINS], t[:, COL_ATTEMPTED], t[:, COL_COMPLETED], t[:, COL_SAFETY]
+    w_f = w_i.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rate = w_f / attempted  # (int / int in Python = the float64 quotient of the two integers, as here: both below 2^53)
+        rate_completed = np.where(completed > 0, w_f / np.where(completed > 0, completed, 1), np.nan)
+        safety_rate = safety.astype(np.float64) / attempted
+        has_win = w_i > 0
+        w_safe = np.where(has_win, w_f, 1.0)
+        label_sum = {label: t[:, COL_SUMS + j].astype(np.float64) for j, label in enumerate(rt.METRIC_LABELS)}
+        label_sq = {label: t[:, COL_SQ_SUMS + j].astype(np.float64) for j, label in enumerate(rt.METRIC_LABELS)}
+        label_mean = {label: np.where(has_win, label_sum[label] / w_safe, 0.0) for label in rt.METRIC_LABELS}
+    summary_cols: dict[str, Any] = {"strategy": strat_col, "wins": w_f, "attempted_exposures": attempted, "completed_exposures": completed,
+                                    "safety_limit_exposures": safety, "losses": attempted - w_i, "win_rate_per_attempt": rate,
+                                    "win_rate": rate, "win_rate_given_completion": rate_completed, "safety_limit_exposure_rate": safety_rate}
+    metrics_cols: dict[str, Any] = {}
+    if cfg.sim.expanded_metrics:
+        for label in rt.METRIC_LABELS:
+            summary_cols[f"mean_{label}"] = label_mean[label]
+        metrics_cols = {"strategy": strat_col, "wins": w_i, "total_games_strat": attempted, "attempted_exposures": attempted,
+                        "completed_exposures": completed, "safety_limit_exposures": safety, "losses": attempted - w_i,
+                        "win_rate_per_attempt": rate, "win_rate": rate, "win_rate_given_completion": rate_completed,
+                        "safety_limit_exposure_rate": safety_rate}
+        for label in rt.METRIC_LABELS:
+            mean = label_mean[label]
+            # mean ** 2 stays Python's float power (the reference's expression, runner.py:1690): C pow(x, 2) is not guaranteed to round
+            # like x * x, and the column is compared bit for bit with the reference's file
+            mean_sq = np.array([m ** 2 for m in mean.tolist()], dtype=np.float64)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                var = np.where(has_win, np.maximum(label_sq[label] / w_safe - mean_sq, 0.0), 0.0)
+            metrics_cols[f"sum_{label}"] = label_sum[label]
+            metrics_cols[f"sq_sum_{label}"] = label_sq[label]
+            metrics_cols[f"mean_{label}"] = mean
+            metrics_cols[f"var_{label}"] = var
+        metrics_cols["expected_score"] = label_sum["winning_score"] / attempted
+    summary = len(order) > 0
+    metrics_rows = summary and bool(metrics_cols)
     if summary:
-        _write_parquet_atomic(pa.Table.from_pylist(summary), n_dir / f"{n}p_checkpoint.parquet")
+        _write_parquet_atomic(pa.table(summary_cols), n_dir / f"{n}p_checkpoint.parquet")
         sidecars.write("checkpoint_summary", n_dir / f"{n}p_checkpoint.parquet", sources=[ckpt_path])
     if metrics_rows:
-        _write_parquet_atomic(pa.Table.from_pylist(metrics_rows), cfg.metrics_path(n))
+        _write_parquet_atomic(pa.table(metrics_cols), cfg.metrics_path(n))
         sidecars.write("metrics_summary", cfg.metrics_path(n), sources=[ckpt_path])
     # the completion stamp, in the reference's shape (write_simulation_done, simulation/runner.py:685-743 -> write_stage_done,
     # utils/stage_completion.py:391-512): the simulation contract at the TOP level, where ingest reads it (ingest.py:191-215)
