@@ -1156,7 +1156,7 @@ int fk_init(int device_ordinal, fk_ctx **out) {
         }
     }
     // score table (fk_device.h): 512 KiB, built by one small kernel, read by every roll of the game kernel
-    if (ensure(c, c->score_lut, SCORE_LUT_KEYS * sizeof(uint16_t)) != FK_OK) {
+    if (ensure(c, c->score_lut, SCORE_LUT_KEYS * sizeof(uint32_t)) != FK_OK) {
         fk_destroy(c);
         return FK_ERR_HIP;
     }
@@ -1165,7 +1165,7 @@ int fk_init(int device_ordinal, fk_ctx **out) {
         return FK_ERR_HIP;
     }
     hipLaunchKernelGGL(fk_score_lut_kernel, dim3(SCORE_LUT_KEYS / 256), dim3(256), 0, c->stream,
-                       static_cast<uint16_t *>(c->score_lut.p));
+                       static_cast<uint32_t *>(c->score_lut.p));
     hipLaunchKernelGGL(fk_discard_lut_kernel, dim3(DISCARD_LUT_KEYS / 256), dim3(256), 0, c->stream,
                        static_cast<uint8_t *>(c->discard_lut.p));
     {
@@ -1568,7 +1568,7 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
 
         PlayArgs pa{};
         pa.strat = static_cast<const uint2 *>(c->strat.p);
-        pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
+        pa.score_lut = static_cast<const uint32_t *>(c->score_lut.p);
         pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
         pa.perm_T = static_cast<const uint16_t *>(CSET(c).perm.p);
         pa.perm_slots = slots;
@@ -1799,7 +1799,7 @@ int fk_play_games(fk_ctx *c, const fk_coord *coords, int64_t n_games, const fk_s
 
     PlayArgs pa{};
     pa.strat = static_cast<const uint2 *>(c->strat.p);
-    pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
+    pa.score_lut = static_cast<const uint32_t *>(c->score_lut.p);
     pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
     pa.lds_tables = static_cast<const uint8_t *>(c->lds_tables.p);
     pa.seat_strategy = static_cast<const int32_t *>(c->seatlist.p);
@@ -1972,7 +1972,7 @@ int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_
             }
             PlayArgs pa{};
             pa.strat = static_cast<const uint2 *>(c->strat.p);
-            pa.score_lut = static_cast<const uint16_t *>(c->score_lut.p);
+            pa.score_lut = static_cast<const uint32_t *>(c->score_lut.p);
             pa.discard_lut = static_cast<const uint8_t *>(c->discard_lut.p);
             pa.lds_tables = static_cast<const uint8_t *>(c->lds_tables.p);
             pa.game_block = sas[i].game_row; // the kernel wants table rows: seat s of a game plays strategy 2 * row + s
@@ -2255,7 +2255,7 @@ int fk_debug_score(fk_ctx *c, int64_t n, const uint8_t *faces, const int32_t *le
     hipLaunchKernelGGL(fk_dbg_score_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n,
                        static_cast<const uint8_t *>(c->dbg[0].p), static_cast<const int32_t *>(c->dbg[1].p),
                        static_cast<const int32_t *>(c->dbg[2].p), static_cast<const uint2 *>(c->dbg[3].p),
-                       static_cast<const uint16_t *>(c->score_lut.p), static_cast<const uint8_t *>(c->discard_lut.p),
+                       static_cast<const uint32_t *>(c->score_lut.p), static_cast<const uint8_t *>(c->discard_lut.p),
                        static_cast<int32_t *>(c->dbg[4].p));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->dbg[4].p, sz[4], hipMemcpyDeviceToHost, c->stream));

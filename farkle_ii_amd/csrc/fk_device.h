@@ -387,6 +387,21 @@ __host__ __device__ inline uint16_t score_lut_entry(uint32_t key) {
                       (((uint32_t)r.used == n ? 1u : 0u) << 15));
 }
 
+// The kernels' score table holds 32-bit entries: the low half is the u16 entry above with bit 15 repurposed (no reader ever used "all dice
+// used") as "the roll has lone 1s or 5s"; the high half is the ROLL's share of the discard table's key, already in place (DKEY_* below):
+//   [17:16] min(lone fives, 2)   [19:18] min(lone ones, 2)   [28:26] min(score / 50, 7)
+// so that the key of a roll is (entry >> 16) | (strategy bits & SF_DISCARD_KEY_BITS) | vmin << 4 | cmin << 7: nine full-rate and five
+// half-rate vector instructions where round 4 assembled it from the decoded fields with 25 (profiles/r05_valu_issue_rates.txt prices them).
+constexpr uint32_t SE_SINGLES = 1u << 15;
+
+__host__ __device__ inline uint32_t score_lut_entry32(uint32_t key) {
+    const uint32_t e = score_lut_entry(key);
+    if (e == 0u) return 0u;
+    const uint32_t raw50 = e & 63u, sf = (e >> 9) & 7u, so = (e >> 12) & 7u;
+    const uint32_t keypart = (sf < 2u ? sf : 2u) | ((so < 2u ? so : 2u) << 2) | ((raw50 < 7u ? raw50 : 7u) << 10);
+    return (e & 0x7fffu) | (((sf | so) != 0u) ? SE_SINGLES : 0u) | (keypart << 16);
+}
+
 __host__ __device__ inline RawScore raw_from_lut(uint32_t e) {
     RawScore r;
     r.score = (int32_t)((e & 63u) * 50u);
@@ -401,15 +416,18 @@ __host__ __device__ inline RawScore raw_from_lut(uint32_t e) {
 //   x = score_threshold (i32)
 //   y = bits 0..7 dice_threshold (i8) | flag bits from 8
 // ----------------------------------------------------------------------------------------
+// (round 5: smart_one, require_both and favor_score sit at bits 13, 14, 15 — exactly where the discard table's key wants them, so the
+// strategy's share of that key is `bits & SF_DISCARD_KEY_BITS`, one instruction per roll; see DKEY_* below)
 enum : uint32_t {
     SF_SMART_FIVE = 1u << 8,
-    SF_SMART_ONE = 1u << 9,
+    SF_AUTO_HOT = 1u << 9,
     SF_CONSIDER_SCORE = 1u << 10,
     SF_CONSIDER_DICE = 1u << 11,
-    SF_REQUIRE_BOTH = 1u << 12,
-    SF_AUTO_HOT = 1u << 13,
-    SF_RUN_UP = 1u << 14,
-    SF_FAVOR_SCORE = 1u << 15
+    SF_RUN_UP = 1u << 12,
+    SF_SMART_ONE = 1u << 13,
+    SF_REQUIRE_BOTH = 1u << 14,
+    SF_FAVOR_SCORE = 1u << 15,
+    SF_DISCARD_KEY_BITS = SF_SMART_ONE | SF_REQUIRE_BOTH | SF_FAVOR_SCORE
 };
 
 struct Strat {
@@ -488,6 +506,8 @@ constexpr uint32_t NIB_H = 0x88888888u, NIB_1 = 0x11111111u;
 // The inputs of the discard choice, reduced to the few values it really depends on.
 struct DiscardQuery {
     uint32_t sf, m1;     // lone fives / lone ones that may be returned (0..2 each; ones only with smart_one)
+    uint32_t so;         // lone ones of the roll whatever the strategy (the table key carries them and the smart_one flag apart)
+    bool smart_one;
     uint32_t vmin, cmin; // thresholds in candidate units (0..7 / 0..5), see above
     uint32_t r15;        // min(raw score / 50, 15): the candidate with v == raw score / 50 would score 0 (score_lister :262)
     bool rb, fav;        // require_both, favor score
@@ -498,6 +518,8 @@ __host__ __device__ inline DiscardQuery discard_query(const RawScore raw, int32_
     DiscardQuery q;
     const uint32_t sf = (uint32_t)raw.sf, so = (uint32_t)raw.so;
     q.sf = sf;
+    q.so = so;
+    q.smart_one = s.has(SF_SMART_ONE);
     q.m1 = s.has(SF_SMART_ONE) ? so : 0u;
     q.eligible = s.has(SF_SMART_FIVE) & (raw.used != n) & ((sf | so) != 0u); // :433
     const bool cs = s.has(SF_CONSIDER_SCORE), cd = s.has(SF_CONSIDER_DICE);
@@ -537,19 +559,27 @@ __host__ __device__ inline uint32_t discard_choice(uint32_t sf, uint32_t m1, uin
     return take ? (((D5 >> l4) & 3u) | (((D1 >> l4) & 3u) << 2)) : 0u;
 }
 
-// Discard table: the choice above for every (sf, m1, vmin, cmin, r15, rb, fav), 2^16 one-byte entries (64 KiB, built on
-// the device once per context by running discard_choice on every key).  Key layout:
-//   [1:0] min(sf, 2)  [3:2] min(m1, 2)  [6:4] vmin  [9:7] cmin  [13:10] r15  [14] require_both  [15] favor score
+// Discard table: the choice above for every (sf, so, vmin, cmin, r7, smart_one, rb, fav), 2^16 one-byte entries (64 KiB, built on
+// the device once per context by running discard_choice on every key).  Key layout (round 5):
+//   [1:0] min(lone fives, 2)  [3:2] min(lone ones, 2)  [6:4] vmin  [9:7] cmin  [12:10] r7 = min(raw score / 50, 7)
+//   [13] smart_one  [14] require_both  [15] favor score                       (= the strategy's flag bits, SF_DISCARD_KEY_BITS)
+// The lone ones count only under smart_one (m1 = smart_one ? so : 0): the TABLE applies that, so the roll's part of the key (bits 3:0
+// and 12:10) depends on the roll alone and rides in the score table's entry (score_lut_entry32).  r7: a candidate scores 0 iff its
+// discarded points v (<= 6) equal the raw score / 50, so every raw score of 350 and more behaves like 350 (the LDS image always had r7).
 constexpr uint32_t DISCARD_LUT_KEYS = 1u << 16;
+constexpr uint32_t DKEY_VMIN_SHIFT = 4, DKEY_CMIN_SHIFT = 7, DKEY_R7_SHIFT = 10;
 
 __host__ __device__ inline uint32_t discard_key(const DiscardQuery &q) {
-    return (q.sf < 2u ? q.sf : 2u) | ((q.m1 < 2u ? q.m1 : 2u) << 2) | (q.vmin << 4) | (q.cmin << 7) | (q.r15 << 10) |
-           ((q.rb ? 1u : 0u) << 14) | ((q.fav ? 1u : 0u) << 15);
+    const uint32_t r7 = q.r15 < 7u ? q.r15 : 7u, so = q.so;
+    const bool smart_one = q.smart_one;
+    return (q.sf < 2u ? q.sf : 2u) | ((so < 2u ? so : 2u) << 2) | (q.vmin << DKEY_VMIN_SHIFT) | (q.cmin << DKEY_CMIN_SHIFT) | (r7 << DKEY_R7_SHIFT) |
+           (smart_one ? (uint32_t)SF_SMART_ONE : 0u) | (q.rb ? (uint32_t)SF_REQUIRE_BOTH : 0u) | (q.fav ? (uint32_t)SF_FAVOR_SCORE : 0u);
 }
 
 __host__ __device__ inline uint8_t discard_lut_entry(uint32_t key) {
-    return (uint8_t)discard_choice(key & 3u, (key >> 2) & 3u, (key >> 4) & 7u, (key >> 7) & 7u, (key >> 10) & 15u,
-                                   ((key >> 14) & 1u) != 0u, ((key >> 15) & 1u) != 0u);
+    const uint32_t so = (key >> 2) & 3u, r7 = (key >> DKEY_R7_SHIFT) & 7u;
+    return (uint8_t)discard_choice(key & 3u, (key & SF_SMART_ONE) ? so : 0u, (key >> DKEY_VMIN_SHIFT) & 7u, (key >> DKEY_CMIN_SHIFT) & 7u,
+                                   r7 < 7u ? r7 : 15u, (key & SF_REQUIRE_BOTH) != 0u, (key & SF_FAVOR_SCORE) != 0u);
 }
 
 __host__ __device__ inline RollResult apply_discards(const RawScore raw, uint32_t choice) {
@@ -573,9 +603,9 @@ __host__ __device__ inline RollResult default_score(uint32_t counts, int32_t n, 
 }
 
 // 3-bit-packed counts -> score table (the kernels)
-__device__ inline RollResult default_score_lut(const uint16_t *lut, const uint8_t *dlut, uint32_t key, int32_t n, int32_t turn_pre,
+__device__ inline RollResult default_score_lut(const uint32_t *lut, const uint8_t *dlut, uint32_t key, int32_t n, int32_t turn_pre,
                                                const Strat &s) {
-    const RawScore raw = raw_from_lut(lut[key]);
+    const RawScore raw = raw_from_lut(lut[key] & 0xffffu);
     const DiscardQuery q = discard_query(raw, n, turn_pre, s);
     return apply_discards(raw, q.eligible ? (uint32_t)dlut[discard_key(q)] : 0u);
 }
@@ -615,6 +645,8 @@ __host__ __device__ inline DiscardQuery discard_query50(uint32_t entry, int32_t 
     DiscardQuery q;
     const uint32_t raw50 = entry & 63u, used = (entry >> 6) & 7u, sf = (entry >> 9) & 7u, so = (entry >> 12) & 7u;
     q.sf = sf;
+    q.so = so;
+    q.smart_one = s.has(SF_SMART_ONE);
     q.m1 = s.has(SF_SMART_ONE) ? so : 0u;
     q.eligible = s.has(SF_SMART_FIVE) & ((int32_t)used != n) & ((sf | so) != 0u); // :433
     const bool cs = s.has(SF_CONSIDER_SCORE), cd = s.has(SF_CONSIDER_DICE);
@@ -635,12 +667,36 @@ __host__ __device__ inline Roll50 apply_discards50(uint32_t entry, uint32_t choi
     return Roll50{(int32_t)(entry & 63u) - d5 - 2 * d1, (int32_t)((entry >> 6) & 7u) - d5 - d1, d5, d1};
 }
 
-// 3-bit-packed counts -> score table -> discard table (the game kernel's path), units of 50
-__host__ __device__ inline Roll50 default_score_lut50(const uint16_t *lut, const uint8_t *dlut, uint32_t key, int32_t n, int32_t pre50,
-                                                      const Strat50 &s) {
-    const uint32_t e = lut[key];
+// 3-bit-packed counts -> score table -> discard table, units of 50: the readable form (every field decoded, the key assembled from the
+// query) ...
+__host__ __device__ inline Roll50 default_score_lut50_decoded(const uint32_t *lut, const uint8_t *dlut, uint32_t key, int32_t n, int32_t pre50,
+                                                              const Strat50 &s) {
+    const uint32_t e = lut[key] & 0xffffu;
     const DiscardQuery q = discard_query50(e, n, pre50, s);
     return apply_discards50(e, q.eligible ? (uint32_t)dlut[discard_key(q)] : 0u);
+}
+
+// ... and the game kernels' path (round 5): the same key from parts that are already in place.  The roll's share comes with the
+// entry (high half), the strategy's share is three of its flag bits, the two thresholds are clamped sums shifted into their fields:
+//     vmin = consider_score ? clamp(pre50 + raw50 - thr50 + 1, 0, 7) : 0        cmin = consider_dice ? clamp(dthr - (n - used) + 1, 0, 5) : 0
+// (tests/native/device_header_host_check.hip runs it against the loop form of the rule on every multiset x flag set x threshold).
+__host__ __device__ inline Roll50 default_score_lut50(const uint32_t *lut, const uint8_t *dlut, uint32_t key, int32_t n, int32_t pre50,
+                                                      const Strat50 &s) {
+    const uint32_t e = lut[key];
+    const int32_t raw50 = (int32_t)(e & 63u), used = (int32_t)((e >> 6) & 7u);
+    const bool eligible = s.has(SF_SMART_FIVE) & ((e & SE_SINGLES) != 0u) & (used != n); // scoring.py:433
+    uint32_t choice = 0u;
+    if (eligible) {
+        int32_t v = pre50 + raw50 - s.thr50;             // vmin - 1 before clamping
+        v = v < -1 ? -1 : (v > 6 ? 6 : v);
+        int32_t c = s.dice_thr() - n + used;              // cmin - 1 before clamping
+        c = c < -1 ? -1 : (c > 4 ? 4 : c);
+        const uint32_t vpart = s.has(SF_CONSIDER_SCORE) ? (uint32_t)(v + 1) << DKEY_VMIN_SHIFT : 0u;
+        const uint32_t cpart = s.has(SF_CONSIDER_DICE) ? (uint32_t)(c + 1) << DKEY_CMIN_SHIFT : 0u;
+        choice = dlut[(e >> 16) | (s.bits & SF_DISCARD_KEY_BITS) | vpart | cpart];
+    }
+    const int32_t d5 = (int32_t)(choice & 3u), d1 = (int32_t)((choice >> 2) & 3u);
+    return Roll50{raw50 - d5 - 2 * d1, used - d5 - d1, d5, d1};
 }
 
 // ----------------------------------------------------------------------------------------

@@ -130,7 +130,7 @@ struct SeedArgs {
 
 struct PlayArgs {
     const uint2 *strat;          // [S] packed strategies
-    const uint16_t *score_lut;   // [SCORE_LUT_KEYS] score table (fk_device.h)
+    const uint32_t *score_lut;   // [SCORE_LUT_KEYS] score table, 32-bit entries (fk_device.h: score_lut_entry32)
     const uint8_t *discard_lut;  // [DISCARD_LUT_KEYS] discard table (fk_device.h)
     const uint16_t *perm_T;      // blocked permutations (MODE_PERM), see perm_at()
     uint32_t perm_slots;
@@ -1729,9 +1729,9 @@ __device__ inline uint32_t pack_faces(const uint8_t *f, int32_t n) {
     return c;
 }
 
-__global__ void fk_score_lut_kernel(uint16_t *lut) { // the score table of fk_device.h, built on the device once per context
+__global__ void fk_score_lut_kernel(uint32_t *lut) { // the score table of fk_device.h, built on the device once per context
     const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key < SCORE_LUT_KEYS) lut[key] = score_lut_entry(key);
+    if (key < SCORE_LUT_KEYS) lut[key] = score_lut_entry32(key);
 }
 
 __global__ void fk_discard_lut_kernel(uint8_t *lut) { // the discard table of fk_device.h
@@ -1740,7 +1740,7 @@ __global__ void fk_discard_lut_kernel(uint8_t *lut) { // the discard table of fk
 }
 
 __global__ void fk_dbg_score_kernel(int64_t n, const uint8_t *faces, const int32_t *len, const int32_t *pre,
-                                    const uint2 *strat, const uint16_t *lut, const uint8_t *dlut, int32_t *out) {
+                                    const uint2 *strat, const uint32_t *lut, const uint8_t *dlut, int32_t *out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Strat50 s{(int32_t)strat[i].x, strat[i].y}; // packed strategies carry ceil(score_threshold / 50)

@@ -67,13 +67,19 @@ def _atomic_write_bytes(path: Path, content: bytes) -> None:
     os.replace(tmp, path)
 
 
-def _write_parquet_atomic(table, path: Path) -> None:
+def _write_parquet_atomic(table, path: Path, **writer_options) -> None:
     import pyarrow.parquet as pq
 
     path.parent.mkdir(parents=True, exist_ok=True)
     tmp = path.with_name(path.name + ".tmp")
-    pq.write_table(table, tmp)
+    pq.write_table(table, tmp, **writer_options)
     os.replace(tmp, path)
+
+
+# Metric chunk files: 11 x S rows of eight columns per deterministic batch.  Dictionary pages for the one string column only and no
+# column statistics (nothing reads them: the reference's reducer scans whole chunks, run_tournament.py:905-922) halve the encoding —
+# 15.1 -> 7.5 ms per 56 760-row chunk, same file size; the table content is what the artifact contract pins, not the page layout.
+_CHUNK_WRITER_OPTIONS = {"use_dictionary": ["metric"], "write_statistics": False}
 
 
 _HELPER = None
@@ -555,7 +561,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 if metric_chunk_dir is not None:
                     chunk = _metric_chunk_table(group[n], ids, k)
                     name = f"metrics_{b + 1:06d}.parquet"  # chunk / process-block indices count from 1 (run_tournament.py:1603-1642)
-                    _write_parquet_atomic(chunk, metric_chunk_dir / name)
+                    _write_parquet_atomic(chunk, metric_chunk_dir / name, **_CHUNK_WRITER_OPTIONS)
                     sidecars.write("metric_chunk", metric_chunk_dir / name)
                     first_sh, last_sh = b * spb, min((b + 1) * spb, plan.required_shuffles)
                     record = {"path": name, "rows": chunk.num_rows, "chunk_index": b + 1, "process_block_index": b + 1,

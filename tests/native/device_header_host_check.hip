@@ -16,7 +16,9 @@ using namespace fk;
 int main() {
     std::vector<uint8_t> dlut(DISCARD_LUT_KEYS);
     for (uint32_t k = 0; k < DISCARD_LUT_KEYS; ++k) dlut[k] = discard_lut_entry(k);
-    long cases = 0, bad_swar = 0, bad_table = 0, bad_lut = 0, multisets = 0;
+    std::vector<uint32_t> lut32(SCORE_LUT_KEYS);
+    for (uint32_t k = 0; k < SCORE_LUT_KEYS; ++k) lut32[k] = score_lut_entry32(k);
+    long cases = 0, bad_swar = 0, bad_table = 0, bad_lut = 0, multisets = 0, bad_fast = 0, fast_cases = 0;
     for (uint32_t key = 1; key < SCORE_LUT_KEYS; ++key) {
         uint32_t n = 0;
         bool ok = true;
@@ -30,6 +32,7 @@ int main() {
         const uint32_t nib = lut_key_to_nibbles(key);
         if (nibbles_to_lut_key(nib) != key) ++bad_lut;
         const RawScore raw = score_counts(nib), dec = raw_from_lut(score_lut_entry(key));
+        if ((lut32[key] & 0x7fffu) != ((uint32_t)score_lut_entry(key) & 0x7fffu)) ++bad_lut;
         if (raw.score != dec.score || raw.used != dec.used || raw.sf != dec.sf || raw.so != dec.so) ++bad_lut;
         for (uint32_t flags = 0; flags < 256; ++flags) {
             // the two combinations ThresholdStrategy.__post_init__ rejects (strategies.py:196-207) never reach a kernel:
@@ -48,11 +51,22 @@ int main() {
                         ++cases;
                         if (swar.score != want.score || swar.used != want.used || swar.d5 != want.d5 || swar.d1 != want.d1) ++bad_swar;
                         if (tab.score != want.score || tab.used != want.used || tab.d5 != want.d5 || tab.d1 != want.d1) ++bad_table;
+                        // 4. the game kernels' path (units of 50, 32-bit score entries carrying the roll's share of the discard key, the
+                        //    strategy's share = three flag bits) and its readable twin, for thresholds and turn scores that are multiples of 50
+                        if (pre % 50 == 0) {
+                            const Strat50 s50 = to_units50(s);
+                            const Roll50 fast = default_score_lut50(lut32.data(), dlut.data(), key, (int32_t)n, pre / 50, s50);
+                            const Roll50 slow = default_score_lut50_decoded(lut32.data(), dlut.data(), key, (int32_t)n, pre / 50, s50);
+                            ++fast_cases;
+                            if (fast.score50 * 50 != want.score || fast.used != want.used || fast.d5 != want.d5 || fast.d1 != want.d1) ++bad_fast;
+                            if (slow.score50 * 50 != want.score || slow.used != want.used || slow.d5 != want.d5 || slow.d1 != want.d1) ++bad_fast;
+                        }
                     }
                 }
             }
         }
     }
-    printf("multisets %ld cases %ld bad_swar %ld bad_table %ld bad_lut %ld\n", multisets, cases, bad_swar, bad_table, bad_lut);
-    return (multisets == 923 && bad_swar == 0 && bad_table == 0 && bad_lut == 0) ? 0 : 1;
+    printf("multisets %ld cases %ld bad_swar %ld bad_table %ld bad_lut %ld fast_cases %ld bad_fast %ld\n", multisets, cases, bad_swar, bad_table, bad_lut,
+           fast_cases, bad_fast);
+    return (multisets == 923 && bad_swar == 0 && bad_table == 0 && bad_lut == 0 && bad_fast == 0 && fast_cases > 0) ? 0 : 1;
 }

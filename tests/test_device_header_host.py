@@ -23,4 +23,4 @@ def test_swar_scorer_and_tables_match_loop_form_on_host(tmp_path):
                    capture_output=True, text=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "multisets 923" in out.stdout and "bad_swar 0 bad_table 0 bad_lut 0" in out.stdout
+    assert "multisets 923" in out.stdout and "bad_swar 0 bad_table 0 bad_lut 0" in out.stdout and "bad_fast 0" in out.stdout
