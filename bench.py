@@ -667,10 +667,10 @@ def main() -> None:
         # HBM bytes per launch from the PMC passes of the same launch shape (rocprofv3 cannot run inside this process):
         # profiles/r*_hbm_traffic.json carries the commit it was taken at; dropped when that is not an ancestor's kernel
         def kernel_of(shape: dict, k_seats: int) -> str:
-            """fk_play_hc_kernel launches are recognisable by their LDS size: 16 bytes per seat and lane (+ the 10 816-byte table
+            """fk_play_hc_kernel launches are recognisable by their LDS size: 16 bytes per seat and lane (+ the 12 656-byte table
             image), or 32 with the cold records in LDS (csrc/fk_play_hc.h); everything else is fk_play_kernel."""
             block, lds = shape.get("play_block"), shape.get("play_lds_bytes")
-            hc = bool(block) and lds in (block * 16 * k_seats, block * 16 * k_seats + 10816, block * 32 * k_seats)
+            hc = bool(block) and lds in (block * 16 * k_seats, block * 16 * k_seats + 12656, block * 32 * k_seats)
             return "fk_play_hc_kernel" if hc else "fk_play_kernel"
 
         dominant = kernel_of(t, int(wl.k)) if isinstance(getattr(wl, "k", None), int) else "fk_play_kernel"  # (sweep / H2H lines: per_k / k = 2)

@@ -425,45 +425,10 @@ bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const Launch
 }
 
 // LDS image of the score / discard tables (fk_play_hc.h), from the same __host__ __device__ functions that build the
-// global tables
+// global tables (fk_device.h: lt_build_image — also what tests/native/device_header_host_check.hip checks the LDS path on)
 std::vector<uint8_t> build_lds_tables() {
     std::vector<uint8_t> img(LT_BYTES, 0);
-    uint32_t *pair = reinterpret_cast<uint32_t *>(img.data() + LT_PAIR_OFF);
-    uint16_t *score = reinterpret_cast<uint16_t *>(img.data() + LT_SCORE_OFF);
-    auto hsum = [](uint32_t h) { return (h & 7u) + ((h >> 3) & 7u) + ((h >> 6) & 7u); };
-    auto valid = [&](uint32_t h) { return (h & 7u) <= 6u && ((h >> 3) & 7u) <= 6u && ((h >> 6) & 7u) <= 6u && hsum(h) <= 6u; };
-    std::vector<uint32_t> order;
-    for (uint32_t h = 0; h < 512; ++h)
-        if (valid(h)) order.push_back(h);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return hsum(x) < hsum(y); });
-    uint32_t rank[512] = {0}, upto[8] = {0};
-    for (uint32_t i = 0; i < order.size(); ++i) {
-        rank[order[i]] = i;
-        for (uint32_t t = hsum(order[i]); t <= 6; ++t) upto[t] += 1; // halves with at most t dice
-    }
-    uint32_t running = 0, base[512] = {0};
-    for (uint32_t h = 0; h < 512; ++h)
-        if (valid(h)) {
-            base[h] = running;
-            running += upto[6u - hsum(h)];
-        }
-    // running == 924: every multiset of at most six dice (the empty one included)
-    for (uint32_t h = 0; h < 512; ++h) pair[h] = valid(h) ? (base[h] | (rank[h] << 16)) : 0u;
-    for (uint32_t lo = 0; lo < 512; ++lo)
-        for (uint32_t hi = 0; hi < 512; ++hi)
-            if (valid(lo) && valid(hi) && hsum(lo) + hsum(hi) <= 6u) score[base[lo] + rank[hi]] = score_lut_entry(lo | (hi << 9));
-    uint8_t *disc = img.data() + LT_DISC_OFF;
-    for (uint32_t fav = 0; fav < 2; ++fav)
-        for (uint32_t rb = 0; rb < 2; ++rb)
-            for (uint32_t r7 = 0; r7 < 8; ++r7)
-                for (uint32_t cmin = 0; cmin < 6; ++cmin)
-                    for (uint32_t vmin = 0; vmin < 8; ++vmin)
-                        for (uint32_t m1 = 0; m1 < 3; ++m1)
-                            for (uint32_t sf = 0; sf < 3; ++sf) {
-                                const uint32_t idx = (((((fav * 2u + rb) * 8u + r7) * 6u + cmin) * 8u + vmin) * 9u) + m1 * 3u + sf;
-                                const uint32_t ch = discard_choice(sf, m1, vmin, cmin, r7, rb != 0u, fav != 0u) & 15u;
-                                disc[idx >> 1] |= (uint8_t)(ch << ((idx & 1u) * 4u));
-                            }
+    lt_build_image(img.data());
     return img;
 }
 
@@ -815,14 +780,22 @@ int finish_timers(fk_ctx *c) {
     if (c->clk_grid > 0) { // shader clock of the last game kernel: median over its blocks of d(s_memtime) / d(s_memrealtime) x 100 MHz
         std::vector<unsigned long long> h((size_t)c->clk_grid * 4);
         HIPCHK(c, hipMemcpy(h.data(), c->clk.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        std::vector<double> mhz;
+        std::vector<double> mhz, ends;
+        unsigned long long first = ~0ull;
         for (int b = 0; b < c->clk_grid; ++b) {
             const unsigned long long t0 = h[(size_t)b * 4], r0 = h[(size_t)b * 4 + 1], t1 = h[(size_t)b * 4 + 2], r1 = h[(size_t)b * 4 + 3];
-            if (r1 > r0 && t1 > t0) mhz.push_back(100.0 * (double)(t1 - t0) / (double)(r1 - r0));
+            if (r1 > r0 && t1 > t0) {
+                mhz.push_back(100.0 * (double)(t1 - t0) / (double)(r1 - r0));
+                ends.push_back((double)r1);
+                first = r0 < first ? r0 : first;
+            }
         }
         if (!mhz.empty()) {
             std::nth_element(mhz.begin(), mhz.begin() + (std::ptrdiff_t)(mhz.size() / 2), mhz.end());
             c->timing.play_clock_mhz = (int32_t)(mhz[mhz.size() / 2] + 0.5);
+            std::nth_element(ends.begin(), ends.begin() + (std::ptrdiff_t)(ends.size() / 2), ends.end());
+            c->timing.play_block_end_p50_ms = (float)((ends[ends.size() / 2] - (double)first) * 1e-5); // 100 MHz ticks -> ms
+            c->timing.play_block_end_max_ms = (float)((*std::max_element(ends.begin(), ends.end()) - (double)first) * 1e-5);
         }
         c->clk_grid = 0;
     }

@@ -710,29 +710,84 @@ __host__ __device__ inline Roll50 default_score_lut50(const uint32_t *lut, const
 //   score table u16[924]: the entry of fk_device.h's score table for that multiset
 //   discard table, 4 bits per entry: the choice of fk_device.h's discard_choice() for
 //               index = ((((fav * 2 + rb) * 8 + min(r15, 7)) * 6 + cmin) * 8 + vmin) * 9 + m1 * 3 + sf   (13 824 entries)
-constexpr uint32_t LT_PAIR_OFF = 0, LT_SCORE_OFF = 2048, LT_SCORE_N = 924, LT_DISC_OFF = LT_SCORE_OFF + 2 * LT_SCORE_N + 8 /* 3904 */,
-                   LT_DISC_N = 13824, LT_BYTES = LT_DISC_OFF + LT_DISC_N / 2 /* 10816 */;
+// (round 5) score entries are 32 bits wide: the low half as in the global table's entry (bit 15 = the roll has lone 1s or 5s), the high
+// half the roll's share of the DISCARD INDEX, already multiplied out:   [27:16] min(score / 50, 7) * 432 + min(lone fives, 2)
+//                                                                        [31:28] 3 * min(lone ones, 2)   (counts under smart_one only)
+// so that the index is that sum + (fav * 2 + rb) * 3456 + cmin * 72 + vmin * 9: two multiply-adds instead of the five of the nested form.
+constexpr uint32_t LT_PAIR_OFF = 0, LT_SCORE_OFF = 2048, LT_SCORE_N = 924, LT_DISC_OFF = LT_SCORE_OFF + 4 * LT_SCORE_N /* 5744 */,
+                   LT_DISC_N = 13824, LT_BYTES = LT_DISC_OFF + LT_DISC_N / 2 /* 12656 */;
 static_assert(LT_DISC_OFF % 16 == 0 && LT_BYTES % 16 == 0, "table image is copied in 16-byte pieces");
 
-__host__ __device__ inline uint32_t lt_discard_index(const DiscardQuery &q) {
-    const uint32_t r7 = q.r15 < 7u ? q.r15 : 7u, sf = q.sf < 2u ? q.sf : 2u, m1 = q.m1 < 2u ? q.m1 : 2u;
-    const uint32_t top = ((q.fav ? 2u : 0u) + (q.rb ? 1u : 0u)) * 8u + r7;
-    return ((top * 6u + q.cmin) * 8u + q.vmin) * 9u + m1 * 3u + sf;
+__host__ __device__ inline uint32_t lt_score_entry32(uint32_t key) {
+    const uint32_t e = score_lut_entry(key);
+    if (e == 0u) return 0u;
+    const uint32_t raw50 = e & 63u, sf = (e >> 9) & 7u, so = (e >> 12) & 7u;
+    const uint32_t part = (raw50 < 7u ? raw50 : 7u) * 432u + (sf < 2u ? sf : 2u), so3 = 3u * (so < 2u ? so : 2u);
+    return (e & 0x7fffu) | (((sf | so) != 0u) ? SE_SINGLES : 0u) | (part << 16) | (so3 << 28);
 }
 
 // score + discard choice of one roll from the LDS image (the kernels' path of default_score_lut50, same results)
-__device__ inline Roll50 default_score_lds50(const uint8_t *img, uint32_t key, int32_t n, int32_t pre50, const Strat50 &s) {
+__host__ __device__ inline Roll50 default_score_lds50(const uint8_t *img, uint32_t key, int32_t n, int32_t pre50, const Strat50 &s) {
     const uint32_t *pair = reinterpret_cast<const uint32_t *>(img + LT_PAIR_OFF);
     const uint32_t pa = pair[key & 511u], pb = pair[key >> 9];
-    const uint32_t e = reinterpret_cast<const uint16_t *>(img + LT_SCORE_OFF)[(pa & 0xffffu) + (pb >> 16)];
-    const DiscardQuery q = discard_query50(e, n, pre50, s);
+    const uint32_t e = reinterpret_cast<const uint32_t *>(img + LT_SCORE_OFF)[(pa & 0xffffu) + (pb >> 16)];
+    const int32_t raw50 = (int32_t)(e & 63u), used = (int32_t)((e >> 6) & 7u);
+    const bool eligible = s.has(SF_SMART_FIVE) & ((e & SE_SINGLES) != 0u) & (used != n); // scoring.py:433
     uint32_t choice = 0u;
-    if (q.eligible) {
-        const uint32_t di = lt_discard_index(q);
+    if (eligible) {
+        int32_t v = pre50 + raw50 - s.thr50; // vmin - 1 before clamping (see default_score_lut50)
+        v = v < -1 ? -1 : (v > 6 ? 6 : v);
+        int32_t c = s.dice_thr() - n + used;  // cmin - 1
+        c = c < -1 ? -1 : (c > 4 ? 4 : c);
+        const uint32_t vmin = s.has(SF_CONSIDER_SCORE) ? (uint32_t)(v + 1) : 0u, cmin = s.has(SF_CONSIDER_DICE) ? (uint32_t)(c + 1) : 0u;
+        const uint32_t so3 = s.has(SF_SMART_ONE) ? (e >> 28) : 0u;
+        const uint32_t strat = ((s.bits >> 14) & 3u) * 3456u; // (favor score * 2 + require_both) * 8 * 6 * 8 * 9: flags at bits 15, 14
+        const uint32_t di = ((e >> 16) & 0xfffu) + so3 + strat + cmin * 72u + vmin * 9u;
         choice = ((uint32_t)(img + LT_DISC_OFF)[di >> 1] >> ((di & 1u) * 4u)) & 15u;
     }
-    return apply_discards50(e, choice);
+    const int32_t d5 = (int32_t)(choice & 3u), d1 = (int32_t)((choice >> 2) & 3u);
+    return Roll50{raw50 - d5 - 2 * d1, used - d5 - d1, d5, d1};
 }
+// The image itself (LT_BYTES, zero-filled by the caller): pair table, 32-bit score entries in dense multiset order, 4-bit discard choices.
+inline void lt_build_image(uint8_t *img) {
+    uint32_t *pair = reinterpret_cast<uint32_t *>(img + LT_PAIR_OFF);
+    uint32_t *score = reinterpret_cast<uint32_t *>(img + LT_SCORE_OFF);
+    auto hsum = [](uint32_t h) { return (h & 7u) + ((h >> 3) & 7u) + ((h >> 6) & 7u); };
+    auto valid = [&](uint32_t h) { return (h & 7u) <= 6u && ((h >> 3) & 7u) <= 6u && ((h >> 6) & 7u) <= 6u && hsum(h) <= 6u; };
+    uint32_t order[512], n_order = 0;
+    for (uint32_t t = 0; t <= 6; ++t) // halves ordered by dice count first (stable in h)
+        for (uint32_t h = 0; h < 512; ++h)
+            if (valid(h) && hsum(h) == t) order[n_order++] = h;
+    uint32_t rank[512] = {0}, upto[8] = {0};
+    for (uint32_t i = 0; i < n_order; ++i) {
+        rank[order[i]] = i;
+        for (uint32_t t = hsum(order[i]); t <= 6; ++t) upto[t] += 1; // halves with at most t dice
+    }
+    uint32_t running = 0, base[512] = {0};
+    for (uint32_t h = 0; h < 512; ++h)
+        if (valid(h)) {
+            base[h] = running;
+            running += upto[6u - hsum(h)];
+        }
+    // running == 924: every multiset of at most six dice (the empty one included)
+    for (uint32_t h = 0; h < 512; ++h) pair[h] = valid(h) ? (base[h] | (rank[h] << 16)) : 0u;
+    for (uint32_t lo = 0; lo < 512; ++lo)
+        for (uint32_t hi = 0; hi < 512; ++hi)
+            if (valid(lo) && valid(hi) && hsum(lo) + hsum(hi) <= 6u) score[base[lo] + rank[hi]] = lt_score_entry32(lo | (hi << 9));
+    uint8_t *disc = img + LT_DISC_OFF;
+    for (uint32_t fav = 0; fav < 2; ++fav)
+        for (uint32_t rb = 0; rb < 2; ++rb)
+            for (uint32_t r7 = 0; r7 < 8; ++r7)
+                for (uint32_t cmin = 0; cmin < 6; ++cmin)
+                    for (uint32_t vmin = 0; vmin < 8; ++vmin)
+                        for (uint32_t m1 = 0; m1 < 3; ++m1)
+                            for (uint32_t sf = 0; sf < 3; ++sf) {
+                                const uint32_t idx = (((((fav * 2u + rb) * 8u + r7) * 6u + cmin) * 8u + vmin) * 9u) + m1 * 3u + sf;
+                                const uint32_t ch = discard_choice(sf, m1, vmin, cmin, r7, rb != 0u, fav != 0u) & 15u;
+                                disc[idx >> 1] |= (uint8_t)(ch << ((idx & 1u) * 4u));
+                            }
+}
+
 // Cold seat record of the hot / cold game kernel (fk_play_hc.h), three dwords.  The top bit of every counter field is a
 // guard bit: a count that reaches it raises FK_ERR_COUNTER_OVERFLOW (the host replays the call on fk_play_kernel, whose
 // fields are 16 bits wide) before the field can carry into its neighbour.

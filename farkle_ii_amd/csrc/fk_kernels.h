@@ -160,14 +160,22 @@ struct PlayArgs {
     uint4 *cold;                 // fk_play_hc_kernel: [resident lanes][k] cold seat records (fk_play_hc.h)
     const uint8_t *lds_tables;   // fk_play_hc_kernel, LT instances: the LDS image of the score / discard tables (LT_BYTES, fk_device.h)
     unsigned long long *clk;     // nullable (option "clock_stamps"): [grid][4] = s_memtime, s_memrealtime at the block's first and last
-                                 // instruction — the shader clock the launch really ran at (MI355X_MICROARCH.md, DVFS give-back item 6)
+                                 // instruction (zeroed before the launch) — the shader clock the launch really ran at (MI355X_MICROARCH.md, DVFS give-back item 6)
 };
 
-// One pair of stamps per block and end of the kernel: shader-clock ticks and the constant 100 MHz reference counter.
+// One pair of stamps per block and end of the kernel: shader-clock ticks and the constant 100 MHz reference counter.  The first
+// is the block's first wave's, the last is the LAST wave's to leave (the waves of a persistent block drain at different times).
 __device__ inline void clock_stamp(unsigned long long *clk, uint32_t which) {
-    if (clk && threadIdx.x == 0) {
-        clk[(size_t)blockIdx.x * 4u + 2u * which] = __builtin_amdgcn_s_memtime();
-        clk[(size_t)blockIdx.x * 4u + 2u * which + 1u] = __builtin_amdgcn_s_memrealtime();
+    if (!clk) return;
+    unsigned long long *slot = clk + (size_t)blockIdx.x * 4u + 2u * which;
+    if (which == 0u) {
+        if (threadIdx.x == 0) {
+            slot[0] = __builtin_amdgcn_s_memtime();
+            slot[1] = __builtin_amdgcn_s_memrealtime();
+        }
+    } else if ((threadIdx.x & 63u) == 0u) {
+        atomicMax(slot, (unsigned long long)__builtin_amdgcn_s_memtime());
+        atomicMax(slot + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
 

@@ -117,6 +117,9 @@ typedef struct {
                                   not in perm_ms / seed_ms */
     int32_t play_clock_mhz;    /* option "clock_stamps": shader clock of the call's last game kernel, measured inside it (median over
                                   its workgroups of d(s_memtime) / d(s_memrealtime) x 100 MHz); 0 = not measured */
+    float play_block_end_p50_ms, play_block_end_max_ms; /* same option, same kernel: when the median and the last of its workgroups
+                                  finished, from the first workgroup's start (100 MHz counter) — max - p50 is the launch's tail, the
+                                  stretch in which the chip drains behind the longest games */
 } fk_timing;
 
 typedef struct fk_ctx fk_ctx;

@@ -18,6 +18,8 @@ int main() {
     for (uint32_t k = 0; k < DISCARD_LUT_KEYS; ++k) dlut[k] = discard_lut_entry(k);
     std::vector<uint32_t> lut32(SCORE_LUT_KEYS);
     for (uint32_t k = 0; k < SCORE_LUT_KEYS; ++k) lut32[k] = score_lut_entry32(k);
+    std::vector<uint8_t> lds_image(LT_BYTES, 0); // the hot / cold kernels' LDS image of both tables
+    lt_build_image(lds_image.data());
     long cases = 0, bad_swar = 0, bad_table = 0, bad_lut = 0, multisets = 0, bad_fast = 0, fast_cases = 0;
     for (uint32_t key = 1; key < SCORE_LUT_KEYS; ++key) {
         uint32_t n = 0;
@@ -60,6 +62,9 @@ int main() {
                             ++fast_cases;
                             if (fast.score50 * 50 != want.score || fast.used != want.used || fast.d5 != want.d5 || fast.d1 != want.d1) ++bad_fast;
                             if (slow.score50 * 50 != want.score || slow.used != want.used || slow.d5 != want.d5 || slow.d1 != want.d1) ++bad_fast;
+                            // 5. the same roll through the LDS image (pair table -> dense multiset index -> 32-bit entry -> additive discard index)
+                            const Roll50 lds = default_score_lds50(lds_image.data(), key, (int32_t)n, pre / 50, s50);
+                            if (lds.score50 * 50 != want.score || lds.used != want.used || lds.d5 != want.d5 || lds.d1 != want.d1) ++bad_fast;
                         }
                     }
                 }

@@ -32,7 +32,7 @@ def po():
     return pyoracle
 
 
-LDS_TABLE_BYTES = 10816  # LT_BYTES of csrc/fk_play_hc.h
+LDS_TABLE_BYTES = 12656  # LT_BYTES of csrc/fk_device.h (32-bit score entries since round 5)
 
 
 FOUR_WAVE_BLOCK = {5: 256, 6: 512, 7: 1024}  # the register instances of k = 5 .. 7 run four waves per SIMD in these blocks

@@ -40,7 +40,8 @@ if __name__ == "__main__":
         t = eng.timing()
         print(f"grid={S} k={k} shuffles={n_sh} games={games}: wall {dt*1e3:.2f} ms ({games/dt/1e6:.1f} M games/s) | device {t['total_ms']:.2f} "
               f"play {t['play_ms']:.2f} seed {t['seed_ms']:.2f} perm {t['perm_ms']:.2f} ms | block {t['play_block']} grid {t['play_grid']} "
-              f"lds {t['play_lds_bytes']}", flush=True)
+              f"lds {t['play_lds_bytes']}" + (f" | clock {t['play_clock_mhz']} MHz blocks end p50 {t['play_block_end_p50_ms']:.2f} max "
+                                              f"{t['play_block_end_max_ms']:.2f} ms" if t.get("play_clock_mhz") else ""), flush=True)
         tl = r["tally"][0]
         assert (tl[:, 1] == n_sh).all() and (tl[:, 1] == tl[:, 2] + tl[:, 3]).all()
     if rows:
