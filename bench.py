@@ -148,7 +148,7 @@ class Tournament:
     def sample(self, eng):
         # measured R, T of SURVEY 8d over ALL games of one launch of the step's own size (every fk_play_kernel launch of the
         # process has the step's shape, so the rocprofv3 per-kernel average stays comparable): the all-seat statistics
-        res = eng.tournament(self.table, self.k, self.root, 0, self.shuffles, want_seat_stats=True)
+        res = eng.tournament(self.table, self.k, self.root, 0, self.shuffles, want_seat_stats=True, want_seat_ratios=False)
         games = self.shuffles * self.gps
         return work_from_seat_stats(res["seat_stats"], games, self.k), None, f"all {games} games of shuffles 0..{self.shuffles - 1} (all-seat statistics of one launch)"
 
@@ -234,7 +234,7 @@ class KSweep:
         # W of the sweep = games-weighted mean over k (equal games per k): all-seat statistics of one full-size launch per k
         parts = []
         for k in self.ks:
-            res = eng.tournament(self.table, k, self.root, 0, self.n_sh[k], want_seat_stats=True)
+            res = eng.tournament(self.table, k, self.root, 0, self.n_sh[k], want_seat_stats=True, want_seat_ratios=False)
             parts.append(work_from_seat_stats(res["seat_stats"], self.n_sh[k] * (self.S // k), k))
         mean = {key: float(np.mean([p[key] for p in parts])) for key in parts[0]}
         mean["per_k"] = {k: p for k, p in zip(self.ks, parts)}

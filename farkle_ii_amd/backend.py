@@ -203,10 +203,11 @@ class Engine:
     def tournament(self, table: np.ndarray, k: int, root_seed: int, shuffle_begin: int, shuffle_end: int,
                    shuffles_per_batch: int | None = None, target_score: int = 10_000, max_rounds: int = 200,
                    overrides: np.ndarray | None = None, want_rows: bool = False, want_perms: bool = False,
-                   want_seat_stats: bool = False, rows_out: np.ndarray | None = None) -> dict:
+                   want_seat_stats: bool = False, rows_out: np.ndarray | None = None, want_seat_ratios: bool = True) -> dict:
         """All games of shuffles ``[shuffle_begin, shuffle_end)``: per-batch tallies (+ rows / permutations / the all-seat
         integer statistics ``[n_batches][S][SEAT_STAT_COLS]``, columns ``SEAT_STAT_NAMES``, with the four float64 ratio sums
-        ``seat_ratio_sums [n_batches][S][SEAT_RATIO_COLS]`` of the same table)."""
+        ``seat_ratio_sums [n_batches][S][SEAT_RATIO_COLS]`` of the same table unless ``want_seat_ratios`` is off: they are one
+        sequential sum per (batch, strategy), which a caller that only reads the integer columns need not wait for)."""
         table = np.ascontiguousarray(table, dtype=STRATEGY_DTYPE)
         S = len(table)
         n_sh = int(shuffle_end) - int(shuffle_begin)
@@ -228,8 +229,8 @@ class Engine:
         ov = overrides if overrides is not None else np.zeros(0, dtype=OVERRIDE_DTYPE)
         ov = np.ascontiguousarray(ov, dtype=OVERRIDE_DTYPE)
         stats = np.zeros((max(n_batches, 1), S, SEAT_STAT_COLS), dtype=np.int64) if want_seat_stats else None
-        ratios = np.zeros((max(n_batches, 1), S, SEAT_RATIO_COLS), dtype=np.float64) if want_seat_stats else None
-        if want_seat_stats:  # the all-player accumulators: 31 integer sums + the four float64 sums in (shuffle, game, seat) order
+        ratios = np.zeros((max(n_batches, 1), S, SEAT_RATIO_COLS), dtype=np.float64) if want_seat_stats and want_seat_ratios else None
+        if ratios is not None:  # the all-player accumulators: 31 integer sums + the four float64 sums in (shuffle, game, seat) order
             self._check(self._lib.fk_tournament_run_all_player(
                 self._ctx, _p(table), C.c_int32(S), C.c_int32(k), C.c_uint64(root_seed), C.c_uint64(shuffle_begin),
                 C.c_uint64(shuffle_end), C.c_uint32(spb), C.c_int32(target_score), C.c_int32(max_rounds), _p(ov),

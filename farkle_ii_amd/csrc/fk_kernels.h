@@ -1707,10 +1707,7 @@ __global__ __launch_bounds__(256) void fk_seat_ratio_kernel(const uint4 *digest,
     if (s >= S || sh_hi <= sh_lo) return;
     double *out = ratios + ((size_t)batch * S + s) * FK_SEAT_RATIO_COLS;
     double exact_sum = out[0], exact_sq = out[1], proxy_sum = out[2], proxy_sq = out[3];
-    for (uint32_t sh = sh_lo; sh < sh_hi; ++sh) {
-        const uint32_t p = perm_at(inv_T, S, perm_slots, sh, s);
-        const uint4 *d = digest + ((size_t)sh * gps * k + p) * 2;
-        const uint4 q0 = d[0], q1 = d[1];
+    auto add = [&](const uint4 &q0, const uint4 &q1) __attribute__((always_inline)) {
         const double score = (double)((long long)(int32_t)q0.x * 50), rounds = (double)(q0.y & 0xffffu), turns = (double)(q1.w & 0xffffu);
         const double exact = turns != 0.0 ? score / turns : 0.0, proxy = rounds != 0.0 ? score / rounds : 0.0;
         const double exact2 = exact * exact, proxy2 = proxy * proxy;
@@ -1718,6 +1715,28 @@ __global__ __launch_bounds__(256) void fk_seat_ratio_kernel(const uint4 *digest,
         exact_sq = exact_sq + exact2;
         proxy_sum = proxy_sum + proxy;
         proxy_sq = proxy_sq + proxy2;
+    };
+    // The additions are one chain per sum, but the two dependent loads in front of them (inverse permutation -> digest record) are
+    // not on it: sixteen shuffles' loads are issued together, then their quotients are added in shuffle order (a one-batch call is a
+    // single thread per strategy over the whole shuffle range: 212 -> 27 ms for 312 500 shuffles of the 64-strategy grid).
+    constexpr uint32_t U = 16;
+    uint32_t sh = sh_lo;
+    for (; sh + U <= sh_hi; sh += U) {
+        uint32_t p[U];
+        uint4 q0[U], q1[U];
+#pragma unroll
+        for (uint32_t j = 0; j < U; ++j) p[j] = perm_at(inv_T, S, perm_slots, sh + j, s);
+#pragma unroll
+        for (uint32_t j = 0; j < U; ++j) {
+            const uint4 *d = digest + ((size_t)(sh + j) * gps * k + p[j]) * 2;
+            q0[j] = d[0], q1[j] = d[1];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < U; ++j) add(q0[j], q1[j]);
+    }
+    for (; sh < sh_hi; ++sh) {
+        const uint4 *d = digest + ((size_t)sh * gps * k + perm_at(inv_T, S, perm_slots, sh, s)) * 2;
+        add(d[0], d[1]);
     }
     out[0] = exact_sum, out[1] = exact_sq, out[2] = proxy_sum, out[3] = proxy_sq;
 }

@@ -99,7 +99,7 @@ class Engine:
                 "play_grid": 0, "play_lds_bytes": 0, "games": self._games}
 
     def tournament(self, table, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=None, target_score=10_000,
-                   max_rounds=200, overrides=None, want_rows=False, want_perms=False, want_seat_stats=False) -> dict:
+                   max_rounds=200, overrides=None, want_rows=False, want_perms=False, want_seat_stats=False, want_seat_ratios=True) -> dict:
         t = np.ascontiguousarray(table).view(po.STRATEGY_DTYPE)
         ov = None if overrides is None or len(overrides) == 0 else np.ascontiguousarray(overrides).view(po.OVERRIDE_DTYPE)
         res = po.tournament(t, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=shuffles_per_batch,
@@ -110,7 +110,7 @@ class Engine:
         if want_seat_stats:
             spb = (shuffle_end - shuffle_begin) if not shuffles_per_batch else shuffles_per_batch
             stats = seat_stats_from_rows(res["rows"], k, len(t), len(t) // k, spb)
-            ratios = seat_ratio_sums_from_rows(res["rows"], k, len(t), len(t) // k, spb)
+            ratios = seat_ratio_sums_from_rows(res["rows"], k, len(t), len(t) // k, spb) if want_seat_ratios else None
         return {"tally": res["tally"], "rows": res["rows"] if want_rows else None, "perms": res["perms"], "seat_stats": stats,
                 "seat_ratio_sums": ratios}
 

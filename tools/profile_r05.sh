@@ -38,7 +38,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 echo "c3 stats rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r05_bench_c6_stats -- python3 bench.py --config 6 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/r05_bench_c6_under_rocprof.json 2> gpurun_out/r05_bench_c6_under_rocprof.err
 echo "c6 stats rc=$?"
-for c in 2 3 4 5 6; do timeout -k 10 400 python3 bench.py --config $c > gpurun_out/r05_bench_config$c.json 2> gpurun_out/r05_bench_config$c.err; echo "bench config $c rc=$?"; done
+for c in 2 3; do timeout -k 10 400 python3 bench.py --config $c > gpurun_out/r05_bench_config$c.json 2> gpurun_out/r05_bench_config$c.err; echo "bench config $c rc=$?"; done
+fi
+if [ "$part" = all ] || [ "$part" = d ]; then
+for c in 4 5 6; do timeout -k 10 400 python3 bench.py --config $c > gpurun_out/r05_bench_config$c.json 2> gpurun_out/r05_bench_config$c.err; echo "bench config $c rc=$?"; done
 timeout -k 10 120 python3 bench.py > gpurun_out/r05_bench.json 2> gpurun_out/r05_bench.err; echo "default bench rc=$?"
 timeout -k 10 400 python3 tools/time_farkle_run.py 51200 gpurun_out/r05_farkle_run_end_to_end.json > gpurun_out/r05_e2e.log 2>&1; echo "e2e rc=$?"
 FK_DIST_BACKEND=gloo timeout -k 10 200 python3 bench.py --gpus 2 --steps 3 --warmup 1 > gpurun_out/r05_bench_2rank_gloo_one_gpu.json 2> gpurun_out/r05_bench_2rank_gloo.err; echo "2-rank gloo rc=$?"
