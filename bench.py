@@ -87,8 +87,14 @@ def add_timing(acc: dict, t: dict) -> dict:
     """Accumulate fk_timing records (HIP events on the engine's stream) over the engine calls of a step."""
     for key in ("play_ms", "seed_ms", "perm_ms", "play_launches", "games", "prefetched_chunks"):
         acc[key] = acc.get(key, 0) + t.get(key, 0)
-    for key in ("play_block", "play_grid", "play_lds_bytes"):
+    for key in ("play_block", "play_grid", "play_lds_bytes", "play_mixed_flags"):
         acc[key] = t.get(key)
+    if t.get("play_block_end_max_ms"):  # the launch's drain tail (same option): last workgroup's end - median workgroup's end
+        acc["tail_ms_sum"] = acc.get("tail_ms_sum", 0.0) + (t["play_block_end_max_ms"] - t["play_block_end_p50_ms"])
+        acc["tail_n"] = acc.get("tail_n", 0) + 1
+    elif t.get("tail_n"):
+        acc["tail_ms_sum"] = acc.get("tail_ms_sum", 0.0) + t["tail_ms_sum"]
+        acc["tail_n"] = acc.get("tail_n", 0) + t["tail_n"]
     if t.get("play_clock_mhz"):  # option "clock_stamps": the shader clock the call's last game kernel ran at, measured inside it
         acc["clock_sum"] = acc.get("clock_sum", 0) + t["play_clock_mhz"]
         acc["clock_n"] = acc.get("clock_n", 0) + 1
@@ -685,6 +691,35 @@ def main() -> None:
                 break
             return None
 
+        def mix_for(kernel: str, shape: dict, k_seats: int, frac: float):
+            """Static instruction mix of the instance's roll loop priced with the two measured issue classes (tools/isa_mix.py ->
+            profiles/r*_isa_mix.json, valid while the kernel sources are the ones it was taken on): `ceiling_frac` is the fraction of the
+            NOMINAL peak a SIMD issuing this mix back to back would reach, `frac_of_mix_ceiling` = frac / that.  None when unknown."""
+            for mpath in sorted((ROOT / "profiles").glob("r*_isa_mix.json"), reverse=True):
+                doc = json.loads(mpath.read_text())
+                if doc.get("kernel_source_sha256") != kernel_source_sha():
+                    break
+                block, mixed = shape.get("play_block"), shape.get("play_mixed_flags")
+                hits = []
+                for name, rec in doc["instances"].items():
+                    a = [int(x) for x in name[name.index("<") + 1:-1].split(",")]
+                    if not name.startswith(kernel + "<") or a[0] != block:
+                        continue
+                    if kernel == "fk_play_kernel":  # <BLOCK, LEAN, WPE, MIXED, GS, BLK, KC>
+                        ok = a[1] == 1 and a[3] == mixed and a[4] == 0 and a[5] == (1 if wl.config == 5 else 0) and a[6] == (2 if k_seats == 2 else 0)
+                    else:  # <BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS, CR, IL>: KI seats in registers (0 = the cold-in-LDS instance of k <= 4)
+                        ki = 0 if k_seats <= 4 else 6 if k_seats <= 6 else k_seats if k_seats <= 8 else 10 if k_seats <= 10 else 12
+                        ok = a[1] == mixed and a[3] == ki
+                    if ok:
+                        hits.append((name, rec))
+                if len(hits) == 1:
+                    name, rec = hits[0]
+                    return {"instance": name, "source": f"profiles/{mpath.name} (static mix of the roll loop; classes: profiles/r05_valu_issue_rates.txt)",
+                            **{key: rec[key] for key in ("valu_static", "full_rate", "half_rate", "mean_issue_cycles", "ceiling_frac")},
+                            "frac_of_mix_ceiling": frac / rec["ceiling_frac"]}
+                break
+            return None
+
         traffic = traffic_for(dominant)
         roofline = {
             "bound": "valu", "kernel": dominant,
@@ -698,8 +733,9 @@ def main() -> None:
             "seed_kernel_ms": t.get("seed_ms", 0.0) / max(launches - int(t.get("prefetched_chunks", 0)), 1),
             "perm_kernel_ms": t.get("perm_ms", 0.0) / max(launches, 1),
             "launches_seeded_behind_the_previous_kernel": int(t.get("prefetched_chunks", 0)),
-            "launch": {k2: t.get(k2) for k2 in ("play_block", "play_grid", "play_lds_bytes")},
+            "launch": {k2: t.get(k2) for k2 in ("play_block", "play_grid", "play_lds_bytes", "play_mixed_flags")},
         }
+        roofline["mix"] = mix_for(dominant, t, int(wl.k) if isinstance(getattr(wl, "k", None), int) else 2, roofline["frac"])
 
         def with_clock(rec: dict, tt: dict) -> None:
             """`frac` stays defined against the NOMINAL clock (as every round before); next to it the clock the game kernels
@@ -709,6 +745,8 @@ def main() -> None:
                 mhz = tt["clock_sum"] / tt["clock_n"]
                 rec["clock_mhz_measured"] = mhz
                 rec["frac_at_measured_clock"] = rec["frac"] * info["clock_mhz"] / mhz
+            if tt.get("tail_n"):  # how long the last launch of a call took to drain behind its longest games
+                rec["launch_tail_ms"] = tt["tail_ms_sum"] / tt["tail_n"]
 
         with_clock(roofline, t)
         if "per_k" in wpg:  # config 4: one roofline record per player count (kernel time, W and fraction of each k's launches)
@@ -722,7 +760,8 @@ def main() -> None:
                 per_k.append({"k": int(k2), "kernel": kernel_of(tk, int(k2)), "kernel_ms": ms,
                               "games_per_launch": gpl, "kernel_games_per_s": rate, **w2,
                               "frac": rate * w2["ops_per_game"] / peak_ops, "traffic": traffic_for(kernel_of(tk, int(k2)), int(k2)),
-                              "launch": {k3: tk.get(k3) for k3 in ("play_block", "play_grid", "play_lds_bytes")}})
+                              "launch": {k3: tk.get(k3) for k3 in ("play_block", "play_grid", "play_lds_bytes", "play_mixed_flags")}})
+                per_k[-1]["mix"] = mix_for(per_k[-1]["kernel"], tk, int(k2), per_k[-1]["frac"])
                 with_clock(per_k[-1], tk)
             roofline["per_k"] = per_k
             # The line's headline record is ONE kernel's, whole: the player count furthest below its roofline (every field — kernel, time,

@@ -66,7 +66,7 @@ class _Timing(C.Structure):
     _fields_ = [("perm_ms", C.c_float), ("seed_ms", C.c_float), ("play_ms", C.c_float), ("total_ms", C.c_float),
                 ("play_launches", C.c_int32), ("play_block", C.c_int32), ("play_grid", C.c_int32),
                 ("play_lds_bytes", C.c_int32), ("games", C.c_int64), ("prefetched_chunks", C.c_int32), ("play_clock_mhz", C.c_int32),
-                ("play_block_end_p50_ms", C.c_float), ("play_block_end_max_ms", C.c_float)]
+                ("play_block_end_p50_ms", C.c_float), ("play_block_end_max_ms", C.c_float), ("play_mixed_flags", C.c_int32)]
 
 
 class FarkleHipError(RuntimeError):

@@ -765,6 +765,8 @@ int launch_play_stage(fk_ctx *c, const SeedArgs &sa, PlayArgs &pa, const LaunchP
         t.stop();
         HIPCHK(c, e);
         c->timing.play_grid = lp.launched_grid;
+        c->timing.play_mixed_flags = lp.mixed_flags == MIXED_NONE ? (int32_t)MIXED_NONE
+                                     : (lp.mixed_flags & ~MIXED_RB_FAV) == 0u ? (int32_t)MIXED_RB_FAV : (int32_t)MIXED_ALL;
         if (pa.clk) c->clk_grid = lp.launched_grid;
     }
     c->timing.play_launches += 1;

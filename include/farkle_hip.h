@@ -120,6 +120,8 @@ typedef struct {
     float play_block_end_p50_ms, play_block_end_max_ms; /* same option, same kernel: when the median and the last of its workgroups
                                   finished, from the first workgroup's start (100 MHz counter) — max - p50 is the launch's tail, the
                                   stretch in which the chip drains behind the longest games */
+    int32_t play_mixed_flags;  /* the strategy-flag form of the last game kernel instance: 0 (every flag shared by the whole table: scalar),
+                                  0xc000 (only require_both / favor_score differ) or 0xff00 (any flag may differ) */
 } fk_timing;
 
 typedef struct fk_ctx fk_ctx;
