@@ -102,6 +102,7 @@ struct fk_ctx {
     int32_t hc_block = 256;    // its block size: 256, 768 or 1024
     int32_t hc_tables = 1;     // 1: score / discard tables in LDS (LT instances)
     int32_t hc_inc_regs = 1;   // 1: the seats' PCG increments in registers (k >= 5, 256-thread blocks, LDS tables)
+    int32_t hc_ip = 0;         // option "hot_cold_ip": increments in the cold-plane slots, fetched one turn ahead (1: k = 8 at four waves, 2: at three)
     int32_t hc_cr = 0;         // FK_EXPERIMENTS builds: cold records in registers (1: with the increments, 2: increments loaded per turn)
     int32_t hc_cl = -1;        // cold records in LDS beside the hot part (k = 3 .. 5): -1 auto (k = 4), 0 never, 1 always
     DevBuf lds_tables;         // their LDS image (fk_play_hc.h)
@@ -256,6 +257,7 @@ struct LaunchPlan {
     int hc_ki = 0;      // ... with every seat's PCG increment in registers (2: the four-wave instances of k = 5 .. 7)
     bool hc_cl = false; // ... with the cold records in LDS (32 bytes per seat and lane, no plane)
     int hc_cr = 0;      // ... with the cold records in registers (experiment)
+    bool hc_ip = false; // ... with the increments in the cold-plane slots (32-byte slots), the next owner's fetched one turn ahead
     int wpe = 4;       // waves per SIMD the chosen instance is compiled for
     uint32_t mixed_flags = 0xff00u; // flag bits that differ between strategies of the table (selects the kernel instance)
 };
@@ -374,6 +376,36 @@ bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const Launch
         out.cus = c->prop.multiProcessorCount;
         return true;
     }
+#ifdef FK_EXPERIMENTS
+    if (c->hc_ip && k >= 5) {
+        // (measured round 5, profiles/r05_increments_in_the_plane.log: 15 - 47 % SLOWER than the register instances — one more scattered
+        // 16-byte access per turn and lane is what the texture addresser does not have to spare; kept for the record)
+        // increments in the plane (fk_play_hc.h, IP): no register arrays, so four waves per SIMD wherever the hot planes (16 k bytes per lane)
+        // and the table image fit — 4 x 256 threads at k = 5, 2 x 512 at k = 6 and k = 8, 1 x 1 024 at k = 7 — and one 768-thread block from k = 9
+        const int want4 = max_waves >= 4 && !(k == 8 && c->hc_ip == 2);
+        const int block_ip = k >= 9 ? 768 : !want4 ? 256 : k == 5 ? 256 : k == 7 ? 1024 : 512;
+        const size_t lds_ip = (size_t)block_ip * 16 * (size_t)k + LT_BYTES;
+        if (lds_ip > LDS_LIMIT || max_waves < 3) return false;
+        int per_cu = k >= 9 ? 1 : !want4 ? 3 : 1024 / block_ip;
+        per_cu = (int)std::min<size_t>((size_t)per_cu, LDS_LIMIT / lds_ip);
+        if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
+        per_cu = std::max(per_cu, 1);
+        out = base;
+        out.hc = true;
+        out.hc_lt = true;
+        out.hc_ki = 0;
+        out.hc_ip = true;
+        out.lean = true;
+        out.gs = false;
+        out.blk = false;
+        out.block = block_ip;
+        out.lds = lds_ip;
+        out.wpe = (per_cu * block_ip + 255) / 256;
+        out.grid = c->prop.multiProcessorCount * per_cu;
+        out.cus = c->prop.multiProcessorCount;
+        return true;
+    }
+#endif
     const bool lt = c->hc_tables != 0;
     // register instances (increments of every seat in registers, tables in LDS).  k = 5 .. 7 run FOUR waves per SIMD — 128
     // registers hold the increments when the packed strategies are loaded per turn instead — in whatever block size lets
@@ -471,12 +503,12 @@ hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) 
     return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS, BLK, KC>(p, a, s);
 }
 
-template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8, bool CR = false, bool IL = false>
+template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8, bool CR = false, bool IL = false, bool IP = false>
 hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     static int configured_dev = -1; // dynamic-LDS ceiling and occupancy are per device
     static size_t occ_lds = ~(size_t)0;
     static int occ_blocks = 0;
-    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS, CR, IL>);
+    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS, CR, IL, IP>);
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (configured_dev != dev) {
@@ -494,15 +526,15 @@ hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t 
     }
     const int grid = std::min(p.grid, occ_blocks * p.cus);
     p.launched_grid = grid;
-    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS, CR, IL>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
+    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS, CR, IL, IP>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
     return hipGetLastError();
 }
 
-template <int BLOCK, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8, bool CR = false, bool IL = false>
+template <int BLOCK, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8, bool CR = false, bool IL = false, bool IP = false>
 hipError_t launch_play_hc_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI, WPE, PKR, CL, NS, CR, IL>(p, a, s);
-    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI, WPE, PKR, CL, NS, CR, IL>(p, a, s);
-    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI, WPE, PKR, CL, NS, CR, IL>(p, a, s);
+    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI, WPE, PKR, CL, NS, CR, IL, IP>(p, a, s);
+    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI, WPE, PKR, CL, NS, CR, IL, IP>(p, a, s);
+    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI, WPE, PKR, CL, NS, CR, IL, IP>(p, a, s);
 }
 
 // The instances the launch plan can reach (plan_play_hc): k = 4 cold records in LDS (four 320-thread blocks, five waves per
@@ -532,6 +564,17 @@ hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s)
     if (p.hc_cr && p.hc_ki && p.block == 256 && p.hc_lt && a.k > 6u) { // cold records in registers, three waves
         if (p.hc_cr == 1) return launch_play_hc_t<256, true, 8, 0, false, false, 8, true, false>(p, a, s);
         return launch_play_hc_t<256, true, 8, 0, false, false, 8, true, true>(p, a, s);
+    }
+#endif
+#ifdef FK_EXPERIMENTS
+    if (p.hc_ip) { // increments in the plane: <BLOCK, LT, KI = 0, WPE, PKR, CL, NS, CR, IL, IP>
+        if (p.block == 256 && a.k == 5u) return launch_play_hc_t<256, true, 0, 4, false, false, 8, false, false, true>(p, a, s);
+        if (p.block == 512 && a.k <= 8u) return launch_play_hc_t<512, true, 0, 4, false, false, 8, false, false, true>(p, a, s);
+        if (p.block == 1024 && a.k <= 8u) return launch_play_hc_t<1024, true, 0, 4, false, false, 8, false, false, true>(p, a, s);
+        if (p.block == 256 && a.k <= 8u) return launch_play_hc_t<256, true, 0, 3, false, false, 8, false, false, true>(p, a, s);
+        if (p.block == 768 && a.k <= 10u) return launch_play_hc_t<768, true, 0, 3, false, false, 10, false, false, true>(p, a, s);
+        if (p.block == 768) return launch_play_hc_t<768, true, 0, 3, false, false, 12, false, false, true>(p, a, s);
+        return hipErrorInvalidValue;
     }
 #endif
     if (p.hc_ki == 3) { // nine to twelve seats: one block per CU, increments in registers, strategies loaded per turn
@@ -1262,6 +1305,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "hot_cold_inc_regs") c->hc_inc_regs = (int32_t)value;
     else if (n == "hot_cold_lds") c->hc_cl = (int32_t)value;
     else if (n == "hot_cold_cold_regs") c->hc_cr = (int32_t)value;
+    else if (n == "hot_cold_ip") c->hc_ip = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
 #endif
     else if (n == "clock_stamps") c->clock_stamps = value != 0;
     else if (n == "perm_split") c->perm_split = (int32_t)value;
@@ -1409,7 +1453,7 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
     }
     if (plan.hc) c->ran_hc = true;
     if (plan.hc && !plan.hc_cl && !plan.hc_cr) { // cold seat records of every lane the grid can seat
-        rc = ensure(c, c->cold, (size_t)plan.grid * (size_t)plan.block * (size_t)k * 16);
+        rc = ensure(c, c->cold, (size_t)plan.grid * (size_t)plan.block * (size_t)k * (plan.hc_ip ? 32 : 16));
         if (rc) return rc;
     }
     const bool want_state = rows != nullptr || seat_stats != nullptr;
