@@ -341,8 +341,9 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                    checkpoint_path: Path, collect_metrics: bool, row_dir: Path | None, metric_chunk_dir: Path | None,
                    resume: bool, checkpoint_metadata: Mapping[str, Any], oracle_game_profile: GameProfile | None = None,
                    all_player_dir: Path | None = None, sidecars: "_Sidecars | None" = None,
-                   rng_lags: Sequence[int] | None = None) -> dict:
-    """Play every deterministic batch not yet owned by the checkpoint and persist the aggregates.  ``rng_lags``: also accumulate the lag
+                   rng_lags: Sequence[int] | None = None, defer_final_checkpoint: bool = False) -> dict:
+    """Play every deterministic batch not yet owned by the checkpoint and persist the aggregates.  ``defer_final_checkpoint``: the final
+    checkpoint's file write may still be in flight on return — the caller joins ``result["checkpoint_written"]`` before reading the file.  ``rng_lags``: also accumulate the lag
     sufficient statistics of the RNG diagnostics' strategy family over the WHOLE shuffle range (``fk_tournament_run_lags``; launch
     groups and ranks are contiguous ranges that merge in order, rng_lags.LagSummary) — returned as ``result["lag_summary"]``."""
     rank, world = _rank_world()
@@ -438,23 +439,36 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
     t_start = time.perf_counter()
     games_done = 0
 
+    # The final checkpoint lists every shuffle index of the run (the reference's format: 312 500 Python ints on BASELINE config 2 — 5 ms
+    # to build, as long as everything else the host does after the last launch): built on the helper thread under the first engine call.
+    every_shuffle = (_helper_thread().submit(lambda: list(range(plan.required_shuffles))) if rank == 0 and pending else None)
+    checkpoint_written: list = []  # the final checkpoint's write, in flight on the helper thread (joined before anything reads the file)
+
     def save(final: bool) -> None:
         wins, sums, sqs = rt.tally_to_counters(total, ids, k, dense=metric_chunk_dir is not None)
         completed = sorted(done_batches)
         # process blocks are numbered from 1 (run_tournament.py:1576-1586); one block = one deterministic batch here
-        shuffle_list: list[int] = []
-        run_first = run_last = None  # runs of consecutive batches become ONE range (a complete run: list(range(n)), 2 ms per 312 500)
-        for b in completed + [None]:
-            if run_last is not None and b is not None and b == run_last + 1:
-                run_last = b
-                continue
-            if run_first is not None:
-                shuffle_list.extend(range(run_first * spb, min((run_last + 1) * spb, plan.required_shuffles)))
-            run_first = run_last = b
+        if every_shuffle is not None and len(completed) == n_batches:
+            shuffle_list: list[int] = every_shuffle.result()
+        else:
+            shuffle_list = []
+            run_first = run_last = None  # runs of consecutive batches become ONE range
+            for b in completed + [None]:
+                if run_last is not None and b is not None and b == run_last + 1:
+                    run_last = b
+                    continue
+                if run_first is not None:
+                    shuffle_list.extend(range(run_first * spb, min((run_last + 1) * spb, plan.required_shuffles)))
+                run_first = run_last = b
         ck_meta = {**meta, "completed_shuffle_indices": shuffle_list,
                    "completed_process_block_indices": [b + 1 for b in completed], "complete": final}
-        _atomic_write_bytes(checkpoint_path, ckpt.dump_checkpoint(wins, sums if collect_metrics else None,
-                                                                  sqs if collect_metrics else None, ck_meta))
+        content = ckpt.dump_checkpoint(wins, sums if collect_metrics else None, sqs if collect_metrics else None, ck_meta)
+        if final and defer_final_checkpoint and not sidecars.enabled:
+            # 1.4 MB for config 2: the write goes to the helper thread (file I/O drops the GIL) while the caller builds the summary tables;
+            # `checkpoint_written` is joined before the completion stamp — or anything else — reads the file
+            checkpoint_written.append(_helper_thread().submit(_atomic_write_bytes, checkpoint_path, content))
+        else:
+            _atomic_write_bytes(checkpoint_path, content)
 
     i = 0
     while i < len(pending):
@@ -599,7 +613,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 sidecars.write("shard_manifest", manifest)
     barrier()
     return {"tally": total, "games": games_done, "seconds": time.perf_counter() - t_start, "lag_summary": lag_total,
-            "shard_identities": shard_identities}
+            "shard_identities": shard_identities, "checkpoint_written": checkpoint_written}
 
 
 def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | None = None, *, force: bool = False,
@@ -679,7 +693,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
                             collect_metrics=cfg.sim.expanded_metrics, row_dir=row_dir, metric_chunk_dir=metric_chunk_dir,
                             resume=not force, checkpoint_metadata={"strategy_manifest_sha": manifest_sha},
                             oracle_game_profile=oracle_game_profile, all_player_dir=all_player_dir, sidecars=sidecars,
-                            rng_lags=cfg.rng_diagnostic_lags() if cfg.sim.rng_lag_sums else None)
+                            rng_lags=cfg.rng_diagnostic_lags() if cfg.sim.rng_lag_sums else None, defer_final_checkpoint=True)
     finally:
         if published is not None:
             published.result()  # the inputs are on disk (or their error is raised) before the summaries and the stamp name them
@@ -758,6 +772,8 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         "tournament_method_version": TOURNAMENT_METHOD_VERSION, "n_strategies": grid_size}
     if profile_sha is not None:
         metadata["game_profile_sha256"] = profile_sha
+    for pending_write in result.get("checkpoint_written", ()):
+        pending_write.result()  # the final checkpoint is on disk (or its error is raised) before the stamp names and hashes it
     done_path = simulation_done_path(cfg, n)
     outputs: list[Path] = [ckpt_path, n_dir / "simulation_workload_plan.json"]  # the order of simulation/runner.py:1714-1727
     for extra in (n_dir / f"{n}p_checkpoint.parquet", cfg.metrics_path(n), cfg.strategy_manifest_root_path(),

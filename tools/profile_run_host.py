@@ -35,3 +35,23 @@ with tempfile.TemporaryDirectory(prefix="fk_hostprof_") as tmp:
             main(argv)
         print(name, f"{(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
     run("fill"); run("warm"); run("timed"); run("timed2"); run("profiled", True)
+
+# timeline: where the engine call sits inside the run (memoised: its own duration is ~0)
+marks = []
+orig = e.tournament
+def marked(*a, **kw):
+    marks.append(("engine call", time.perf_counter()))
+    time.sleep(0.025)  # the real call's duration at this container's speed (GIL released, as inside ctypes): what the helper thread can use
+    r = orig(*a, **kw)
+    marks.append(("engine return", time.perf_counter()))
+    return r
+e.tournament = marked
+with tempfile.TemporaryDirectory(prefix="fk_hostprof_") as tmp:
+    for rep in range(3):
+        marks.clear()
+        cfg = json.loads(json.dumps(base)); cfg["io"]["results_dir_prefix"] = str(Path(tmp) / f"t{rep}")
+        p = Path(tmp) / f"t{rep}.yaml"; p.write_text(yaml.safe_dump(cfg))
+        t0 = time.perf_counter()
+        main(["--config", str(p), "--log-level", "WARNING", "run", "--metrics"])
+        t1 = time.perf_counter()
+        print(f"timeline: before the engine call {(marks[0][1] - t0) * 1e3:.1f} ms, after it {(t1 - marks[-1][1]) * 1e3:.1f} ms, total {(t1 - t0) * 1e3:.1f} ms")
