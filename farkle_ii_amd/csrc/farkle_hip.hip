@@ -94,7 +94,7 @@ struct fk_ctx {
     uint32_t table_flags = 0;            // set by upload_strategies: flag bits shared by the whole table ...
     uint32_t table_mixed_flags = 0xff00u; // ... and the flag bits that differ between its strategies
     int64_t chunk_bytes = (int64_t)48 << 30;
-    int32_t batch_threshold = 8;
+    int32_t batch_threshold = 0;  // 0 = auto: 8 waiting lanes up to eight seats, 12 at nine / ten, 16 at eleven / twelve (swept per k)
     int32_t use_lds_tally = -1;
     int32_t block = 0;
     int32_t hc = -1;           // hot / cold game kernel (fk_play_hc.h): -1 auto, 0 never, 1 whenever the table allows it
@@ -788,7 +788,10 @@ int launch_play_stage(fk_ctx *c, const SeedArgs &sa, PlayArgs &pa, const LaunchP
     pa.gs_out = (want_state && !plan.gs) ? 1u : 0u;
     pa.ticket = static_cast<uint32_t *>(cs.misc.p);
     pa.err = reinterpret_cast<int32_t *>(static_cast<uint8_t *>(cs.misc.p) + 16);
-    pa.batch_threshold = (uint32_t)std::max(1, std::min(64, c->batch_threshold));
+    // hand-over threshold: the measured optimum is 8 up to eight seats (rounds 1 - 3) and grows with the game length beyond (round 5,
+    // 5 160-strategy grid: k = 12 at 16 -1.5 %, k = 10 at 12 -0.6 % kernel time against 8)
+    const int auto_thr = sa.k >= 11 ? 16 : sa.k >= 9 ? 12 : 8;
+    pa.batch_threshold = (uint32_t)std::max(1, std::min(64, c->batch_threshold > 0 ? c->batch_threshold : auto_thr));
     pa.use_lds_tally = plan.lds_tally ? 1u : 0u;
     pa.clk = nullptr;
     c->clk_grid = 0;

@@ -137,7 +137,7 @@ int fk_get_timing(fk_ctx *ctx, fk_timing *out);
 int fk_host_alloc(fk_ctx *ctx, size_t bytes, void **out);
 int fk_host_free(fk_ctx *ctx, void *p);
 /* Tunables: "chunk_bytes" (device workspace budget per chunk), "batch_threshold" (lanes that must be waiting
- * before a wave runs its game hand-over), "use_lds_tally" (0/1/-1 auto), "block" (0 auto), "lean" (seat-record layout:
+ * before a wave runs its game hand-over; 0, the default = auto: 8 up to eight seats, 12 at nine / ten, 16 at eleven / twelve), "use_lds_tally" (0/1/-1 auto), "block" (0 auto), "lean" (seat-record layout:
  * -1 auto, 0 full, 1 lean), "state_store" (-1 auto: seat records live in the HBM state store, with only the turn owner's staged in LDS, when
  * k of them do not fit LDS (k > 64); 0 the same; 1 always), "blocks_per_cu", "max_waves" (resident waves per SIMD the launch plan counts
  * on, default 6), "longest_first" (1 = deal

@@ -383,7 +383,7 @@ def test_tournament_batches_chunks_options_and_overrides(eng, po):
             one = eng.tournament(table, 2, 42, 0, 50, overrides=make_overrides(ovs))
             assert np.array_equal(one["tally"][0], ref["tally"].sum(axis=0)), (name, value)
     finally:
-        for name, value in [("chunk_bytes", 24 << 30), ("batch_threshold", 8), ("block", 0), ("use_lds_tally", -1), ("lean", -1),
+        for name, value in [("chunk_bytes", 24 << 30), ("batch_threshold", 0), ("block", 0), ("use_lds_tally", -1), ("lean", -1),
                             ("longest_first", 1), ("uniform_flags", -1), ("max_waves", 6)]:
             eng.set_option(name, value)
 

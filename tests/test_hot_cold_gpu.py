@@ -332,3 +332,32 @@ def test_hot_cold_kernels_in_chunked_hinted_and_unpipelined_calls(eng, po, k):
     finally:
         eng.set_option("pipeline", 1)
         eng.set_option("chunk_bytes", 48 << 30)
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_timing_carries_the_clock_the_launch_tail_and_the_flag_form(eng, po, k):
+    """Option ``clock_stamps``: fk_timing reports the shader clock measured inside the game kernel, when its median and its last
+    workgroup finished (the last wave of every block stamps its end), and which strategy-flag form of the instance ran; the stamps
+    change no result.  ``want_seat_ratios=False`` returns the integer statistics alone (no float sums)."""
+    S = 96
+    table = _random_valid_table(S, 5200 + k)
+    uniform = table.copy()
+    for name in ("smart_five", "smart_one", "consider_score", "consider_dice", "auto_hot_dice", "run_up_score", "require_both", "favor_score"):
+        uniform[name] = uniform[name][0]
+    plain = eng.tournament(table, k, 3, 0, 24, want_seat_stats=True)
+    try:
+        eng.set_option("clock_stamps", 1)
+        got = eng.tournament(table, k, 3, 0, 24, want_seat_stats=True, want_seat_ratios=False)
+        t = eng.timing()
+        assert np.array_equal(got["tally"], plain["tally"]) and np.array_equal(got["seat_stats"], plain["seat_stats"])
+        assert got["seat_ratio_sums"] is None and plain["seat_ratio_sums"] is not None
+        assert 500 < t["play_clock_mhz"] < 3000, t
+        assert 0.0 < t["play_block_end_p50_ms"] <= t["play_block_end_max_ms"] <= t["play_ms"] * 1.05 + 0.05, t
+        assert t["play_mixed_flags"] in (0xC000, 0xFF00), t  # a random table: some flag differs between its strategies
+        eng.tournament(uniform, k, 3, 0, 8)
+        assert eng.timing()["play_mixed_flags"] == 0, eng.timing()  # every flag shared by the whole table: the scalar form
+    finally:
+        eng.set_option("clock_stamps", 0)
+    eng.tournament(table, k, 3, 0, 8)
+    t = eng.timing()
+    assert t["play_clock_mhz"] == 0 and t["play_block_end_max_ms"] == 0.0, t
