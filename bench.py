@@ -708,7 +708,7 @@ def main() -> None:
                     if kernel == "fk_play_kernel":  # <BLOCK, LEAN, WPE, MIXED, GS, BLK, KC>
                         ok = a[1] == 1 and a[3] == mixed and a[4] == 0 and a[5] == (1 if wl.config == 5 else 0) and a[6] == (2 if k_seats == 2 else 0)
                     else:  # <BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS, CR, IL>: KI seats in registers (0 = the cold-in-LDS instance of k <= 4)
-                        ki = 0 if k_seats <= 4 else 6 if k_seats <= 6 else k_seats if k_seats <= 8 else 10 if k_seats <= 10 else 12
+                        ki = 0 if k_seats <= 4 else k_seats if k_seats <= 8 else 10 if k_seats <= 10 else 12
                         ok = a[1] == mixed and a[3] == ki
                     if ok:
                         hits.append((name, rec))

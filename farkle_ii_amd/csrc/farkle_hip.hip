@@ -583,8 +583,10 @@ hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s)
         return launch_play_hc_t<768, true, 12, 3, false, false, 12>(p, a, s);
     }
     if (p.hc_ki == 2) { // four waves per SIMD: increments in registers, strategies loaded per turn
-        if (a.k == 5u && p.block == 256) return launch_play_hc_t<256, true, 6, 4, false>(p, a, s);
-        if (a.k == 6u && p.block == 512) return launch_play_hc_t<512, true, 6, 4, false>(p, a, s);
+        // (register arrays and select trees sized for the launch's own seat count: five seats take four selects per increment dword
+        // instead of six seats' five, and three index words instead of four — the reference's default configuration plays k = 5)
+        if (a.k == 5u && p.block == 256) return launch_play_hc_t<256, true, 5, 4, false, false, 6>(p, a, s);
+        if (a.k == 6u && p.block == 512) return launch_play_hc_t<512, true, 6, 4, false, false, 6>(p, a, s);
         if (a.k == 7u && p.block == 1024) return launch_play_hc_t<1024, true, 7, 4, false>(p, a, s);
         return hipErrorInvalidValue;
     }
