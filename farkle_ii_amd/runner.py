@@ -144,6 +144,24 @@ def build_strategy_manifest(strategies: Sequence[ThresholdStrategy]):
     return frame
 
 
+class _SweepShared:
+    """What every player count of one sweep derives from the SAME strategy list (run_multi): the prepared strategies, their manifest
+    frame / Arrow table / sha256, the packed table for the C-ABI and which manifest files have been checked against it — 60 % of the host
+    time of the reference's eight-count production sweep when each count rebuilt them (tools/profile_run_host_null.py)."""
+
+    def __init__(self, strategies: list[ThresholdStrategy]):
+        import hashlib
+
+        import pyarrow as pa
+
+        self.strategies = strategies
+        self.manifest = build_strategy_manifest(strategies)
+        self.manifest_sha = hashlib.sha256(self.manifest.to_csv(index=False).encode("utf-8")).hexdigest()  # runner.py:790-800
+        self.table = pa.Table.from_pandas(self.manifest, preserve_index=False)
+        self.packed = rt.pack_strategies(strategies)
+        self.verified: set[str] = set()  # manifest files known to equal `table`
+
+
 def _plan_workload_from_config(cfg: AppConfig, n_strategies: int, n_players: int) -> TournamentWorkloadPlan:
     return plan_tournament_workload(
         root_seed=cfg.sim.seed, k=n_players, strategy_count=n_strategies, resolution_delta=cfg.screening.resolution_delta,
@@ -341,7 +359,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                    checkpoint_path: Path, collect_metrics: bool, row_dir: Path | None, metric_chunk_dir: Path | None,
                    resume: bool, checkpoint_metadata: Mapping[str, Any], oracle_game_profile: GameProfile | None = None,
                    all_player_dir: Path | None = None, sidecars: "_Sidecars | None" = None,
-                   rng_lags: Sequence[int] | None = None, defer_final_checkpoint: bool = False) -> dict:
+                   rng_lags: Sequence[int] | None = None, defer_final_checkpoint: bool = False, packed_table: np.ndarray | None = None) -> dict:
     """Play every deterministic batch not yet owned by the checkpoint and persist the aggregates.  ``defer_final_checkpoint``: the final
     checkpoint's file write may still be in flight on return — the caller joins ``result["checkpoint_written"]`` before reading the file.  ``rng_lags``: also accumulate the lag
     sufficient statistics of the RNG diagnostics' strategy family over the WHOLE shuffle range (``fk_tournament_run_lags``; launch
@@ -431,7 +449,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
     target = oracle_game_profile.default_target_score if oracle_game_profile else 10_000
     max_rounds = oracle_game_profile.default_max_rounds if oracle_game_profile else 200
     ov = oracle_game_profile.tournament_overrides() if oracle_game_profile else None
-    table = rt.pack_strategies(strategies)
+    table = packed_table if packed_table is not None else rt.pack_strategies(strategies)
     gps = S // k
     group_batches = max(1, MAX_GAMES_PER_LAUNCH // max(spb * gps, 1))
     want_rows = row_dir is not None
@@ -617,14 +635,15 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
 
 
 def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | None = None, *, force: bool = False,
-                 oracle_game_profile: GameProfile | None = None) -> int:
+                 oracle_game_profile: GameProfile | None = None, _shared: "_SweepShared | None" = None) -> int:
     """Run a Farkle tournament for a single player count ``n``; returns the number of games of the plan."""
-    import hashlib
-
     import pyarrow as pa
 
     rank, _ = _rank_world()
-    strategies, grid_size = _resolve_strategies(cfg, strategies)
+    if _shared is not None:
+        strategies, grid_size = _shared.strategies, len(_shared.strategies)
+    else:
+        strategies, grid_size = _resolve_strategies(cfg, strategies)
     plan = _plan_workload_from_config(cfg, grid_size, n)
     n_dir = cfg.n_dir(n)
     n_dir.mkdir(parents=True, exist_ok=True)
@@ -645,8 +664,8 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
             write_workload_plan(plan_path, plan)
         raise WorkloadCapExceeded(plan)
     ckpt_path = cfg.checkpoint_path(n)
-    manifest = build_strategy_manifest(strategies)
-    manifest_sha = hashlib.sha256(manifest.to_csv(index=False).encode("utf-8")).hexdigest()  # runner.py:790-800
+    shared = _shared if _shared is not None else _SweepShared(strategies)
+    manifest_sha = shared.manifest_sha
     if rank == 0:
         if force:
             for path in (ckpt_path, n_dir / f"{n}p_checkpoint.parquet", cfg.metrics_path(n), simulation_done_path(cfg, n),
@@ -659,12 +678,14 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
                         if f.suffix in {".parquet", ".jsonl", ".tmp", ".json"}:  # (.json: the sidecars of a previous run)
                             f.unlink()
         manifest_path = cfg.strategy_manifest_root_path()
-        table = pa.Table.from_pandas(manifest, preserve_index=False)
+        table = shared.table
         if manifest_path.exists():
-            import pyarrow.parquet as pq
+            if str(manifest_path) not in shared.verified:  # (the sweep's other player counts share the root's manifest: checked once)
+                import pyarrow.parquet as pq
 
-            if not pq.read_table(manifest_path).equals(table):
-                raise ValueError(f"Strategy manifest at {manifest_path} does not match the configured grid")
+                if not pq.read_table(manifest_path).equals(table):
+                    raise ValueError(f"Strategy manifest at {manifest_path} does not match the configured grid")
+                shared.verified.add(str(manifest_path))
             table = None  # (nothing to write)
     sidecars = _Sidecars(cfg, n, [cfg.strategy_manifest_root_path(), plan_path], bool(cfg.sim.sidecars))
 
@@ -673,6 +694,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         process writes them on the helper thread while the first launch plays (joined before anything reads them back)."""
         if table is not None:
             _write_parquet_atomic(table, cfg.strategy_manifest_root_path())
+            shared.verified.add(str(cfg.strategy_manifest_root_path()))
         write_workload_plan(plan_path, plan)
         sidecars.write("strategy_manifest", cfg.strategy_manifest_root_path(), sources=(),
                        support_counts=sorted({int(v) for v in cfg.sim.n_players_list}))
@@ -693,7 +715,8 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
                             collect_metrics=cfg.sim.expanded_metrics, row_dir=row_dir, metric_chunk_dir=metric_chunk_dir,
                             resume=not force, checkpoint_metadata={"strategy_manifest_sha": manifest_sha},
                             oracle_game_profile=oracle_game_profile, all_player_dir=all_player_dir, sidecars=sidecars,
-                            rng_lags=cfg.rng_diagnostic_lags() if cfg.sim.rng_lag_sums else None, defer_final_checkpoint=True)
+                            rng_lags=cfg.rng_diagnostic_lags() if cfg.sim.rng_lag_sums else None, defer_final_checkpoint=True,
+                            packed_table=shared.packed)
     finally:
         if published is not None:
             published.result()  # the inputs are on disk (or their error is raised) before the summaries and the stamp name them
@@ -800,8 +823,9 @@ def run_multi(cfg: AppConfig, player_counts: Sequence[int] | None = None, *, for
     strategies, grid_size = _resolve_strategies(cfg, None)
     valid, _ = _filter_player_counts(counts, grid_size)
     results: dict[int, int] = {}
+    shared = _SweepShared(strategies)  # manifest, packed table, ... once for the sweep (every player count plays the same grid)
     for n in valid:
-        results[n] = run_single_n(cfg, n, strategies=strategies, force=force, oracle_game_profile=oracle_game_profile)
+        results[n] = run_single_n(cfg, n, strategies=strategies, force=force, oracle_game_profile=oracle_game_profile, _shared=shared)
     return results
 
 

@@ -896,3 +896,41 @@ def test_two_gloo_ranks_merge_their_lag_ranges_in_order(tmp_path):
     table = pack_strategies(strategies)
     want = LagSummary.from_engine(oracle_engine_stub.Engine(0).tournament_lags(table, 2, 7, 0, n_sh, (1, 2, 5)), (1, 2, 5))
     assert pq.read_table(cfg.n_dir(2) / "2p_rng_lag_sums.parquet").equals(lag_sums_table(want, list(range(len(table))), 7, 2))
+
+
+def test_a_sweep_over_player_counts_writes_what_the_single_count_runs_write(engine, tmp_path):
+    """`farkle run` with several player counts (run_multi) derives the strategy manifest, its sha256 and the packed table ONCE for the
+    sweep (_SweepShared): every per-count artifact — checkpoint payload, summary / metrics parquets, workload plan — and the root's
+    strategy manifest equal those of one run per player count; a second sweep over the finished root preserves them (manifest check
+    against the file on disk)."""
+    import pickle
+
+    import pyarrow.parquet as pq
+
+    from farkle_ii_amd.cli import main
+
+    def cfg(name: str, counts: str) -> Path:
+        path = _tiny_config(tmp_path, "")
+        text = path.read_text().replace("n_players_list: [2]", f"n_players_list: {counts}").replace(str(tmp_path / "out"), str(tmp_path / name))
+        out = tmp_path / f"{name}.yaml"
+        out.write_text(text)
+        return out
+
+    main(["--config", str(cfg("sweep", "[2, 4, 8]")), "--log-level", "WARNING", "run", "--metrics"])
+    for k in (2, 4, 8):
+        main(["--config", str(cfg(f"single{k}", f"[{k}]")), "--log-level", "WARNING", "run", "--metrics"])
+        a, b = tmp_path / "sweep_seed_7" / f"{k}_players", tmp_path / f"single{k}_seed_7" / f"{k}_players"
+        pa_, pb = pickle.loads((a / f"{k}p_checkpoint.pkl").read_bytes()), pickle.loads((b / f"{k}p_checkpoint.pkl").read_bytes())
+        assert pa_ == pb, k
+        for name in (f"{k}p_checkpoint.parquet", f"{k}p_metrics.parquet"):
+            assert pq.read_table(a / name).equals(pq.read_table(b / name)), (k, name)
+        assert (a / "simulation_workload_plan.json").read_text() == (b / "simulation_workload_plan.json").read_text()
+        assert pq.read_table(tmp_path / "sweep_seed_7" / "strategy_manifest.parquet").equals(
+            pq.read_table(tmp_path / f"single{k}_seed_7" / "strategy_manifest.parquet"))
+    before = {p: p.stat().st_mtime_ns for p in (tmp_path / "sweep_seed_7").rglob("*.parquet")}
+    main(["--config", str(tmp_path / "sweep.yaml"), "--log-level", "WARNING", "run", "--metrics"])  # complete: nothing rewritten
+    assert before == {p: p.stat().st_mtime_ns for p in (tmp_path / "sweep_seed_7").rglob("*.parquet")}
+    main(["--config", str(tmp_path / "sweep.yaml"), "--log-level", "WARNING", "run", "--metrics", "--force"])  # replay against the manifest on disk
+    for k in (2, 4, 8):
+        a, b = tmp_path / "sweep_seed_7" / f"{k}_players", tmp_path / f"single{k}_seed_7" / f"{k}_players"
+        assert pickle.loads((a / f"{k}p_checkpoint.pkl").read_bytes()) == pickle.loads((b / f"{k}p_checkpoint.pkl").read_bytes())

@@ -84,6 +84,30 @@ with tempfile.TemporaryDirectory(prefix="fk_e2e_") as tmp:
     del out["runs"]["config3_warm"]
     run3("config3_rows_off", {})
     run3("config3_rows_off_metric_chunks", {"metric_chunk_dir": "metric_chunks"})
+    # the reference's production list of player counts through one `farkle run --metrics` (configs/bench_mega_rows_off.yaml)
+    base_m = yaml.safe_load((ROOT / "configs" / "bench_mega_rows_off.yaml").read_text())
+
+    def run_mega(name):
+        cfg = json.loads(json.dumps(base_m))
+        cfg["io"]["results_dir_prefix"] = str(Path(tmp) / name)
+        path = Path(tmp) / f"{name}.yaml"
+        path.write_text(yaml.safe_dump(cfg))
+        for key in acc: acc[key] = 0
+        t0 = time.perf_counter()
+        main(["--config", str(path), "--log-level", "WARNING", "run", "--metrics"])
+        wall = time.perf_counter() - t0
+        plans = {int(p.parent.name.split("_")[0]): json.loads(p.read_text()) for p in Path(tmp).glob(f"{name}_seed_102/*_players/simulation_workload_plan.json")}
+        games = sum(p["required_games"] for p in plans.values())
+        out["runs"][name] = {"config": "configs/bench_mega_rows_off.yaml (k in {2,3,4,5,6,8,10,12}, 5 160-strategy grid, root seed 102, default screening resolution)",
+                             "games": games, "games_per_k": {str(k): plans[k]["required_games"] for k in sorted(plans)},
+                             "shuffles_per_k": {str(k): plans[k]["required_shuffles"] for k in sorted(plans)}, "wall_s": wall, "games_per_s": games / wall,
+                             "engine_s": acc["engine_s"], "engine_calls": acc["calls"], "host_s": wall - acc["engine_s"],
+                             "host_share": (wall - acc["engine_s"]) / wall,
+                             "reference_cpu_hours_at_its_published_12_worker_rate": games / 1142.9 / 3600}
+        print(name, json.dumps(out["runs"][name]), flush=True)
+    run_mega("mega_warm")
+    del out["runs"]["mega_warm"]
+    run_mega("mega_rows_off")
 for rec in out["runs"].values():
     rec.setdefault("host_share", rec["host_s"] / rec["wall_s"])
 r = out["runs"]
