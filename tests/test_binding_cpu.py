@@ -204,7 +204,7 @@ def _ctypes_blocks():
 
 def test_integration_md_ctypes_blocks_compile_and_use_declared_entry_points():
     blocks = _ctypes_blocks()
-    assert [name for name, _ in blocks] == ["load", "tournament", "play_games", "h2h", "h2h_blocks"]
+    assert [name for name, _ in blocks] == ["load", "tournament", "play_games", "h2h", "h2h_blocks", "all_player"]
     header = (ROOT / "include" / "farkle_hip.h").read_text()
     declared = set(re.findall(r"\b(fk_[a-z0-9_]+)\s*\(", header))
     for name, code in blocks:

@@ -297,7 +297,7 @@ def test_reference_binding_on_a_stand_in_module_runs_the_hip_engine():
 
 
 def test_integration_md_ctypes_blocks_run():
-    """INTEGRATION.md §1-§4a as ONE program on the MI355X: the ctypes stub a reference maintainer would add, checked against the oracle."""
+    """INTEGRATION.md §1-§4c as ONE program on the MI355X: the ctypes stub a reference maintainer would add, checked against the oracle."""
     import re
     from pathlib import Path
 
@@ -336,6 +336,12 @@ def test_integration_md_ctypes_blocks_run():
         for i, o in enumerate(outs):
             w = po.h2h_block(pairs[i].view(po.STRATEGY_DTYPE), 42, 5 + i, i & 1, 200, 400, 300)
             assert [o[key] for key in ns["STATE_KEYS"]] == [int(v) for v in w], i
+        from oracle_engine_stub import seat_ratio_sums_from_rows, seat_stats_from_rows
+
+        t2, stats, ratios = ns["all_player_accumulators"](table, 4, 42, 3, 11, 3)
+        assert np.array_equal(t2, ref["tally"])
+        assert np.array_equal(stats, seat_stats_from_rows(ref["rows"], 4, len(table), len(table) // 4, 3))
+        assert ratios.tobytes() == seat_ratio_sums_from_rows(ref["rows"], 4, len(table), len(table) // 4, 3).tobytes()
     finally:
         ns["lib"].fk_destroy.restype = None
         ns["lib"].fk_destroy.argtypes = [ns["C"].c_void_p]

@@ -15,7 +15,7 @@ python3 tools/make_traffic_json.py r05k6 4 30500000000 "tools/pmc_cfg.sh r05k6 5
 python3 tools/make_traffic_json.py r05k8 4 39000000000 "tools/pmc_cfg.sh r05k8 5160 8 193798 (one of the k = 8 call's two launches)" $R 8
 python3 tools/make_traffic_json.py r05c5 5 45600000000 "bench.py --config 5 --steps 1 --warmup 0 under tools/pmc_cfg.sh (6 x 10^8 attempts per launch x 76 B)" $R
 cp gpurun_out/r05_play_kernel_pmc_summary_config2.txt gpurun_out/r05_play_hc_kernel_pmc_summary_config3.txt gpurun_out/r05_pmc_summary_config6_k*.txt profiles/
-for c in 2 3 6; do cp "$(ls -t gpurun_out/r05_bench_c${c}_stats/*/*_kernel_stats.csv | head -1)" profiles/r05_bench_c${c}_kernel_stats.csv; cp gpurun_out/r05_bench_c${c}_under_rocprof.json profiles/; done
+for c in 2 3 4 5 6; do cp "$(ls -t gpurun_out/r05_bench_c${c}_stats/*/*_kernel_stats.csv | head -1)" profiles/r05_bench_c${c}_kernel_stats.csv; cp gpurun_out/r05_bench_c${c}_under_rocprof.json profiles/; done
 for c in 2 3 4 5 6; do cp gpurun_out/r05_bench_config$c.json profiles/; done
 cp gpurun_out/r05_bench.json gpurun_out/r05_farkle_run_end_to_end.json gpurun_out/r05_bench_2rank_gloo_one_gpu.json gpurun_out/r05_bench_2rank_one_gpu_rccl_refused_fallback.json profiles/
 ls profiles | grep -c r05
