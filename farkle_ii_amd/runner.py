@@ -26,7 +26,7 @@ import logging
 import os
 import time
 from pathlib import Path
-from typing import Any, Mapping, Sequence
+from typing import Any, Callable, Mapping, Sequence
 
 import numpy as np
 
@@ -163,17 +163,40 @@ class _SweepShared:
     frame / Arrow table / sha256, the packed table for the C-ABI and which manifest files have been checked against it — 60 % of the host
     time of the reference's eight-count production sweep when each count rebuilt them (tools/profile_run_host_null.py)."""
 
-    def __init__(self, strategies: list[ThresholdStrategy]):
+    def __init__(self, strategies: list[ThresholdStrategy], background: bool = False):
+        self.strategies = strategies
+        self.packed = rt.pack_strategies(strategies)  # (the engine call needs it; the rest is for the artifacts)
+        self.verified: set[str] = set()  # manifest files known to equal `table`
+        self._derived: tuple | None = None
+        # background: the manifest frame / sha256 / Arrow table are made on the helper thread (2 ms for 64 strategies, 70 ms for 5 160)
+        # while the caller goes on to the first engine call; whoever reads them first waits for that job
+        self._job = _helper_thread().submit(self._derive) if background else None
+
+    def _derive(self) -> tuple:
         import hashlib
 
         import pyarrow as pa
 
-        self.strategies = strategies
-        self.manifest = build_strategy_manifest(strategies)
-        self.manifest_sha = hashlib.sha256(self.manifest.to_csv(index=False).encode("utf-8")).hexdigest()  # runner.py:790-800
-        self.table = pa.Table.from_pandas(self.manifest, preserve_index=False)
-        self.packed = rt.pack_strategies(strategies)
-        self.verified: set[str] = set()  # manifest files known to equal `table`
+        manifest = build_strategy_manifest(self.strategies)
+        sha = hashlib.sha256(manifest.to_csv(index=False).encode("utf-8")).hexdigest()  # runner.py:790-800
+        return manifest, sha, pa.Table.from_pandas(manifest, preserve_index=False)
+
+    def _get(self) -> tuple:
+        if self._derived is None:
+            self._derived = self._job.result() if self._job is not None else self._derive()
+        return self._derived
+
+    @property
+    def manifest(self):
+        return self._get()[0]
+
+    @property
+    def manifest_sha(self) -> str:
+        return self._get()[1]
+
+    @property
+    def table(self):
+        return self._get()[2]
 
 
 def _plan_workload_from_config(cfg: AppConfig, n_strategies: int, n_players: int) -> TournamentWorkloadPlan:
@@ -371,7 +394,7 @@ def _check_ownership(total: np.ndarray, done_batches: set[int], spb: int, requir
 
 def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[ThresholdStrategy], plan: TournamentWorkloadPlan,
                    checkpoint_path: Path, collect_metrics: bool, row_dir: Path | None, metric_chunk_dir: Path | None,
-                   resume: bool, checkpoint_metadata: Mapping[str, Any], oracle_game_profile: GameProfile | None = None,
+                   resume: bool, checkpoint_metadata: "Mapping[str, Any] | Callable[[], Mapping[str, Any]]", oracle_game_profile: GameProfile | None = None,
                    all_player_dir: Path | None = None, sidecars: "_Sidecars | None" = None,
                    rng_lags: Sequence[int] | None = None, defer_final_checkpoint: bool = False, packed_table: np.ndarray | None = None) -> dict:
     """Play every deterministic batch not yet owned by the checkpoint and persist the aggregates.  ``defer_final_checkpoint``: the final
@@ -386,20 +409,29 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
     ids = [int(s.strategy_id) for s in strategies]
     spb = plan.shuffles_per_batch
     n_batches = plan.batch_count
-    meta = {
-        "n_players": k, "num_shuffles": plan.required_shuffles, "global_seed": cfg.sim.seed, "n_strategies": S,
-        "rng_scheme_version": urandom.RNG_SCHEME_VERSION, "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
-        "tournament_method_version": TOURNAMENT_METHOD_VERSION, "rng_bit_generator": "PCG64DXSM",
-        "coordinate_contract_version": 1, "shuffle_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
-        "shuffle_permutation_purpose_namespace": int(urandom.RandomPurpose.SHUFFLE_PERMUTATION),
-        "game_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_GAME),
-        "player_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_PLAYER), "deterministic_batch_size": spb,
-        **({"game_profile_sha256": oracle_game_profile.sha256} if oracle_game_profile is not None else {}),  # run_tournament.py:1156
-        **dict(checkpoint_metadata),
-        "workload_plan_version": plan.plan_version, "screening_resolution_delta": plan.resolution_delta,
-        "screening_interval_confidence": plan.confidence, "batch_count": plan.batch_count, "shuffles_per_batch": spb,
-        "batch_construction": plan.batch_construction,
-    }
+    meta_cache: list[dict] = []
+
+    def get_meta() -> dict:
+        """The checkpoint's contract metadata (built on first use: ``checkpoint_metadata`` may be a callable whose value — the strategy
+        manifest's sha256 — is still being computed on the helper thread while the first launch plays)."""
+        if not meta_cache:
+            extra = checkpoint_metadata() if callable(checkpoint_metadata) else checkpoint_metadata
+            meta_cache.append({
+                "n_players": k, "num_shuffles": plan.required_shuffles, "global_seed": cfg.sim.seed, "n_strategies": S,
+                "rng_scheme_version": urandom.RNG_SCHEME_VERSION, "outcome_schema_version": OUTCOME_SCHEMA_VERSION,
+                "tournament_method_version": TOURNAMENT_METHOD_VERSION, "rng_bit_generator": "PCG64DXSM",
+                "coordinate_contract_version": 1, "shuffle_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE),
+                "shuffle_permutation_purpose_namespace": int(urandom.RandomPurpose.SHUFFLE_PERMUTATION),
+                "game_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_GAME),
+                "player_purpose_namespace": int(urandom.RandomPurpose.TOURNAMENT_PLAYER), "deterministic_batch_size": spb,
+                **({"game_profile_sha256": oracle_game_profile.sha256} if oracle_game_profile is not None else {}),  # run_tournament.py:1156
+                **dict(extra),
+                "workload_plan_version": plan.plan_version, "screening_resolution_delta": plan.resolution_delta,
+                "screening_interval_confidence": plan.confidence, "batch_count": plan.batch_count, "shuffles_per_batch": spb,
+                "batch_construction": plan.batch_construction,
+            })
+        return meta_cache[0]
+
     total = np.zeros((S, 26), dtype=np.int64)
     done_batches: set[int] = set()
     row_manifest = (row_dir / "manifest.jsonl") if row_dir is not None else None
@@ -413,7 +445,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 old = payload.get("meta", {})
                 stale = [key for key in ("n_players", "num_shuffles", "global_seed", "n_strategies", "deterministic_batch_size",
                                          "strategy_manifest_sha", "rng_scheme_version")
-                         if key in old and old.get(key) != meta.get(key)]
+                         if key in old and old.get(key) != get_meta().get(key)]
                 if stale:
                     raise ValueError(f"checkpoint {checkpoint_path} was written under a different contract: {stale}; use --force")
                 done_batches = set(int(b) - 1 for b in old.get("completed_process_block_indices", []))  # recorded 1-based
@@ -492,7 +524,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 if run_first is not None:
                     shuffle_list.extend(range(run_first * spb, min((run_last + 1) * spb, plan.required_shuffles)))
                 run_first = run_last = b
-        ck_meta = {**meta, "completed_shuffle_indices": shuffle_list,
+        ck_meta = {**get_meta(), "completed_shuffle_indices": shuffle_list,
                    "completed_process_block_indices": [b + 1 for b in completed], "complete": final}
         content = ckpt.dump_checkpoint(wins, sums if collect_metrics else None, sqs if collect_metrics else None, ck_meta)
         if final and defer_final_checkpoint and not sidecars.enabled:
@@ -679,8 +711,9 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
             write_workload_plan(plan_path, plan)
         raise WorkloadCapExceeded(plan)
     ckpt_path = cfg.checkpoint_path(n)
-    shared = _shared if _shared is not None else _SweepShared(strategies)
-    manifest_sha = shared.manifest_sha
+    # (a single process derives the manifest frame / sha256 / Arrow table on the helper thread, under the first engine call)
+    shared = _shared if _shared is not None else _SweepShared(strategies, background=rank == 0 and _rank_world()[1] == 1)
+    write_manifest = False
     if rank == 0:
         if force:
             for path in (ckpt_path, n_dir / f"{n}p_checkpoint.parquet", cfg.metrics_path(n), simulation_done_path(cfg, n),
@@ -693,22 +726,22 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
                         if f.suffix in {".parquet", ".jsonl", ".tmp", ".json"}:  # (.json: the sidecars of a previous run)
                             f.unlink()
         manifest_path = cfg.strategy_manifest_root_path()
-        table = shared.table
         if manifest_path.exists():
             if str(manifest_path) not in shared.verified:  # (the sweep's other player counts share the root's manifest: checked once)
                 import pyarrow.parquet as pq
 
-                if not pq.read_table(manifest_path).equals(table):
+                if not pq.read_table(manifest_path).equals(shared.table):
                     raise ValueError(f"Strategy manifest at {manifest_path} does not match the configured grid")
                 shared.verified.add(str(manifest_path))
-            table = None  # (nothing to write)
+        else:
+            write_manifest = True
     sidecars = _Sidecars(cfg, n, [cfg.strategy_manifest_root_path(), plan_path], bool(cfg.sim.sidecars))
 
     def publish_inputs() -> None:
         """The run's two input artifacts (strategy manifest, workload plan) and their sidecars.  Nothing the engine needs: a single
         process writes them on the helper thread while the first launch plays (joined before anything reads them back)."""
-        if table is not None:
-            _write_parquet_atomic(table, cfg.strategy_manifest_root_path())
+        if write_manifest:
+            _write_parquet_atomic(shared.table, cfg.strategy_manifest_root_path())
             shared.verified.add(str(cfg.strategy_manifest_root_path()))
         write_workload_plan(plan_path, plan)
         sidecars.write("strategy_manifest", cfg.strategy_manifest_root_path(), sources=(),
@@ -728,7 +761,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
     try:
         result = run_tournament(cfg=cfg, n_players=n, strategies=strategies, plan=plan, checkpoint_path=ckpt_path,
                             collect_metrics=cfg.sim.expanded_metrics, row_dir=row_dir, metric_chunk_dir=metric_chunk_dir,
-                            resume=not force, checkpoint_metadata={"strategy_manifest_sha": manifest_sha},
+                            resume=not force, checkpoint_metadata=lambda: {"strategy_manifest_sha": shared.manifest_sha},
                             oracle_game_profile=oracle_game_profile, all_player_dir=all_player_dir, sidecars=sidecars,
                             rng_lags=cfg.rng_diagnostic_lags() if cfg.sim.rng_lag_sums else None, defer_final_checkpoint=True,
                             packed_table=shared.packed)
@@ -853,11 +886,11 @@ def run_multi(cfg: AppConfig, player_counts: Sequence[int] | None = None, *, for
     strategies, grid_size = _resolve_strategies(cfg, None)
     valid, _ = _filter_player_counts(counts, grid_size)
     results: dict[int, int] = {}
-    shared = _SweepShared(strategies)  # manifest, packed table, ... once for the sweep (every player count plays the same grid)
     # A player count's publishing tail (summary tables, completion stamp: 10 - 20 ms of Python on the 5 160-strategy grid) runs on its own
     # thread under the NEXT player count's engine call (ctypes drops the GIL for its duration): one tail in flight, joined — and any error
     # of it raised — before the next one starts and before the sweep returns.  Ranked runs publish in line (their barriers order the ranks).
     overlap = _rank_world()[1] == 1
+    shared = _SweepShared(strategies, background=overlap)  # manifest, packed table, ... once for the sweep (every count plays the same grid)
     in_flight = None
     try:
         for n in valid:
