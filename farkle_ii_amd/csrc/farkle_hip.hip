@@ -539,7 +539,7 @@ hipError_t launch_play_hc_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t 
 
 // The instances the launch plan can reach (plan_play_hc): k = 4 cold records in LDS (four 320-thread blocks, five waves per
 // SIMD), k = 5 .. 7 four waves per SIMD with the increments in registers, k = 8 three.  Every other variant that was built and
-// measured (global tables, increments / strategies loaded or held, three-wave forms, other block sizes, cold
+// measured (profiles/HISTORY.md, section 4.9 of the round-4 document: global tables, increments / strategies loaded or held, three-wave forms, other block sizes, cold
 // records in LDS at k = 3 / 5, cold records in registers) lost or tied; they are compiled only with -DFK_EXPERIMENTS
 // (tools/build_experiments.sh), where the tools/exp_*.py scripts that produced the log still run.
 hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {

@@ -27,17 +27,21 @@
 //         ten-dword records seat four (+5 % games/s), six at k = 3 and four at k = 5 (both +-0) — with no plane, no select trees
 //         and the global tables (the texture addresser is not saturated there).  k = 4 launches four 320-thread blocks per CU:
 //         five 256-thread blocks of exactly 32 KB do not fit 160 KB of LDS once each is rounded up to the allocation granule;
-//   READ-ONLY per seat (KI instances, k <= 8): the PCG increment (4 dwords) and the packed strategy (2 dwords, k <= 6) of
-//         EVERY seat stay in registers for the whole game and are picked by a select tree on the seat index at a turn start
-//         (7 v_cndmask per dword at k = 8): no increment / strategy request per turn, no increment lines in L2;
-//   TABLES (LT instances): the score / discard tables are read from an LDS image (fk_device.h) instead of the 512 KiB /
+//   READ-ONLY per seat (KI instances, k <= 12): the PCG increment (4 dwords; and in the three-wave instances up to six seats the packed
+//         strategy, 2 dwords) of EVERY seat stay in registers for the whole game and are picked by a select tree on the seat index at a
+//         turn start (k - 1 v_cndmask per dword): no increment / strategy request per turn, no increment lines in L2.  Round 5 measured
+//         the alternative — increments in 32-byte cold-plane slots, the next owner's fetched one turn ahead (IP) — 15 - 47 % slower: a
+//         third scattered access per turn is more than the texture addresser has to spare;
+//   TABLES (LT instances): the score / discard tables are read from a 12.4-KB LDS image (fk_device.h) instead of the 1 MiB /
 //         64 KiB global tables — two gathers per roll less for the texture addresser (-14 % kernel time here; in
 //         fk_play_kernel, which does not saturate it, the same change measured +1.7 % and was dropped);
 //   has_buf of all seats is one bit mask per lane; the seats' strategy indices are eight 16-bit fields in four registers.
 //   FOUR WAVES per SIMD for k = 5 .. 7 (WPE = 4, PKR_I = false): with the packed strategies loaded per turn instead, 128
 //         registers hold the increments of six or seven seats without a spill in the roll loop, and the hot planes + table
-//         image fit as 4 x 256 threads (k = 5), 2 x 512 (k = 6) or 1 x 1 024 (k = 7) per CU.  k = 8 stays at three waves: its
-//         hot planes alone are 160 KB at four.
+//         image fit as 4 x 256 threads (k = 5), 2 x 512 (k = 6) or 1 x 1 024 (k = 7) per CU.  k = 8 stays at three waves: at four its
+//         cold plane (1 024 lanes x 8 x 16 B = 131 KB per CU) no longer fits the CU's 128 KB of L2 (measured +8 %, round 5).
+//   NINE TO TWELVE seats (round 5): one 768-thread block per CU (three waves per SIMD, 168 VGPRs, KI = 10 / 12); the hot planes are
+//         16 k bytes per lane (147 KB at twelve seats) beside the table image.
 // Measured against fk_play_kernel in the same process on the 5 160-strategy grid (tools/exp_hc2.py, tools/exp_hc3.py):
 // k = 8 +27 %, k = 7 +25 %, k = 6 +23 %, k = 5 +10 % games/s (three-wave instances: +27 / +20 / +13 / +-0 %); k = 4 +-0 at five
 // waves (spilling) and -2 % at four, k = 3 -7 %: the launch plan picks the register instances from k = 5 and the cold-in-LDS

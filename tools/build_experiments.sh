@@ -1,6 +1,5 @@
 #!/bin/bash
-# The library WITH the kernel instances and fk_set_option names that lost or tied against the launch plan's choices (DESIGN.md
-# sections 4.3 / 4.9 logs): tools/ab/lib_experiments.so, selected with FARKLE_HIP_LIB=$PWD/tools/ab/lib_experiments.so.  The
+# The library WITH the kernel instances and fk_set_option names that lost or tied against the launch plan's choices (profiles/HISTORY.md): tools/ab/lib_experiments.so, selected with FARKLE_HIP_LIB=$PWD/tools/ab/lib_experiments.so.  The
 # tools/exp_*.py scripts that produced the logs need it; the shipped farkle_ii_amd/libfarkle_hip.so does not contain them.
 set -e
 cd "$(dirname "$0")/.."
