@@ -820,13 +820,18 @@ def main() -> None:
 
 
 def kernel_source_sha() -> str:
-    """sha256 over the DEVICE sources (kernels + per-roll device functions): profiles carry it so that an HBM-traffic figure
-    taken on other kernels is never attached."""
+    """sha256 over the CODE of the device sources (kernels + per-roll device functions; comments and white space left out, so that
+    a reworded comment does not orphan a measurement): profiles carry it so that an HBM-traffic figure or an instruction mix taken on
+    other kernels is never attached."""
     import hashlib
+    import re
 
     h = hashlib.sha256()
     for name in ("fk_kernels.h", "fk_play_hc.h", "fk_device.h"):
-        h.update((ROOT / "farkle_ii_amd" / "csrc" / name).read_bytes())
+        text = (ROOT / "farkle_ii_amd" / "csrc" / name).read_text(encoding="utf-8")
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)   # (no string literal of these files holds a comment marker)
+        text = re.sub(r"//[^\n]*", " ", text)
+        h.update(" ".join(text.split()).encode("utf-8"))
     return h.hexdigest()
 
 
