@@ -467,7 +467,7 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5, 6))
     ap.add_argument("--shuffles", type=int, default=0, help="configs 2/3: shuffles per rank per step (default: the BASELINE size)")
     ap.add_argument("--games", type=int, default=0, help="configs 4 / 6: games per k per step; config 5: completed games per pair")
@@ -475,7 +475,12 @@ def main() -> None:
     ap.add_argument("--dump-tally", type=Path, default=None, help="rank 0 saves the reduced tally here (.npy; tests)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {2: 5, 3: 2, 4: 1, 5: 1, 6: 1}[args.config]
+        args.steps = {2: 20, 3: 2, 4: 1, 5: 1, 6: 1}[args.config]
+    if args.warmup is None:
+        # config 2's steps are 9 ms: a fresh process reaches its steady shader clock (2.39 GHz) only after ~50 ms of launches (measured:
+        # 2.0 - 2.2 GHz in the first launches), so five warm-up steps, like the driver's own command; the other configurations' steps are
+        # 170 ms and longer, one warm-up step is past the ramp
+        args.warmup = 5 if args.config == 2 else 1
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
