@@ -502,9 +502,12 @@ def _run_rank(rank: int, world: int, port: int, cfg_path: str, k: int) -> None:
     dist.destroy_process_group()
 
 
-def test_two_gloo_ranks_write_the_same_artifacts_as_one_process(tmp_path):
-    """`farkle run` with two ranks (whole batches per rank, one tally reduce per launch group, row shards written by the
-    rank that played them, manifest lines gathered to rank 0) against the single-process run of the same configuration."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_two_gloo_ranks_write_the_same_artifacts_as_one_process(tmp_path, world):
+    """`farkle run` with two — and with eight — ranks (whole batches per rank, one tally reduce per launch group, row shards written by
+    the rank that played them, manifest lines gathered to rank 0) against the single-process run of the same configuration; with
+    eight ranks there are fewer batches than ranks in some launch groups, so some ranks play nothing and still take part in every
+    collective."""
     import pyarrow.parquet as pq
     import torch.multiprocessing as mp
     import yaml
@@ -527,7 +530,7 @@ def test_two_gloo_ranks_write_the_same_artifacts_as_one_process(tmp_path):
         runner.run_single_n(roots["one"], 2)
     finally:
         eng_mod.set_engine(None)
-    mp.spawn(_run_rank, args=(2, 33500 + os.getpid() % 2000, str(tmp_path / "two.yaml"), 2), nprocs=2, join=True)
+    mp.spawn(_run_rank, args=(world, 33500 + os.getpid() % 2000 + world, str(tmp_path / "two.yaml"), 2), nprocs=world, join=True)
     a, b = roots["one"].results_root, roots["two"].results_root
     files_a = sorted(str(f.relative_to(a)) for f in a.rglob("*") if f.is_file())
     files_b = sorted(str(f.relative_to(b)) for f in b.rglob("*") if f.is_file())
