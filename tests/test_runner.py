@@ -880,7 +880,8 @@ def test_farkle_run_rng_lag_sums(engine, tmp_path, monkeypatch):
         main(["--config", str(cfg_path), "run", "--rng-lag-sums"])
 
 
-def test_two_gloo_ranks_merge_their_lag_ranges_in_order(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_two_gloo_ranks_merge_their_lag_ranges_in_order(tmp_path, world):
     import pyarrow.parquet as pq
     import torch.multiprocessing as mp
 
@@ -892,7 +893,7 @@ def test_two_gloo_ranks_merge_their_lag_ranges_in_order(tmp_path):
 
     cfg_path = _tiny_config(tmp_path)
     cfg_path.write_text(cfg_path.read_text() + "analysis:\n  rng_diagnostic_lags: [1, 2, 5]\n")
-    mp.spawn(_run_rank_lags, args=(2, 35500 + os.getpid() % 2000, str(cfg_path), 2), nprocs=2, join=True)
+    mp.spawn(_run_rank_lags, args=(world, 35500 + os.getpid() % 2000 + world, str(cfg_path), 2), nprocs=world, join=True)  # (eight: ranks without a batch contribute no range)
     cfg = load_app_config(cfg_path, seed_list_len=1)
     n_sh = pickle.loads((cfg.n_dir(2) / "2p_checkpoint.pkl").read_bytes())["meta"]["num_shuffles"]
     strategies, _ = runner._resolve_strategies(cfg, None)
