@@ -41,6 +41,13 @@ def build_parser() -> argparse.ArgumentParser:
                           "invocation asks for --force), and a run completed without it must be replayed with --force")
     run.add_argument("--sidecars", action="store_true",
                      help="Write <artifact>.sidecar.json (producer contract + SHA-256 / size of the artifact) beside every output")
+    run.add_argument("--code-identity", metavar="COMMIT[:DIRTY_SHA256[:POLICY]]",
+                     help="Write artifact-contract-v3 sidecars, sealed shard manifests and the authenticated simulation.done.json, signed with "
+                          "this code identity: the one the checkout that will run the reference's `analyze ingest` resolves (its Git commit and, "
+                          "for a dirty tree, the worktree fingerprint).  Implies --sidecars")
+    run.add_argument("--reference-checkout", type=Path, metavar="PATH",
+                     help="Like --code-identity, with the identity resolved from the Git checkout at PATH the way the reference does "
+                          "(rev-parse HEAD; staged + worktree diff + inventoried untracked files for a dirty tree)")
     run.add_argument("--force", action="store_true", help="Recompute even when existing run artifacts are available")
     t = sub.add_parser("time", help="Benchmark simulation throughput")
     t.add_argument("--players", type=int, default=5, help="Players per game (default: 5)")
@@ -91,6 +98,13 @@ def main(argv: Sequence[str] | None = None) -> None:
     if args.row_dir is not None:
         cfg.sim.row_dir = args.row_dir
     if args.sidecars:
+        cfg.sim.sidecars = True
+    if args.code_identity and args.reference_checkout:
+        raise SystemExit("farkle run: --code-identity and --reference-checkout are two ways to say the same thing; pass one")
+    if args.code_identity or args.reference_checkout:
+        from .contract_v3 import parse_code_identity, resolve_code_identity
+
+        cfg._code_identity = parse_code_identity(args.code_identity) if args.code_identity else resolve_code_identity(args.reference_checkout)
         cfg.sim.sidecars = True
     if args.all_player_batches is not None:
         cfg.sim.all_player_batch_dir = args.all_player_batches

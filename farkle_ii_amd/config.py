@@ -107,6 +107,11 @@ class AppConfig:
     screening: ScreeningConfig = field(default_factory=ScreeningConfig)
     batching: BatchingConfig = field(default_factory=BatchingConfig)
     opaque: dict = field(default_factory=dict)  # analysis-only sections, untouched
+    # run identities a caller hands in (config.py:472-474 of the reference: private, never part of a configuration digest) — what
+    # artifact-contract version 3 signs with (contract_v3.py)
+    _code_identity: dict | None = field(default=None, init=False, repr=False, compare=False)
+    _run_lineage_sha256: str | None = field(default=None, init=False, repr=False, compare=False)
+    _game_profile_sha256: str | None = field(default=None, init=False, repr=False, compare=False)
 
     @property
     def results_root(self) -> Path:
@@ -120,6 +125,16 @@ class AppConfig:
 
     def n_dir(self, n: int) -> Path:
         return self.results_root / f"{n}_players"
+
+    @property
+    def artifact_contract_version(self) -> int:
+        """The contract the sidecar writers follow.  ``artifact_contract.artifact_contract_version`` when the configuration states it
+        (the section is carried opaquely; the reference's default is 3, config.py:210); otherwise 3 when the caller supplied the code
+        identity version 3 signs with, and the structural version 2 when not."""
+        stated = (self.opaque.get("artifact_contract") or {}).get("artifact_contract_version")
+        if stated is not None:
+            return int(stated)
+        return 3 if self._code_identity is not None else 2
 
     def _per_n_dir(self, raw_value, n: int, what: str) -> Path | None:
         if not raw_value:

@@ -39,7 +39,7 @@ from .engine import get_engine
 from .game_profile import GameProfile
 from .all_player import all_player_batch_table
 from .backend import COL_ATTEMPTED, COL_COMPLETED, COL_SAFETY, COL_SQ_SUMS, COL_SUMS, COL_WINS, SEAT_RATIO_COLS, SEAT_STAT_COLS
-from .rows import OUTCOME_SCHEMA_VERSION, TOURNAMENT_METHOD_VERSION
+from .rows import OUTCOME_SCHEMA_VERSION, TOURNAMENT_METHOD_VERSION, raw_simulation_schema_for
 from .strategies import (STRATEGY_TUPLE_FIELDS, FavorDiceOrScore, ThresholdStrategy, generate_strategy_grid,
                          prepare_public_helper_strategies, strategy_tuple)
 from .workload_planner import TournamentWorkloadPlan, WorkloadCapExceeded, plan_tournament_workload, write_workload_plan
@@ -158,6 +158,27 @@ def build_strategy_manifest(strategies: Sequence[ThresholdStrategy]):
     return frame
 
 
+def _publish_shard_v3(table, path: Path, template: Mapping[str, Any], **writer_options) -> dict[str, Any]:
+    """Write one Parquet shard and its contract-v3 sidecar; returns the identity fields its manifest record carries."""
+    import hashlib
+
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    from .contract_v3 import fill_shard_template, sidecar_path
+
+    sink = pa.BufferOutputStream()
+    pq.write_table(table, sink, **writer_options)
+    blob = sink.getvalue().to_pybytes()
+    digest = hashlib.sha256(blob).hexdigest()
+    text, side_sha = fill_shard_template(template, path.name, len(blob), digest)
+    sidecar_path(path).unlink(missing_ok=True)  # never new bytes under an old sidecar
+    _atomic_write_bytes(path, blob)
+    _atomic_write_bytes(sidecar_path(path), text)
+    return {"byte_length": len(blob), "data_sha256": digest, "sidecar_sha256": side_sha,
+            "schema_fingerprint_sha256": template["schema_fingerprint_sha256"]}
+
+
 class _SweepShared:
     """What every player count of one sweep derives from the SAME strategy list (run_multi): the prepared strategies, their manifest
     frame / Arrow table / sha256, the packed table for the C-ABI and which manifest files have been checked against it — 60 % of the host
@@ -227,6 +248,22 @@ def simulation_is_complete(cfg: AppConfig, n_players: int, plan: TournamentWorkl
         meta = json.loads(path.read_text(encoding="utf-8"))  # the contract sits at the top level (stage_completion.py:505-512)
     except (OSError, json.JSONDecodeError):
         return False
+    if isinstance(meta, dict) and "stage_identity_sha256" in meta and "outputs" in meta and "status" not in meta:
+        # an authenticated (contract v3) completion: valid iff the stage identity recomputed from the outputs' sidecars under the CURRENT
+        # configuration and code identity is the stamp's (runner.py:274-317 of the reference); the workload plan is one of those outputs
+        from .contract_v3 import ContractError, SimulationContract
+
+        if cfg._code_identity is None:
+            raise ContractError(f"{path} is an authenticated contract-v3 completion: pass the code identity it was written under "
+                                "(--code-identity / --reference-checkout) to validate it, or --force to replace the run")
+        if plan is not None:
+            from .workload_planner import workload_plan_bytes
+
+            plan_path = cfg.n_dir(n_players) / "simulation_workload_plan.json"
+            if not plan_path.exists() or plan_path.read_bytes() != workload_plan_bytes(plan):
+                return False
+        return SimulationContract(cfg, cfg._code_identity, game_profile_sha256=cfg._game_profile_sha256,
+                                  run_lineage_sha256=cfg._run_lineage_sha256).is_complete(path)
     if not isinstance(meta, dict) or meta.get("status") != "success" or meta.get("completion_state") != "complete_valid":
         return False
     if plan is not None and (meta.get("num_shuffles") != plan.required_shuffles or meta.get("n_strategies") != plan.strategy_count
@@ -287,24 +324,68 @@ def _shuffle_seeds(eng, root_seed: int, k: int, first: int, last: int) -> np.nda
 
 
 class _Sidecars:
-    """Sidecar templates of one (root, k) run (sidecars.py; reference: runner.py:1470-1505) — or a no-op when they are off."""
+    """Sidecar writers of one (root, k) run — or a no-op when they are off.  ``artifact_contract.artifact_contract_version`` (default 3,
+    as in the reference) picks the contract: 3 = the authenticated sidecars / sealed manifests / completion of contract_v3.py, signed
+    with the code identity the caller supplied; 2 = the structural sidecars of sidecars.py (reference: runner.py:1470-1505)."""
+
+    _V3_SOURCES = {"strategy_manifest": 0, "workload_plan": 1}  # how many of (strategy manifest, workload plan) an artifact kind names
 
     def __init__(self, cfg: AppConfig, n_players: int, sources: Sequence[Path], enabled: bool):
         self.cfg, self.k, self.sources, self.enabled = cfg, n_players, list(sources), enabled
+        self.v3 = None
+        self._templates: dict = {}
+        if enabled and cfg.artifact_contract_version == 3:
+            from .contract_v3 import ContractError, SimulationContract
 
-    def template(self, kind: str, path: Path, *, sources: Sequence[Path] | None = None, support_counts: Sequence[int] | None = None):
+            if cfg._code_identity is None:
+                raise ContractError(
+                    "artifact-contract version 3 signs every sidecar with the code identity of the checkout that will ingest the results "
+                    "(the reference's analyze ingest recomputes it): pass --code-identity COMMIT[:DIRTY_SHA256] or --reference-checkout PATH, "
+                    "or ask for the structural contract with --set artifact_contract.artifact_contract_version=2")
+            self.v3 = SimulationContract(cfg, cfg._code_identity, game_profile_sha256=cfg._game_profile_sha256,
+                                         run_lineage_sha256=cfg._run_lineage_sha256)
+        elif enabled and cfg.artifact_contract_version != 2:
+            raise ValueError(f"artifact_contract.artifact_contract_version must be 2 or 3, got {cfg.artifact_contract_version}")
+
+    def _v3_sources(self, kind: str) -> list[Path]:
+        return self.sources[:self._V3_SOURCES.get(kind, 2)]
+
+    def template(self, kind: str, path: Path, *, sources: Sequence[Path] | None = None, support_counts: Sequence[int] | None = None,
+                 schema=None):
+        """What a shard writer needs to publish the sidecar of a shard in ``path``'s directory (picklable)."""
         if not self.enabled:
             return None
+        if self.v3 is not None:
+            key = (kind, str(Path(path).parent))
+            if key not in self._templates:
+                self._templates[key] = self.v3.shard_template(kind, Path(path).parent, schema() if callable(schema) else schema,
+                                                              n_players=self.k, sources=self._v3_sources(kind))
+            return self._templates[key]
         from .sidecars import OPERATIONS, simulation_output_sidecar
 
         return simulation_output_sidecar(self.cfg, path, n_players=self.k, operation=OPERATIONS[kind],
                                          sources=self.sources if sources is None else sources, support_counts=support_counts)
 
-    def write(self, kind: str, path: Path, **kw) -> None:
-        if self.enabled and Path(path).exists():
-            from .sidecars import write_sidecar
+    def write(self, kind: str, path: Path, *, sources: Sequence[Path] | None = None, support_counts: Sequence[int] | None = None) -> None:
+        if not self.enabled or not Path(path).exists():
+            return
+        if self.v3 is not None:  # (the sources of a v3 simulation output are fixed by its kind, runner.py:1438-1505, 1649, 1708)
+            self.v3.write_sidecar(path, kind, n_players=self.k, sources=self._v3_sources(kind), support_counts=support_counts)
+            return
+        from .sidecars import write_sidecar
 
-            write_sidecar(path, self.template(kind, path, **kw))
+        write_sidecar(path, self.template(kind, path, sources=sources, support_counts=support_counts))
+
+
+def _stored_schema(schema, **writer_options):
+    """The Arrow schema a reader gets back from a Parquet file of ``schema`` written with ``writer_options`` — what the reference
+    fingerprints (``parquet_schema_identity``, authenticated_contract.py:293-300)."""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    sink = pa.BufferOutputStream()
+    pq.write_table(schema.empty_table(), sink, **writer_options)
+    return pq.read_schema(pa.BufferReader(sink.getvalue()))
 
 
 def _read_manifest(path: Path) -> list[dict]:
@@ -599,7 +680,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                             if hasattr(eng, "game_seeds") else None)  # the rows' game_seed column, hashed on the device
                 row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
                                                        game_seeds=seeds102, as_lines=True,
-                                                       sidecar=sidecars.template("row_shard", row_dir / "rows_template.parquet")))
+                                                       sidecar=sidecars.template("row_shard", row_dir / "rows_template.parquet",
+                                                                                 schema=lambda: _stored_schema(raw_simulation_schema_for(k), **rt.SHARD_WRITER_OPTIONS))))
         if rng_lags:  # this group's ranges in rank order (contiguous whole batches per rank), appended to the run's summary
             from .rng_lags import LagSummary
 
@@ -639,8 +721,16 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 if metric_chunk_dir is not None:
                     chunk = _metric_chunk_table(group[n], ids, k)
                     name = f"metrics_{b + 1:06d}.parquet"  # chunk / process-block indices count from 1 (run_tournament.py:1603-1642)
-                    _write_parquet_atomic(chunk, metric_chunk_dir / name, **_CHUNK_WRITER_OPTIONS)
-                    sidecars.write("metric_chunk", metric_chunk_dir / name)
+                    chunk_identity = None
+                    if sidecars.v3 is not None:
+                        # encoded in memory: the chunk's bytes give its sidecar (a template around size / SHA-256 / name) and the four
+                        # identity fields a sealed manifest needs of every shard (runner.py:570-577 of the reference)
+                        chunk_identity = _publish_shard_v3(chunk, metric_chunk_dir / name, sidecars.template(
+                            "metric_chunk", metric_chunk_dir / name, schema=lambda: _stored_schema(chunk.schema, **_CHUNK_WRITER_OPTIONS)),
+                            **_CHUNK_WRITER_OPTIONS)
+                    else:
+                        _write_parquet_atomic(chunk, metric_chunk_dir / name, **_CHUNK_WRITER_OPTIONS)
+                        sidecars.write("metric_chunk", metric_chunk_dir / name)
                     first_sh, last_sh = b * spb, min((b + 1) * spb, plan.required_shuffles)
                     record = {"path": name, "rows": chunk.num_rows, "chunk_index": b + 1, "process_block_index": b + 1,
                               "root_seed": cfg.sim.seed, "n_players": k, "deterministic_batch_id": b,
@@ -652,6 +742,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                               "tournament_method_version": TOURNAMENT_METHOD_VERSION}
                     if oracle_game_profile is not None:  # run_tournament.py:1668
                         record["game_profile_sha256"] = oracle_game_profile.sha256
+                    if chunk_identity is not None:
+                        record.update(chunk_identity)
                     indices, seeds = lists[n]
                     chunk_lines.append(json.dumps(record, sort_keys=True).replace('"@indices@"', indices).replace('"@seeds@"', seeds))
                 if per_batch:
@@ -673,7 +765,10 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         save(final=True)
         sidecars.write("checkpoint", checkpoint_path)
         for manifest in (row_manifest, metrics_manifest):  # the manifests are final now: their sidecars bind the complete files
-            if manifest is not None:
+            if manifest is not None and sidecars.v3 is not None:
+                if manifest.exists():  # sealed: canonical lines in coordinate order + the coordinate-sorted root over the shards' identities
+                    sidecars.v3.publish_manifest(manifest, _read_manifest(manifest), n_players=k)
+            elif manifest is not None:
                 sidecars.write("shard_manifest", manifest)
     barrier()
     return {"tally": total, "games": games_done, "seconds": time.perf_counter() - t_start, "lag_summary": lag_total,
@@ -868,6 +963,13 @@ def _publish_results(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy]
                   cfg.rng_lag_sums_path(n) if cfg.sim.rng_lag_sums else None, cfg.rng_lag_stats_path(n) if cfg.sim.rng_lag_sums else None):
         if extra is not None and Path(extra).exists():
             outputs.append(Path(extra))
+    if sidecars.v3 is not None:
+        # the authenticated completion (write_simulation_done -> write_v3_stage_completion, release_identity.py:1227-1284): the reference's
+        # output inventory only — every entry has a contract-v3 sidecar, shard directories stand as their sealed manifests; this engine's
+        # extra outputs (all-player batches, lag statistics) are not part of the stage the reference's consumers authenticate
+        reference_outputs = [p for p in outputs if p not in (cfg.all_player_batch_dir(n), cfg.rng_lag_sums_path(n), cfg.rng_lag_stats_path(n))]
+        sidecars.v3.write_completion(done_path, sc.completion_output_files(reference_outputs, done_path))
+        return
     engine_config_sha = config_hash(cfg)
     sc.write_stage_done(
         done_path, inputs=[cfg.strategy_manifest_root_path(), n_dir / "simulation_workload_plan.json"],
@@ -916,7 +1018,7 @@ def write_active_config(cfg: AppConfig, dest_dir: Path) -> Path:
 
     def plain(obj):
         if dataclasses.is_dataclass(obj):
-            return {f.name: plain(getattr(obj, f.name)) for f in dataclasses.fields(obj)}
+            return {f.name: plain(getattr(obj, f.name)) for f in dataclasses.fields(obj) if not f.name.startswith("_")}
         if isinstance(obj, Path):
             return str(obj)
         if isinstance(obj, (list, tuple)):

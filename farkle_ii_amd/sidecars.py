@@ -71,7 +71,7 @@ def config_hash(cfg) -> str:
 
     def plain(obj: Any) -> Any:
         if dataclasses.is_dataclass(obj):
-            return {f.name: plain(getattr(obj, f.name)) for f in dataclasses.fields(obj)}
+            return {f.name: plain(getattr(obj, f.name)) for f in dataclasses.fields(obj) if not f.name.startswith("_")}
         if isinstance(obj, Mapping):
             return {str(k): plain(v) for k, v in obj.items()}
         if isinstance(obj, (list, tuple)):

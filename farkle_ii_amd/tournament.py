@@ -340,6 +340,9 @@ def write_row_shard(row_dir: Path, manifest_path: Path | None, task: ShuffleTask
     return (out, record) if return_record else out
 
 
+SHARD_WRITER_OPTIONS = {"write_statistics": False, "use_dictionary": False}  # how a row shard is encoded (_write_shard_group)
+
+
 def _shard_record(name: str, gps: int, root_seed: int, k: int, shuffle_index: int, shuffle_seed: int, batch_id: int, pid: int,
                   game_profile_sha256: str | None) -> dict:
     record = {"path": name, "rows": gps, "root_seed": root_seed, "n_players": k, "shuffle_index": shuffle_index,
@@ -386,7 +389,7 @@ def _write_shard_group(row_dir: str, k: int, ids: np.ndarray, gps: int, root_see
         # encoded in memory, so that the writer can hand the shard's byte identity (size, SHA-256) back with its manifest line: the
         # completion stamp (stage_completion.py) then does not read 51 200 files again
         sink = pa.BufferOutputStream()
-        pq.write_table(table.slice(i * gps, gps), sink, write_statistics=False, use_dictionary=False)
+        pq.write_table(table.slice(i * gps, gps), sink, **SHARD_WRITER_OPTIONS)
         blob = sink.getvalue()
         fd = os.open(out + ".tmp" if atomic else out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
         try:
@@ -396,14 +399,34 @@ def _write_shard_group(row_dir: str, k: int, ids: np.ndarray, gps: int, root_see
         if atomic:
             os.replace(out + ".tmp", out)
         # (not atomic: one directory operation per shard instead of two, see write_row_shards)
-        if sidecar is not None:
+        record = _shard_record(name, gps, root_seed, k, int(shuffle_index[i]), int(shuffle_seed[i]), int(batch_id[i]), pid,
+                               game_profile_sha256)
+        digest = None
+        if sidecar is not None and "body" in sidecar:
+            # artifact-contract version 3 (contract_v3.SimulationContract.shard_template): the sidecar is constant text around the shard's
+            # size, SHA-256 and name; its manifest record carries the shard's byte / sidecar / schema identity (what a sealed manifest's
+            # root is computed from, simulation/runner.py:570-590 of the reference) and no process id
+            from .contract_v3 import arrow_schema_identity, fill_shard_template
+
+            if i == 0 and arrow_schema_identity(pq.read_schema(pa.BufferReader(blob)))["fingerprint_sha256"] != sidecar["schema_fingerprint_sha256"]:
+                raise ValueError(f"row shard {name}: the stored Arrow schema is not the one its sidecar template was built for")
+            digest = hashlib.sha256(blob).hexdigest()
+            text, side_sha = fill_shard_template(sidecar, name, blob.size, digest)
+            fd = os.open(out + ".sidecar.json", os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            try:
+                os.write(fd, text)
+            finally:
+                os.close(fd)
+            del record["pid"]
+            record.update(byte_length=blob.size, data_sha256=digest, sidecar_sha256=side_sha,
+                          schema_fingerprint_sha256=sidecar["schema_fingerprint_sha256"])
+        elif sidecar is not None:
             from .sidecars import write_sidecar
 
             write_sidecar(out, sidecar)
-        record = _shard_record(name, gps, root_seed, k, int(shuffle_index[i]), int(shuffle_seed[i]), int(batch_id[i]), pid,
-                               game_profile_sha256)
         if as_lines:  # (shuffle, manifest line, shard size, shard SHA-256; without a sidecar the stamp needs nothing else of the file)
-            records.append((int(shuffle_index[i]), json.dumps(record, sort_keys=True), blob.size, hashlib.sha256(blob).hexdigest()))
+            records.append((int(shuffle_index[i]), json.dumps(record, sort_keys=True, separators=(",", ":")) if digest else json.dumps(record, sort_keys=True),
+                            blob.size, digest or hashlib.sha256(blob).hexdigest()))
         else:
             records.append(record)
     return records

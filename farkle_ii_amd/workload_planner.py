@@ -148,10 +148,15 @@ def plan_tournament_workload(*, root_seed: int, k: int, strategy_count: int, res
     return plan if projected_games_per_second is None else plan.with_games_per_second(projected_games_per_second)
 
 
+def workload_plan_bytes(plan: TournamentWorkloadPlan) -> bytes:
+    """The plan file's exact bytes: canonical JSON, indent 2, sorted keys, trailing newline (simulation/runner.py:408)."""
+    return json.dumps(plan.to_dict(), indent=2, sort_keys=True).encode("utf-8") + b"\n"
+
+
 def write_workload_plan(path: Path, plan: TournamentWorkloadPlan) -> None:
-    """Atomic, canonical JSON (indent 2, sorted keys, trailing newline)."""
+    """Atomic write of ``workload_plan_bytes``."""
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
     tmp = path.with_name(path.name + ".tmp")
-    tmp.write_text(json.dumps(plan.to_dict(), indent=2, sort_keys=True) + "\n", encoding="utf-8")
+    tmp.write_bytes(workload_plan_bytes(plan))
     os.replace(tmp, path)
