@@ -458,29 +458,40 @@ class SimulationContract:
                    "versions": versions, "source_artifacts": list(sources), "manifest_roots": []}
         return canonical_json_bytes({**payload, "sidecar_contract_sha256": identity_sha256(payload)}) + b"\n"
 
+    def sidecar_for_identity(self, relative_path: str, kind: str, *, byte_length: int, content_sha256: str, arrow_schema: Mapping | None = None,
+                             format_identity: Mapping | None = None, n_players: int, sources: Sequence[Path | str] = (),
+                             support_counts: Sequence[int] | None = None) -> bytes:
+        """The sidecar text of an artifact known by its identity: exactly one of ``arrow_schema`` (ArrowSchemaIdentity of a Parquet file)
+        and ``format_identity`` (ArtifactFormatIdentity of anything else), as ArtifactIdentity demands (authenticated_contract.py:815-818)."""
+        if (arrow_schema is None) == (format_identity is None):
+            raise ContractError("artifact identity requires exactly one Arrow schema or non-Parquet format identity")
+        if byte_length <= 0:
+            raise ContractError(f"artifact writer did not create {relative_path}")
+        operation = OPERATIONS[kind]
+        artifact = {"location": location(relative_path), "byte_length": int(byte_length), "content_sha256": content_sha256,
+                    "arrow_schema": arrow_schema, "logical_operation": operation, "format_identity": format_identity}
+        method, versions, stage, captured = self._frame(operation, support_counts if support_counts is not None else [n_players], sources)
+        return self._document(artifact, method, versions, stage, captured)
+
     def sidecar_bytes(self, path: Path | str, kind: str, *, n_players: int, sources: Sequence[Path | str] = (),
                       support_counts: Sequence[int] | None = None, data: bytes | None = None, schema=None) -> bytes:
         """The sidecar text of the artifact at ``path`` (bytes read from disk unless ``data`` holds them; Parquet: ``schema`` = its Arrow
         schema when the caller has it, else read from the file's footer)."""
-        operation = OPERATIONS[kind]
         name = Path(path).name
         if data is None:
             data = Path(path).read_bytes()
-        if not data:
-            raise ContractError(f"artifact writer did not create {path}")
+        arrow = fmt = None
         if name.endswith(".parquet"):
             if schema is None:
                 import pyarrow as pa
                 import pyarrow.parquet as pq
 
                 schema = pq.read_schema(pa.BufferReader(data))
-            arrow, fmt = arrow_schema_identity(schema), None
+            arrow = arrow_schema_identity(schema)
         else:
-            arrow, fmt = None, format_identity(name, data)
-        artifact = {"location": location(self.relative(path)), "byte_length": len(data), "content_sha256": sha256_bytes(data),
-                    "arrow_schema": arrow, "logical_operation": operation, "format_identity": fmt}
-        method, versions, stage, captured = self._frame(operation, support_counts if support_counts is not None else [n_players], sources)
-        return self._document(artifact, method, versions, stage, captured)
+            fmt = format_identity(name, data)
+        return self.sidecar_for_identity(self.relative(path), kind, byte_length=len(data), content_sha256=sha256_bytes(data), arrow_schema=arrow,
+                                         format_identity=fmt, n_players=n_players, sources=sources, support_counts=support_counts)
 
     def write_sidecar(self, path: Path | str, kind: str, **kw) -> bytes:
         text = self.sidecar_bytes(path, kind, **kw)

@@ -223,19 +223,19 @@ def main() -> None:
     tmp = Path(tempfile.mkdtemp(prefix="fk_contract_v3_"))
     try:
         cfg_path, root = standalone_run(tmp)
+        standalone_docs = documents(root, digests_only=True)  # (what the reference accepts below; the texts that travel whole are its own)
         verdict = reference_judges(cfg_path, root)
         print(f"(b) the reference accepts the standalone tree: {len(verdict['validate_artifact_sidecar'])} sidecars, "
               f"{len(verdict['load_immutable_manifest_sidecar'])} sealed manifests, simulation_is_complete {verdict['simulation_is_complete']}, "
               f"ingest snapshot {({k: v['shards'] for k, v in verdict['ingest_source_snapshot'].items()})} shards, "
               f"analyze ingest wrote {verdict['analyze_ingest']['rows']}")
-        standalone_docs = documents(root, digests_only=True)  # (what the reference accepted; the texts that travel whole are its own, below)
         ref_cfg_path, ref_root = reference_writes(tmp)
         reference_docs = documents(ref_root)
         checked = reproduce_reference_documents(ref_cfg_path, ref_root)
         print(f"(c) contract_v3 reproduces {checked} of the reference's own documents byte for byte")
         # a few whole artifacts travel (small ones), so the replay also exercises the file-reading path
         samples = {}
-        for rel in ("strategy_manifest.parquet", "2_players/simulation_workload_plan.json", "2_players/2p_metric_chunks/metrics_000001.parquet",
+        for rel in ("strategy_manifest.parquet", "2_players/simulation_workload_plan.json", "4_players/simulation_workload_plan.json", "2_players/2p_metric_chunks/metrics_000001.parquet",
                     "2_players/2p_rows/rows_11_2p_000000000000.parquet", "2_players/2p_checkpoint.parquet"):
             samples[rel] = base64.b64encode((ref_root / rel).read_bytes()).decode("ascii")
         doc = {"generated_by": "oracle/gen_contract_v3.py (reference imported in the build container; engine = CPU oracle stub)",
