@@ -83,7 +83,7 @@ def hip_sources() -> list[Path]:
 
 def build_library(force: bool = False, verbose: bool = False) -> Path:
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    deps = hip_sources() + [SRC_DIR / "fk_device.h", SRC_DIR / "fk_kernels.h", SRC_DIR / "fk_play_hc.h", PKG_DIR.parent / "include" / "farkle_hip.h"]
+    deps = hip_sources() + [SRC_DIR / "fk_device.h", SRC_DIR / "fk_kernels.h", SRC_DIR / "fk_play_hc.h", SRC_DIR / "fk_shard_writer.h", PKG_DIR.parent / "include" / "farkle_hip.h"]
     if LIB_PATH.exists() and not force and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return LIB_PATH
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(LIB_PATH),
@@ -99,7 +99,8 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
 
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
             "fk_tournament_run", "fk_tournament_run_stats", "fk_tournament_run_all_player", "fk_tournament_run_lags", "fk_tournament_hint_next", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
-            "fk_debug_dice", "fk_debug_dice_state", "fk_debug_dice_keys", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy", "fk_tally_resident_reduce", "fk_comm_ranks", "fk_host_alloc", "fk_host_free", "fk_game_seeds"]
+            "fk_debug_dice", "fk_debug_dice_state", "fk_debug_dice_keys", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy", "fk_tally_resident_reduce", "fk_comm_ranks", "fk_host_alloc", "fk_host_free", "fk_game_seeds",
+            "fk_tournament_run_columns", "fk_row_columns_bytes", "fk_write_row_shards", "fk_debug_sha256"]
 _lib = None
 
 
@@ -124,6 +125,67 @@ def load_library() -> C.CDLL:
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def row_columns_bytes(k: int, games_per_shuffle: int) -> int:
+    """``fk_row_columns_bytes``: bytes of one shuffle's column image."""
+    lib = load_library()
+    lib.fk_row_columns_bytes.restype = C.c_size_t
+    return int(lib.fk_row_columns_bytes(C.c_int32(k), C.c_int32(games_per_shuffle)))
+
+
+class _ShardJob(C.Structure):
+    _fields_ = [("k", C.c_int32), ("games_per_shuffle", C.c_int32), ("n_shuffles", C.c_int32), ("threads", C.c_int32), ("atomic", C.c_int32),
+                ("rng_purpose_namespace", C.c_int32), ("root_seed", C.c_uint64), ("shuffle_index", C.c_void_p), ("shuffle_seed", C.c_void_p),
+                ("batch_id", C.c_void_p), ("game_seed", C.c_void_p), ("columns", C.c_void_p), ("shard_stride", C.c_size_t),
+                ("directory", C.c_char_p), ("footer_head", C.c_char_p), ("footer_head_len", C.c_size_t), ("footer_kv", C.c_char_p),
+                ("footer_kv_len", C.c_size_t), ("footer_orders", C.c_char_p), ("footer_orders_len", C.c_size_t), ("leaf_type", C.c_void_p),
+                ("leaf_paths", C.c_char_p), ("n_leaves", C.c_int32), ("side_body", C.POINTER(C.c_char_p)), ("side_full", C.POINTER(C.c_char_p)),
+                ("side_directory", C.c_char_p)]
+
+
+def write_row_shards_native(row_dir, k: int, root_seed: int, columns: np.ndarray, shuffle_index, shuffle_seed, batch_id, game_seeds,
+                            rng_purpose_namespace: int, *, threads: int = 1, atomic: bool = True, sidecar: dict | None = None) -> dict:
+    """``fk_write_row_shards``: the row-shard files of ``columns`` (``[n_shuffles][stride]`` column images) in ``row_dir``, written by
+    ``threads`` host threads of the library.  Returns ``byte_length`` int64 ``[n]``, ``sha256`` uint8 ``[n][32]`` and — with a contract-v3
+    ``sidecar`` template (``contract_v3.SimulationContract.shard_template``) — ``sidecar_sha256``."""
+    from .parquet_template import shard_footer_template
+
+    lib = load_library()
+    columns = np.ascontiguousarray(columns, dtype=np.uint8)
+    n = len(columns)
+    stride = columns.shape[1] if columns.ndim == 2 else 0
+    gps = np.asarray(game_seeds).size // max(n, 1)
+    tpl = shard_footer_template(k)
+    sh = np.ascontiguousarray(shuffle_index, dtype=np.int64)
+    seeds = np.ascontiguousarray(shuffle_seed, dtype=np.int64)
+    batch = np.ascontiguousarray(batch_id, dtype=np.int32)
+    gs = np.ascontiguousarray(game_seeds, dtype=np.uint32).reshape(-1)
+    if not (len(sh) == len(seeds) == len(batch) == n) or gs.size != n * gps or stride < row_columns_bytes(k, gps):
+        raise ValueError("shard job arrays disagree about the number of shuffles / games per shuffle")
+    leaf_type = np.ascontiguousarray(tpl["leaf_type"], dtype=np.int32)
+    leaf_paths = b"".join(b"".join(part.encode("utf-8") + b"\0" for part in path) + b"\0" for path in tpl["leaf_paths"])
+    job = _ShardJob(k=k, games_per_shuffle=gps, n_shuffles=n, threads=max(1, int(threads)), atomic=1 if atomic else 0,
+                    rng_purpose_namespace=int(rng_purpose_namespace), root_seed=int(root_seed), shuffle_index=sh.ctypes.data,
+                    shuffle_seed=seeds.ctypes.data, batch_id=batch.ctypes.data, game_seed=gs.ctypes.data, columns=columns.ctypes.data,
+                    shard_stride=stride, directory=os.fspath(row_dir).encode("utf-8"), footer_head=tpl["footer_head"],
+                    footer_head_len=len(tpl["footer_head"]), footer_kv=tpl["footer_kv"], footer_kv_len=len(tpl["footer_kv"]),
+                    footer_orders=tpl["footer_orders"], footer_orders_len=len(tpl["footer_orders"]), leaf_type=leaf_type.ctypes.data,
+                    leaf_paths=leaf_paths, n_leaves=len(leaf_type))
+    side_sha = None
+    if sidecar is not None:
+        body = (C.c_char_p * 4)(*[piece.encode("utf-8") for piece in sidecar["body"]])
+        full = (C.c_char_p * 5)(*[piece.encode("utf-8") for piece in sidecar["full"]])
+        job.side_body, job.side_full, job.side_directory = body, full, sidecar["directory"].encode("utf-8")
+        side_sha = np.zeros((n, 32), dtype=np.uint8)
+    sizes = np.zeros(n, dtype=np.int64)
+    sha = np.zeros((n, 32), dtype=np.uint8)
+    err = C.create_string_buffer(512)
+    lib.fk_write_row_shards.restype = C.c_int
+    rc = lib.fk_write_row_shards(C.byref(job), _p(sizes), _p(sha), _p(side_sha), err, C.c_size_t(len(err)))
+    if rc != 0:
+        raise OSError(f"fk_write_row_shards failed ({rc}): {err.value.decode('utf-8', 'replace')}")
+    return {"byte_length": sizes, "sha256": sha, "sidecar_sha256": side_sha}
 
 
 def make_overrides(items) -> np.ndarray:
@@ -243,6 +305,34 @@ class Engine:
         return {"tally": tally[:n_batches], "rows": rows, "perms": perms,
                 "seat_stats": None if stats is None else stats[:n_batches],
                 "seat_ratio_sums": None if ratios is None else ratios[:n_batches]}
+
+    def tournament_columns(self, table: np.ndarray, k: int, root_seed: int, shuffle_begin: int, shuffle_end: int, strategy_ids,
+                           shuffles_per_batch: int | None = None, target_score: int = 10_000, max_rounds: int = 200,
+                           overrides: np.ndarray | None = None, columns_out: np.ndarray | None = None) -> dict:
+        """``tournament`` with the rows as per-shuffle COLUMN IMAGES (``fk_tournament_run_columns``): ``columns`` uint8
+        ``[n_shuffles][fk_row_columns_bytes(k, S / k)]`` — what ``write_row_shards_native`` frames as the row-shard Parquet files."""
+        table = np.ascontiguousarray(table, dtype=STRATEGY_DTYPE)
+        S = len(table)
+        ids = np.ascontiguousarray(strategy_ids, dtype=np.int32)
+        if len(ids) != S:
+            raise ValueError("strategy_ids must name every strategy of the table")
+        n_sh = max(int(shuffle_end) - int(shuffle_begin), 0)
+        spb = max(n_sh if not shuffles_per_batch else int(shuffles_per_batch), 1)
+        n_batches = (n_sh + spb - 1) // spb
+        stride = row_columns_bytes(k, S // k)
+        tally = np.zeros((max(n_batches, 1), S, TALLY_COLS), dtype=np.int64)
+        if columns_out is not None:
+            if columns_out.dtype != np.uint8 or columns_out.size < n_sh * stride or not columns_out.flags["C_CONTIGUOUS"]:
+                raise ValueError("columns_out must be a contiguous uint8 array with room for every shuffle's image")
+            columns = columns_out.reshape(-1)[:n_sh * stride].reshape(n_sh, stride)
+        else:
+            columns = np.zeros((n_sh, stride), dtype=np.uint8)
+        ov = np.ascontiguousarray(overrides if overrides is not None else np.zeros(0, dtype=OVERRIDE_DTYPE), dtype=OVERRIDE_DTYPE)
+        if n_sh:
+            self._check(self._lib.fk_tournament_run_columns(
+                self._ctx, _p(table), C.c_int32(S), C.c_int32(k), C.c_uint64(root_seed), C.c_uint64(shuffle_begin), C.c_uint64(shuffle_end),
+                C.c_uint32(spb), C.c_int32(target_score), C.c_int32(max_rounds), _p(ov), C.c_int32(len(ov)), _p(tally), _p(ids), _p(columns)))
+        return {"tally": tally[:n_batches], "columns": columns}
 
     def tournament_lags(self, table: np.ndarray, k: int, root_seed: int, shuffle_begin: int, shuffle_end: int, lags,
                         shuffles_per_batch: int | None = None, target_score: int = 10_000, max_rounds: int = 200,

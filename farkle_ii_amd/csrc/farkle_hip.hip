@@ -5,6 +5,7 @@
 //
 // No MFMA (integer/table work), no CPU fallback.
 #include "fk_kernels.h" // device side: every kernel of the engine (pulls in farkle_hip.h, fk_device.h, hip_runtime.h)
+#include "fk_shard_writer.h" // host side: column images -> row-shard Parquet files
 
 #include <dlfcn.h>
 #include <rccl/rccl.h> // TYPES ONLY (ncclConfig_t, result codes): the library itself is bound with dlopen on first use
@@ -126,6 +127,9 @@ struct fk_ctx {
     // the reduce; one D2H, on the root)
     // rows mode: the device row buffer exists twice and a copy stream moves chunk i's rows to the host while chunk i + 1 plays
     DevBuf rows_alt;
+    // fk_tournament_run_columns: the rows buffer receives per-shuffle column images (fk_row_columns_kernel); the strategy ids they name
+    const int32_t *columns_ids = nullptr;
+    DevBuf ids;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
     int64_t rows_chunk_games = 4000000; // rows mode plays in chunks of about this many games (overlap granularity)
@@ -1217,7 +1221,7 @@ void fk_destroy(fk_ctx *c) {
     release(c->comm_buf);
     if (c->prep_stream) (void)hipStreamSynchronize(c->prep_stream);
     for (DevBuf *b : {&c->strat, &c->recs, &c->rec0, &c->tally, &c->rows, &c->ov, &c->seatlist, &c->coords, &c->inv, &c->slow, &c->digest, &c->score_lut,
-                      &c->discard_lut, &c->block_out, &c->stats, &c->ratios, &c->cold, &c->clk, &c->lds_tables, &c->acc, &c->rows_alt, &c->lag_v, &c->lag_out, &c->lag_lags, &c->lag_edge, &c->lag_tmp})
+                      &c->discard_lut, &c->block_out, &c->stats, &c->ratios, &c->cold, &c->clk, &c->lds_tables, &c->acc, &c->rows_alt, &c->ids, &c->lag_v, &c->lag_out, &c->lag_lags, &c->lag_edge, &c->lag_tmp})
         release(*b);
     for (auto &cs : c->sets) {
         for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc, &cs.pools, &cs.blocks, &cs.game_block, &cs.game_row}) release(*b);
@@ -1331,6 +1335,55 @@ int fk_tournament_run(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32
                                    max_rounds, ov, n_ov, tally, rows, perms, nullptr);
 }
 
+int fk_tournament_run_columns(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed, uint64_t shuffle_begin,
+                              uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score, int32_t max_rounds,
+                              const fk_override *ov, int32_t n_ov, int64_t *tally, const int32_t *strategy_ids, void *columns) {
+    if (!c) return FK_ERR_ARG;
+    if (!strategy_ids || !columns) return fail(c, FK_ERR_ARG, "strategy_ids and columns are required");
+    c->columns_ids = strategy_ids;
+    const int rc = fk_tournament_run_stats(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score,
+                                           max_rounds, ov, n_ov, tally, columns, nullptr, nullptr);
+    c->columns_ids = nullptr;
+    return rc;
+}
+
+size_t fk_row_columns_bytes(int32_t k, int32_t games_per_shuffle) {
+    return (k < 1 || games_per_shuffle < 1) ? 0 : fksw::shard_image_bytes(k, games_per_shuffle);
+}
+
+int fk_write_row_shards(const fk_shard_job *job, int64_t *byte_length, uint8_t *sha256, uint8_t *sidecar_sha256, char *error, size_t error_len) {
+    auto say = [&](const std::string &m) {
+        if (error && error_len) std::snprintf(error, error_len, "%s", m.c_str());
+        return FK_ERR_ARG;
+    };
+    if (!job || !byte_length || !sha256) return say("job, byte_length and sha256 are required");
+    if (!job->shuffle_index || !job->shuffle_seed || !job->batch_id || !job->game_seed || !job->columns || !job->directory || !job->footer_head ||
+        !job->footer_kv || !job->footer_orders || !job->leaf_type || !job->leaf_paths)
+        return say("a required field of the shard job is null");
+    if ((job->side_body != nullptr) != (job->side_full != nullptr) || (job->side_body && (!job->side_directory || !sidecar_sha256)))
+        return say("the sidecar template needs body, full, directory and a sidecar_sha256 output");
+    fksw::Job j{};
+    j.k = job->k; j.gps = job->games_per_shuffle; j.n_shuffles = job->n_shuffles; j.threads = job->threads; j.atomic = job->atomic;
+    j.root_seed = job->root_seed; j.rng_purpose_namespace = job->rng_purpose_namespace;
+    j.shuffle_index = job->shuffle_index; j.shuffle_seed = job->shuffle_seed; j.batch_id = job->batch_id; j.game_seed = job->game_seed;
+    j.columns = static_cast<const uint8_t *>(job->columns); j.shard_stride = job->shard_stride; j.directory = job->directory;
+    j.footer_head = job->footer_head; j.footer_head_len = job->footer_head_len; j.footer_kv = job->footer_kv; j.footer_kv_len = job->footer_kv_len;
+    j.footer_orders = job->footer_orders; j.footer_orders_len = job->footer_orders_len; j.leaf_type = job->leaf_type; j.leaf_paths = job->leaf_paths;
+    j.n_leaves = job->n_leaves; j.side_body = job->side_body; j.side_full = job->side_full; j.side_directory = job->side_directory;
+    std::string err;
+    if (fksw::write_shards(j, byte_length, sha256, sidecar_sha256, err) != 0) {
+        if (error && error_len) std::snprintf(error, error_len, "%s", err.c_str());
+        return FK_ERR_IO;
+    }
+    return FK_OK;
+}
+
+int fk_debug_sha256(const void *data, size_t n, uint8_t *out32, int32_t portable) {
+    if ((!data && n) || !out32) return FK_ERR_ARG;
+    fksw::sha256(static_cast<const uint8_t *>(data), n, out32, portable != 0);
+    return FK_OK;
+}
+
 struct LagReq { // fk_tournament_run_lags: host pointers of the request
     const int32_t *lags;
     int32_t n_lags, max_lag;
@@ -1441,9 +1494,17 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
     const size_t tally_bytes = sizeof(int64_t) * (size_t)n_batches * (size_t)S * FK_TALLY_COLS;
     if (n_sh_total == 0) return FK_OK;
     const size_t row_bytes = sizeof(fk_row_hdr) + sizeof(fk_seat) * (size_t)k;
+    const bool columns = rows != nullptr && c->columns_ids != nullptr; // fk_tournament_run_columns
+    const size_t rows_per_shuffle = columns ? fksw::shard_image_bytes(k, (int)gps) : (size_t)gps * row_bytes;
 
     int rc = upload_strategies(c, strategies, S);
     if (rc) return rc;
+    if (columns) {
+        if (k > 64) return fail(c, FK_ERR_ARG, "column images hold tables of at most 64 seats, got %d", (int)k);
+        rc = ensure(c, c->ids, sizeof(int32_t) * (size_t)S);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->ids.p, c->columns_ids, sizeof(int32_t) * (size_t)S, hipMemcpyHostToDevice, c->stream));
+    }
     rc = ensure(c, c->tally, tally_bytes);
     if (rc) return rc;
     HIPCHK(c, hipMemsetAsync(c->tally.p, 0, tally_bytes, c->stream));
@@ -1480,6 +1541,7 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
     const size_t bytes_per_shuffle = (size_t)S * 2 + (size_t)gps * (game_workspace_bytes(k, plan.gs || want_state, want_recs, rows != nullptr) +
                                                                     (seat_stats ? (size_t)k * 32 : 0)) // + the exposure digests
                                      + (lag ? (size_t)S * 2 : 0);                                        // + the lag value matrix row
+    // (column images are larger than AoS rows: the workspace figure above counts 4 + 28 k bytes per game)
     uint64_t chunk_sh = std::max<uint64_t>(1, (uint64_t)c->chunk_bytes / bytes_per_shuffle);
     chunk_sh = std::min<uint64_t>(chunk_sh, (uint64_t)0x7fffffff / gps);
     if (rows) // rows mode: several chunks per call, so that the rows of chunk i cross PCIe while chunk i + 1 plays
@@ -1585,8 +1647,8 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
         const int rb = (int)((done / chunk_sh) & 1u);
         DevBuf &row_buf = rb ? c->rows_alt : c->rows;
         if (rows) {
-            if ((size_t)n_games * row_bytes > row_buf.cap) HIPCHK(c, hipStreamSynchronize(c->copy_stream)); // growing: no copy may be reading it
-            rc = ensure(c, row_buf, (size_t)n_games * row_bytes);
+            if ((size_t)n_sh * rows_per_shuffle > row_buf.cap) HIPCHK(c, hipStreamSynchronize(c->copy_stream)); // growing: no copy may be reading it
+            rc = ensure(c, row_buf, (size_t)n_sh * rows_per_shuffle);
             if (rc) return rc;
         }
 
@@ -1745,12 +1807,20 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
             // rows kernel on the main stream (behind this buffer's previous copy), the copy to the host on the copy stream: it
             // runs beside the next chunk's game kernel.  With a pinned destination (fk_host_alloc) it is one DMA at PCIe rate.
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy[rb], 0));
-            rc = rows_pass(c, sa, scheduled, n_games, gps, n_sh, true, static_cast<uint8_t *>(row_buf.p));
-            if (rc) return rc;
+            if (columns) {
+                hipLaunchKernelGGL(fk_row_columns_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
+                                   static_cast<const uint32_t *>(CSET(c).state.p), static_cast<const uint32_t *>(c->recs.p),
+                                   scheduled ? static_cast<const uint32_t *>(c->inv.p) : nullptr, n_games, gps, n_sh, (uint32_t)k, 1u,
+                                   static_cast<const int32_t *>(c->ids.p), static_cast<uint8_t *>(row_buf.p), rows_per_shuffle);
+                HIPCHK(c, hipGetLastError());
+            } else {
+                rc = rows_pass(c, sa, scheduled, n_games, gps, n_sh, true, static_cast<uint8_t *>(row_buf.p));
+                if (rc) return rc;
+            }
             HIPCHK(c, hipEventRecord(c->ev_rows[rb], c->stream));
             HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_rows[rb], 0));
-            HIPCHK(c, hipMemcpyAsync(static_cast<uint8_t *>(rows) + (size_t)done * gps * row_bytes, row_buf.p,
-                                     (size_t)n_games * row_bytes, hipMemcpyDeviceToHost, c->copy_stream));
+            HIPCHK(c, hipMemcpyAsync(static_cast<uint8_t *>(rows) + (size_t)done * rows_per_shuffle, row_buf.p,
+                                     (size_t)n_sh * rows_per_shuffle, hipMemcpyDeviceToHost, c->copy_stream));
             HIPCHK(c, hipEventRecord(c->ev_copy[rb], c->copy_stream));
         }
     }

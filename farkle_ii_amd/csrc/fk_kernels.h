@@ -1582,6 +1582,79 @@ __global__ void fk_rows_kernel(const uint32_t *state, const uint32_t *recs, cons
     for (uint32_t i = threadIdx.x; i < n_dw; i += blockDim.x) dst[i] = row_tile[i];
 }
 
+// State store + result records -> the COLUMN IMAGE of every shuffle: what a row shard's Parquet pages hold, value for value, in
+// their physical type (csrc/fk_shard_writer.h frames them on host threads; the reference's per-shuffle row shard,
+// run_tournament.py:530-558, schema utils/schema_helpers.py:23-90).  Per shuffle, `stride` bytes:
+//     int32 planes [4 + 13 k][gps]:  winner_strategy (id), winning_score, victory_margin, n_rounds, then per seat
+//                                    score, farkles, rolls, highest_turn, strategy (id), rank, loss_margin, smart_five_uses,
+//                                    n_smart_five_dice, smart_one_uses, n_smart_one_dice, hot_dice, n_turns   (schema order)
+//     u8 status[gps] (1 = safety limit: every nullable field of the row is null), u8 winner_seat[gps], u8 rank_order[gps][k]
+// One thread per game; a wave's stores to a plane are 64 consecutive int32 (whole lines), its loads one contiguous 48 k-byte
+// state group per lane as in build_row.  Ranks by stable sort on score desc (engine.py:477-483); the margin is the winner's
+// score minus the best of the others (ties: 0), as sorted(scores)[-2] in simulation.py:628-655.
+__global__ __launch_bounds__(256) void fk_row_columns_kernel(const uint32_t *state, const uint32_t *recs, const uint32_t *inv_sched,
+                                                             uint32_t n_games, uint32_t gps, uint32_t n_sh, uint32_t k, uint32_t perm_mode,
+                                                             const int32_t *ids, uint8_t *out, size_t stride) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_games) return;
+    const uint32_t sh = id / gps, g = id - sh * gps;
+    const uint32_t slot = inv_sched ? inv_sched[id] : walk_slot(id, gps, n_sh, perm_mode != 0u);
+    const uint4 q0 = *reinterpret_cast<const uint4 *>(recs + (size_t)id * REC_DW);
+    const bool completed = !(q0.x & REC_SAFETY);
+    const uint32_t w = completed ? ((q0.x >> 24) & 0x7fu) : 0u;
+    const uint32_t *gs = state + (size_t)slot * k * STATE_DW;
+    uint8_t *image = out + (size_t)sh * stride;
+    int32_t *plane = reinterpret_cast<int32_t *>(image) + g;
+    uint8_t *bytes = image + (size_t)(4u + 13u * k) * 4u * gps;
+    const int32_t win50 = (int32_t)gs[(size_t)w * STATE_DW + R_SCORE];
+    int32_t second50 = 0;
+    bool any = false;
+    for (uint32_t j = 0; j < k; ++j) {
+        const int32_t o = (int32_t)gs[(size_t)j * STATE_DW + R_SCORE];
+        if (j != w && (!any || o > second50)) {
+            second50 = o;
+            any = true;
+        }
+    }
+    plane[0] = completed ? ids[gs[(size_t)w * STATE_DW + R_IDX]] : 0;
+    plane[(size_t)gps] = completed ? win50 * 50 : 0;
+    plane[(size_t)2 * gps] = completed ? (win50 - (any ? second50 : 0)) * 50 : 0;
+    plane[(size_t)3 * gps] = (int32_t)(q0.z & 0xffffu);
+    bytes[g] = completed ? 0u : 1u;
+    bytes[gps + g] = (uint8_t)w;
+    uint8_t *order = bytes + (size_t)2 * gps + (size_t)g * k;
+    for (uint32_t s = 0; s < k; ++s) {
+        const uint32_t *x = gs + (size_t)s * STATE_DW;
+        const int32_t sc = (int32_t)x[R_SCORE];
+        uint32_t rank = 0;
+        if (completed) {
+            rank = 1;
+            for (uint32_t j = 0; j < k; ++j) {
+                const int32_t o = (int32_t)gs[(size_t)j * STATE_DW + R_SCORE];
+                rank += (o > sc || (o == sc && j < s)) ? 1u : 0u;
+            }
+            order[rank - 1u] = (uint8_t)s;
+        } else {
+            order[s] = 0;
+        }
+        const uint32_t xa = x[R_CA], xb = x[R_CB], xc = x[R_CC], xd = x[R_CD], xe = x[R_CE];
+        int32_t *p = plane + (size_t)(4u + 13u * s) * gps;
+        p[0] = sc * 50;
+        p[(size_t)1 * gps] = (int32_t)(xa >> 16);             // farkles
+        p[(size_t)2 * gps] = (int32_t)(xa & 0xffffu);         // rolls
+        p[(size_t)3 * gps] = (int32_t)((xb & 0xffffu) * 50u); // highest_turn
+        p[(size_t)4 * gps] = ids[x[R_IDX]];                   // strategy id
+        p[(size_t)5 * gps] = (int32_t)rank;
+        p[(size_t)6 * gps] = completed ? (win50 - sc) * 50 : 0; // loss_margin
+        p[(size_t)7 * gps] = (int32_t)(xc & 0xffffu);         // smart_five_uses
+        p[(size_t)8 * gps] = (int32_t)(xc >> 16);             // n_smart_five_dice
+        p[(size_t)9 * gps] = (int32_t)(xd & 0xffffu);         // smart_one_uses
+        p[(size_t)10 * gps] = (int32_t)(xd >> 16);            // n_smart_one_dice
+        p[(size_t)11 * gps] = (int32_t)(xe & 0xffffu);        // hot_dice
+        p[(size_t)12 * gps] = (int32_t)(xb >> 16);            // n_turns
+    }
+}
+
 // Integer sufficient statistics of ALL seats per (batch, strategy) — what the reference's unconditional all-player
 // metrics are sums of (analysis/all_player_metrics.py:257-340): exposures, completed / safety / wins, sums and square
 // sums of final score, n_turns, turns - rounds, rank, loss margin and the eight behaviour counters.  Exact in int64; the

@@ -638,6 +638,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             group_seeds = _shuffle_seeds(eng, cfg.sim.seed, k, g_first, g_last)
             bounds = [(b * spb, min((b + 1) * spb, plan.required_shuffles)) for b in range(b0, b1)]
             fragments = _helper_thread().submit(_shuffle_list_fragments, group_seeds, g_first, spb, bounds)
+        use_columns = False
         if hi > lo:
             if j + 1 < len(pending) and hasattr(eng, "hint_next"):
                 # the launch group after this one (same table, k, root): prepared in the drain tail of this group's kernel
@@ -649,7 +650,17 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 if hi2 > lo2:
                     eng.hint_next(lo2, hi2, need_state=want_rows)
             extra: dict[str, Any] = {"want_seat_stats": True} if all_player_dir is not None else {}
-            if want_rows and hasattr(eng, "pinned_empty"):
+            # rows as per-shuffle column images (fk_tournament_run_columns) whenever the engine offers them: the shards are then framed by
+            # the library's own Parquet writer on host threads instead of Arrow in writer processes (tournament.write_row_shards_from_columns)
+            use_columns = want_rows and hasattr(eng, "tournament_columns") and k <= 64 and not rng_lags and all_player_dir is None
+            if use_columns:
+                from .backend import row_columns_bytes
+
+                need = (hi - lo) * row_columns_bytes(k, gps)
+                if hasattr(eng, "pinned_empty") and (pinned_rows is None or pinned_rows.dtype != np.uint8 or len(pinned_rows) < need):
+                    pinned_rows = None
+                    pinned_rows = eng.pinned_empty(need, np.uint8)
+            elif want_rows and hasattr(eng, "pinned_empty"):
                 # rows land in a page-locked buffer (one per run, sized for the largest launch group): one DMA per chunk at PCIe
                 # rate, under the next chunk's game kernel
                 need = (hi - lo) * gps
@@ -659,7 +670,10 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                     pinned_rows = None
                     pinned_rows = eng.pinned_empty(need, row_dtype(k))
                 extra["rows_out"] = pinned_rows
-            if rng_lags:
+            if use_columns:
+                res = eng.tournament_columns(table, k, cfg.sim.seed, lo, hi, ids, shuffles_per_batch=spb if per_batch else hi - lo,
+                                             target_score=target, max_rounds=max_rounds, overrides=ov, columns_out=pinned_rows)
+            elif rng_lags:
                 res = eng.tournament_lags(table, k, cfg.sim.seed, lo, hi, rng_lags, shuffles_per_batch=spb if per_batch else hi - lo,
                                           target_score=target, max_rounds=max_rounds, overrides=ov)
             else:
@@ -678,10 +692,18 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 # file creation — one vectorised conversion per 64 shuffles, shards and their manifest lines by writer processes
                 seeds102 = (eng.game_seeds(int(urandom.RandomPurpose.TOURNAMENT_GAME), cfg.sim.seed, k, lo, hi, gps)
                             if hasattr(eng, "game_seeds") else None)  # the rows' game_seed column, hashed on the device
-                row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
-                                                       game_seeds=seeds102, as_lines=True,
-                                                       sidecar=sidecars.template("row_shard", row_dir / "rows_template.parquet",
-                                                                                 schema=lambda: _stored_schema(raw_simulation_schema_for(k), **rt.SHARD_WRITER_OPTIONS))))
+                shard_sidecar = sidecars.template("row_shard", row_dir / "rows_template.parquet",
+                                                  schema=lambda: _stored_schema(raw_simulation_schema_for(k), **rt.SHARD_WRITER_OPTIONS))
+                if use_columns:
+                    if seeds102 is None:
+                        seeds102 = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=cfg.sim.seed, k=k,
+                                                            shuffle_index=np.repeat(np.arange(lo, hi, dtype=np.uint64), gps),
+                                                            game_index=np.tile(np.arange(gps, dtype=np.uint64), hi - lo), dtype=np.uint32)
+                    row_records.extend(rt.write_row_shards_from_columns(row_dir, tasks, res["columns"], seeds102, sha, threads=ROW_WRITER_THREADS,
+                                                                        sidecar=shard_sidecar))
+                else:
+                    row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
+                                                           game_seeds=seeds102, as_lines=True, sidecar=shard_sidecar))
         if rng_lags:  # this group's ranges in rank order (contiguous whole batches per rank), appended to the run's summary
             from .rng_lags import LagSummary
 

@@ -12,6 +12,8 @@ from dataclasses import dataclass, field
 from pathlib import Path
 from typing import Any, Dict, List, Mapping, Sequence, Tuple
 
+import json
+
 import numpy as np
 
 from . import random as urandom
@@ -507,6 +509,68 @@ def write_row_shards(row_dir: Path, tasks: "Sequence[ShuffleTask] | ShuffleRange
     else:
         parts = [_write_shard_group(*job) for job in jobs]
     return [r for part in parts for r in part]
+
+
+def write_row_shards_from_columns(row_dir: Path, tasks: ShuffleRange, columns: np.ndarray, game_seeds: np.ndarray,
+                                  game_profile_sha256: str | None = None, *, threads: int = 1, sidecar: Mapping[str, Any] | None = None,
+                                  atomic: bool = True) -> list:
+    """The row shards of ``tasks`` from per-shuffle COLUMN IMAGES (``Engine.tournament_columns``): the files are framed by the library's
+    own Parquet writer on ``threads`` host threads (``fk_write_row_shards``, csrc/fk_shard_writer.h) — the same tables and Arrow schema as
+    ``write_row_shards`` writes through Arrow (run_tournament.py:530-558), without the AoS -> Arrow conversion and Arrow's per-column
+    encoder set-up.  ``sidecar``: a contract-v3 shard template (the library writes each shard's sidecar too).  Returns
+    ``(shuffle_index, manifest line, shard bytes, shard sha256)`` tuples in task order, as ``write_row_shards(as_lines=True)`` does."""
+    import os
+
+    from .backend import write_row_shards_native
+
+    n = len(tasks)
+    if n == 0:
+        return []
+    row_dir.mkdir(parents=True, exist_ok=True)
+    k, root = tasks.k, tasks.root_seed
+    gps = np.asarray(game_seeds).size // n
+    v3 = sidecar is not None and "body" in sidecar
+    res = write_row_shards_native(row_dir, k, root, columns, tasks.shuffle_index, tasks.shuffle_seed, tasks.deterministic_batch_id, game_seeds,
+                                  int(urandom.RandomPurpose.TOURNAMENT_GAME), threads=threads, atomic=atomic, sidecar=sidecar if v3 else None)
+    sizes = res["byte_length"].tolist()
+    digests = [d.tobytes().hex() for d in res["sha256"]]
+    sh, seeds, batch = (np.asarray(a).tolist() for a in (tasks.shuffle_index, tasks.shuffle_seed, tasks.deterministic_batch_id))
+    # one manifest line per shard: the record of _shard_record, JSON text assembled around the values that change
+    probe = _shard_record("@path@", gps, root, k, -1, -2, -3, os.getpid(), game_profile_sha256)
+    if v3:
+        del probe["pid"]
+        probe.update(byte_length=-4, data_sha256="@data@", sidecar_sha256="@side@", schema_fingerprint_sha256=sidecar["schema_fingerprint_sha256"])
+        text = json.dumps(probe, sort_keys=True, separators=(",", ":"))
+        side = [d.tobytes().hex() for d in res["sidecar_sha256"]]
+    else:
+        text = json.dumps(probe, sort_keys=True)
+        side = [None] * n
+    marks = {'"@path@"': None, "-1": None, "-2": None, "-3": None}
+    if v3:
+        marks.update({"-4": None, '"@data@"': None, '"@side@"': None})
+    pieces, order, rest = [], [], text
+    found = sorted((text.index(m), m) for m in marks)
+    if any(text.count(m) != 1 for m in marks):
+        raise ValueError("manifest record template: a marker value occurs twice")
+    cursor = 0
+    for pos, m in found:
+        pieces.append(text[cursor:pos])
+        order.append(m)
+        cursor = pos + len(m)
+    pieces.append(text[cursor:])
+    out = []
+    for i in range(n):
+        name = f"rows_{root}_{k}p_{sh[i]:012d}.parquet"
+        values = {'"@path@"': f'"{name}"', "-1": str(sh[i]), "-2": str(seeds[i]), "-3": str(batch[i]), "-4": str(sizes[i]),
+                  '"@data@"': f'"{digests[i]}"', '"@side@"': f'"{side[i]}"'}
+        line = "".join(p + values[m] for p, m in zip(pieces, order)) + pieces[-1]
+        out.append((sh[i], line, sizes[i], digests[i]))
+    if not v3 and sidecar is not None:  # the structural (contract-2) sidecars are written here, after the files
+        from .sidecars import write_sidecar
+
+        for i in range(n):
+            write_sidecar(row_dir / f"rows_{root}_{k}p_{sh[i]:012d}.parquet", sidecar)
+    return out
 
 
 def shuffle_tasks(root_seed: int, k: int, shuffle_begin: int, shuffle_end: int, deterministic_batch_size: int) -> list[ShuffleTask]:

@@ -41,7 +41,8 @@ enum {
     FK_ERR_COUNTER_OVERFLOW = -3, /* a per-seat u16 counter left its guarded range */
     FK_ERR_HIP = -4,              /* HIP runtime failure */
     FK_ERR_NO_DEVICE = -5,
-    FK_ERR_COMM = -6              /* RCCL not loadable / communicator failure */
+    FK_ERR_COMM = -6,             /* RCCL not loadable / communicator failure */
+    FK_ERR_IO = -7                /* a row shard could not be written (fk_write_row_shards) */
 };
 
 enum { FK_COMPLETED = 0, FK_SAFETY_LIMIT = 1 };
@@ -166,6 +167,57 @@ int fk_tournament_run(fk_ctx *ctx, const fk_strategy *strategies, int32_t S, int
                       uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch,
                       int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov,
                       int64_t *tally, void *rows, int32_t *perms);
+
+/* ---- row shards without a host-side conversion -------------------------------------------------------------------------------
+ * The reference persists rows as ONE PARQUET FILE PER SHUFFLE (`rows_<root>_<k>p_<shuffle:012d>.parquet`, run_tournament.py:530-558,
+ * schema raw_simulation_schema_for(k), utils/schema_helpers.py:23-90).  fk_tournament_run_columns is fk_tournament_run with the rows
+ * delivered as per-shuffle COLUMN IMAGES: every column of that schema that depends on the games, already in its Parquet physical type
+ * (strategy ids resolved on the device through `strategy_ids`, ranks / margins / loss margins computed there).  Image of one shuffle,
+ * fk_row_columns_bytes(k, gps) bytes (a multiple of 64), gps = S / k:
+ *     int32 planes [4 + 13 k][gps]   winner_strategy, winning_score, victory_margin, n_rounds, then for seat 1..k: score, farkles, rolls,
+ *                                    highest_turn, strategy, rank, loss_margin, smart_five_uses, n_smart_five_dice, smart_one_uses,
+ *                                    n_smart_one_dice, hot_dice, n_turns                                   (the schema's column order)
+ *     uint8 status[gps]              1 = safety limit: the row's nullable fields are null and every hit flag is set (engine.py:485-489)
+ *     uint8 winner_seat[gps]         0-based; uint8 rank_order[gps][k]: seats in rank order (the seat_ranks list)
+ *   columns     n_shuffles images, shuffle-major; k <= 64.     strategy_ids   int32 [S]: the strategy_id of table row i. */
+int fk_tournament_run_columns(fk_ctx *ctx, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                              uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch,
+                              int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov,
+                              int64_t *tally, const int32_t *strategy_ids, void *columns);
+size_t fk_row_columns_bytes(int32_t k, int32_t games_per_shuffle);
+
+/* Column images -> the row-shard files, on `threads` host threads (no ctx: plain host code).  Each file is a complete Parquet file
+ * (one row group, uncompressed PLAIN / RLE_DICTIONARY pages, no statistics) whose Arrow schema — restored by a reader from the
+ * ARROW:schema entry — and rows equal what the reference writes for the same games.  The FileMetaData parts that only depend on the
+ * schema come from the footer of a file Arrow wrote for raw_simulation_schema_for(k) (farkle_ii_amd/parquet_template.py): `footer_head`
+ * = its fields 1-2 (version, schema), `footer_kv` = field 5 (key-value metadata), `footer_orders` = field 7 (column orders), as raw Thrift
+ * spans; `leaf_type[i]` / `leaf_paths` (components '\0'-separated, each path '\0'-terminated) = physical type and path_in_schema of leaf i.
+ * Outputs per shuffle: the file's size and SHA-256 (the manifest record's byte_length / data_sha256) and — with a contract-v3 sidecar
+ * template (contract_v3.SimulationContract.shard_template: the text around size, digest and name) — the written sidecar's SHA-256.
+ * `atomic`: write `<name>.tmp` and rename.  Returns FK_OK, FK_ERR_ARG or FK_ERR_IO with a message in `error`. */
+typedef struct {
+    int32_t k, games_per_shuffle, n_shuffles, threads, atomic, rng_purpose_namespace;
+    uint64_t root_seed;
+    const int64_t *shuffle_index;   /* [n_shuffles] */
+    const int64_t *shuffle_seed;    /* [n_shuffles] namespace-100 fingerprints */
+    const int32_t *batch_id;        /* [n_shuffles] deterministic_batch_id */
+    const uint32_t *game_seed;      /* [n_shuffles][gps] namespace-102 fingerprints (fk_game_seeds) */
+    const void *columns;            /* [n_shuffles] images, `shard_stride` bytes apart */
+    size_t shard_stride;
+    const char *directory;
+    const uint8_t *footer_head; size_t footer_head_len;
+    const uint8_t *footer_kv; size_t footer_kv_len;
+    const uint8_t *footer_orders; size_t footer_orders_len;
+    const int32_t *leaf_type;       /* [n_leaves], n_leaves = 18 + 14 k */
+    const char *leaf_paths;
+    int32_t n_leaves;
+    const char *const *side_body;   /* nullable: 4 pieces */
+    const char *const *side_full;   /* nullable: 5 pieces */
+    const char *side_directory;     /* results-root-relative directory of the shards, with a trailing '/' */
+} fk_shard_job;
+int fk_write_row_shards(const fk_shard_job *job, int64_t *byte_length, uint8_t *sha256, uint8_t *sidecar_sha256, char *error, size_t error_len);
+/* SHA-256 as the shard writer computes it (SHA-NI when the CPU has it; portable != 0 forces the scalar rounds): parity probe. */
+int fk_debug_sha256(const void *data, size_t n, uint8_t *out32, int32_t portable);
 
 /* fk_tournament_run plus the integer sufficient statistics of ALL seats (not winners only), per batch and strategy:
  *   seat_stats  nullable; int64 [n_batches][S][FK_SEAT_STAT_COLS]; overwritten.  Columns:

@@ -70,6 +70,50 @@ def seat_ratio_sums_from_rows(rows: np.ndarray, k: int, S: int, gps: int, spb: i
     return out
 
 
+def column_images(rows: np.ndarray, k: int, ids: np.ndarray, gps: int) -> np.ndarray:
+    """Device rows (AoS) -> the per-shuffle column images of include/farkle_hip.h (fk_tournament_run_columns), with NumPy: int32 planes
+    [4 + 13 k][gps] in the row schema's column order, then status / winner_seat / rank_order bytes.  Null fields hold 0."""
+    from farkle_ii_amd.backend import row_columns_bytes
+
+    n = len(rows)
+    n_sh = n // gps if gps else 0
+    out = np.zeros((n_sh, row_columns_bytes(k, gps)), dtype=np.uint8)
+    if n == 0:
+        return out
+    seats = rows["seats"]
+    completed = rows["status"] == 0
+    w = np.where(completed, rows["winner_seat"].astype(np.int64), 0)
+    ar = np.arange(n)
+    scores = seats["score"].astype(np.int64)
+    win = scores[ar, w]
+    others = scores.copy()
+    others[ar, w] = np.iinfo(np.int64).min
+    second = others.max(axis=1) if k > 1 else np.zeros(n, dtype=np.int64)
+    planes = np.zeros((4 + 13 * k, n), dtype=np.int32)
+    planes[0] = np.where(completed, ids[seats["strategy"][ar, w]], 0)
+    planes[1] = np.where(completed, win, 0)
+    planes[2] = np.where(completed, win - second, 0)
+    planes[3] = rows["n_rounds"]
+    for s in range(k):
+        x, b = seats[:, s], 4 + 13 * s
+        for f, name in enumerate(("score", "farkles", "rolls", "highest_turn")):
+            planes[b + f] = x[name]
+        planes[b + 4] = ids[x["strategy"]]
+        planes[b + 5] = np.where(completed, x["rank"], 0)
+        planes[b + 6] = np.where(completed, win - scores[:, s], 0)
+        for f, name in enumerate(("smart_five_uses", "n_smart_five_dice", "smart_one_uses", "n_smart_one_dice", "hot_dice", "n_turns")):
+            planes[b + 7 + f] = x[name]
+    order = np.where(completed[:, None], np.argsort(seats["rank"].astype(np.int64), axis=1, kind="stable"), 0).astype(np.uint8)
+    ni = (4 + 13 * k) * 4 * gps
+    for i in range(n_sh):
+        sl = slice(i * gps, (i + 1) * gps)
+        out[i, :ni] = np.ascontiguousarray(planes[:, sl]).view(np.uint8).reshape(-1)
+        out[i, ni:ni + gps] = (~completed[sl]).astype(np.uint8)
+        out[i, ni + gps:ni + 2 * gps] = w[sl].astype(np.uint8)
+        out[i, ni + 2 * gps:ni + 2 * gps + gps * k] = order[sl].reshape(-1)
+    return out
+
+
 class Engine:
     def __init__(self, device: int = 0):
         self.device = device
@@ -113,6 +157,13 @@ class Engine:
             ratios = seat_ratio_sums_from_rows(res["rows"], k, len(t), len(t) // k, spb) if want_seat_ratios else None
         return {"tally": res["tally"], "rows": res["rows"] if want_rows else None, "perms": res["perms"], "seat_stats": stats,
                 "seat_ratio_sums": ratios}
+
+    def tournament_columns(self, table, k, root_seed, shuffle_begin, shuffle_end, strategy_ids, shuffles_per_batch=None, target_score=10_000,
+                           max_rounds=200, overrides=None, columns_out=None) -> dict:
+        """fk_tournament_run_columns from the oracle's ROWS: the per-shuffle column images, restated with NumPy."""
+        res = self.tournament(table, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=shuffles_per_batch,
+                              target_score=target_score, max_rounds=max_rounds, overrides=overrides, want_rows=True)
+        return {"tally": res["tally"], "columns": column_images(res["rows"], k, np.asarray(strategy_ids, dtype=np.int32), len(table) // k)}
 
     def tournament_lags(self, table, k, root_seed, shuffle_begin, shuffle_end, lags, shuffles_per_batch=None, target_score=10_000,
                         max_rounds=200, overrides=None) -> dict:
