@@ -1,0 +1,197 @@
+"""Row shards without a host-side conversion: the device's per-shuffle column images (``fk_tournament_run_columns``) and the library's own
+Parquet writer (``fk_write_row_shards``, csrc/fk_shard_writer.h).
+
+What the reference fixes is the TABLE of a shard and its Arrow schema (``raw_simulation_schema_for(k)``, utils/schema_helpers.py:23-90;
+one file per shuffle, run_tournament.py:530-558) — `analyze ingest` reads the files with Arrow (oracle/gen_contract_v3.py runs it over
+natively written shards).  So the bar here: a natively written file, read back by Arrow, EQUALS ``rows.rows_to_table`` of the same games
+(the conversion every earlier round pinned against the reference's frozen rows), schema metadata included; sizes and SHA-256 are the
+files'; the contract-v3 sidecar the library writes is the text ``contract_v3.fill_shard_template`` produces.  On the GPU: the kernel's
+images are byte-equal to the NumPy restatement over the AoS rows of the same launch, for k in {2, 5, 12} with safety-limit games.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import struct
+
+import numpy as np
+import pytest
+
+from oracle_engine_stub import column_images
+
+
+def _random_rows(rng, k: int, gps: int, n_sh: int, null_rate: float):
+    from farkle_ii_amd.backend import row_dtype
+
+    n = gps * n_sh
+    rows = np.zeros(n, dtype=row_dtype(k))
+    rows["n_rounds"] = rng.integers(0, 201, n)
+    rows["status"] = rng.random(n) < null_rate
+    rows["seats"]["score"] = rng.integers(0, 40, (n, k)) * 50  # (ties are frequent: ranks and margins must follow the stable sort)
+    for name in ("farkles", "rolls", "n_turns", "smart_five_uses", "n_smart_five_dice", "smart_one_uses", "n_smart_one_dice", "hot_dice"):
+        rows["seats"][name] = rng.integers(0, 2048, (n, k))
+    rows["seats"]["highest_turn"] = rng.integers(0, 600, (n, k)) * 50
+    rows["seats"]["strategy"] = rng.integers(0, 5160, (n, k))
+    completed = rows["status"] == 0
+    rank = np.argsort(np.argsort(-rows["seats"]["score"].astype(np.int64), axis=1, kind="stable"), axis=1, kind="stable") + 1
+    rows["seats"]["rank"] = np.where(completed[:, None], rank, 0)
+    rows["winner_seat"] = np.where(completed, np.argmin(rank, axis=1), 255)
+    rows["seats"]["hit_max_rounds"] = ~completed[:, None]
+    return rows
+
+
+def _reference_table(rows, k, ids, gps, sh, seeds, batch, game_seeds):
+    from farkle_ii_amd.rows import rows_to_table
+
+    n_sh = len(sh)
+    return rows_to_table(rows, k, ids, root_seed=102, shuffle_index=np.repeat(sh, gps), game_index=np.tile(np.arange(gps, dtype=np.int32), n_sh),
+                         deterministic_batch_id=np.repeat(batch, gps), shuffle_seed=np.repeat(seeds, gps),
+                         game_seed=game_seeds.astype(np.int64), rng_purpose_namespace=102)
+
+
+def test_sha256_of_the_shard_writer_matches_hashlib():
+    from farkle_ii_amd.backend import load_library
+
+    lib = load_library()
+    rng = np.random.default_rng(7)
+    for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 1000, 65536 + 17):
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        for portable in (0, 1):  # SHA-NI (when the CPU has it) and the scalar rounds
+            out = np.zeros(32, dtype=np.uint8)
+            assert lib.fk_debug_sha256(data.ctypes.data_as(C.c_void_p), C.c_size_t(n), out.ctypes.data_as(C.c_void_p), C.c_int32(portable)) == 0
+            assert out.tobytes() == hashlib.sha256(data.tobytes()).digest(), (n, portable)
+
+
+@pytest.mark.parametrize("k,gps,n_sh,null_rate", [(2, 32, 6, 0.2), (5, 7, 3, 0.5), (12, 430, 3, 0.02), (3, 1, 4, 0.5), (2, 2580, 2, 0.0),
+                                                  (4, 9, 3, 1.0), (8, 16, 2, 0.1), (1, 5, 2, 0.3)])
+def test_native_shards_read_back_as_the_reference_tables(tmp_path, k, gps, n_sh, null_rate):
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+
+    from farkle_ii_amd import tournament as rt
+    from farkle_ii_amd.backend import write_row_shards_native
+    from farkle_ii_amd.parquet_template import footer_of, read_struct
+
+    rng = np.random.default_rng(k * 1000 + gps)
+    rows = _random_rows(rng, k, gps, n_sh, null_rate)
+    ids = (np.arange(5160, dtype=np.int32) * 7 + 3)
+    sh = np.arange(10**9, 10**9 + n_sh, dtype=np.int64)
+    seeds = rng.integers(0, 2**32, n_sh).astype(np.int64)
+    batch = (sh // 3 % 1000).astype(np.int32)
+    game_seeds = rng.integers(0, 2**32, gps * n_sh, dtype=np.uint64).astype(np.uint32)
+    want = _reference_table(rows, k, ids, gps, sh, seeds, batch, game_seeds)
+    images = column_images(rows, k, ids, gps)
+    res = write_row_shards_native(tmp_path, k, 102, images, sh, seeds, batch, game_seeds, 102, threads=3)
+    assert not list(tmp_path.glob("*.tmp"))
+    for i in range(n_sh):
+        path = tmp_path / f"rows_102_{k}p_{sh[i]:012d}.parquet"
+        blob = path.read_bytes()
+        assert len(blob) == res["byte_length"][i] and hashlib.sha256(blob).digest() == res["sha256"][i].tobytes()
+        got = pq.read_table(path)
+        shard = want.slice(i * gps, gps)
+        assert got.schema.equals(shard.schema, check_metadata=False) and got.equals(shard), (k, gps, i)
+        # the Arrow schema a reader sees — what contract v3 fingerprints — is the Arrow-written shard's
+        sink = pa.BufferOutputStream()
+        pq.write_table(shard, sink, **rt.SHARD_WRITER_OPTIONS)
+        assert pq.read_schema(path).equals(pq.read_schema(pa.BufferReader(sink.getvalue())), check_metadata=True)
+        # the footer is well-formed Thrift: one row group of gps rows, 18 + 14 k uncompressed column chunks that tile the file
+        meta, end = read_struct(footer_of(blob))
+        assert end == struct.unpack("<I", blob[-8:-4])[0] and meta[3][0] == gps and meta[6][0].startswith(b"farkle_ii_amd shard writer")
+        (group,) = meta[4][0]
+        chunks = [c[3][0] for c in group[1][0]]
+        assert len(chunks) == 18 + 14 * k and group[3][0] == gps
+        cursor = 4
+        for c in chunks:
+            first = c[11][0] if 11 in c else c[9][0]
+            assert c[4][0] == 0 and first == cursor and c[6][0] == c[7][0]
+            cursor += c[6][0]
+        assert cursor == len(blob) - 8 - end and group[2][0] == cursor - 4
+    md = pq.read_metadata(tmp_path / f"rows_102_{k}p_{sh[0]:012d}.parquet")
+    assert md.num_rows == gps and md.num_row_groups == 1 and md.num_columns == 18 + 14 * k
+
+
+def test_native_writer_publishes_the_contract_v3_sidecar(tmp_path):
+    """The sidecar the library writes per shard = contract_v3.fill_shard_template(template, name, size, sha256): same text, same digest."""
+    import yaml
+
+    from farkle_ii_amd import contract_v3 as c3
+    from farkle_ii_amd.backend import write_row_shards_native
+    from farkle_ii_amd.config import load_app_config
+    from farkle_ii_amd.rows import raw_simulation_schema_for
+    from farkle_ii_amd.runner import _stored_schema
+    from farkle_ii_amd import tournament as rt
+
+    cfg_path = tmp_path / "c.yaml"
+    cfg_path.write_text(yaml.safe_dump({"io": {"results_dir_prefix": str(tmp_path / "out")}, "sim": {"n_players_list": [3], "seed_list": [5], "row_dir": "rows"}}))
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    sc = c3.SimulationContract(cfg, c3.make_code_identity("a" * 40))
+    row_dir = cfg.simulation_row_dir(3)
+    row_dir.mkdir(parents=True)
+    template = sc.shard_template("row_shard", row_dir, _stored_schema(raw_simulation_schema_for(3), **rt.SHARD_WRITER_OPTIONS), n_players=3, sources=[])
+    rng = np.random.default_rng(3)
+    gps, n_sh = 11, 5
+    rows = _random_rows(rng, 3, gps, n_sh, 0.3)
+    ids = np.arange(5160, dtype=np.int32)
+    sh = np.arange(n_sh, dtype=np.int64)
+    res = write_row_shards_native(row_dir, 3, 5, column_images(rows, 3, ids, gps), sh, sh + 9, sh.astype(np.int32),
+                                  rng.integers(0, 2**32, gps * n_sh, dtype=np.uint64).astype(np.uint32), 102, threads=2, sidecar=template)
+    for i in range(n_sh):
+        name = f"rows_5_3p_{i:012d}.parquet"
+        text, side_sha = c3.fill_shard_template(template, name, int(res["byte_length"][i]), res["sha256"][i].tobytes().hex())
+        assert (row_dir / (name + ".sidecar.json")).read_bytes() == text
+        assert res["sidecar_sha256"][i].tobytes().hex() == side_sha
+        doc = __import__("json").loads(text)
+        assert doc["artifact"]["location"]["relative_path"] == f"3_players/3p_rows/{name}" and doc["artifact"]["byte_length"] == res["byte_length"][i]
+
+
+def test_native_writer_reports_io_errors(tmp_path):
+    from farkle_ii_amd.backend import write_row_shards_native
+
+    rows = _random_rows(np.random.default_rng(1), 2, 4, 2, 0.0)
+    images = column_images(rows, 2, np.arange(5160, dtype=np.int32), 4)
+    with pytest.raises(OSError, match="open .*no_such_dir"):
+        write_row_shards_native(tmp_path / "no_such_dir", 2, 1, images, [0, 1], [1, 2], [0, 0], np.zeros(8, dtype=np.uint32), 102)
+    with pytest.raises(ValueError):
+        write_row_shards_native(tmp_path, 2, 1, images, [0, 1, 2], [1, 2], [0, 0], np.zeros(8, dtype=np.uint32), 102)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,max_rounds", [(2, 200), (5, 3), (12, 200), (12, 2), (4, 0)])
+def test_column_images_of_the_kernel_equal_the_rows_of_the_same_launch(tmp_path, k, max_rounds):
+    """fk_tournament_run_columns vs fk_tournament_run(rows) on the 5 160-strategy grid (production shard shape) — max_rounds 3 / 2 / 0 make
+    most or all games safety-limit games — then the native writer's files against rows_to_table."""
+    import pyarrow.parquet as pq
+
+    from farkle_ii_amd import random as urandom
+    from farkle_ii_amd.backend import write_row_shards_native
+    from farkle_ii_amd.engine import get_engine, set_engine
+    from farkle_ii_amd.strategies import generate_strategy_grid, pack_strategies, prepare_public_helper_strategies
+
+    set_engine(None)
+    eng = get_engine()
+    strategies = prepare_public_helper_strategies(generate_strategy_grid()[0])
+    table = pack_strategies(strategies)
+    ids = np.asarray([int(s.strategy_id) for s in strategies], dtype=np.int32)[::-1].copy()  # (any id per table row: not the row index)
+    S, gps = len(table), len(table) // k
+    lo, hi = 1000, 1007
+    eng.set_option("rows_chunk_games", 3 * gps)  # several chunks: images of chunk i cross PCIe while chunk i + 1 plays
+    try:
+        rows = eng.tournament(table, k, 42, lo, hi, max_rounds=max_rounds, want_rows=True)
+        cols = eng.tournament_columns(table, k, 42, lo, hi, ids, max_rounds=max_rounds)
+    finally:
+        eng.set_option("rows_chunk_games", 4_000_000)
+    assert np.array_equal(rows["tally"], cols["tally"])
+    status = rows["rows"]["status"]
+    if max_rounds <= 3:
+        assert (status != 0).mean() > 0.5
+    want_images = column_images(rows["rows"], k, ids, gps)
+    assert cols["columns"].shape == want_images.shape and np.array_equal(cols["columns"], want_images)
+    sh = np.arange(lo, hi, dtype=np.int64)
+    seeds = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_SHUFFLE, root_seed=42, k=k, shuffle_index=sh.astype(np.uint64), dtype=np.uint32)
+    game_seeds = eng.game_seeds(int(urandom.RandomPurpose.TOURNAMENT_GAME), 42, k, lo, hi, gps)
+    res = write_row_shards_native(tmp_path, k, 42, cols["columns"], sh, seeds, (sh // 5).astype(np.int32), game_seeds, 102, threads=4)
+    want = _reference_table(rows["rows"], k, ids, gps, sh, seeds.astype(np.int64), (sh // 5).astype(np.int32), np.asarray(game_seeds).reshape(-1))
+    for i in range(hi - lo):
+        got = pq.read_table(tmp_path / f"rows_42_{k}p_{sh[i]:012d}.parquet")
+        assert got.equals(want.slice(i * gps, gps)), (k, i)
+    assert int(res["byte_length"].min()) > 0

@@ -1,5 +1,6 @@
 """Diagnostic (CPU): host time of `farkle run --metrics` with a NULL engine (a plausible tally made up in no time): what the Python side costs
-per player count on wide grids, where the oracle-backed stub would take minutes.  usage: python tools/profile_run_host_null.py [config] [top=30]"""
+per player count on wide grids, where the oracle-backed stub would take minutes.  usage: python tools/profile_run_host_null.py [config] [top=30] [extra run args ...]   (rows on: column images of random games, so that the
+native shard writer, manifests, sidecars and the completion stamp are timed at production shape)"""
 import cProfile, io, json, pstats, sys, tempfile, time
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -29,6 +30,21 @@ class NullEngine:
         t[:, :, 0] = rng.integers(0, per[:, None] // k + 1, (nb, S))
         t[:, :, 4:15] = t[:, :, 0:1] * 7; t[:, :, 15:26] = t[:, :, 0:1] * 50
         return {"tally": t, "rows": None, "perms": None, "seat_stats": None, "seat_ratio_sums": None}
+    def game_seeds(self, purpose, root, k, lo, hi, gps):
+        return np.arange((hi - lo) * gps, dtype=np.uint32)
+    def tournament_columns(self, table, k, root, lo, hi, ids, shuffles_per_batch=None, columns_out=None, **kw):
+        from farkle_ii_amd.backend import row_columns_bytes
+        S, n = len(table), hi - lo
+        gps = S // k
+        stride = row_columns_bytes(k, gps)
+        if getattr(self, "_img", None) is None or self._img.shape != (n, stride):
+            rng = np.random.default_rng(k)
+            one = rng.integers(0, 200, stride, dtype=np.uint8)  # one random shard, repeated: the writer's cost does not depend on the values
+            ni = (4 + 13 * k) * 4 * gps
+            one[ni:ni + gps] = rng.random(gps) < 0.01
+            one[ni + gps:] %= k
+            self._img = np.broadcast_to(one, (n, stride)).copy()
+        return {"tally": self.tournament(table, k, root, lo, hi, shuffles_per_batch)["tally"], "columns": self._img}
 
 
 eng_mod.set_engine(NullEngine())
@@ -39,7 +55,7 @@ with tempfile.TemporaryDirectory(prefix="fk_hostprof_") as tmp:
     def run(name, profile=False):
         cfg = json.loads(json.dumps(base)); cfg["io"]["results_dir_prefix"] = str(Path(tmp) / name)
         p = Path(tmp) / f"{name}.yaml"; p.write_text(yaml.safe_dump(cfg))
-        argv = ["--config", str(p), "--log-level", "WARNING", "run", "--metrics"]
+        argv = ["--config", str(p), "--log-level", "WARNING", "run", "--metrics", *sys.argv[3:]]
         t0 = time.perf_counter()
         if profile:
             pr = cProfile.Profile(); pr.enable(); main(argv); pr.disable()
@@ -47,4 +63,7 @@ with tempfile.TemporaryDirectory(prefix="fk_hostprof_") as tmp:
         else:
             main(argv)
         print(name, f"{(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
-    run("warm"); run("timed"); run("profiled", True)
+    import shutil
+    for name, prof in (("warm", False), ("timed", False), ("profiled", True)):
+        run(name, prof)
+        shutil.rmtree(Path(tmp) / f"{name}_seed_{base['sim']['seed_list'][0]}", ignore_errors=True)
