@@ -726,8 +726,9 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             if want_rows:
                 row_records.sort()
                 rt.append_manifest_lines(row_manifest, [rec[1] for rec in row_records])
+                shard_prefix = f"{os.fspath(row_dir)}{os.sep}rows_{cfg.sim.seed}_{k}p_"
                 for sh, _, size, sha in row_records:  # the shards' byte identities, for the completion stamp
-                    shard_identities[str(row_dir / f"rows_{cfg.sim.seed}_{k}p_{sh:012d}.parquet")] = (int(size), sha)
+                    shard_identities[f"{shard_prefix}{sh:012d}.parquet"] = (int(size), sha)
             chunk_lines, all_player_records = [], []
             lists = fragments.result() if fragments is not None else None
             for n, b in enumerate(range(b0, b1)):

@@ -40,11 +40,11 @@ def _random_rows(rng, k: int, gps: int, n_sh: int, null_rate: float):
     return rows
 
 
-def _reference_table(rows, k, ids, gps, sh, seeds, batch, game_seeds):
+def _reference_table(rows, k, ids, gps, sh, seeds, batch, game_seeds, root_seed=102):
     from farkle_ii_amd.rows import rows_to_table
 
     n_sh = len(sh)
-    return rows_to_table(rows, k, ids, root_seed=102, shuffle_index=np.repeat(sh, gps), game_index=np.tile(np.arange(gps, dtype=np.int32), n_sh),
+    return rows_to_table(rows, k, ids, root_seed=root_seed, shuffle_index=np.repeat(sh, gps), game_index=np.tile(np.arange(gps, dtype=np.int32), n_sh),
                          deterministic_batch_id=np.repeat(batch, gps), shuffle_seed=np.repeat(seeds, gps),
                          game_seed=game_seeds.astype(np.int64), rng_purpose_namespace=102)
 
@@ -190,7 +190,7 @@ def test_column_images_of_the_kernel_equal_the_rows_of_the_same_launch(tmp_path,
     seeds = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_SHUFFLE, root_seed=42, k=k, shuffle_index=sh.astype(np.uint64), dtype=np.uint32)
     game_seeds = eng.game_seeds(int(urandom.RandomPurpose.TOURNAMENT_GAME), 42, k, lo, hi, gps)
     res = write_row_shards_native(tmp_path, k, 42, cols["columns"], sh, seeds, (sh // 5).astype(np.int32), game_seeds, 102, threads=4)
-    want = _reference_table(rows["rows"], k, ids, gps, sh, seeds.astype(np.int64), (sh // 5).astype(np.int32), np.asarray(game_seeds).reshape(-1))
+    want = _reference_table(rows["rows"], k, ids, gps, sh, seeds.astype(np.int64), (sh // 5).astype(np.int32), np.asarray(game_seeds).reshape(-1), root_seed=42)
     for i in range(hi - lo):
         got = pq.read_table(tmp_path / f"rows_42_{k}p_{sh[i]:012d}.parquet")
         assert got.equals(want.slice(i * gps, gps)), (k, i)

@@ -39,8 +39,29 @@ def timed_shard(*a, **kw):
 
 eng.tournament = timed_tournament
 rt.write_row_shards = timed_shard
+real_tc, real_wc = eng.tournament_columns, rt.write_row_shards_from_columns
+
+def timed_tournament_columns(*a, **kw):
+    t0 = time.perf_counter()
+    try:
+        return real_tc(*a, **kw)
+    finally:
+        acc["engine_s"] += time.perf_counter() - t0
+        acc["calls"] += 1
+
+def timed_shard_columns(*a, **kw):
+    t0 = time.perf_counter()
+    try:
+        return real_wc(*a, **kw)
+    finally:
+        acc["shard_s"] += time.perf_counter() - t0
+
+eng.tournament_columns = timed_tournament_columns
+rt.write_row_shards_from_columns = timed_shard_columns
 out = {"config": "configs/bench_config2.yaml (k=2, 64-strategy grid, root seed 42), `farkle run --metrics`", "runs": {}}
-with tempfile.TemporaryDirectory(prefix="fk_e2e_") as tmp:
+import os
+with tempfile.TemporaryDirectory(prefix="fk_e2e_", dir=os.environ.get("FK_E2E_DIR")) as tmp:  # FK_E2E_DIR=/dev/shm: file IO into memory
+    out["results_dir"] = tmp
     def run(name, sim_extra, batching=None, screening=None):
         cfg = json.loads(json.dumps(base))
         cfg["io"]["results_dir_prefix"] = str(Path(tmp) / name)
