@@ -657,9 +657,13 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 from .backend import row_columns_bytes
 
                 need = (hi - lo) * row_columns_bytes(k, gps)
-                if hasattr(eng, "pinned_empty") and (pinned_rows is None or pinned_rows.dtype != np.uint8 or len(pinned_rows) < need):
-                    pinned_rows = None
-                    pinned_rows = eng.pinned_empty(need, np.uint8)
+                if hasattr(eng, "pinned_empty"):
+                    # one page-locked buffer per ENGINE, grown when a launch group needs more: page-locking a gigabyte takes ~0.25 s, and a
+                    # sweep over eight player counts asked for eight of them (2.4 s of the 3.5-s production sweep, round 6)
+                    pinned_rows = getattr(eng, "_pinned_columns", None)
+                    if pinned_rows is None or len(pinned_rows) < need:
+                        eng._pinned_columns = pinned_rows = None
+                        eng._pinned_columns = pinned_rows = eng.pinned_empty(need + need // 8, np.uint8)
             elif want_rows and hasattr(eng, "pinned_empty"):
                 # rows land in a page-locked buffer (one per run, sized for the largest launch group): one DMA per chunk at PCIe
                 # rate, under the next chunk's game kernel
