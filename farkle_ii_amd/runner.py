@@ -46,6 +46,7 @@ from .workload_planner import TournamentWorkloadPlan, WorkloadCapExceeded, plan_
 
 LOGGER = logging.getLogger(__name__)
 MAX_GAMES_PER_LAUNCH = 200_000_000  # checkpoint cadence on the GPU: a launch group is at most this many games
+ROWS_GROUP_BYTES = 256 << 20  # rows mode: a launch group's column images (one of two page-locked buffers; group i is written while i + 1 plays)
 ROW_WRITER_THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))  # row-shard writer PROCESSES (rows mode)
 
 
@@ -96,6 +97,20 @@ def _helper_thread():
 
         _HELPER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="fk-manifest")
     return _HELPER
+
+
+_SHARD_THREAD = None
+
+
+def _shard_thread():
+    """The thread that hands a launch group's column images to the library's shard writer (its own host threads do the work; the call
+    drops the GIL) while the main thread is inside the next group's engine call."""
+    global _SHARD_THREAD
+    if _SHARD_THREAD is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _SHARD_THREAD = ThreadPoolExecutor(max_workers=1, thread_name_prefix="fk-shards")
+    return _SHARD_THREAD
 
 
 _PUBLISHER = None
@@ -580,6 +595,16 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
     gps = S // k
     group_batches = max(1, MAX_GAMES_PER_LAUNCH // max(spb * gps, 1))
     want_rows = row_dir is not None
+    # rows as per-shuffle column images (fk_tournament_run_columns) whenever the engine offers them: the shards are framed by the library's
+    # own Parquet writer on host threads instead of Arrow in writer processes (tournament.write_row_shards_from_columns).  Launch groups
+    # are then cut by image bytes, and group i's shards are written while group i + 1 plays (two page-locked buffers per engine).
+    columns_mode = want_rows and hasattr(eng, "tournament_columns") and k <= 64 and not rng_lags and all_player_dir is None
+    checkpoint_batches = group_batches  # an intermediate checkpoint at least every this many batches (or sim.ckpt_every_sec)
+    if columns_mode:
+        from .backend import row_columns_bytes
+
+        image_bytes = row_columns_bytes(k, gps)
+        group_batches = max(1, min(group_batches, ROWS_GROUP_BYTES // max(spb * image_bytes, 1)))
     pinned_rows = None
     t_start = time.perf_counter()
     games_done = 0
@@ -615,99 +640,15 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         else:
             _atomic_write_bytes(checkpoint_path, content)
 
-    i = 0
-    while i < len(pending):
-        # contiguous run of pending batches, capped by the launch-group size
-        j = i
-        while j + 1 < len(pending) and pending[j + 1] == pending[j] + 1 and (j + 1 - i) < group_batches:
-            j += 1
-        b0, b1 = pending[i], pending[j] + 1
-        lo, hi = shard_shuffle_range(b0 * spb, min(b1 * spb, plan.required_shuffles), rank, world, batch_size=spb)
-        # Per-batch tallies are only needed for the metric chunk files; without them the group is one tally, which the
-        # engine keeps in LDS when the table is small.
-        per_batch = metric_chunk_dir is not None or all_player_dir is not None
-        local = np.zeros((b1 - b0 if per_batch else 1, S, 26), dtype=np.int64)
-        local_stats = np.zeros((b1 - b0, S, SEAT_STAT_COLS), dtype=np.int64) if all_player_dir is not None else None
-        local_ratios = np.zeros((b1 - b0, S, SEAT_RATIO_COLS), dtype=np.float64) if all_player_dir is not None else None
-        row_records: list[tuple] = []  # (shuffle index, manifest line, shard bytes, shard sha256)
-        fragments = None
-        if metric_chunk_dir is not None and rank == 0:
-            # the shuffle fingerprints of the whole group in one vectorised pass (on the device), and their JSON text on the
-            # helper thread while the group plays
-            g_first, g_last = b0 * spb, min(b1 * spb, plan.required_shuffles)
-            group_seeds = _shuffle_seeds(eng, cfg.sim.seed, k, g_first, g_last)
-            bounds = [(b * spb, min((b + 1) * spb, plan.required_shuffles)) for b in range(b0, b1)]
-            fragments = _helper_thread().submit(_shuffle_list_fragments, group_seeds, g_first, spb, bounds)
-        use_columns = False
-        if hi > lo:
-            if j + 1 < len(pending) and hasattr(eng, "hint_next"):
-                # the launch group after this one (same table, k, root): prepared in the drain tail of this group's kernel
-                j2 = j + 1
-                while j2 + 1 < len(pending) and pending[j2 + 1] == pending[j2] + 1 and (j2 + 1 - (j + 1)) < group_batches:
-                    j2 += 1
-                lo2, hi2 = shard_shuffle_range(pending[j + 1] * spb, min((pending[j2] + 1) * spb, plan.required_shuffles), rank, world,
-                                               batch_size=spb)
-                if hi2 > lo2:
-                    eng.hint_next(lo2, hi2, need_state=want_rows)
-            extra: dict[str, Any] = {"want_seat_stats": True} if all_player_dir is not None else {}
-            # rows as per-shuffle column images (fk_tournament_run_columns) whenever the engine offers them: the shards are then framed by
-            # the library's own Parquet writer on host threads instead of Arrow in writer processes (tournament.write_row_shards_from_columns)
-            use_columns = want_rows and hasattr(eng, "tournament_columns") and k <= 64 and not rng_lags and all_player_dir is None
-            if use_columns:
-                from .backend import row_columns_bytes
+    n_groups = 0
+    in_flight: dict | None = None  # the launch group whose shards are being written while the next one plays
+    batches_since_save, last_save = 0, time.perf_counter()
 
-                need = (hi - lo) * row_columns_bytes(k, gps)
-                if hasattr(eng, "pinned_empty"):
-                    # one page-locked buffer per ENGINE, grown when a launch group needs more: page-locking a gigabyte takes ~0.25 s, and a
-                    # sweep over eight player counts asked for eight of them (2.4 s of the 3.5-s production sweep, round 6)
-                    pinned_rows = getattr(eng, "_pinned_columns", None)
-                    if pinned_rows is None or len(pinned_rows) < need:
-                        eng._pinned_columns = pinned_rows = None
-                        eng._pinned_columns = pinned_rows = eng.pinned_empty(need + need // 8, np.uint8)
-            elif want_rows and hasattr(eng, "pinned_empty"):
-                # rows land in a page-locked buffer (one per run, sized for the largest launch group): one DMA per chunk at PCIe
-                # rate, under the next chunk's game kernel
-                need = (hi - lo) * gps
-                if pinned_rows is None or len(pinned_rows) < need:
-                    from .backend import row_dtype
-
-                    pinned_rows = None
-                    pinned_rows = eng.pinned_empty(need, row_dtype(k))
-                extra["rows_out"] = pinned_rows
-            if use_columns:
-                res = eng.tournament_columns(table, k, cfg.sim.seed, lo, hi, ids, shuffles_per_batch=spb if per_batch else hi - lo,
-                                             target_score=target, max_rounds=max_rounds, overrides=ov, columns_out=pinned_rows)
-            elif rng_lags:
-                res = eng.tournament_lags(table, k, cfg.sim.seed, lo, hi, rng_lags, shuffles_per_batch=spb if per_batch else hi - lo,
-                                          target_score=target, max_rounds=max_rounds, overrides=ov)
-            else:
-                res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=spb if per_batch else hi - lo,
-                                     target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows, **extra)
-            first = lo // spb - b0 if per_batch else 0
-            local[first:first + len(res["tally"])] = res["tally"]
-            if local_stats is not None:
-                local_stats[first:first + len(res["seat_stats"])] = res["seat_stats"]
-                local_ratios[first:first + len(res["seat_ratio_sums"])] = res["seat_ratio_sums"]
-            if want_rows:  # every rank writes the shards of its own shuffles; rank 0 appends the manifest lines
-                sh_index = np.arange(lo, hi, dtype=np.int64)  # the ShuffleTask identities (run_tournament.py:97-105), as arrays
-                tasks = rt.ShuffleRange(cfg.sim.seed, k, sh_index, _shuffle_seeds(eng, cfg.sim.seed, k, lo, hi), sh_index // spb)
-                sha = oracle_game_profile.sha256 if oracle_game_profile else None
-                # one parquet file per shuffle is the reference's format: the host side of rows mode is Arrow encoding and
-                # file creation — one vectorised conversion per 64 shuffles, shards and their manifest lines by writer processes
-                seeds102 = (eng.game_seeds(int(urandom.RandomPurpose.TOURNAMENT_GAME), cfg.sim.seed, k, lo, hi, gps)
-                            if hasattr(eng, "game_seeds") else None)  # the rows' game_seed column, hashed on the device
-                shard_sidecar = sidecars.template("row_shard", row_dir / "rows_template.parquet",
-                                                  schema=lambda: _stored_schema(raw_simulation_schema_for(k), **rt.SHARD_WRITER_OPTIONS))
-                if use_columns:
-                    if seeds102 is None:
-                        seeds102 = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=cfg.sim.seed, k=k,
-                                                            shuffle_index=np.repeat(np.arange(lo, hi, dtype=np.uint64), gps),
-                                                            game_index=np.tile(np.arange(gps, dtype=np.uint64), hi - lo), dtype=np.uint32)
-                    row_records.extend(rt.write_row_shards_from_columns(row_dir, tasks, res["columns"], seeds102, sha, threads=ROW_WRITER_THREADS,
-                                                                        sidecar=shard_sidecar))
-                else:
-                    row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
-                                                           game_seeds=seeds102, as_lines=True, sidecar=shard_sidecar))
+    def finish(b0, b1, lo, hi, j, local, local_stats, local_ratios, row_records, fragments, res, shard_job, per_batch) -> None:
+        """What follows a launch group's engine call: its shards' manifest lines, the reduction over ranks, chunk files, checkpoint."""
+        nonlocal total, games_done, lag_total, batches_since_save, last_save
+        if shard_job is not None:
+            row_records = shard_job.result()
         if rng_lags:  # this group's ranges in rank order (contiguous whole batches per rank), appended to the run's summary
             from .rng_lags import LagSummary
 
@@ -783,11 +724,128 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             if not per_batch:
                 total += group[0]
             games_done += (min(b1 * spb, plan.required_shuffles) - b0 * spb) * gps
-            if j + 1 < len(pending):
-                save(final=False)  # the checkpoint that owns the manifest lines just appended (the last group's is the final one below)
+            batches_since_save += b1 - b0
+            if j + 1 < len(pending) and (batches_since_save >= checkpoint_batches or
+                                         time.perf_counter() - last_save >= max(float(cfg.sim.ckpt_every_sec), 0.0)):
+                save(final=False)  # the checkpoint that owns the manifest lines appended so far (the last group's is the final one below)
+                batches_since_save, last_save = 0, time.perf_counter()
             LOGGER.info("Batches %d..%d done: %.3g games/s so far", b0, b1 - 1,
                         games_done / max(time.perf_counter() - t_start, 1e-9))
-        i = j + 1
+    i = 0
+    try:
+      while i < len(pending):
+          # contiguous run of pending batches, capped by the launch-group size
+          j = i
+          while j + 1 < len(pending) and pending[j + 1] == pending[j] + 1 and (j + 1 - i) < group_batches:
+              j += 1
+          b0, b1 = pending[i], pending[j] + 1
+          lo, hi = shard_shuffle_range(b0 * spb, min(b1 * spb, plan.required_shuffles), rank, world, batch_size=spb)
+          # Per-batch tallies are only needed for the metric chunk files; without them the group is one tally, which the
+          # engine keeps in LDS when the table is small.
+          per_batch = metric_chunk_dir is not None or all_player_dir is not None
+          local = np.zeros((b1 - b0 if per_batch else 1, S, 26), dtype=np.int64)
+          local_stats = np.zeros((b1 - b0, S, SEAT_STAT_COLS), dtype=np.int64) if all_player_dir is not None else None
+          local_ratios = np.zeros((b1 - b0, S, SEAT_RATIO_COLS), dtype=np.float64) if all_player_dir is not None else None
+          row_records: list[tuple] = []  # (shuffle index, manifest line, shard bytes, shard sha256)
+          shard_job = res = None
+          fragments = None
+          if metric_chunk_dir is not None and rank == 0:
+              # the shuffle fingerprints of the whole group in one vectorised pass (on the device), and their JSON text on the
+              # helper thread while the group plays
+              g_first, g_last = b0 * spb, min(b1 * spb, plan.required_shuffles)
+              group_seeds = _shuffle_seeds(eng, cfg.sim.seed, k, g_first, g_last)
+              bounds = [(b * spb, min((b + 1) * spb, plan.required_shuffles)) for b in range(b0, b1)]
+              fragments = _helper_thread().submit(_shuffle_list_fragments, group_seeds, g_first, spb, bounds)
+          use_columns = False
+          if hi > lo:
+              if j + 1 < len(pending) and hasattr(eng, "hint_next"):
+                  # the launch group after this one (same table, k, root): prepared in the drain tail of this group's kernel
+                  j2 = j + 1
+                  while j2 + 1 < len(pending) and pending[j2 + 1] == pending[j2] + 1 and (j2 + 1 - (j + 1)) < group_batches:
+                      j2 += 1
+                  lo2, hi2 = shard_shuffle_range(pending[j + 1] * spb, min((pending[j2] + 1) * spb, plan.required_shuffles), rank, world,
+                                                 batch_size=spb)
+                  if hi2 > lo2:
+                      eng.hint_next(lo2, hi2, need_state=want_rows)
+              extra: dict[str, Any] = {"want_seat_stats": True} if all_player_dir is not None else {}
+              use_columns = columns_mode
+              if use_columns:
+                  need = (hi - lo) * image_bytes
+                  if hasattr(eng, "pinned_empty"):
+                      # two page-locked buffers per ENGINE (kept for its life, grown when a launch group needs more: page-locking a gigabyte
+                      # takes ~0.25 s, and a sweep over eight player counts that asked for one per count spent 2.4 of its 3.5 s there)
+                      slots = getattr(eng, "_pinned_columns", None)
+                      if slots is None:
+                          slots = eng._pinned_columns = [None, None]
+                      slot = n_groups & 1
+                      if slots[slot] is None or len(slots[slot]) < need:
+                          slots[slot] = None
+                          slots[slot] = eng.pinned_empty(max(need, min(ROWS_GROUP_BYTES, plan.required_shuffles * image_bytes)), np.uint8)
+                      pinned_rows = slots[slot]
+              elif want_rows and hasattr(eng, "pinned_empty"):
+                  # rows land in a page-locked buffer (one per run, sized for the largest launch group): one DMA per chunk at PCIe
+                  # rate, under the next chunk's game kernel
+                  need = (hi - lo) * gps
+                  if pinned_rows is None or len(pinned_rows) < need:
+                      from .backend import row_dtype
+
+                      pinned_rows = None
+                      pinned_rows = eng.pinned_empty(need, row_dtype(k))
+                  extra["rows_out"] = pinned_rows
+              if use_columns:
+                  res = eng.tournament_columns(table, k, cfg.sim.seed, lo, hi, ids, shuffles_per_batch=spb if per_batch else hi - lo,
+                                               target_score=target, max_rounds=max_rounds, overrides=ov, columns_out=pinned_rows)
+              elif rng_lags:
+                  res = eng.tournament_lags(table, k, cfg.sim.seed, lo, hi, rng_lags, shuffles_per_batch=spb if per_batch else hi - lo,
+                                            target_score=target, max_rounds=max_rounds, overrides=ov)
+              else:
+                  res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=spb if per_batch else hi - lo,
+                                       target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows, **extra)
+              first = lo // spb - b0 if per_batch else 0
+              local[first:first + len(res["tally"])] = res["tally"]
+              if local_stats is not None:
+                  local_stats[first:first + len(res["seat_stats"])] = res["seat_stats"]
+                  local_ratios[first:first + len(res["seat_ratio_sums"])] = res["seat_ratio_sums"]
+              if want_rows:  # every rank writes the shards of its own shuffles; rank 0 appends the manifest lines
+                  sh_index = np.arange(lo, hi, dtype=np.int64)  # the ShuffleTask identities (run_tournament.py:97-105), as arrays
+                  tasks = rt.ShuffleRange(cfg.sim.seed, k, sh_index, _shuffle_seeds(eng, cfg.sim.seed, k, lo, hi), sh_index // spb)
+                  sha = oracle_game_profile.sha256 if oracle_game_profile else None
+                  # one parquet file per shuffle is the reference's format: the host side of rows mode is Arrow encoding and
+                  # file creation — one vectorised conversion per 64 shuffles, shards and their manifest lines by writer processes
+                  seeds102 = (eng.game_seeds(int(urandom.RandomPurpose.TOURNAMENT_GAME), cfg.sim.seed, k, lo, hi, gps)
+                              if hasattr(eng, "game_seeds") else None)  # the rows' game_seed column, hashed on the device
+                  shard_sidecar = sidecars.template("row_shard", row_dir / "rows_template.parquet",
+                                                    schema=lambda: _stored_schema(raw_simulation_schema_for(k), **rt.SHARD_WRITER_OPTIONS))
+                  if use_columns:
+                      if seeds102 is None:
+                          seeds102 = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=cfg.sim.seed, k=k,
+                                                              shuffle_index=np.repeat(np.arange(lo, hi, dtype=np.uint64), gps),
+                                                              game_index=np.tile(np.arange(gps, dtype=np.uint64), hi - lo), dtype=np.uint32)
+                      shard_job = _shard_thread().submit(rt.write_row_shards_from_columns, row_dir, tasks, res["columns"], seeds102, sha,
+                                                         threads=ROW_WRITER_THREADS, sidecar=shard_sidecar)
+                  else:
+                      row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
+                                                             game_seeds=seeds102, as_lines=True, sidecar=shard_sidecar))
+          group_args = dict(b0=b0, b1=b1, lo=lo, hi=hi, j=j, local=local, local_stats=local_stats, local_ratios=local_ratios,
+                            row_records=row_records, fragments=fragments, res=res, shard_job=shard_job, per_batch=per_batch)
+          n_groups += 1
+          if in_flight is not None:  # the previous group: its shards were written while this one played
+              previous, in_flight = in_flight, None
+              finish(**previous)
+          if shard_job is not None:
+              in_flight = group_args
+          else:
+              finish(**group_args)
+          i = j + 1
+      if in_flight is not None:
+          previous, in_flight = in_flight, None
+          finish(**previous)
+    finally:
+        if in_flight is not None and in_flight["shard_job"] is not None:  # an error above: no writer thread may outlive the call
+            try:
+                in_flight["shard_job"].result()
+            except Exception:  # noqa: BLE001 - the first error is the one that propagates
+                pass
     if rank == 0:
         save(final=True)
         sidecars.write("checkpoint", checkpoint_path)
