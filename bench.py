@@ -541,7 +541,8 @@ def main() -> None:
     eng = make_engine(local_rank)
     info = eng.device_info()
     try:  # every game-kernel workgroup stamps s_memtime / s_memrealtime at its first and last instruction (two scalar reads and one
-        eng.set_option("clock_stamps", 1)  # 32-byte store per workgroup and launch): the clock the fractions below are also priced at
+        # (FK_BENCH_CLOCK_STAMPS=0 turns them off: the A/B of profiles/r06_ab_clock_stamps.json — their cost inside the timed steps)
+        eng.set_option("clock_stamps", 0 if os.environ.get("FK_BENCH_CLOCK_STAMPS") == "0" else 1)  # 32-byte store per workgroup and launch): the clock the fractions below are also priced at
     except Exception:
         pass  # (the CPU test stub has no such option)
     dev = torch.device("cuda", local_rank) if have_gpu else torch.device("cpu")

@@ -81,12 +81,21 @@ def hip_sources() -> list[Path]:
     return [SRC_DIR / "farkle_hip.hip"]
 
 
-def build_library(force: bool = False, verbose: bool = False) -> Path:
-    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+VARIANTS = {"detour": ["-DFK_FORCE_DETOUR=4"]}  # test builds: libfarkle_hip_<variant>.so beside the product library
+
+
+def library_path(variant: str | None = None) -> Path:
+    return LIB_PATH if not variant else LIB_PATH.with_name(f"libfarkle_hip_{variant}.so")
+
+
+def build_library(force: bool = False, verbose: bool = False, variant: str | None = None) -> Path:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU).  ``variant``: a test build with extra
+    definitions (``VARIANTS``), never loaded by the product."""
+    out = library_path(variant)
     deps = hip_sources() + [SRC_DIR / "fk_device.h", SRC_DIR / "fk_kernels.h", SRC_DIR / "fk_play_hc.h", SRC_DIR / "fk_shard_writer.h", PKG_DIR.parent / "include" / "farkle_hip.h"]
-    if LIB_PATH.exists() and not force and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
-        return LIB_PATH
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(LIB_PATH),
+    if out.exists() and not force and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return out
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *(VARIANTS[variant] if variant else []), "-o", str(out),
            *[str(s) for s in hip_sources()]]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
@@ -94,33 +103,33 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
         print(res.stdout, res.stderr)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed ({res.returncode}): {res.stderr[-2000:]}")
-    return LIB_PATH
+    return out
 
 
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
             "fk_tournament_run", "fk_tournament_run_stats", "fk_tournament_run_all_player", "fk_tournament_run_lags", "fk_tournament_hint_next", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
             "fk_debug_dice", "fk_debug_dice_state", "fk_debug_dice_keys", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy", "fk_tally_resident_reduce", "fk_comm_ranks", "fk_host_alloc", "fk_host_free", "fk_game_seeds",
-            "fk_tournament_run_columns", "fk_row_columns_bytes", "fk_write_row_shards", "fk_debug_sha256"]
-_lib = None
+            "fk_tournament_run_columns", "fk_row_columns_bytes", "fk_write_row_shards", "fk_debug_sha256", "fk_get_option", "fk_debug_deadline_handshake"]
+_libs: dict = {}
 
 
-def load_library() -> C.CDLL:
+def load_library(variant: str | None = None) -> C.CDLL:
     """dlopen the in-tree library; loud failure when it has not been built."""
-    global _lib
-    if _lib is None:
-        if not LIB_PATH.exists():
+    if variant not in _libs:
+        path = library_path(variant)
+        if not path.exists():
             raise FileNotFoundError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the simulation path)")
-        lib = C.CDLL(str(LIB_PATH))
+        lib = C.CDLL(str(path))
         for name in _EXPORTS:
             getattr(lib, name)  # AttributeError if a declared symbol is not exported
         lib.fk_last_error.restype = C.c_char_p
         lib.fk_last_error.argtypes = [C.c_void_p]
         lib.fk_destroy.restype = None
         lib.fk_destroy.argtypes = [C.c_void_p]
-        _lib = lib
-    return _lib
+        _libs[variant] = lib
+    return _libs[variant]
 
 
 def _p(a):
@@ -210,8 +219,8 @@ def make_coords(purpose, root_seed, k, shuffle_index=0, pair_id=0, order=0, game
 class Engine:
     """One context (HIP stream + device workspace) on one GPU."""
 
-    def __init__(self, device: int = 0):
-        self._lib = load_library()
+    def __init__(self, device: int = 0, variant: str | None = None):
+        self._lib = load_library(variant)  # (variant: a test build of the library, backend.VARIANTS)
         self._ctx = C.c_void_p()
         rc = self._lib.fk_init(C.c_int(device), C.byref(self._ctx))
         if rc != 0:
@@ -357,6 +366,12 @@ class Engine:
             C.c_uint64(shuffle_end), C.c_uint32(spb), C.c_int32(target_score), C.c_int32(max_rounds), _p(ov), C.c_int32(len(ov)),
             _p(tally), _p(lags), C.c_int32(len(lags)), _p(sums), _p(head), _p(tail)))
         return {"tally": tally[:n_batches], "lag_sums": sums, "lag_head": head[:m], "lag_tail": tail[:m], "n_shuffles": n_sh}
+
+    def get_option(self, name: str) -> int:
+        """``fk_get_option``: an option's value or a figure of the last call (``last_budget``, ``oom_replays``, the effective ``comm_timeout_ms``)."""
+        value = C.c_int64(0)
+        self._check(self._lib.fk_get_option(self._ctx, name.encode("utf-8"), C.byref(value)))
+        return int(value.value)
 
     def pinned_empty(self, n: int, dtype) -> np.ndarray:
         """``n`` elements of ``dtype`` in page-locked host memory (``fk_host_alloc``), freed when the array is collected — the

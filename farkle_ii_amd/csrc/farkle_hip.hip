@@ -95,6 +95,15 @@ struct fk_ctx {
     uint32_t table_flags = 0;            // set by upload_strategies: flag bits shared by the whole table ...
     uint32_t table_mixed_flags = 0xff00u; // ... and the flag bits that differ between its strategies
     int64_t chunk_bytes = (int64_t)48 << 30;
+    // The workspace budget of one buffer set is min(chunk_bytes, workspace_percent % of the memory this context can have — what is free now
+    // plus what its own per-chunk buffers already hold — divided by the two sets); a call that still meets hipErrorOutOfMemory (another
+    // process took the memory in between) releases its workspace, halves the budget and is replayed (round-5 finding: four ranks sharing
+    // one device each sized two 48-GiB sets and rank 2 died in hipMalloc).
+    int32_t workspace_percent = 80; // option "workspace_percent" (tests set it above 100 to provoke the replay)
+    int64_t chunk_limit = 0;        // the replay's halved budget (0: none)
+    int64_t last_budget = 0;        // the budget the last call planned with (fk_timing has no room: read through option "last_budget")
+    bool oom = false;               // ensure() met hipErrorOutOfMemory
+    int32_t oom_replays = 0;        // how many times the last call was replayed with a smaller workspace
     int32_t batch_threshold = 0;  // 0 = auto: 8 waiting lanes up to eight seats, 12 at nine / ten, 16 at eleven / twelve (swept per k)
     int32_t use_lds_tally = -1;
     int32_t block = 0;
@@ -165,7 +174,14 @@ int ensure(fk_ctx *c, DevBuf &b, size_t bytes) {
     b.p = nullptr;
     b.cap = 0;
     size_t want = std::max<size_t>(bytes, 256);
-    HIPCHK(c, hipMalloc(&b.p, want));
+    const hipError_t e = hipMalloc(&b.p, want);
+    if (e == hipErrorOutOfMemory) {
+        c->oom = true;
+        b.p = nullptr;
+        (void)hipGetLastError(); // (the sticky error would fail the next, unrelated call)
+        return fail(c, FK_ERR_HIP, "hipMalloc(%zu bytes) failed: out of memory", want);
+    }
+    HIPCHK(c, e);
     b.cap = want;
     return FK_OK;
 }
@@ -174,6 +190,42 @@ void release(DevBuf &b) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
+}
+
+// per-chunk buffers: what workspace_budget counts as this context's own and release_workspace gives back
+static std::vector<DevBuf *> workspace_buffers(fk_ctx *c) {
+    std::vector<DevBuf *> out;
+    for (auto &cs : c->sets)
+        for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc, &cs.pools, &cs.blocks,
+                          &cs.game_block, &cs.game_row})
+            out.push_back(b);
+    for (DevBuf *b : {&c->recs, &c->rec0, &c->rows, &c->rows_alt, &c->digest, &c->inv, &c->slow, &c->lag_v, &c->lag_tmp}) out.push_back(b);
+    return out;
+}
+
+// bytes one buffer set of a call may plan for (see fk_ctx::workspace_percent)
+static int64_t workspace_budget(fk_ctx *c) {
+    int64_t budget = c->chunk_bytes;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        size_t held = 0;
+        for (DevBuf *b : workspace_buffers(c)) held += b->cap;
+        const double have = (double)free_b + (double)held;
+        budget = std::min<int64_t>(budget, std::max<int64_t>((int64_t)(have * (double)c->workspace_percent / 100.0 / 2.0), (int64_t)32 << 20));
+    } else {
+        (void)hipGetLastError();
+    }
+    if (c->chunk_limit > 0) budget = std::min(budget, c->chunk_limit);
+    c->last_budget = budget;
+    return budget;
+}
+
+static void release_workspace(fk_ctx *c) {
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    for (DevBuf *b : workspace_buffers(c)) release(*b);
+    for (auto &cs : c->sets) cs.prepared = false;
+    c->hint_valid = false;
 }
 
 uint2 pack_strategy(const fk_strategy &s) {
@@ -1282,10 +1334,26 @@ int fk_get_timing(fk_ctx *c, fk_timing *out) {
     return FK_OK;
 }
 
+static int32_t effective_comm_timeout_ms(const fk_ctx *c);
+
+int fk_get_option(fk_ctx *c, const char *name, int64_t *value) {
+    if (!c || !name || !value) return FK_ERR_ARG;
+    const std::string n(name);
+    if (n == "chunk_bytes") *value = c->chunk_bytes;
+    else if (n == "workspace_percent") *value = c->workspace_percent;
+    else if (n == "last_budget") *value = c->last_budget;
+    else if (n == "oom_replays") *value = c->oom_replays;
+    else if (n == "comm_timeout_ms") *value = effective_comm_timeout_ms(c);
+    else if (n == "rows_chunk_games") *value = c->rows_chunk_games;
+    else return fail(c, FK_ERR_ARG, "fk_get_option: unknown option %s", name);
+    return FK_OK;
+}
+
 int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return FK_ERR_ARG;
     std::string n(name);
     if (n == "chunk_bytes") c->chunk_bytes = std::max<int64_t>(value, 1 << 20);
+    else if (n == "workspace_percent") c->workspace_percent = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 100000);
     else if (n == "comm_timeout_ms") {
         c->comm_timeout_ms = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 86400000);
         c->comm_timeout_set = true; // from now on the FK_COMM_TIMEOUT_MS environment default is not consulted
@@ -1444,8 +1512,23 @@ static int tournament_call(fk_ctx *c, const fk_strategy *strategies, int32_t S, 
     if (!c) return FK_ERR_ARG;
     c->ran_hc = false;
     c->last_tally_bytes = 0;
+    c->oom = false;
+    c->oom_replays = 0;
+    c->chunk_limit = 0;
     int rc = tournament_run_impl(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds,
                                  ov, n_ov, tally, rows, perms, seat_stats, lag, seat_ratios);
+    while (rc == FK_ERR_HIP && c->oom && c->oom_replays < 8 && c->last_budget > ((int64_t)32 << 20)) {
+        // out of device memory although the budget was sized from hipMemGetInfo: somebody else's allocation came in between.  Give the
+        // workspace back, plan with half, play the call again from its first shuffle (every output is overwritten).
+        c->oom = false;
+        ++c->oom_replays;
+        release_workspace(c);
+        c->chunk_limit = c->last_budget / 2;
+        if (getenv("FK_DEBUG_REPLAY")) fprintf(stderr, "out of device memory: replay %d with a %lld-byte workspace\n", c->oom_replays, (long long)c->chunk_limit);
+        rc = tournament_run_impl(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds,
+                                 ov, n_ov, tally, rows, perms, seat_stats, lag, seat_ratios);
+    }
+    c->chunk_limit = 0;
     if (rc == FK_ERR_COUNTER_OVERFLOW && c->ran_hc) {
         // the hot / cold kernel's narrower counter fields (fk_play_hc.h) left their guard bands: the call is replayed on
         // fk_play_kernel, whose 16-bit fields are the ABI's stated limits
@@ -1542,7 +1625,7 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
                                                                     (seat_stats ? (size_t)k * 32 : 0)) // + the exposure digests
                                      + (lag ? (size_t)S * 2 : 0);                                        // + the lag value matrix row
     // (column images are larger than AoS rows: the workspace figure above counts 4 + 28 k bytes per game)
-    uint64_t chunk_sh = std::max<uint64_t>(1, (uint64_t)c->chunk_bytes / bytes_per_shuffle);
+    uint64_t chunk_sh = std::max<uint64_t>(1, (uint64_t)workspace_budget(c) / bytes_per_shuffle);
     chunk_sh = std::min<uint64_t>(chunk_sh, (uint64_t)0x7fffffff / gps);
     if (rows) // rows mode: several chunks per call, so that the rows of chunk i cross PCIe while chunk i + 1 plays
         chunk_sh = std::min<uint64_t>(chunk_sh, std::max<uint64_t>(1, (uint64_t)c->rows_chunk_games / gps));
@@ -1921,9 +2004,34 @@ int fk_play_games(fk_ctx *c, const fk_coord *coords, int64_t n_games, const fk_s
 // first attempt index at which `target` games have completed, h2h_schedule.py:1165-1235), because it reaches the target
 // only if every one of its attempts completes, i.e. at its last attempt.  Blocks with safety-limit games need further
 // (geometrically smaller) passes; all blocks share each pass's launch.
+static int h2h_run_blocks_impl(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_t root_seed, uint64_t chunk_games,
+                               int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov);
+
 int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_t root_seed, uint64_t chunk_games,
                       int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov) {
     if (!c) return FK_ERR_ARG;
+    c->oom = false;
+    c->oom_replays = 0;
+    c->chunk_limit = 0;
+    // the blocks are advanced in place: a replay after an out-of-memory failure starts from the states the caller handed in
+    std::vector<fk_h2h_block> saved;
+    if (blocks && n_blocks > 0 && n_blocks <= (1 << 22)) saved.assign(blocks, blocks + n_blocks);
+    int rc = h2h_run_blocks_impl(c, blocks, n_blocks, root_seed, chunk_games, target_score, max_rounds, ov, n_ov);
+    while (rc == FK_ERR_HIP && c->oom && c->oom_replays < 8 && c->last_budget > ((int64_t)32 << 20)) {
+        c->oom = false;
+        ++c->oom_replays;
+        release_workspace(c);
+        c->chunk_limit = c->last_budget / 2;
+        std::copy(saved.begin(), saved.end(), blocks);
+        if (getenv("FK_DEBUG_REPLAY")) fprintf(stderr, "out of device memory: replay %d with a %lld-byte workspace\n", c->oom_replays, (long long)c->chunk_limit);
+        rc = h2h_run_blocks_impl(c, blocks, n_blocks, root_seed, chunk_games, target_score, max_rounds, ov, n_ov);
+    }
+    c->chunk_limit = 0;
+    return rc;
+}
+
+static int h2h_run_blocks_impl(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_t root_seed, uint64_t chunk_games,
+                               int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov) {
     if (!blocks || n_blocks < 0 || n_blocks > (1 << 22)) return fail(c, FK_ERR_ARG, "blocks are required (at most 2^22 per call)");
     if (max_rounds < 0 || max_rounds > 65535) return fail(c, FK_ERR_ARG, "max_rounds must be in [0, 65535]");
     if (n_ov < 0 || (n_ov > 0 && !ov)) return fail(c, FK_ERR_ARG, "bad override list");
@@ -1952,7 +2060,7 @@ int fk_h2h_run_blocks(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks, uint64_
     if (plan.block == 0)
         return fail(c, FK_ERR_ARG, "target_score %d: batched head-to-head plays with lean records (totals up to %d points)", target_score,
                     50 * LEAN_MAX_TARGET50);
-    const uint64_t max_launch = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)c->chunk_bytes / (game_workspace_bytes(2, plan.gs, false, false) + 8), 1u << 30));
+    const uint64_t max_launch = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)workspace_budget(c) / (game_workspace_bytes(2, plan.gs, false, false) + 8), 1u << 30));
     rc = ensure(c, c->block_out, (size_t)n_blocks * 4 * 8);
     if (rc) return rc;
 
@@ -2169,6 +2277,81 @@ int fk_comm_unique_id(fk_comm_id *out) {
     return r.GetUniqueId(out) == 0 ? FK_OK : FK_ERR_COMM;
 }
 
+// A blocking initialisation under a deadline, on a helper thread.  Ownership of what `init` made is decided by ONE atomic state
+// (0 running, 1 done, 2 abandoned): the helper EXCHANGES in "done" when `init` returns and, if the waiter had already abandoned the call,
+// tears its own product down with `orphaned`; the waiter, at the deadline, COMPARE-EXCHANGES running -> abandoned and, if that fails, the
+// helper has finished and the product is the waiter's.  Exactly one side ever touches the product (the round-5 handshake of two flags
+// let both act when `init` returned at the deadline itself: the waiter installed a communicator the helper was about to abort).
+// Returns true when `init` finished in time (rc / product handed over), false when the call was abandoned (the helper stays detached).
+extern "C++" {
+struct DeadlineCall {
+    std::atomic<int> state{0};
+    int rc = 0;
+    void *product = nullptr;
+};
+template <class Init, class Orphaned>
+static bool init_under_deadline(Init init, Orphaned orphaned, int timeout_ms, int &rc, void *&product, std::atomic<int> *helper_exits = nullptr) {
+    auto call = std::make_shared<DeadlineCall>();
+    const double t0 = now_ms();
+    std::thread([call, init, orphaned, helper_exits]() {
+        call->rc = init(&call->product);
+        if (call->state.exchange(1) == 2 && call->rc == 0 && call->product) { // abandoned before this returned: built for nobody
+            void *mine = call->product;
+            call->product = nullptr;
+            orphaned(mine);
+        }
+        if (helper_exits) helper_exits->fetch_add(1);
+    }).detach();
+    while (call->state.load(std::memory_order_acquire) != 1) {
+        if (now_ms() - t0 > (double)timeout_ms) {
+            int expected = 0;
+            if (call->state.compare_exchange_strong(expected, 2)) return false; // the helper will find "abandoned" and clean up after itself
+            break;                                                               // it finished in this very moment: the product is ours
+        }
+        usleep(200);
+    }
+    rc = call->rc;
+    product = call->product;
+    return true;
+}
+} // extern "C++"
+
+// FK_COMM_TIMEOUT_MS is the default for contexts whose "comm_timeout_ms" option was never set (an explicit fk_set_option wins);
+// anything that is not a non-negative integer is ignored rather than silently turned into the blocking path
+static int32_t effective_comm_timeout_ms(const fk_ctx *c) {
+    if (!c->comm_timeout_set) {
+        if (const char *env = getenv("FK_COMM_TIMEOUT_MS")) {
+            char *endp = nullptr;
+            const long v = strtol(env, &endp, 10);
+            if (endp != env && *endp == '\0' && v >= 0 && v <= 86400000L) return (int32_t)v;
+        }
+    }
+    return c->comm_timeout_ms;
+}
+
+// The handshake above with a stand-in for ncclCommInitRank that sleeps `init_ms` and hands out a token: out[0] = 1 the caller received
+// the product (in time), 0 abandoned; out[1] = how many products were torn down as orphans, counted after the helper has exited.  For
+// every timing exactly one of the two happens (tests/test_abi_cpu.py sweeps init_ms across the deadline).
+int fk_debug_deadline_handshake(int32_t init_ms, int32_t timeout_ms, int64_t *out) {
+    if (!out || init_ms < 0 || timeout_ms < 1) return FK_ERR_ARG;
+    auto orphans = std::make_shared<std::atomic<int>>(0);
+    std::atomic<int> exits{0};
+    int rc = 0;
+    void *product = nullptr;
+    static int token;
+    const bool in_time = init_under_deadline(
+        [init_ms](void **made) {
+            usleep((useconds_t)init_ms * 1000u);
+            *made = &token;
+            return 0;
+        },
+        [orphans](void *) { orphans->fetch_add(1); }, timeout_ms, rc, product, &exits);
+    while (!exits.load()) usleep(200); // (a test wants the helper's verdict; fk_comm_init never waits for an abandoned helper)
+    out[0] = in_time && product == &token ? 1 : 0;
+    out[1] = orphans->load();
+    return FK_OK;
+}
+
 int fk_comm_init(fk_ctx *c, const fk_comm_id *id, int32_t rank, int32_t world_size) {
     if (!c) return FK_ERR_ARG;
     if (!id || world_size < 1 || rank < 0 || rank >= world_size) return fail(c, FK_ERR_ARG, "bad communicator id / rank / world size");
@@ -2179,15 +2362,7 @@ int fk_comm_init(fk_ctx *c, const fk_comm_id *id, int32_t rank, int32_t world_si
         (void)r.CommDestroy(c->comm);
         c->comm = nullptr;
     }
-    // FK_COMM_TIMEOUT_MS is the default for contexts whose "comm_timeout_ms" option was never set (an explicit fk_set_option wins);
-    // anything that is not a non-negative integer is ignored rather than silently turned into the blocking path
-    if (!c->comm_timeout_set) {
-        if (const char *env = getenv("FK_COMM_TIMEOUT_MS")) {
-            char *endp = nullptr;
-            const long v = strtol(env, &endp, 10);
-            if (endp != env && *endp == '\0' && v >= 0 && v <= 86400000L) c->comm_timeout_ms = (int32_t)v;
-        }
-    }
+    c->comm_timeout_ms = effective_comm_timeout_ms(c);
     c->comm_async = false;
     const bool dbg = getenv("FK_DEBUG_COMM") != nullptr;
     if (c->comm_timeout_ms > 0) {
@@ -2196,45 +2371,30 @@ int fk_comm_init(fk_ctx *c, const fk_comm_id *id, int32_t rank, int32_t world_si
         // peers here until the job's time limit: the call runs on a helper thread and this thread waits for it under the deadline.
         // On expiry the helper stays parked in RCCL's bootstrap (a socket wait; it owns nothing of this context and is never
         // joined), the context has no communicator, and the caller gets FK_ERR_COMM — bench.py / farkle run then agree on gloo.
-        // Should the peer join after all, the helper finds `abandoned` set and aborts the communicator it just made itself
-        // (ncclCommAbort: nobody else holds it), so a late join leaks nothing.  A process that has seen this error should end
-        // (exit code != 0 is the caller's call): a thread may still sit inside librccl.
-        struct Pending {
-            std::atomic<int> done{0};
-            std::atomic<int> abandoned{0};
-            int rc = 0;
-            void *comm = nullptr;
-        };
-        auto pending = std::make_shared<Pending>();
+        // Should the peer join after all, the helper finds the call abandoned and aborts the communicator it just made itself
+        // (ncclCommAbort: nobody else holds it), so a late join leaks nothing — init_under_deadline decides with ONE atomic who owns the
+        // result.  A process that has seen this error should end (exit code != 0 is the caller's call): a thread may still sit inside librccl.
         const fk_comm_id id_copy = *id;
         const int device = c->device;
         const double t0 = now_ms();
-        std::thread([pending, id_copy, device, world_size, rank, &r]() {
-            (void)hipSetDevice(device);
-            pending->rc = r.CommInitRank(&pending->comm, world_size, id_copy, rank);
-            pending->done.store(1); // (sequentially consistent, like the three accesses it pairs with: a store-then-load handshake)
-            // the waiter gave up before this returned (it tests `done` once more after setting `abandoned`, so at least one side
-            // sees the other's flag): tear down what was built for nobody
-            if (pending->abandoned.load() && pending->rc == 0 && pending->comm) {
-                void *orphan = pending->comm;
-                pending->comm = nullptr;
-                (void)(r.CommAbort ? r.CommAbort(orphan) : r.CommDestroy(orphan));
-            }
-        }).detach();
-        while (!pending->done.load(std::memory_order_acquire)) {
-            if (now_ms() - t0 > (double)c->comm_timeout_ms) {
-                pending->abandoned.store(1);
-                if (pending->done.load()) break; // it finished in this very moment (the helper may have torn it down already: checked below)
-                if (dbg) fprintf(stderr, "[fk comm] ncclCommInitRank still waiting after %.0f ms: giving up\n", now_ms() - t0);
-                return fail(c, FK_ERR_COMM, "ncclCommInitRank did not complete within %d ms (comm_timeout_ms): a peer rank never joined",
-                            c->comm_timeout_ms);
-            }
-            usleep(500);
+        Rccl *rp = &r;
+        int init_rc = 0;
+        void *made = nullptr;
+        const bool in_time = init_under_deadline(
+            [id_copy, device, world_size, rank, rp](void **out) {
+                (void)hipSetDevice(device);
+                return rp->CommInitRank(out, world_size, id_copy, rank);
+            },
+            [rp](void *orphan) { (void)(rp->CommAbort ? rp->CommAbort(orphan) : rp->CommDestroy(orphan)); }, c->comm_timeout_ms, init_rc, made);
+        if (!in_time) {
+            if (dbg) fprintf(stderr, "[fk comm] ncclCommInitRank still waiting after %.0f ms: giving up\n", now_ms() - t0);
+            return fail(c, FK_ERR_COMM, "ncclCommInitRank did not complete within %d ms (comm_timeout_ms): a peer rank never joined",
+                        c->comm_timeout_ms);
         }
+        struct { int rc; void *comm; } done{init_rc, made}, *pending = &done;
         if (dbg) fprintf(stderr, "[fk comm] ncclCommInitRank returned %d after %.1f ms\n", pending->rc, now_ms() - t0);
         if (pending->rc != 0) return rccl_fail(c, "ncclCommInitRank", pending->rc);
-        if (!pending->comm) // (both sides raced at the deadline and the helper tore the communicator down)
-            return fail(c, FK_ERR_COMM, "ncclCommInitRank completed at the deadline (%d ms) and was abandoned", c->comm_timeout_ms);
+        if (!pending->comm) return fail(c, FK_ERR_COMM, "ncclCommInitRank returned no communicator");
         c->comm = pending->comm;
         c->comm_rank = rank;
         c->comm_world = world_size;

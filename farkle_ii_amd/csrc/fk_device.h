@@ -275,6 +275,13 @@ __device__ inline uint32_t roll_counts_fast(Rng &r, uint32_t n, bool &detour, ui
     r.has_buf = (n + hb) & 1u;
     r.buf = last_hi;
     detour = minleft < (STRIDE == 4u ? 16u : 4u); // rare (STRIDE 4: a superset of the rejections)
+#ifdef FK_FORCE_DETOUR
+    // Test builds only (tests/test_detour_gpu.py): a real rejection happens once in ~2^30 dice, so the kernels' detour — generator re-read
+    // from the seat record / hot planes, the roll replayed sequentially — would never run in a parity test.  Here every
+    // FK_FORCE_DETOUR-th roll (a power of two; picked by bits of the advanced state, so lanes of a wave disagree) takes it; the detour is
+    // exact whether or not a word was rejected, so every result must stay bit-identical.
+    detour = detour || ((((uint32_t)(r.lo >> 17)) & (uint32_t)(FK_FORCE_DETOUR - 1)) == 0u);
+#endif
     if (faces_out) *faces_out = faces;
     return counts;
 }

@@ -219,7 +219,12 @@ class _SweepShared:
 
     def _get(self) -> tuple:
         if self._derived is None:
-            self._derived = self._job.result() if self._job is not None else self._derive()
+            import threading
+
+            # Called FROM the helper thread (a job queued there that reads the manifest) the pending job cannot be waited for: it sits
+            # behind the caller in the same single-worker queue — derive inline instead of deadlocking (round-5 advisor finding).
+            on_helper = threading.current_thread().name.startswith("fk-manifest")
+            self._derived = self._job.result() if self._job is not None and not (on_helper and not self._job.done()) else self._derive()
         return self._derived
 
     @property
@@ -633,7 +638,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         ck_meta = {**get_meta(), "completed_shuffle_indices": shuffle_list,
                    "completed_process_block_indices": [b + 1 for b in completed], "complete": final}
         content = ckpt.dump_checkpoint(wins, sums if collect_metrics else None, sqs if collect_metrics else None, ck_meta)
-        if final and defer_final_checkpoint and not sidecars.enabled:
+        if final and defer_final_checkpoint and not (sidecars is not None and sidecars.enabled):
             # 1.4 MB for config 2: the write goes to the helper thread (file I/O drops the GIL) while the caller builds the summary tables;
             # `checkpoint_written` is joined before the completion stamp — or anything else — reads the file
             checkpoint_written.append(_helper_thread().submit(_atomic_write_bytes, checkpoint_path, content))

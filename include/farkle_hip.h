@@ -155,6 +155,12 @@ int fk_host_free(fk_ctx *ctx, void *p);
  * shader-clock and the 100 MHz reference counters at its first and last instruction; fk_timing.play_clock_mhz).  All of them
  * are scheduling / layout choices: results are identical for every setting. */
 int fk_set_option(fk_ctx *ctx, const char *name, int64_t value);
+/* Read back an option or a figure of the last call: "chunk_bytes", "workspace_percent" (a buffer set's workspace is at most this share of
+ * the device memory the context can have — free now + its own per-chunk buffers — halved for the two sets; default 80), "last_budget" (the
+ * bytes per buffer set the last tournament / H2H call planned with), "oom_replays" (how often that call met hipErrorOutOfMemory, gave
+ * its workspace back and was replayed with half the budget: results are identical), "comm_timeout_ms" (the EFFECTIVE deadline: the option
+ * if it was ever set, else a well-formed FK_COMM_TIMEOUT_MS, else 120 000), "rows_chunk_games". */
+int fk_get_option(fk_ctx *ctx, const char *name, int64_t *value);
 
 /* Tournament shuffles [shuffle_begin, shuffle_end) of the S-strategy table at k players.
  *   tally       int64 [n_batches][S][26], n_batches = ceil(n_shuffles / shuffles_per_batch); overwritten.
@@ -341,6 +347,10 @@ int fk_coordinate_seeds(fk_ctx *ctx, int64_t n, const fk_coord *coords, uint32_t
  * (run_tournament.py:340-350; purpose 102 for tournaments). */
 int fk_game_seeds(fk_ctx *ctx, uint32_t purpose, uint64_t root_seed, uint64_t k, uint64_t shuffle_begin, uint64_t n_shuffles,
                   uint32_t games_per_shuffle, uint32_t *seed32);
+
+/* The deadline handshake of fk_comm_init with a stand-in for ncclCommInitRank that takes init_ms: out[0] = 1 when the caller received the
+ * communicator in time, 0 when it gave up at timeout_ms; out[1] = communicators torn down as orphans by the helper thread.  Host code. */
+int fk_debug_deadline_handshake(int32_t init_ms, int32_t timeout_ms, int64_t *out);
 
 /* ---- single-op probes of the device functions (parity tests) ---- */
 /* n rolls: roll i scores faces[i*6 .. i*6+len[i]) for strategy[i] with turn_score_pre[i];

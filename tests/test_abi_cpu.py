@@ -17,7 +17,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     backend.build_library()
     lib = backend.load_library()
     header = (ROOT / "include" / "farkle_hip.h").read_text()
-    declared = set(re.findall(r"^(?:int|void|const char \*)\s*\*?(fk_\w+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|size_t|const char \*)\s*\*?(fk_\w+)\(", header, flags=re.M))
     assert {"fk_init", "fk_tournament_run", "fk_play_games", "fk_h2h_run", "fk_last_error", "fk_destroy"} <= declared
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/farkle_hip.h but not exported"
@@ -51,3 +51,24 @@ def test_product_never_touches_the_oracle():
         if path.suffix in {".py", ".hip", ".h", ".cpp"}:
             text = path.read_text()
             assert "pyoracle" not in text and "liboracle" not in text and "farkle_oracle" not in text, path
+
+
+def test_comm_init_deadline_handshake_has_exactly_one_owner():
+    """fk_comm_init runs ncclCommInitRank on a helper thread under a deadline.  Whatever the timing — the initialisation returning long
+    before, long after or AT the deadline — the communicator ends up with exactly one owner: the caller received it, or the helper tore it
+    down as an orphan; never both (the round-5 two-flag handshake could install a communicator that was being aborted), never neither."""
+    import ctypes as C
+
+    import numpy as np
+
+    from farkle_ii_amd.backend import load_library
+
+    lib = load_library()
+    out = np.zeros(2, dtype=np.int64)
+    received = {}
+    for init_ms in (0, 5, 18, 19, 20, 21, 22, 45):
+        for _ in range(10):
+            assert lib.fk_debug_deadline_handshake(C.c_int32(init_ms), C.c_int32(20), out.ctypes.data_as(C.c_void_p)) == 0
+            assert int(out[0]) + int(out[1]) == 1, (init_ms, out.tolist())
+            received[init_ms] = received.get(init_ms, 0) + int(out[0])
+    assert received[0] == received[5] == 10 and received[45] == 0  # (the timings around 20 ms may go either way: that is the point)

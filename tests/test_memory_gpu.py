@@ -1,0 +1,101 @@
+"""Device-memory pressure (round-5 finding: four ranks sharing one device each planned two 48-GiB buffer sets and one died in hipMalloc).
+
+The workspace of a call is sized from ``hipMemGetInfo`` — a share of what is free plus what the context already holds — and a call that
+still meets ``hipErrorOutOfMemory`` gives its workspace back, halves the budget and is replayed.  Results never depend on the chunking:
+checked against the CPU oracle with most of the device taken by somebody else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class _Hog:
+    """Device memory held outside the engine (hipMalloc through the HIP runtime the library already loaded)."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.ptrs: list[C.c_void_p] = []
+
+    def free_bytes(self) -> int:
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        assert self.hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return int(free.value)
+
+    def leave(self, n_bytes: int) -> None:
+        """Allocate until about ``n_bytes`` are free."""
+        while True:
+            take = self.free_bytes() - n_bytes
+            if take < (64 << 20):
+                return
+            p = C.c_void_p()
+            step = min(take, 32 << 30)
+            if self.hip.hipMalloc(C.byref(p), C.c_size_t(step)) != 0:
+                self.hip.hipGetLastError()
+                return
+            self.ptrs.append(p)
+
+    def release(self) -> None:
+        for p in self.ptrs:
+            self.hip.hipFree(p)
+        self.ptrs = []
+
+
+@pytest.fixture
+def engine_and_hog():
+    from farkle_ii_amd.engine import get_engine, set_engine
+
+    set_engine(None)
+    eng = get_engine()
+    hog = _Hog()
+    yield eng, hog
+    hog.release()
+    eng.set_option("workspace_percent", 80)
+    set_engine(None)
+
+
+def _case():
+    import pyoracle as po
+
+    from farkle_ii_amd.strategies import generate_strategy_grid, pack_strategies, prepare_public_helper_strategies
+
+    table = pack_strategies(prepare_public_helper_strategies(generate_strategy_grid()[0]))  # the 5 160-strategy grid
+    k, lo, hi = 4, 500, 900  # 400 shuffles x 1 290 games = 516 000 games: ~75 MB of workspace per 10^5 games
+    want = po.tournament(table.view(po.STRATEGY_DTYPE), k, 7, lo, hi, shuffles_per_batch=100, n_threads=16)["tally"]
+    return table, k, lo, hi, want
+
+
+def test_chunked_under_memory_pressure_equals_the_oracle(engine_and_hog):
+    eng, hog = engine_and_hog
+    table, k, lo, hi, want = _case()
+    roomy = eng.tournament(table, k, 7, lo, hi, shuffles_per_batch=100)["tally"]
+    assert np.array_equal(roomy, want)
+    budget_roomy = eng.get_option("last_budget")
+    hog.leave(700 << 20)  # somebody else holds the device: ~0.7 GB left (+ what the context's own buffers hold)
+    tight = eng.tournament(table, k, 7, lo, hi, shuffles_per_batch=100)
+    assert np.array_equal(tight["tally"], want)
+    assert eng.get_option("last_budget") < budget_roomy and eng.get_option("oom_replays") == 0  # sized from hipMemGetInfo: nothing failed
+    rows = eng.tournament(table, k, 7, lo, lo + 40, want_rows=True)  # the rows path allocates its buffers under the same pressure
+    assert np.array_equal(rows["tally"].sum(axis=0), eng.tournament(table, k, 7, lo, lo + 40)["tally"].sum(axis=0))
+
+
+def test_out_of_memory_is_replayed_with_half_the_workspace(engine_and_hog):
+    """An allocation that fails although the budget said it would fit (here: a budget of 2 000 % of what is free) releases the workspace,
+    halves the budget and plays the call again — same results, and the H2H entry point does the same."""
+    eng, hog = engine_and_hog
+    table, k, lo, hi, want = _case()
+    hog.leave(1 << 30)
+    eng.set_option("workspace_percent", 2000)
+    eng.set_option("chunk_bytes", 256 << 30)
+    try:
+        got = eng.tournament(table, k, 7, lo, hi, shuffles_per_batch=100)["tally"]
+        replays = eng.get_option("oom_replays")
+    finally:
+        eng.set_option("workspace_percent", 80)
+        eng.set_option("chunk_bytes", 48 << 30)
+    assert np.array_equal(got, want)
+    assert replays >= 1
