@@ -492,6 +492,7 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     backend_note = None
+    fallback_reasons: list[str] = []  # THIS rank's reasons for every fallback taken on the way to the tally reduce (gathered into the JSON line)
     have_gpu = torch.cuda.is_available()
     # FK_DIST_BACKEND=gloo rehearses the multi-rank path on a one-GPU box (ranks share GPU 0, tallies reduced on CPU);
     # the real runs use nccl = RCCL over xGMI with one GPU per rank.
@@ -523,6 +524,8 @@ def main() -> None:
                 ok = int(int(probe.item()) == world)
             except Exception as exc:
                 ok, why = 0, f"{type(exc).__name__}: {str(exc)[:200]}"
+            if not ok:
+                fallback_reasons.append(f"torch.distributed nccl group: {why or 'all_reduce probe returned a wrong sum'}")
             flag = torch.tensor([ok], dtype=torch.int64)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) != 1:
@@ -570,7 +573,11 @@ def main() -> None:
             try:
                 ok = int(bool(init_engine_comm(eng)))
             except Exception as exc:
+                fallback_reasons.append(f"engine communicator (fk_comm_init): {type(exc).__name__}: {str(exc)[:200]}")
                 print(f"rank {rank}: fk_comm_init failed ({type(exc).__name__}: {str(exc)[:200]}); torch.distributed reduce instead", file=sys.stderr)
+            else:
+                if not ok:
+                    fallback_reasons.append("engine communicator (fk_comm_init): returned no communicator")
             flag = torch.tensor([ok], dtype=torch.int64)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             use_fk_comm = int(flag.item()) == 1
@@ -616,6 +623,7 @@ def main() -> None:
         if not (distributed and use_fk_comm):
             raise
         reduce_ok, reduce_why = 0, f"{type(exc).__name__}: {str(exc)[:200]}"
+        fallback_reasons.append(f"engine communicator's first reduce: {reduce_why}")
     if distributed and use_fk_comm:
         flag = torch.tensor([reduce_ok], dtype=torch.int64)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -652,6 +660,12 @@ def main() -> None:
         played = int(g_all.item())
     else:
         played = my_games
+    dist_fallback_reason = None
+    if distributed:  # every rank's reasons to rank 0 (gloo, outside the timed region)
+        gathered = [None] * n_gpus if rank == 0 else None
+        dist.gather_object(fallback_reasons, gathered, dst=0)
+        if rank == 0 and any(gathered):
+            dist_fallback_reason = {f"rank {r}": why for r, why in enumerate(gathered) if why}
 
     total_games = wl.games_per_step(n_gpus) * args.steps
     value = total_games / elapsed
@@ -793,6 +807,9 @@ def main() -> None:
             "dist_backend": (("nccl (RCCL over xGMI) for the tally reduce; gloo control plane" if data_group is not None
                               else (backend_note or "gloo")) if distributed else None),
             "rccl_ranks": rccl_ranks if distributed else None,
+            # why the job is NOT on "engine communicator over RCCL", per rank that had a reason (stderr carried these before round 6): null
+            # when every rank took the first choice
+            "dist_fallback_reason": dist_fallback_reason,
             "launcher": "self (bench.py started the ranks)" if os.environ.get("FK_BENCH_SELF_LAUNCHED") else
                         ("torch.distributed.run" if distributed else "single process"),
             "config": {**wl.describe(n_gpus), "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"],

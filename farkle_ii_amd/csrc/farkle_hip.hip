@@ -199,7 +199,8 @@ static std::vector<DevBuf *> workspace_buffers(fk_ctx *c) {
         for (DevBuf *b : {&cs.perm, &cs.draws, &cs.state, &cs.inc, &cs.seat_idx, &cs.order, &cs.classes, &cs.misc, &cs.pools, &cs.blocks,
                           &cs.game_block, &cs.game_row})
             out.push_back(b);
-    for (DevBuf *b : {&c->recs, &c->rec0, &c->rows, &c->rows_alt, &c->digest, &c->inv, &c->slow, &c->lag_v, &c->lag_tmp}) out.push_back(b);
+    // (only buffers that every call sizes and ensures per chunk: c->slow — the patience table upload_strategies fills once per TABLE — is not one)
+    for (DevBuf *b : {&c->recs, &c->rec0, &c->rows, &c->rows_alt, &c->digest, &c->inv, &c->lag_v, &c->lag_tmp}) out.push_back(b);
     return out;
 }
 

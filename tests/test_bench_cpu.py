@@ -35,6 +35,7 @@ def test_bench_gpus_2_starts_its_own_ranks_and_reduces_one_tally(tmp_path):
     line = _run_bench("--gpus", "2", "--shuffles", "120", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--dump-tally", str(out))
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["launcher"].startswith("self") and line["dist_backend"] == "gloo" and "TEST STUB" in line["engine"]
+    assert "dist_fallback_reason" in line and line["dist_fallback_reason"] is None  # (gloo was asked for: nothing fell back)
     assert line["config"]["games_per_gpu_per_step"] == 120 * 32
     # steps 1..2 (after one warm-up step) of two ranks = shuffles [240, 720) of the single-process run
     table = gu.strategies_from_tuples(gu.load("grid_vectors.json")["g64"], po.STRATEGY_DTYPE)

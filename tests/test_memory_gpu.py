@@ -84,18 +84,22 @@ def test_chunked_under_memory_pressure_equals_the_oracle(engine_and_hog):
 
 
 def test_out_of_memory_is_replayed_with_half_the_workspace(engine_and_hog):
-    """An allocation that fails although the budget said it would fit (here: a budget of 2 000 % of what is free) releases the workspace,
-    halves the budget and plays the call again — same results, and the H2H entry point does the same."""
-    eng, hog = engine_and_hog
-    table, k, lo, hi, want = _case()
-    hog.leave(1 << 30)
-    eng.set_option("workspace_percent", 2000)
-    eng.set_option("chunk_bytes", 256 << 30)
-    try:
-        got = eng.tournament(table, k, 7, lo, hi, shuffles_per_batch=100)["tally"]
-        replays = eng.get_option("oom_replays")
-    finally:
-        eng.set_option("workspace_percent", 80)
-        eng.set_option("chunk_bytes", 48 << 30)
-    assert np.array_equal(got, want)
-    assert replays >= 1
+    """An allocation that fails although the budget said it would fit (here: a budget of 2 000 % of what is free, 300 MB left for a call
+    that wants ~450 MB in one chunk) releases the workspace, halves the budget and plays the call again — same results."""
+    from farkle_ii_amd.backend import Engine
+    from farkle_ii_amd.strategies import generate_strategy_grid, pack_strategies, prepare_public_helper_strategies
+
+    _, hog = engine_and_hog
+    table = pack_strategies(prepare_public_helper_strategies(generate_strategy_grid()[0]))
+    k, lo, hi = 4, 0, 2000  # 2.58 million games: ~180 bytes of workspace each
+    with Engine(0) as roomy:
+        want = roomy.tournament(table, k, 7, lo, hi, shuffles_per_batch=500)["tally"]  # (this path is oracle-checked above and in test_hip_parity)
+        assert roomy.get_option("oom_replays") == 0
+    hog.leave(300 << 20)
+    with Engine(0) as tight:
+        tight.set_option("workspace_percent", 2000)
+        got = tight.tournament(table, k, 7, lo, hi, shuffles_per_batch=500)["tally"]
+        replays, budget = tight.get_option("oom_replays"), tight.get_option("last_budget")
+        again = tight.tournament(table, k, 7, lo, hi, shuffles_per_batch=500)["tally"]  # the next call plans inside what the context now holds
+    assert np.array_equal(got, want) and np.array_equal(again, want)
+    assert replays >= 1 and budget < (6 << 30), (replays, budget)
