@@ -109,7 +109,7 @@ def build_library(force: bool = False, verbose: bool = False, variant: str | Non
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
             "fk_tournament_run", "fk_tournament_run_stats", "fk_tournament_run_all_player", "fk_tournament_run_lags", "fk_tournament_hint_next", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
             "fk_debug_dice", "fk_debug_dice_state", "fk_debug_dice_keys", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy", "fk_tally_resident_reduce", "fk_comm_ranks", "fk_host_alloc", "fk_host_free", "fk_game_seeds",
-            "fk_tournament_run_columns", "fk_row_columns_bytes", "fk_write_row_shards", "fk_debug_sha256", "fk_get_option", "fk_debug_deadline_handshake"]
+            "fk_tournament_run_columns", "fk_row_columns_bytes", "fk_write_row_shards", "fk_debug_sha256", "fk_get_option", "fk_debug_deadline_handshake", "fk_debug_hold_memory"]
 _libs: dict = {}
 
 
@@ -372,6 +372,12 @@ class Engine:
         value = C.c_int64(0)
         self._check(self._lib.fk_get_option(self._ctx, name.encode("utf-8"), C.byref(value)))
         return int(value.value)
+
+    def hold_memory(self, leave_free: int) -> tuple[int, int]:
+        """``fk_debug_hold_memory``: take device memory until about ``leave_free`` bytes are free (< 0: give it back); (free, total) after."""
+        free, total = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.fk_debug_hold_memory(self._ctx, C.c_int64(leave_free), C.byref(free), C.byref(total)))
+        return int(free.value), int(total.value)
 
     def pinned_empty(self, n: int, dtype) -> np.ndarray:
         """``n`` elements of ``dtype`` in page-locked host memory (``fk_host_alloc``), freed when the array is collected — the

@@ -103,6 +103,7 @@ struct fk_ctx {
     int64_t chunk_limit = 0;        // the replay's halved budget (0: none)
     int64_t last_budget = 0;        // the budget the last call planned with (fk_timing has no room: read through option "last_budget")
     bool oom = false;               // ensure() met hipErrorOutOfMemory
+    std::vector<void *> hog;        // fk_debug_hold_memory: device memory held on purpose (tests of the budget / the replay)
     int32_t oom_replays = 0;        // how many times the last call was replayed with a smaller workspace
     int32_t batch_threshold = 0;  // 0 = auto: 8 waiting lanes up to eight seats, 12 at nine / ten, 16 at eleven / twelve (swept per k)
     int32_t use_lds_tally = -1;
@@ -1267,6 +1268,8 @@ int fk_init(int device_ordinal, fk_ctx **out) {
 
 void fk_destroy(fk_ctx *c) {
     if (!c) return;
+    for (void *p : c->hog) (void)hipFree(p);
+    c->hog.clear();
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
@@ -1332,6 +1335,32 @@ int fk_host_free(fk_ctx *c, void *p) {
 int fk_get_timing(fk_ctx *c, fk_timing *out) {
     if (!c || !out) return FK_ERR_ARG;
     *out = c->timing;
+    return FK_OK;
+}
+
+// Tests of the memory budget: take device memory until about `leave_free` bytes are free (held by the context until the next call
+// with leave_free < 0, or fk_destroy); free_now / total as hipMemGetInfo reports them afterwards.
+int fk_debug_hold_memory(fk_ctx *c, int64_t leave_free, int64_t *free_now, int64_t *total) {
+    if (!c) return FK_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (leave_free < 0) {
+        for (void *p : c->hog) (void)hipFree(p);
+        c->hog.clear();
+    }
+    size_t free_b = 0, total_b = 0;
+    for (;;) {
+        HIPCHK(c, hipMemGetInfo(&free_b, &total_b));
+        if (leave_free < 0 || (int64_t)free_b - leave_free < ((int64_t)64 << 20)) break;
+        void *p = nullptr;
+        const size_t step = std::min<size_t>((size_t)((int64_t)free_b - leave_free), (size_t)32 << 30);
+        if (hipMalloc(&p, step) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        c->hog.push_back(p);
+    }
+    if (free_now) *free_now = (int64_t)free_b;
+    if (total) *total = (int64_t)total_b;
     return FK_OK;
 }
 

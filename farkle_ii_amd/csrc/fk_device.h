@@ -151,13 +151,7 @@ __host__ __device__ inline uint64_t pcg_next64_plain(Rng &r) {
     return h;
 }
 
-#if defined(__HIP_DEVICE_COMPILE__) && defined(FK_PCG_HAND)
-} // namespace fk
-#include "../../tools/pcg_hand.h" // experiment builds only: the draw as one hand-laid asm block (measured slower, see the file)
-namespace fk {
-#else
 __host__ __device__ inline uint64_t pcg_next64(Rng &r) { return pcg_next64_plain(r); }
-#endif
 
 // buffered 32-bit draw: low half first, high half on the next call (persists across rolls)
 __host__ __device__ inline uint32_t pcg_next32(Rng &r) {
@@ -221,14 +215,6 @@ template <uint32_t STRIDE = 4>
 __device__ inline uint32_t roll_counts_fast(Rng &r, uint32_t n, bool &detour, uint32_t *faces_out = nullptr) {
     const uint32_t hb = r.has_buf, buf_in = r.buf;
     const uint32_t need = (n - hb + 1u) >> 1; // new 64-bit outputs: ceil((n - has_buf) / 2), 0..3
-#if defined(__HIP_DEVICE_COMPILE__) && defined(FK_PCG_HAND)
-    // all draws of the roll in one hand-laid block: state as four words updated in place, nothing merged by the compiler
-    uint32_t lo0, hi0, lo1, hi1, lo2, hi2, last_hi = r.buf;
-    uint32_t s0 = (uint32_t)r.lo, s1 = (uint32_t)(r.lo >> 32), s2 = (uint32_t)r.hi, s3 = (uint32_t)(r.hi >> 32);
-    pcg_draws(s0, s1, s2, s3, r.inc_lo, r.inc_hi, need, lo0, hi0, lo1, hi1, lo2, hi2, last_hi);
-    r.lo = (uint64_t)s0 | ((uint64_t)s1 << 32);
-    r.hi = (uint64_t)s2 | ((uint64_t)s3 << 32);
-#else
     uint32_t lo0 = 1, hi0 = 1, lo1 = 1, hi1 = 1, lo2 = 1, hi2 = 1, last_hi = r.buf;
     if (need > 0u) {
         uint64_t o = pcg_next64_plain(r);
@@ -248,7 +234,6 @@ __device__ inline uint32_t roll_counts_fast(Rng &r, uint32_t n, bool &detour, ui
         hi2 = (uint32_t)(o >> 32);
         last_hi = hi2;
     }
-#endif
     uint32_t w[6];
     w[0] = hb ? buf_in : lo0;
     w[1] = hb ? lo0 : hi0;

@@ -348,6 +348,10 @@ int fk_coordinate_seeds(fk_ctx *ctx, int64_t n, const fk_coord *coords, uint32_t
 int fk_game_seeds(fk_ctx *ctx, uint32_t purpose, uint64_t root_seed, uint64_t k, uint64_t shuffle_begin, uint64_t n_shuffles,
                   uint32_t games_per_shuffle, uint32_t *seed32);
 
+/* Hold device memory on purpose until about leave_free bytes are free (leave_free < 0: give everything back); free_now / total as
+ * hipMemGetInfo reports them afterwards (either may be NULL).  Tests of the workspace budget and of the out-of-memory replay. */
+int fk_debug_hold_memory(fk_ctx *ctx, int64_t leave_free, int64_t *free_now, int64_t *total);
+
 /* The deadline handshake of fk_comm_init with a stand-in for ncclCommInitRank that takes init_ms: out[0] = 1 when the caller received the
  * communicator in time, 0 when it gave up at timeout_ms; out[1] = communicators torn down as orphans by the helper thread.  Host code. */
 int fk_debug_deadline_handshake(int32_t init_ms, int32_t timeout_ms, int64_t *out);

@@ -551,12 +551,12 @@ def test_config4_player_count_sweep_properties(eng):
 
 
 def test_config4_full_size_launches_are_additive_over_a_split(eng):
-    """BASELINE config 4 at FULL size for its two extreme player counts: 2.5 x 10^8 games of one call (k = 2: one launch of
+    """BASELINE config 4 at FULL size for all four of its player counts: 2.5 x 10^8 games of one call (k = 2: one launch of
     2.5 x 10^8 tickets; k = 8: two chunks of 1.25 x 10^8) — the 32-bit ticket / game-id arithmetic at that size.  Exposure
     conservation, and the whole range against the sum of an uneven three-way split of it (a lost, duplicated or misaddressed
-    game changes a tally)."""
+    game changes a tally).  (k = 4 and 6 joined in round 6: ~2 s of GPU time each.)"""
     table = _default_table()
-    for k in (2, 8):
+    for k in (2, 4, 6, 8):
         n_sh = 250_000_000 // (5160 // k)
         whole = eng.tournament(table, k, 0, 0, n_sh)["tally"][0]
         assert eng.timing()["games"] == n_sh * (5160 // k)

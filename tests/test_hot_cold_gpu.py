@@ -163,53 +163,6 @@ def test_wide_table_instances_limits_and_overrides(eng, po, k):
     assert np.array_equal(got["tally"], ref["tally"]), k
 
 
-IP_BLOCK = {5: 256, 6: 512, 7: 1024, 8: 512, 9: 768, 10: 768, 11: 768, 12: 768}  # option hot_cold_ip = 1 (k = 8 at four waves per SIMD)
-
-
-@pytest.mark.parametrize("k", [5, 6, 7, 8, 9, 10, 11, 12])
-def test_increments_in_the_plane_instances_agree_with_oracle(eng, po, k):
-    """(FK_EXPERIMENTS builds) Option ``hot_cold_ip``: every seat's increment rides in its cold-plane slot and the next owner's is fetched one turn ahead (no register
-    array, no select tree).  The guess is wrong exactly when a turn opens the final round — short targets make that frequent —; never-banking
-    tables end by the round limit, overrides cut games at 0 / 2 / 9 rounds.  Rows, per-batch tallies and all-seat statistics against the oracle."""
-    from farkle_ii_amd.backend import FarkleHipError, make_overrides
-    from oracle_engine_stub import seat_stats_from_rows
-    from test_state_store_gpu import _default_table
-
-    try:
-        eng.set_option("hot_cold_ip", 0)
-    except FarkleHipError:
-        pytest.skip("the shipped library does not hold the increments-in-the-plane instances: measured 15 - 47 % slower than the register "
-                    "instances (profiles/r05_increments_in_the_plane.log); an -DFK_EXPERIMENTS build has them")
-    S = {5: 100, 6: 96, 7: 98, 8: 96, 9: 99, 10: 100, 11: 99, 12: 96}[k]
-    gps = S // k
-    table = _random_valid_table(S, 9100 + k)
-    never = table.copy()
-    never["dice_threshold"], never["require_both"], never["consider_score"], never["consider_dice"] = 0, 1, 1, 1
-    ovs = [(5, 1, 0, k, 0), (5, 1, gps - 1, k, 2), (5, 3, 2, k, 9), (5, 6, 1, k, 240)]
-    try:
-        for mode in ((1, 2) if k == 8 else (1,)):
-            eng.set_option("hot_cold_ip", mode)
-            block = 256 if (k == 8 and mode == 2) else IP_BLOCK[k]
-            for tbl, target, mr in [(table, 10_000, 200), (table, 1_500, 4), (table, 600, 200), (table, 50, 200), (table, 10_000, 0),
-                                    (table, 135_000, 30), (never, 10_000, 9)]:
-                ref = po.tournament(tbl.view(po.STRATEGY_DTYPE), k, 5, 0, 9, shuffles_per_batch=4, target_score=target, max_rounds=mr,
-                                    overrides=po.make_overrides(ovs), want_rows=True, n_threads=8)
-                got = eng.tournament(tbl, k, 5, 0, 9, shuffles_per_batch=4, target_score=target, max_rounds=mr,
-                                     overrides=make_overrides(ovs), want_rows=True, want_seat_stats=True)
-                assert _ran_hot_cold(eng, k, block=block), (k, mode, target, mr, eng.timing())
-                assert np.array_equal(got["tally"], ref["tally"]), (k, mode, target, mr)
-                assert got["rows"].tobytes() == ref["rows"].tobytes(), (k, mode, target, mr)
-                assert np.array_equal(got["seat_stats"], seat_stats_from_rows(ref["rows"], k, S, gps, 4)), (k, mode, target, mr)
-        big = _default_table()[:len(_default_table()) // k * k].copy()
-        big["strategy_id"] = np.arange(len(big))
-        ref = po.tournament(big.view(po.STRATEGY_DTYPE), k, 0, 3, 7, shuffles_per_batch=3, n_threads=8)
-        got = eng.tournament(big, k, 0, 3, 7, shuffles_per_batch=3)
-        assert _ran_hot_cold(eng, k, block=256 if k == 8 else IP_BLOCK[k]), eng.timing()
-        assert np.array_equal(got["tally"], ref["tally"]), k
-    finally:
-        eng.set_option("hot_cold_ip", 0)
-
-
 @pytest.mark.parametrize("k,waves", [(6, 3), (7, 3), (8, 2), (10, 2), (5, 4), (12, 3)])
 def test_max_waves_option_never_reaches_an_instance_that_was_not_compiled(eng, po, k, waves):
     """Option ``max_waves`` below what the plan's hot / cold instance of k seats needs (round-4 advisor: max_waves = 3 at k = 6 / 7 on a wide

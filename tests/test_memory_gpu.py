@@ -6,8 +6,6 @@ checked against the CPU oracle with most of the device taken by somebody else.
 """
 from __future__ import annotations
 
-import ctypes as C
-
 import numpy as np
 import pytest
 
@@ -15,34 +13,19 @@ pytestmark = pytest.mark.gpu
 
 
 class _Hog:
-    """Device memory held outside the engine (hipMalloc through the HIP runtime the library already loaded)."""
+    """Device memory held outside the engine under test: by a second context of the same library (``fk_debug_hold_memory``)."""
 
     def __init__(self):
-        self.hip = C.CDLL("libamdhip64.so")
-        self.ptrs: list[C.c_void_p] = []
+        from farkle_ii_amd.backend import Engine
 
-    def free_bytes(self) -> int:
-        free, total = C.c_size_t(0), C.c_size_t(0)
-        assert self.hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
-        return int(free.value)
+        self.holder = Engine(0)
 
     def leave(self, n_bytes: int) -> None:
-        """Allocate until about ``n_bytes`` are free."""
-        while True:
-            take = self.free_bytes() - n_bytes
-            if take < (64 << 20):
-                return
-            p = C.c_void_p()
-            step = min(take, 32 << 30)
-            if self.hip.hipMalloc(C.byref(p), C.c_size_t(step)) != 0:
-                self.hip.hipGetLastError()
-                return
-            self.ptrs.append(p)
+        self.holder.hold_memory(n_bytes)
 
     def release(self) -> None:
-        for p in self.ptrs:
-            self.hip.hipFree(p)
-        self.ptrs = []
+        self.holder.hold_memory(-1)
+        self.holder.close()
 
 
 @pytest.fixture
