@@ -182,7 +182,7 @@ def _scrub(obj, volatile_values: set[str]):
     return obj
 
 
-def snapshot_tree(root: Path) -> dict:
+def snapshot_tree(root: Path, pickle_bytes_are_volatile: bool = False) -> dict:
     """Everything under ``root`` in comparable form.  Files whose bytes contain pids / timestamps (JSON-lines manifests) change
     their SHA-256 from run to run; every digest that is the SHA-256 of such a file is replaced by a marker in the JSON files that
     mention it (sidecars, the completion stamp)."""
@@ -216,6 +216,12 @@ def snapshot_tree(root: Path) -> dict:
     volatile_files = {root / rel for rel, recs in snap["jsonl"].items() if has_volatile(recs)}
     volatile_files |= {root / rel for rel, doc in snap["json"].items() if has_volatile(doc)}
     volatile_digests = {digests[p] for p in volatile_files}
+    if pickle_bytes_are_volatile:
+        # counts-only checkpoints pickle the merged OutcomeCounter as it is: its dictionaries list strategies in FIRST-SEEN order — the order
+        # seats and outcomes came up in the reference's per-shuffle loop, table order when a chunk arrives as one tally.  Same mappings
+        # (compared by content below), different bytes: the pickles' digests, their sidecars and the stamps naming those are volatile here.
+        volatile_files |= {p for p in files if p.suffix == ".pkl"}
+        volatile_digests |= {digests[p] for p in files if p.suffix == ".pkl"}
     for _ in range(6):  # sidecars of volatile files, stamps naming those sidecars, ...
         grew = False
         for rel, doc in snap["json"].items():
@@ -234,6 +240,17 @@ def snapshot_tree(root: Path) -> dict:
     volatile_digests |= {digests[p] for p in files if p.suffix == ".pkl"}
     snap["jsonl"] = {rel: _scrub(v, volatile_digests) for rel, v in snap["jsonl"].items()}
     snap["json"] = {rel: _scrub(v, volatile_digests) for rel, v in snap["json"].items()}
+    if pickle_bytes_are_volatile:  # digests COMPUTED OVER a volatile digest (contract digests of the pickle's sidecar, the stamp's identity)
+        derived = {"sidecar_contract_sha256", "stage_identity_sha256", "sidecar_sha256", "content_sha256"}
+
+        def drop(o):
+            if isinstance(o, dict):
+                return {k: drop(v) for k, v in o.items() if k not in derived}
+            return [drop(v) for v in o] if isinstance(o, list) else o
+
+        for rel in list(snap["json"]):
+            if root / rel in volatile_files:
+                snap["json"][rel] = drop(snap["json"][rel])
     snap["stable_sha256"] = {str(p.relative_to(root)): digests[p] for p in files
                              if p not in volatile_files and p.suffix not in (".pkl",) and digests[p] not in volatile_digests}
     return snap
@@ -248,6 +265,42 @@ def diff_snapshots(a: dict, b: dict) -> list[str]:
             if a[kind].get(rel) != b[kind].get(rel):
                 out.append(f"{kind}: {rel} differs")
     return out
+
+
+def gen_tournament_per_chunk(tmp: Path, name: str, sim_override: dict, pickle_bytes_are_volatile: bool = False) -> dict:
+    """The per-CHUNK service of the binding (``_run_chunk`` and ``_run_chunk_metrics`` without row shards: one launch and one tally per
+    deterministic batch, no per-shuffle objects): the reference's ``run_single_n`` unpatched vs patched on the tiny configuration with
+    ``sim_override`` (rows off; metrics on or off) — every artifact equal, and the recorded engine calls for the replay."""
+    gp = oracle_profile()
+    payload = {key: dict(val) for key, val in TINY_CONFIG.items()}
+    payload["sim"].update(sim_override)
+    payload["io"] = {"results_dir_prefix": str(tmp / name), "analysis_subdir": "analysis"}
+    cfg_path = tmp / f"{name}.yaml"
+    cfg_path.write_text(yaml.safe_dump(payload))
+    snaps, launches = {}, 0
+    recorder = RecordingEngine(StubEngine())
+    for mode in ("unpatched", "patched"):
+        cfg = load_app_config(cfg_path, seed_list_len=1)
+        cfg._code_identity = fixture_code_identity()
+        shutil.rmtree(cfg.results_root, ignore_errors=True)
+        for k in (2, 4):
+            if mode == "unpatched":
+                runner.run_single_n(cfg, k, oracle_game_profile=gp)
+            else:
+                ns = run_snippet("tournament", {"rt": rt, "runner": runner, "cfg": cfg, "k": k, "game_profile": gp, "engine": recorder})
+                launches += ns["binding"].launches
+        snaps[mode] = snapshot_tree(cfg.results_root, pickle_bytes_are_volatile)
+        shutil.rmtree(cfg.results_root, ignore_errors=True)
+    problems = diff_snapshots(snaps["unpatched"], snaps["patched"])
+    if problems:
+        for line in problems:
+            print("  ", line)
+        raise SystemExit(f"tournament binding ({name}): the patched run's artifacts differ from the unpatched run's")
+    per_batch = all(c["shuffles_per_batch"] == c["shuffle_end"] - c["shuffle_begin"] and not c["want_rows"] for c in recorder.calls)
+    assert per_batch, f"{name}: the binding did not serve whole chunks from one tally"
+    print(f"tournament ({name}): {len(snaps['patched']['files'])} artifacts equal (unpatched vs binding), {launches} engine launches = "
+          f"{len(recorder.calls)} chunks, one tally each")
+    return {"sim_override": sim_override, "files": snaps["patched"]["files"], "calls": recorder.calls}
 
 
 def gen_tournament(tmp: Path) -> dict:
@@ -398,7 +451,11 @@ def main() -> None:
         snippets = integration_snippets()
         doc = {"generated_by": "oracle/gen_binding.py (reference imported in the build container; engine = CPU oracle stub)",
                "integration_snippets_sha256": {name: hashlib.sha256(code.encode("utf-8")).hexdigest() for name, code in sorted(snippets.items())},
-               "tournament": gen_tournament(tmp), "h2h": gen_h2h(tmp)}
+               "tournament": gen_tournament(tmp),
+               "tournament_metric_chunks_no_rows": gen_tournament_per_chunk(tmp, "chunks", {"row_dir": None}),
+               "tournament_counts_only": gen_tournament_per_chunk(tmp, "counts", {"row_dir": None, "metric_chunk_dir": None, "expanded_metrics": False},
+                                                                  pickle_bytes_are_volatile=True),
+               "h2h": gen_h2h(tmp)}
         OUT.write_text(json.dumps(doc, sort_keys=True, default=lambda o: int(o) if isinstance(o, np.integer) else str(o)))
         print(OUT.name, OUT.stat().st_size)
     finally:

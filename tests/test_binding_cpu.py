@@ -52,9 +52,13 @@ def test_recorded_calls_replay_on_the_oracle():
     doc = gu.load("binding_vectors.json")
     eng = StubEngine()
     n = gu.replay_binding_calls(eng, doc["tournament"]["calls"], STRATEGY_DTYPE, OVERRIDE_DTYPE)
+    for variant in ("tournament_metric_chunks_no_rows", "tournament_counts_only"):  # served per CHUNK: one tally per deterministic batch
+        calls = doc[variant]["calls"]
+        assert all(c["shuffles_per_batch"] == c["shuffle_end"] - c["shuffle_begin"] and not c["want_rows"] for c in calls)
+        n += gu.replay_binding_calls(eng, calls, STRATEGY_DTYPE, OVERRIDE_DTYPE)
     for mode in ("block_runner", "prefetching_block_runner"):
         n += gu.replay_binding_calls(eng, doc["h2h"]["calls"][mode], STRATEGY_DTYPE, OVERRIDE_DTYPE)
-    assert n == 6 + 12 + 2
+    assert n == 6 + 6 + 6 + 12 + 2
 
 
 def test_integration_md_snippets_are_the_ones_that_ran():
@@ -83,7 +87,7 @@ def _stand_in_module(strategies, k):
             total.absorb(rt._play_shuffle(t))
         return total
 
-    def _run_chunk_metrics(tasks, *, collect_rows=False, seen_rows=None):
+    def _run_chunk_metrics(tasks, *, collect_rows=False, row_dir=None, seen_rows=None):
         wins_total = rt.OutcomeCounter()
         sums = {m: defaultdict(float) for m in tn.METRIC_LABELS}
         sqs = {m: defaultdict(float) for m in tn.METRIC_LABELS}
@@ -100,6 +104,8 @@ def _stand_in_module(strategies, k):
         return wins_total, sums, sqs
 
     rt._run_chunk, rt._run_chunk_metrics = _run_chunk, _run_chunk_metrics
+    rt.progress = []
+    rt.report_worker_progress = lambda name, *, event_id, counters: rt.progress.append((name, event_id, dict(counters)))
     rt._play_shuffle = rt._play_one_shuffle = lambda *a, **kw: (_ for _ in ()).throw(AssertionError("unpatched shuffle function"))
     return rt
 
@@ -116,10 +122,20 @@ def test_tournament_binding_serves_a_chunk_from_one_launch_and_restores_the_modu
     binding = rb.TournamentBinding(rt, engine=eng)
     rows: list = []
     with binding:
-        wins, sums, sqs = rt._run_chunk_metrics(tasks, collect_rows=True, seen_rows=rows)
+        # row shards to write: the reference's own chunk body runs, every shuffle's rows served from ONE launch
+        wins, sums, sqs = rt._run_chunk_metrics(tasks, collect_rows=True, row_dir=Path("rows"), seen_rows=rows)
+        assert binding.launches == 1 and rt.progress == []  # (the stand-in body reports nothing; the reference's reports per shuffle)
+        # nothing to write: the chunk is ONE tally, converted once — no per-shuffle counters, one progress event with the summed counters
+        wins2, sums2, sqs2 = rt._run_chunk_metrics(tasks)
         plain = rt._run_chunk(tasks)
+        assert binding.launches == 3 and not binding._served
+        gps = len(strategies) // k
+        assert rt.progress == [("simulation_shuffle_complete", "simulation:7:2:3-8", {"worker_completed_shuffles": 6, "worker_completed_games": 6 * gps})] * 2
         single = rt._play_shuffle(tasks[2])  # outside a chunk: played alone
-    assert binding.launches == 3  # one per chunk + the single shuffle
+    assert binding.launches == 4
+    assert dict(wins2) == dict(wins) and wins2.outcome_payload() == wins.outcome_payload()
+    assert {m: dict(v) for m, v in sums2.items()} == {m: dict(v) for m, v in sums.items()}
+    assert {m: dict(v) for m, v in sqs2.items()} == {m: dict(v) for m, v in sqs.items()}
     assert {name: getattr(rt, name) for name in originals} == originals
     # the same numbers as this package's own chunk function on the same engine
     from farkle_ii_amd import engine as engine_holder

@@ -267,9 +267,11 @@ def test_reference_binding_calls_replay_on_the_hip_engine():
     doc = gu.load("binding_vectors.json")
     eng = get_engine()
     n = gu.replay_binding_calls(eng, doc["tournament"]["calls"], STRATEGY_DTYPE, OVERRIDE_DTYPE)
+    for variant in ("tournament_metric_chunks_no_rows", "tournament_counts_only"):  # the per-chunk service (round 6): one tally per batch
+        n += gu.replay_binding_calls(eng, doc[variant]["calls"], STRATEGY_DTYPE, OVERRIDE_DTYPE)
     for mode in ("block_runner", "prefetching_block_runner"):
         n += gu.replay_binding_calls(eng, doc["h2h"]["calls"][mode], STRATEGY_DTYPE, OVERRIDE_DTYPE)
-    assert n == 20
+    assert n == 32
 
 
 def test_reference_binding_on_a_stand_in_module_runs_the_hip_engine():

@@ -1,9 +1,9 @@
 """Host cost of the engine binding per shuffle (build container only: imports the reference through oracle/ref_import.py).
 
-TournamentBinding asks the engine for one tally per shuffle (shuffles_per_batch = 1) and hands every shuffle's result to the reference's own
-chunk body as the reference's types (OutcomeCounter, defaultdict sums).  With a NULL engine (pre-made tallies, no simulation) what is left is
-the binding's Python (tally_to_counters) + the reference's chunk body (_run_chunk / _run_chunk_metrics, run_tournament.py:403-585):
-the ceiling of the binding route in shuffles per second, whatever the GPU does.
+Round 6: TournamentBinding serves `_run_chunk` and `_run_chunk_metrics` (without row shards) per CHUNK — one launch with ONE tally for the
+deterministic batch, converted once to the reference's types (OutcomeCounter, defaultdict sums), one progress event.  (Round 5 asked for a
+tally per shuffle and ran the reference's per-shuffle loop: 0.17 - 8 ms of Python per shuffle, profiles/r05_binding_host_cost.json.)  With a
+NULL engine (pre-made tallies, no simulation) what is left is the binding's Python: the ceiling of the binding route, whatever the GPU does.
     python tools/time_binding_host.py"""
 import json
 import sys
@@ -33,12 +33,15 @@ class NullEngine:
     def tournament(self, table, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=None, **kw):
         self.calls += 1
         n, S = shuffle_end - shuffle_begin, len(table)
-        tally = np.zeros((n, S, 26), dtype=np.int64)
-        tally[:, :, 1] = 1
-        tally[:, :, 2] = 1
-        tally[:, : S // k, 0] = 1
-        tally[:, : S // k, 4:15] = 7
-        tally[:, : S // k, 15:26] = 49
+        spb = shuffles_per_batch or n
+        nb = (n + spb - 1) // spb
+        per = np.minimum(spb, n - np.arange(nb) * spb)[:, None]
+        tally = np.zeros((nb, S, 26), dtype=np.int64)
+        tally[:, :, 1] = per
+        tally[:, :, 2] = per
+        tally[:, : S // k, 0] = per
+        tally[:, : S // k, 4:15] = 7 * per
+        tally[:, : S // k, 15:26] = 49 * per
         return {"tally": tally, "rows": None}
 
 
@@ -47,7 +50,7 @@ def measure(S_label: str, grid_kwargs: dict, k: int, n_shuffles: int) -> dict:
     S = len(strategies)
     cfg = rt.TournamentConfig(n_players=k, num_shuffles=n_shuffles, n_strategies=S)
     rt._init_worker(strategies, cfg, None, None)
-    tasks = [rt.ShuffleTask(root_seed=7, k=k, shuffle_index=i, shuffle_seed=1000 + i, deterministic_batch_id=i // 30) for i in range(n_shuffles)]
+    tasks = [rt.ShuffleTask(root_seed=7, k=k, shuffle_index=i, shuffle_seed=1000 + i, deterministic_batch_id=0) for i in range(n_shuffles)]  # one deterministic batch
     eng = NullEngine()
     out = {"S": S, "k": k, "shuffles": n_shuffles}
     with TournamentBinding(rt, engine=eng) as b:
@@ -63,5 +66,11 @@ def measure(S_label: str, grid_kwargs: dict, k: int, n_shuffles: int) -> dict:
 if __name__ == "__main__":
     small = dict(score_thresholds=[200, 250, 300, 350, 400], dice_thresholds=[0, 1, 2, 3], smart_five_opts=[True], smart_one_opts=[True],
                  consider_score_opts=[True], consider_dice_opts=[True], auto_hot_dice_opts=[True], run_up_score_opts=[True])
-    res = [measure("80", small, 2, 400), measure("5160", {}, 4, 40)]
+    res = [measure("80", small, 2, 400), measure("5160", {}, 4, 43)]  # (43 shuffles: a deterministic batch of the production plan)
+    before = json.loads((ROOT / "profiles" / "r05_binding_host_cost.json").read_text())
+    for now, old in zip(res, before):
+        for name in ("_run_chunk", "_run_chunk_metrics"):
+            now[name]["speedup_vs_round_5_per_shuffle_service"] = now[name]["games_per_s"] / old[name]["games_per_s"]
     print(json.dumps(res, indent=1))
+    if len(sys.argv) > 1:
+        Path(sys.argv[1]).write_text(json.dumps(res, indent=1) + "\n")
