@@ -71,6 +71,21 @@ DEFINE_KERNEL(k_tree_compiler, CND_VCC(0) CND_VCC(1) CND_VCC(2) CND_VCC(3) CND_S
 DEFINE_KERNEL(k_tree_e64, CND_E64_VCC(0) CND_E64_VCC(1) CND_E64_VCC(2) CND_E64_VCC(3) CND_SG(4) CND_SG(5) CND_SG(6) ADD(7))
 DEFINE_KERNEL(k_tree_interleaved, CND_VCC(0) CND_SG(4) CND_VCC(1) CND_SG(5) CND_VCC(2) CND_SG(6) CND_VCC(3) ADD(7))
 DEFINE_KERNEL(k_cnd2_add2, CND_VCC(0) CND_VCC(1) ADD(2) ADD(3) CND_VCC(4) CND_VCC(5) ADD(6) ADD(7))
+// round 6: at which run length / spacing does the e32 form on VCC stop being full rate?  Groups of eight: R selects in a row, then 8 - R adds;
+// one select every second / fourth instruction; a run that starts with the s_mov / v_cmp that sets VCC (what a hand-laid select tree would do).
+DEFINE_KERNEL(k_run1, CND_VCC(0) ADD(1) ADD(2) ADD(3) ADD(4) ADD(5) ADD(6) ADD(7))
+DEFINE_KERNEL(k_run2, CND_VCC(0) CND_VCC(1) ADD(2) ADD(3) ADD(4) ADD(5) ADD(6) ADD(7))
+DEFINE_KERNEL(k_run3, CND_VCC(0) CND_VCC(1) CND_VCC(2) ADD(3) ADD(4) ADD(5) ADD(6) ADD(7))
+DEFINE_KERNEL(k_run4, CND_VCC(0) CND_VCC(1) CND_VCC(2) CND_VCC(3) ADD(4) ADD(5) ADD(6) ADD(7))
+DEFINE_KERNEL(k_run6, CND_VCC(0) CND_VCC(1) CND_VCC(2) CND_VCC(3) CND_VCC(4) CND_VCC(5) ADD(6) ADD(7))
+DEFINE_KERNEL(k_every2, CND_VCC(0) ADD(1) CND_VCC(2) ADD(3) CND_VCC(4) ADD(5) CND_VCC(6) ADD(7))
+DEFINE_KERNEL(k_every4, CND_VCC(0) ADD(1) ADD(2) ADD(3) CND_VCC(4) ADD(5) ADD(6) ADD(7))
+DEFINE_KERNEL(k_every2_e64, CND_SG(0) ADD(1) CND_SG(2) ADD(3) CND_SG(4) ADD(5) CND_SG(6) ADD(7))
+DEFINE_KERNEL(k_run4_e64, CND_SG(0) CND_SG(1) CND_SG(2) CND_SG(3) ADD(4) ADD(5) ADD(6) ADD(7))
+DEFINE_KERNEL(k_smov_run4, "s_mov_b64 vcc, %12\n" CND_VCC(0) CND_VCC(1) CND_VCC(2) CND_VCC(3) ADD(4) ADD(5) ADD(6) ADD(7))
+DEFINE_KERNEL(k_smov_every2, "s_mov_b64 vcc, %12\n" CND_VCC(0) ADD(1) CND_VCC(2) ADD(3) CND_VCC(4) ADD(5) CND_VCC(6) ADD(7))
+DEFINE_KERNEL(k_every2_mad, "v_cndmask_b32_e32 %0, %0, %13, vcc\nv_mad_u64_u32 %8, %12, %13, %14, %8\nv_cndmask_b32_e32 %1, %1, %13, vcc\nv_mad_u64_u32 %9, %12, %14, %13, %9\n"
+                            "v_cndmask_b32_e32 %2, %2, %13, vcc\nv_mad_u64_u32 %10, %12, %13, %14, %10\nv_cndmask_b32_e32 %3, %3, %13, vcc\nv_mad_u64_u32 %11, %12, %14, %13, %11\n")
 DEFINE_KERNEL(k_cnd_vcc_nop, "v_cndmask_b32_e32 %0, %0, %13, vcc\ns_nop 0\nv_cndmask_b32_e32 %1, %1, %13, vcc\ns_nop 0\nv_cndmask_b32_e32 %2, %2, %13, vcc\ns_nop 0\nv_cndmask_b32_e32 %3, %3, %13, vcc\ns_nop 0\nv_cndmask_b32_e32 %4, %4, %13, vcc\ns_nop 0\nv_cndmask_b32_e32 %5, %5, %13, vcc\ns_nop 0\nv_cndmask_b32_e32 %6, %6, %13, vcc\ns_nop 0\nv_cndmask_b32_e32 %7, %7, %13, vcc\ns_nop 0\n")
 DEFINE_KERNEL(k_cnd_vcc_src, "v_cndmask_b32_e32 %0, %13, %14, vcc\nv_cndmask_b32_e32 %1, %14, %13, vcc\nv_cndmask_b32_e32 %2, %13, %14, vcc\nv_cndmask_b32_e32 %3, %14, %13, vcc\nv_cndmask_b32_e32 %4, %13, %14, vcc\nv_cndmask_b32_e32 %5, %14, %13, vcc\nv_cndmask_b32_e32 %6, %13, %14, vcc\nv_cndmask_b32_e32 %7, %14, %13, vcc\n")
 DEFINE_KERNEL(k_addc_e64, R8(ADDC_E64))
@@ -158,6 +173,24 @@ int main(int argc, char **argv) {
     run("tree all e64 + add", k_tree_e64);
     run("tree e32 / e64 interleaved + add", k_tree_interleaved);
     run("cnd32 x2, add x2", k_cnd2_add2);
+    if (getenv("FK_RUN_LENGTH_ONLY")) {
+        run("add x8 (control)", k_add);
+        run("cnd64 x8 (control)", k_cnd_sg);
+        run("cnd32 run 1 + add x7", k_run1);
+        run("cnd32 run 2 + add x6", k_run2);
+        run("cnd32 run 3 + add x5", k_run3);
+        run("cnd32 run 4 + add x4", k_run4);
+        run("cnd32 run 6 + add x2", k_run6);
+        run("cnd32 run 8", k_cnd_vcc);
+        run("cnd32 every 2nd (4 + 4 add)", k_every2);
+        run("cnd32 every 4th (2 + 6 add)", k_every4);
+        run("cnd64 every 2nd (4 + 4 add)", k_every2_e64);
+        run("cnd64 run 4 + add x4", k_run4_e64);
+        run("s_mov vcc; cnd32 run 4 + add x4", k_smov_run4);
+        run("s_mov vcc; cnd32 every 2nd", k_smov_every2);
+        run("cnd32 / v_mad_u64_u32 alternating", k_every2_mad);
+        return 0;
+    }
     run("cnd32 + s_nop 0 (x8)", k_cnd_vcc_nop);
     run("cnd32 x8, independent sources", k_cnd_vcc_src);
     run("v_addc_co e64 sgpr carry", k_addc_e64);
