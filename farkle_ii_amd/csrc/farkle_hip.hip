@@ -113,8 +113,6 @@ struct fk_ctx {
     int32_t hc_block = 256;    // its block size: 256, 768 or 1024
     int32_t hc_tables = 1;     // 1: score / discard tables in LDS (LT instances)
     int32_t hc_inc_regs = 1;   // 1: the seats' PCG increments in registers (k >= 5, 256-thread blocks, LDS tables)
-    int32_t hc_ip = 0;         // option "hot_cold_ip": increments in the cold-plane slots, fetched one turn ahead (1: k = 8 at four waves, 2: at three)
-    int32_t hc_cr = 0;         // FK_EXPERIMENTS builds: cold records in registers (1: with the increments, 2: increments loaded per turn)
     int32_t hc_cl = -1;        // cold records in LDS beside the hot part (k = 3 .. 5): -1 auto (k = 4), 0 never, 1 always
     DevBuf lds_tables;         // their LDS image (fk_play_hc.h)
     DevBuf cold;
@@ -314,8 +312,6 @@ struct LaunchPlan {
     bool hc_lt = false; // ... with the score / discard tables in LDS
     int hc_ki = 0;      // ... with every seat's PCG increment in registers (2: the four-wave instances of k = 5 .. 7)
     bool hc_cl = false; // ... with the cold records in LDS (32 bytes per seat and lane, no plane)
-    int hc_cr = 0;      // ... with the cold records in registers (experiment)
-    bool hc_ip = false; // ... with the increments in the cold-plane slots (32-byte slots), the next owner's fetched one turn ahead
     int wpe = 4;       // waves per SIMD the chosen instance is compiled for
     uint32_t mixed_flags = 0xff00u; // flag bits that differ between strategies of the table (selects the kernel instance)
 };
@@ -363,13 +359,8 @@ LaunchPlan plan_play(const fk_ctx *c, int32_t k, int64_t S, bool single_batch, i
             if (!gs && c->lean >= 0 && lean != c->lean) continue;
             if (!gs && lean && !blocks_mode && S > (1 << (32 - CE_IDX_SHIFT))) continue; // strategy index must fit cE[31:18]
             for (int block : {1024, 768, 512, 256, 128, 64}) {
-#ifdef FK_EXPERIMENTS
-                if (gs && block != 768 && block != 256 && block != 64) continue;
-                if (c->block != 0 && block != c->block && !(gs && block == (c->block >= 768 ? 768 : c->block >= 256 ? 256 : 64))) continue;
-#else
                 if (gs && block != 768) continue; // (one record per lane: 768-thread blocks seat six waves per SIMD whatever k is)
                 if (c->block != 0 && block != c->block && !gs) continue;
-#endif
                 if (block == 768 && !lean) continue;
                 const int wpe = (block == 768) ? 6 : 4;
                 bool tally = want_tally && play_lds_bytes(k, block, lean != 0, gs != 0, true, (int32_t)S) <= LDS_LIMIT / (gs ? 2 : 1);
@@ -434,36 +425,6 @@ bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const Launch
         out.cus = c->prop.multiProcessorCount;
         return true;
     }
-#ifdef FK_EXPERIMENTS
-    if (c->hc_ip && k >= 5) {
-        // (measured round 5, profiles/r05_increments_in_the_plane.log: 15 - 47 % SLOWER than the register instances — one more scattered
-        // 16-byte access per turn and lane is what the texture addresser does not have to spare; kept for the record)
-        // increments in the plane (fk_play_hc.h, IP): no register arrays, so four waves per SIMD wherever the hot planes (16 k bytes per lane)
-        // and the table image fit — 4 x 256 threads at k = 5, 2 x 512 at k = 6 and k = 8, 1 x 1 024 at k = 7 — and one 768-thread block from k = 9
-        const int want4 = max_waves >= 4 && !(k == 8 && c->hc_ip == 2);
-        const int block_ip = k >= 9 ? 768 : !want4 ? 256 : k == 5 ? 256 : k == 7 ? 1024 : 512;
-        const size_t lds_ip = (size_t)block_ip * 16 * (size_t)k + LT_BYTES;
-        if (lds_ip > LDS_LIMIT || max_waves < 3) return false;
-        int per_cu = k >= 9 ? 1 : !want4 ? 3 : 1024 / block_ip;
-        per_cu = (int)std::min<size_t>((size_t)per_cu, LDS_LIMIT / lds_ip);
-        if (c->blocks_per_cu > 0) per_cu = std::min(per_cu, c->blocks_per_cu);
-        per_cu = std::max(per_cu, 1);
-        out = base;
-        out.hc = true;
-        out.hc_lt = true;
-        out.hc_ki = 0;
-        out.hc_ip = true;
-        out.lean = true;
-        out.gs = false;
-        out.blk = false;
-        out.block = block_ip;
-        out.lds = lds_ip;
-        out.wpe = (per_cu * block_ip + 255) / 256;
-        out.grid = c->prop.multiProcessorCount * per_cu;
-        out.cus = c->prop.multiProcessorCount;
-        return true;
-    }
-#endif
     const bool lt = c->hc_tables != 0;
     // register instances (increments of every seat in registers, tables in LDS).  k = 5 .. 7 run FOUR waves per SIMD — 128
     // registers hold the increments when the packed strategies are loaded per turn instead — in whatever block size lets
@@ -474,17 +435,14 @@ bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const Launch
     // nine to twelve seats (round 5): ONE 768-thread block per CU = three waves per SIMD, 168 registers per lane; the hot planes (16 k bytes
     // per lane since the buffered half word moved to the cold slot: 147 456 bytes at twelve seats) fit beside the table image
     const bool wide = ki && k >= 9 && max_waves >= 3;
-#ifndef FK_EXPERIMENTS
     // the shipped library holds the plan's own instances only: k = 5 .. 7 at four waves, k = 8 at three, k = 9 .. 12 as above.  A cap below
     // that (option max_waves) sends the call to the LDS-record kernel instead of to an instance that was not compiled.
     if (k >= 5 && k <= 7 && !four) return false;
     if (k == 8 && !(ki && max_waves >= 3)) return false;
     if (k >= 9 && !wide) return false;
-#endif
     const int block = wide ? 768 : four ? (k == 5 ? 256 : k == 6 ? 512 : 1024) : ki ? 256 : (c->hc_block == 1024 || c->hc_block == 768) ? c->hc_block : 256;
-    // hot part: the generator state, 16 bytes per seat and lane (the buffered half word rides in the cold-plane slot; instances with the
-    // cold records in registers — experiment builds — keep it in LDS: 20 bytes)
-    const size_t hot_bytes = (ki && k >= 5 && c->hc_cr) ? 20 : 16;
+    // hot part: the generator state, 16 bytes per seat and lane (the buffered half word rides in the cold-plane slot)
+    const size_t hot_bytes = 16;
     const size_t lds = (size_t)block * hot_bytes * (size_t)k + (lt ? LT_BYTES : 0);
     if (lds > LDS_LIMIT) return false;
     int per_cu = (int)std::min<size_t>(LDS_LIMIT / lds, (size_t)std::max(1, 256 * max_waves / block));
@@ -502,7 +460,6 @@ bool plan_play_hc(const fk_ctx *c, int32_t k, int32_t target_score, const Launch
     out.hc = true;
     out.hc_lt = lt;
     out.hc_ki = ki ? (wide ? 3 : four ? 2 : 1) : 0;
-    out.hc_cr = (ki && k >= 5) ? c->hc_cr : 0;
     out.lean = true;
     out.gs = false;
     out.blk = false;
@@ -561,12 +518,12 @@ hipError_t launch_play_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) 
     return launch_play_u<BLOCK, LEAN, WPE, MIXED_ALL, GS, BLK, KC>(p, a, s);
 }
 
-template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8, bool CR = false, bool IL = false, bool IP = false>
+template <int BLOCK, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8>
 hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     static int configured_dev = -1; // dynamic-LDS ceiling and occupancy are per device
     static size_t occ_lds = ~(size_t)0;
     static int occ_blocks = 0;
-    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS, CR, IL, IP>);
+    const void *fn = reinterpret_cast<const void *>(&fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS>);
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (configured_dev != dev) {
@@ -584,57 +541,29 @@ hipError_t launch_play_hc_u(const LaunchPlan &p, const PlayArgs &a, hipStream_t 
     }
     const int grid = std::min(p.grid, occ_blocks * p.cus);
     p.launched_grid = grid;
-    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS, CR, IL, IP>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
+    hipLaunchKernelGGL((fk_play_hc_kernel<BLOCK, MIXED, LT, KI, WPE, PKR, CL, NS>), dim3((unsigned)grid), dim3(BLOCK), p.lds, s, a);
     return hipGetLastError();
 }
 
-template <int BLOCK, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8, bool CR = false, bool IL = false, bool IP = false>
+template <int BLOCK, bool LT, int KI = 0, int WPE = 0, bool PKR = true, bool CL = false, int NS = 8>
 hipError_t launch_play_hc_t(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
-    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI, WPE, PKR, CL, NS, CR, IL, IP>(p, a, s);
-    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI, WPE, PKR, CL, NS, CR, IL, IP>(p, a, s);
-    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI, WPE, PKR, CL, NS, CR, IL, IP>(p, a, s);
+    if (p.mixed_flags == MIXED_NONE) return launch_play_hc_u<BLOCK, MIXED_NONE, LT, KI, WPE, PKR, CL, NS>(p, a, s);
+    if ((p.mixed_flags & ~MIXED_RB_FAV) == 0u) return launch_play_hc_u<BLOCK, MIXED_RB_FAV, LT, KI, WPE, PKR, CL, NS>(p, a, s);
+    return launch_play_hc_u<BLOCK, MIXED_ALL, LT, KI, WPE, PKR, CL, NS>(p, a, s);
 }
 
 // The instances the launch plan can reach (plan_play_hc): k = 4 cold records in LDS (four 320-thread blocks, five waves per
 // SIMD), k = 5 .. 7 four waves per SIMD with the increments in registers, k = 8 three.  Every other variant that was built and
 // measured (profiles/HISTORY.md, section 4.9 of the round-4 document: global tables, increments / strategies loaded or held, three-wave forms, other block sizes, cold
-// records in LDS at k = 3 / 5, cold records in registers) lost or tied; they are compiled only with -DFK_EXPERIMENTS
-// (tools/build_experiments.sh), where the tools/exp_*.py scripts that produced the log still run.
+// records in LDS at k = 3 / 5, cold records in registers, increments in the plane) lost or tied; their code left the tree in round 6
+// (the A/B logs stay under profiles/, the sources in the repository's history).
 hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     if (p.hc_cl) { // cold records in LDS
         // (77 VGPRs: a SIMD must be able to take six waves, or the 2 + 1 + 1 + 1 waves of four 320-thread blocks do not all find a
         // slot — a 96-register build seated three blocks.  Strategies in registers as well: 26.7 against 26.5 ms, not kept)
         if (p.block == 320 && a.k <= 4u) return launch_play_hc_t<320, false, 0, 6, false, true, 4>(p, a, s);
-#ifdef FK_EXPERIMENTS
-        if (a.k > 5u) return hipErrorInvalidValue;
-        if (p.block == 256 && a.k <= 4u) return launch_play_hc_t<256, false, 0, 6, false, true, 4>(p, a, s);
-        if (p.block == 256) return launch_play_hc_t<256, false, 0, 6, false, true>(p, a, s); // 77 - 79 registers whatever the player count
-#endif
         return hipErrorInvalidValue;
     }
-#ifdef FK_EXPERIMENTS
-    if (p.hc_cr && p.hc_ki == 2) { // cold records in registers, four waves (increments loaded per turn)
-        if (a.k == 5u && p.block == 256) return launch_play_hc_t<256, true, 6, 4, false, false, 8, true, true>(p, a, s);
-        if (a.k == 6u && p.block == 512) return launch_play_hc_t<512, true, 6, 4, false, false, 8, true, true>(p, a, s);
-        if (a.k == 7u && p.block == 1024) return launch_play_hc_t<1024, true, 7, 4, false, false, 8, true, true>(p, a, s);
-        return hipErrorInvalidValue;
-    }
-    if (p.hc_cr && p.hc_ki && p.block == 256 && p.hc_lt && a.k > 6u) { // cold records in registers, three waves
-        if (p.hc_cr == 1) return launch_play_hc_t<256, true, 8, 0, false, false, 8, true, false>(p, a, s);
-        return launch_play_hc_t<256, true, 8, 0, false, false, 8, true, true>(p, a, s);
-    }
-#endif
-#ifdef FK_EXPERIMENTS
-    if (p.hc_ip) { // increments in the plane: <BLOCK, LT, KI = 0, WPE, PKR, CL, NS, CR, IL, IP>
-        if (p.block == 256 && a.k == 5u) return launch_play_hc_t<256, true, 0, 4, false, false, 8, false, false, true>(p, a, s);
-        if (p.block == 512 && a.k <= 8u) return launch_play_hc_t<512, true, 0, 4, false, false, 8, false, false, true>(p, a, s);
-        if (p.block == 1024 && a.k <= 8u) return launch_play_hc_t<1024, true, 0, 4, false, false, 8, false, false, true>(p, a, s);
-        if (p.block == 256 && a.k <= 8u) return launch_play_hc_t<256, true, 0, 3, false, false, 8, false, false, true>(p, a, s);
-        if (p.block == 768 && a.k <= 10u) return launch_play_hc_t<768, true, 0, 3, false, false, 10, false, false, true>(p, a, s);
-        if (p.block == 768) return launch_play_hc_t<768, true, 0, 3, false, false, 12, false, false, true>(p, a, s);
-        return hipErrorInvalidValue;
-    }
-#endif
     if (p.hc_ki == 3) { // nine to twelve seats: one block per CU, increments in registers, strategies loaded per turn
         if (p.block != 768) return hipErrorInvalidValue;
         if (a.k <= 10u) return launch_play_hc_t<768, true, 10, 3, false, false, 10>(p, a, s);
@@ -650,21 +579,8 @@ hipError_t launch_play_hc(const LaunchPlan &p, const PlayArgs &a, hipStream_t s)
     }
     if (p.hc_ki && p.block == 256 && p.hc_lt) { // three waves: increments in registers, 256-thread blocks with LDS tables
         if (a.k == 8u) return launch_play_hc_t<256, true, 8>(p, a, s);
-#ifdef FK_EXPERIMENTS
-        if (a.k <= 4u) return launch_play_hc_t<256, true, 4>(p, a, s);
-        if (a.k <= 6u) return launch_play_hc_t<256, true, 6>(p, a, s);
-        return launch_play_hc_t<256, true, 8>(p, a, s);
-#endif
     }
-#ifdef FK_EXPERIMENTS
-    switch (p.block) {
-    case 1024: return p.hc_lt ? launch_play_hc_t<1024, true>(p, a, s) : launch_play_hc_t<1024, false>(p, a, s);
-    case 768: return p.hc_lt ? launch_play_hc_t<768, true>(p, a, s) : launch_play_hc_t<768, false>(p, a, s);
-    default: return p.hc_lt ? launch_play_hc_t<256, true>(p, a, s) : launch_play_hc_t<256, false>(p, a, s);
-    }
-#else
     return hipErrorInvalidValue;
-#endif
 }
 
 hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
@@ -673,10 +589,6 @@ hipError_t launch_play(const LaunchPlan &p, const PlayArgs &a, hipStream_t s) {
     if (p.blk) return launch_play_t<768, true, 6, false, true, 2>(p, a, s); // batched H2H: k = 2, lean LDS records
     if (p.gs) { // state-store instances: the path of tables too wide for LDS records (k > 64); 2 x 768 threads per CU
         if (p.block == 768) return launch_play_t<768, true, 6, true>(p, a, s);
-#ifdef FK_EXPERIMENTS
-        if (p.block == 256) return launch_play_t<256, true, 4, true>(p, a, s);
-        if (p.block == 64) return launch_play_t<64, true, 4, true>(p, a, s);
-#endif
         return hipErrorInvalidValue;
     }
     if (p.lean) {
@@ -1400,20 +1312,9 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
         c->resident = value != 0;
         c->acc_n = 0; // the next tournament call starts a fresh accumulator
     } else if (n == "hot_cold") {
-#ifndef FK_EXPERIMENTS
-        if (value != -1 && value != 0) return fail(c, FK_ERR_ARG, "hot_cold is -1 (auto: four and more seats) or 0 (never); forcing it at three seats is an FK_EXPERIMENTS build's option");
-#endif
+        if (value != -1 && value != 0) return fail(c, FK_ERR_ARG, "hot_cold is -1 (auto: four and more seats) or 0 (never)");
         c->hc = (int32_t)value;
     }
-#ifdef FK_EXPERIMENTS
-    else if (n == "hot_cold_waves") c->hc_waves = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 1), 8);
-    else if (n == "hot_cold_block") c->hc_block = (int32_t)value;
-    else if (n == "hot_cold_tables") c->hc_tables = (int32_t)value;
-    else if (n == "hot_cold_inc_regs") c->hc_inc_regs = (int32_t)value;
-    else if (n == "hot_cold_lds") c->hc_cl = (int32_t)value;
-    else if (n == "hot_cold_cold_regs") c->hc_cr = (int32_t)value;
-    else if (n == "hot_cold_ip") c->hc_ip = (int32_t)std::min<int64_t>(std::max<int64_t>(value, 0), 2);
-#endif
     else if (n == "clock_stamps") c->clock_stamps = value != 0;
     else if (n == "perm_split") c->perm_split = (int32_t)value;
     else if (n == "pipeline") c->pipeline = (int32_t)value;
@@ -1631,8 +1532,8 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
         if (plan_play_hc(c, k, target_score, plan, hc_plan)) plan = hc_plan;
     }
     if (plan.hc) c->ran_hc = true;
-    if (plan.hc && !plan.hc_cl && !plan.hc_cr) { // cold seat records of every lane the grid can seat
-        rc = ensure(c, c->cold, (size_t)plan.grid * (size_t)plan.block * (size_t)k * (plan.hc_ip ? 32 : 16));
+    if (plan.hc && !plan.hc_cl) { // cold seat records of every lane the grid can seat
+        rc = ensure(c, c->cold, (size_t)plan.grid * (size_t)plan.block * (size_t)k * 16);
         if (rc) return rc;
     }
     const bool want_state = rows != nullptr || seat_stats != nullptr;

@@ -81,11 +81,10 @@ __device__ __forceinline__ uint32_t hc_pick(uint32_t s, F get) {
 // whole game (0: both are loaded at every turn start); LT: tables from the LDS image; WPE: waves per SIMD the register
 // budget is cut for (0: 4 for KI = 4, 3 for the other KI instances); CL: cold records in LDS beside the buffered half words
 // (no plane); NS: the most seats a launch of the instance has (strategy-index select).  See the file comment.
-// IP: every seat's increment rides in its cold-plane slot (32-byte slots: cold record, increment) and the NEXT owner's is fetched one turn
-// ahead — no register array, no select tree; KI = 0.
-// CR: the cold records of the KI seats in REGISTERS as well (no plane, no store + load per turn: every store to the plane leaves
-// L2 as a 64-byte fabric write on this chip); IL: increments loaded per turn although KI sizes the register arrays.
-template <int HC_BLOCK_I, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR_I = true, bool CL = false, int NS = 8, bool CR = false, bool IL = false, bool IP = false>
+// (Rejected variants — increments in the cold-plane slots fetched one turn ahead, cold records in registers, increments loaded per turn —
+// were template paths of this kernel until round 6; their A/B logs are profiles/r04_cold_records_in_registers.log and
+// profiles/r05_increments_in_the_plane.log, their code is in the repository's history.)
+template <int HC_BLOCK_I, uint32_t MIXED, bool LT, int KI = 0, int WPE = 0, bool PKR_I = true, bool CL = false, int NS = 8>
 __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : KI == 4 ? 4 : KI ? 3 : (HC_BLOCK_I == 256 ? 5 : HC_BLOCK_I / 256)))) void fk_play_hc_kernel(PlayArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr uint32_t HC_BLOCK = (uint32_t)HC_BLOCK_I;
@@ -93,13 +92,10 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     const uint32_t K = a.k;
     clock_stamp(a.clk, 0u);
     static_assert(!CL || (KI == 0 && !LT), "cold-in-LDS instances load increments / strategies per turn and gather from the global tables");
-    static_assert(!CR || (KI != 0 && !CL), "cold-in-register instances size their arrays by KI");
-    static_assert(!IL || CR, "IL only makes sense when KI is there for the cold records");
-    static_assert(!IP || (KI == 0 && !CL && !CR), "increments in the plane: no register arrays, and there must be a plane");
     // BP: the buffered half word of a seat that is not the turn owner rides in the fourth dword of its cold-plane slot (round 5): it is
     // touched once per turn like the rest of the cold record, the owner's lives in a register — 16 instead of 20 bytes of LDS per seat
     // and lane (twelve seats: 768 instead of 576 lanes per CU), two LDS instructions per roll less.  Instances without a plane keep it in LDS.
-    constexpr bool BP = !CL && !CR;
+    constexpr bool BP = !CL;
     constexpr uint32_t HOT_DW = BP ? 4u : 5u;
     uint4 *const lds_state = reinterpret_cast<uint4 *>(lds) + tid;   // [seat][lane] generator state
     uint32_t *const lds_buf = lds + 4u * K * HC_BLOCK + tid;          // [seat][lane] buffered half word (!BP)
@@ -117,15 +113,14 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         for (uint32_t i = tid; i < LT_BYTES / 16u; i += HC_BLOCK) dst[i] = src[i];
         __syncthreads();
     }
-    constexpr uint32_t SLOT = IP ? 2u : 1u;  // uint4s per plane slot
-    uint4 *const cold = (CL || CR) ? nullptr : a.cold + (size_t)(blockIdx.x * HC_BLOCK + tid) * K * SLOT; // [resident lane][seat] slots
+    uint4 *const cold = CL ? nullptr : a.cold + (size_t)(blockIdx.x * HC_BLOCK + tid) * K; // [resident lane][seat] slots
     // (buffered half word when BP, x, y, z)
     auto cold_load = [&](uint32_t s) __attribute__((always_inline)) -> uint4 {
         if (CL) {
             const uint2 xy = lds_xy[SB(s)];
             return make_uint4(0u, xy.x, xy.y, lds_z[SB(s)]);
         }
-        const uint4 c = cold[s * SLOT];
+        const uint4 c = cold[s];
         return make_uint4(c.w, c.x, c.y, c.z);
     };
 
@@ -149,23 +144,11 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     uint32_t own_bits = 0;
     uint32_t cX = 0, cY = 0, cZ = 0;              // the owner's cold record
     uint32_t own_buf = 0;                         // BP: the owner's buffered half word
-    uint32_t nx0 = 0, nx1 = 0, nx2 = 0, nx3 = 0;  // IP: the increment of the seat expected to own the next turn (scalars: a uint4 shared by
-                                                  // two lambdas stays an alloca — scratch) ...
-    uint32_t nxt_seat = 0;                        // ... and which seat that is
-    constexpr bool IR = KI != 0 && !IL;          // increments in registers
+    constexpr bool IR = KI != 0;                  // increments in registers
     uint32_t inc_r[IR ? KI : 1][4] = {};          // KI: every seat's increment (constant indices only: registers)
-    uint32_t cold_r[CR ? KI : 1][3] = {};         // CR: every seat's cold record
     constexpr bool PKR = PKR_I && IR && KI <= 6;      // ... and packed strategy, while 168 registers hold both without spilling
     uint32_t pk_r[PKR ? KI : 1][2] = {};
 
-    // CR: seat s's cold record out of the register array (select tree on the bits of s)
-    auto cold_pick = [&](uint32_t s) __attribute__((always_inline)) -> uint4 {
-        constexpr int NC = CR ? KI : 1;
-        uint32_t c[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) c[j] = hc_pick<NC>(s, [&](int t) __attribute__((always_inline)) { return cold_r[t][j]; });
-        return make_uint4(0u, c[0], c[1], c[2]);
-    };
     auto seat_index = [&](uint32_t s) __attribute__((always_inline)) -> uint32_t {
         const uint32_t w = hc_pick<NIX>(s >> 1, [&](int t) __attribute__((always_inline)) {
             return t == 0 ? ix0 : t == 1 ? ix1 : t == 2 ? ix2 : t == 3 ? ix3 : t == 4 ? ix4 : ix5;
@@ -181,18 +164,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
     // its first generator step, the strategy and the cold record behind the score-table gather.
     auto begin_turn = [&](uint32_t s) __attribute__((always_inline)) {
         uint4 inc;
-        if (IP) {
-            // The increment fetched during the previous turn; a wrong guess (the turn that has just ended opened the final round: the
-            // table jumps to seat 0 / 1) loads it now.  Then the seat after s — exact unless THIS turn opens the final round — and its load.
-            inc = make_uint4(nx0, nx1, nx2, nx3);
-            if (s != nxt_seat) inc = cold[s * SLOT + 1u];
-            const uint32_t n1 = s + 1u;
-            uint32_t p = final_round ? n1 + ((n1 == trigger) ? 1u : 0u) : n1;
-            p = p < K ? p : 0u; // (past the last seat: the next round's first seat, or nobody: a game about to end)
-            nxt_seat = p;
-            const uint4 q = cold[p * SLOT + 1u];
-            nx0 = q.x, nx1 = q.y, nx2 = q.z, nx3 = q.w;
-        } else if (IR) { // select tree on the bits of s (entries beyond k are never selected)
+        if (IR) { // select tree on the bits of s (entries beyond k are never selected)
             constexpr int NI = IR ? KI : 1;
             uint32_t w[4];
 #pragma unroll
@@ -208,7 +180,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         } else {
             pk = a.strat[seat_index(s)];
         }
-        const uint4 c = CR ? cold_pick(s) : cold_load(s);
+        const uint4 c = cold_load(s);
         own_inc_lo = (uint64_t)inc.x | ((uint64_t)inc.y << 32);
         own_inc_hi = (uint64_t)inc.z | ((uint64_t)inc.w << 32);
         own_thr = (int32_t)pk.x;
@@ -235,7 +207,7 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         int32_t best = -1;
         uint4 wrec = make_uint4(0u, 0u, 0u, 0u);
         for (uint32_t s = 0; s < K; ++s) { // stable sort on score desc: first maximum wins (engine.py:477)
-            const uint4 c = (s == seat) ? make_uint4(own_buf, cX, cY, cZ) : CR ? cold_pick(s) : cold_load(s);
+            const uint4 c = (s == seat) ? make_uint4(own_buf, cX, cY, cZ) : cold_load(s);
             const int32_t sc = (int32_t)((c.w >> HC_SCORE_SHIFT) & HC_SCORE_MASK);
             if (sc > best) {
                 best = sc;
@@ -297,15 +269,8 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
                 if (CL) {
                     lds_xy[SB(s)] = make_uint2(0u, 0u);
                     lds_z[SB(s)] = 0u;
-                } else if (CR) {
-                    if (s < (uint32_t)(CR ? KI : 1)) cold_r[s < (uint32_t)(CR ? KI : 1) ? s : 0][0] = cold_r[s < (uint32_t)(CR ? KI : 1) ? s : 0][1] = cold_r[s < (uint32_t)(CR ? KI : 1) ? s : 0][2] = 0u;
                 } else {
-                    cold[s * SLOT] = make_uint4(0u, 0u, 0u, 0u); // the previous game's record of this lane
-                    if (IP) {
-                        const uint4 q = a.inc[(size_t)slot * K + s];
-                        cold[s * SLOT + 1u] = q;
-                        if (s == 0u) nx0 = q.x, nx1 = q.y, nx2 = q.z, nx3 = q.w;
-                    }
+                    cold[s] = make_uint4(0u, 0u, 0u, 0u); // the previous game's record of this lane
                 }
                 const uint32_t idx = (a.state_dw == STATE_DW) ? src[R_IDX] : (uint32_t)a.seat_idx[(size_t)slot * K + s];
                 const uint32_t field = idx << (16u * (s & 1u));
@@ -330,7 +295,6 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
         hasbuf = 0;
         cX = cY = cZ = 0u;
         own_buf = 0u;
-        nxt_seat = 0;
         seat = 0;
         trigger = 0;
         final_round = 0;
@@ -426,16 +390,8 @@ __global__ __launch_bounds__(HC_BLOCK_I) __attribute__((amdgpu_waves_per_eu(WPE 
             if (CL) {
                 lds_xy[SB(s)] = make_uint2(cX, cY);
                 lds_z[SB(s)] = cZ;
-            } else if (CR) { // the owner's record back into its slot of the register array
-#pragma unroll
-                for (int t = 0; t < (CR ? KI : 1); ++t) {
-                    const bool here = s == (uint32_t)t;
-                    cold_r[t][0] = here ? cX : cold_r[t][0];
-                    cold_r[t][1] = here ? cY : cold_r[t][1];
-                    cold_r[t][2] = here ? cZ : cold_r[t][2];
-                }
             } else {
-                cold[s * SLOT] = make_uint4(cX, cY, cZ, own_buf);
+                cold[s] = make_uint4(cX, cY, cZ, own_buf);
             }
             advance(score + (int32_t)banked);
         }

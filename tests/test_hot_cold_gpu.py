@@ -4,7 +4,7 @@ against the CPU oracle: generator state of every seat in LDS, the behaviour coun
 The kernel is chosen by the launch plan for k >= 4 (option ``hot_cold`` = -1; k = 4: the cold-in-LDS instance; k = 5 .. 7: four
 waves per SIMD with the increments in registers; k = 8: three; k = 9 .. 12 (round 5): one 768-thread block per CU) —
 the instances the shipped library holds.  The variants that lost
-or tied against them (profiles/HISTORY.md) are compiled only with -DFK_EXPERIMENTS and are not part of this suite."""
+or tied against them (profiles/HISTORY.md) left the tree in round 6 (logs under profiles/, sources in the repository's history)."""
 from __future__ import annotations
 
 import numpy as np

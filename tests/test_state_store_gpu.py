@@ -63,7 +63,7 @@ def _random_valid_table(n: int, seed: int) -> np.ndarray:
 def test_state_store_and_lds_record_instances_agree_with_oracle(eng, po, k):
     """Same shuffles through the state-store instance, the LDS-record instance (when k records fit) and the oracle:
     tallies per batch, rows.  (The state-store instance is the 768-thread one: the path of tables wider than LDS, k > 64;
-    `state_store = 1` selects it at any k.  Its 256- and 64-thread forms are FK_EXPERIMENTS builds only.)"""
+    `state_store = 1` selects it at any k.  Its 256- and 64-thread forms were experiment builds and left the tree in round 6.)"""
     table = _random_valid_table(96, 100 + k)
     n_sh = 40
     ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 5, 3, 3 + n_sh, shuffles_per_batch=16, want_rows=True, n_threads=8)
