@@ -2,7 +2,7 @@
 buffered half word in the cold slot, instances for nine to twelve seats, per-k hand-over thresholds): random legal tables, k = 2 .. 12,
 targets (units-of-50 rounding), round limits incl. 0 and beyond the farkle field (replays), overrides, and the options a caller can
 set — max_waves, batch_threshold, use_lds_tally, hot_cold, chunk_bytes, pipeline.  Tallies, rows, all-seat statistics and (every
-third trial) the float64 ratio sums.  usage: python tools/fuzz_r05.py [trials=300] [seed=11]"""
+third trial) the float64 ratio sums.  usage: python tools/fuzz_shipped_plan.py [trials=300] [seed=11]"""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
