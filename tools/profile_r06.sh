@@ -6,14 +6,19 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 R=6
 part=${1:-all}
-if [ "$part" = all ] || [ "$part" = a ]; then
+if [ "$part" = all ] || [ "$part" = a ] || [ "$part" = a1 ]; then
 bash tools/pmc_cfg.sh r06c2 64 2 312500 && python3 tools/make_traffic_json.py r06c2 2 760000000 "tools/pmc_cfg.sh r06c2 64 2 312500 (tools/profile_r06.sh)" $R
 python3 tools/pmc_report.py r06c2 1446000000 fk_play > gpurun_out/r06_play_kernel_pmc_summary_config2.txt 2>&1
 bash tools/pmc_cfg.sh r06c3 5160 4 77520 && python3 tools/make_traffic_json.py r06c3 3 17600000000 "tools/pmc_cfg.sh r06c3 5160 4 77520 (tools/profile_r06.sh)" $R
 python3 tools/pmc_report.py r06c3 22990000000 fk_play > gpurun_out/r06_play_hc_kernel_pmc_summary_config3.txt 2>&1
 echo "configs 2, 3 done"
+fi
+if [ "$part" = all ] || [ "$part" = a ] || [ "$part" = a1 ] || [ "$part" = a2 ]; then
+SPECS=("2 38759 154.0" "3 58139 187.4" "4 77519 229.9" "5 96899 273.3" "6 116279 316.0" "8 155038 399.2" "10 193798 479.5" "12 232558 557.5")
+[ "$part" = a1 ] && SPECS=("2 38759 154.0" "3 58139 187.4" "4 77519 229.9" "5 96899 273.3")
+[ "$part" = a2 ] && SPECS=("6 116279 316.0" "8 155038 399.2" "10 193798 479.5" "12 232558 557.5")
 # config 6: one stamp + one PMC summary per player count at the sweep's launch size (10^8 games per k; algorithmic bytes = (34 k + 40) per game)
-for spec in "2 38759 154.0" "3 58139 187.4" "4 77519 229.9" "5 96899 273.3" "6 116279 316.0" "8 155038 399.2" "10 193798 479.5" "12 232558 557.5"; do
+for spec in "${SPECS[@]}"; do
   set -- $spec; k=$1; nsh=$2; rolls=$3
   games=$(( nsh * (5160 / k) ))
   bash tools/pmc_cfg.sh r06s$k 5160 $k $nsh && python3 tools/make_traffic_json.py r06s$k 6 $(( games * (34 * k + 40) )) "tools/pmc_cfg.sh r06s$k 5160 $k $nsh" $R $k
