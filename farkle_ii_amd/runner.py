@@ -24,6 +24,7 @@ from __future__ import annotations
 import json
 import logging
 import os
+import sys
 import time
 from pathlib import Path
 from typing import Any, Callable, Mapping, Sequence
@@ -497,7 +498,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                    checkpoint_path: Path, collect_metrics: bool, row_dir: Path | None, metric_chunk_dir: Path | None,
                    resume: bool, checkpoint_metadata: "Mapping[str, Any] | Callable[[], Mapping[str, Any]]", oracle_game_profile: GameProfile | None = None,
                    all_player_dir: Path | None = None, sidecars: "_Sidecars | None" = None,
-                   rng_lags: Sequence[int] | None = None, defer_final_checkpoint: bool = False, packed_table: np.ndarray | None = None) -> dict:
+                   rng_lags: Sequence[int] | None = None, defer_final_checkpoint: bool = False, packed_table: np.ndarray | None = None,
+                   defer_tail: list | None = None) -> dict:
     """Play every deterministic batch not yet owned by the checkpoint and persist the aggregates.  ``defer_final_checkpoint``: the final
     checkpoint's file write may still be in flight on return — the caller joins ``result["checkpoint_written"]`` before reading the file.  ``rng_lags``: also accumulate the lag
     sufficient statistics of the RNG diagnostics' strategy family over the WHOLE shuffle range (``fk_tournament_run_lags``; launch
@@ -779,10 +781,20 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                   if hasattr(eng, "pinned_empty"):
                       # two page-locked buffers per ENGINE (kept for its life, grown when a launch group needs more: page-locking a gigabyte
                       # takes ~0.25 s, and a sweep over eight player counts that asked for one per count spent 2.4 of its 3.5 s there)
-                      slots = getattr(eng, "_pinned_columns", None)
-                      if slots is None:
-                          slots = eng._pinned_columns = [None, None]
-                      slot = n_groups & 1
+                      # the slots alternate over the ENGINE's launch groups (not this call's): the last group of a player count may still be
+                      # written — its tail deferred to the publisher thread, run_multi — while the next count's first group plays
+                      pin = getattr(eng, "_pinned_columns", None)
+                      if pin is None:
+                          pin = eng._pinned_columns = {"slots": [None, None], "jobs": [None, None], "turn": 0}
+                      slot = pin["turn"] & 1
+                      pin["turn"] += 1
+                      if pin["jobs"][slot] is not None:  # the shard job that read this buffer last
+                          try:
+                              pin["jobs"][slot].result()
+                          except Exception:  # noqa: BLE001 - its own group raises it when it is finished
+                              pass
+                          pin["jobs"][slot] = None
+                      slots = pin["slots"]
                       if slots[slot] is None or len(slots[slot]) < need:
                           slots[slot] = None
                           slots[slot] = eng.pinned_empty(max(need, min(ROWS_GROUP_BYTES, plan.required_shuffles * image_bytes)), np.uint8)
@@ -828,6 +840,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                                                               game_index=np.tile(np.arange(gps, dtype=np.uint64), hi - lo), dtype=np.uint32)
                       shard_job = _shard_thread().submit(rt.write_row_shards_from_columns, row_dir, tasks, res["columns"], seeds102, sha,
                                                          threads=ROW_WRITER_THREADS, sidecar=shard_sidecar)
+                      if getattr(eng, "_pinned_columns", None) is not None and pinned_rows is not None:
+                          eng._pinned_columns["jobs"][slot] = shard_job
                   else:
                       row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
                                                              game_seeds=seeds102, as_lines=True, sidecar=shard_sidecar))
@@ -842,27 +856,40 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
           else:
               finish(**group_args)
           i = j + 1
-      if in_flight is not None:
+      if in_flight is not None and not (defer_tail is not None and world == 1):
           previous, in_flight = in_flight, None
           finish(**previous)
     finally:
-        if in_flight is not None and in_flight["shard_job"] is not None:  # an error above: no writer thread may outlive the call
-            try:
+        if in_flight is not None and in_flight["shard_job"] is not None and sys.exc_info()[0] is not None:
+            try:  # an error above: no writer thread may outlive the call
                 in_flight["shard_job"].result()
             except Exception:  # noqa: BLE001 - the first error is the one that propagates
                 pass
-    if rank == 0:
-        save(final=True)
-        sidecars.write("checkpoint", checkpoint_path)
-        for manifest in (row_manifest, metrics_manifest):  # the manifests are final now: their sidecars bind the complete files
-            if manifest is not None and sidecars.v3 is not None:
-                if manifest.exists():  # sealed: canonical lines in coordinate order + the coordinate-sorted root over the shards' identities
-                    sidecars.v3.publish_manifest(manifest, _read_manifest(manifest), n_players=k)
-            elif manifest is not None:
-                sidecars.write("shard_manifest", manifest)
-    barrier()
-    return {"tally": total, "games": games_done, "seconds": time.perf_counter() - t_start, "lag_summary": lag_total,
-            "shard_identities": shard_identities, "checkpoint_written": checkpoint_written}
+    result = {"shard_identities": shard_identities, "checkpoint_written": checkpoint_written}
+    last_group, in_flight = in_flight, None
+
+    def complete() -> dict:
+        """The run's tail: the last launch group's shards (still being written when the tail is deferred), the final checkpoint, the
+        manifests' sidecars."""
+        if last_group is not None:
+            finish(**last_group)
+        if rank == 0:
+            save(final=True)
+            sidecars.write("checkpoint", checkpoint_path)
+            for manifest in (row_manifest, metrics_manifest):  # the manifests are final now: their sidecars bind the complete files
+                if manifest is not None and sidecars.v3 is not None:
+                    if manifest.exists():  # sealed: canonical lines in coordinate order + the coordinate-sorted root over the shards' identities
+                        sidecars.v3.publish_manifest(manifest, _read_manifest(manifest), n_players=k)
+                elif manifest is not None:
+                    sidecars.write("shard_manifest", manifest)
+        barrier()
+        result.update(tally=total, games=games_done, seconds=time.perf_counter() - t_start, lag_summary=lag_total)
+        return result
+
+    if last_group is not None:  # (only with defer_tail, one process): the caller runs it — run_multi on its publisher thread, under the next count
+        defer_tail.append(complete)
+        return result
+    return complete()
 
 
 def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | None = None, *, force: bool = False,
@@ -943,13 +970,14 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         if d is not None:
             d.mkdir(parents=True, exist_ok=True)
     barrier()  # rank 0's --force cleanup and manifest write are complete before any rank plays or writes a shard
+    run_tail: list = []  # rows mode under run_multi: the last launch group's shard writing + final checkpoint, deferred with the publishing tail
     try:
         result = run_tournament(cfg=cfg, n_players=n, strategies=strategies, plan=plan, checkpoint_path=ckpt_path,
                             collect_metrics=cfg.sim.expanded_metrics, row_dir=row_dir, metric_chunk_dir=metric_chunk_dir,
                             resume=not force, checkpoint_metadata=lambda: {"strategy_manifest_sha": shared.manifest_sha},
                             oracle_game_profile=oracle_game_profile, all_player_dir=all_player_dir, sidecars=sidecars,
                             rng_lags=cfg.rng_diagnostic_lags() if cfg.sim.rng_lag_sums else None, defer_final_checkpoint=True,
-                            packed_table=shared.packed)
+                            packed_table=shared.packed, defer_tail=run_tail if _defer_publish is not None else None)
     finally:
         if published is not None:
             published.result()  # the inputs are on disk (or their error is raised) before the summaries and the stamp name them
@@ -957,6 +985,8 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         return plan.required_games
 
     def publish() -> None:
+        for tail in run_tail:
+            tail()  # (fills `result`)
         _publish_results(cfg, n, strategies, plan, result, grid_size, ckpt_path, n_dir, sidecars, oracle_game_profile)
 
     if _defer_publish is not None:
