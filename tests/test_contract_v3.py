@@ -232,3 +232,103 @@ def test_resolve_code_identity_follows_git(tmp_path):
     want = hashlib.sha256(b"tracked-index\0" + b"tracked-worktree\0" + diff + b"untracked\0src/new.py\0"
                           + hashlib.sha256(b"y = 1\n").hexdigest().encode()).hexdigest()
     assert dirty == {"commit": head, "policy": "development_dirty", "state": "development_dirty", "dirty_fingerprint_sha256": want}
+
+
+def test_interrupted_v3_run_resumes_to_the_documents_of_an_uninterrupted_one(tmp_path, monkeypatch):
+    """A contract-v3 run cut down before its second checkpoint (one launch group per deterministic batch), then resumed: the row shards
+    and sidecars of the owned batches stay, the replayed ones are rewritten, and the finished tree carries exactly the documents of an
+    uninterrupted run — the ones the reference accepted."""
+    import oracle_engine_stub
+
+    from farkle_ii_amd import contract_v3 as c3
+    from farkle_ii_amd import engine as eng_mod
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.config import load_app_config
+
+    eng_mod.set_engine(oracle_engine_stub.Engine(0))
+    try:
+        cfg_path = _config(tmp_path)
+        cfg = load_app_config(cfg_path, seed_list_len=1)
+        cfg._code_identity = c3.make_code_identity(COMMIT, DIRTY)
+        cfg.sim.sidecars = True
+        monkeypatch.setattr(runner, "MAX_GAMES_PER_LAUNCH", 1)  # one deterministic batch per launch group
+        real_write = runner._atomic_write_bytes
+        saves = {"n": 0}
+
+        def dying_write(path, content):
+            if path.name.endswith("checkpoint.pkl"):
+                saves["n"] += 1
+                if saves["n"] == 2:
+                    raise KeyboardInterrupt("power cut before the second checkpoint")
+            real_write(path, content)
+
+        monkeypatch.setattr(runner, "_atomic_write_bytes", dying_write)
+        with pytest.raises(KeyboardInterrupt):
+            runner.run_single_n(cfg, 2)
+        n_dir = cfg.n_dir(2)
+        assert not (n_dir / "simulation.done.json").exists() and not (n_dir / "2p_rows" / ("manifest.jsonl" + SIDE)).exists()
+        monkeypatch.setattr(runner, "_atomic_write_bytes", real_write)
+        runner.run_single_n(cfg, 2)
+        runner.run_single_n(cfg, 4)
+    finally:
+        eng_mod.set_engine(None)
+    root = cfg.results_root
+    for rel, rec in GOLD["standalone_documents"].items():
+        if "completion" in rec:
+            assert (root / rel).read_text() == rec["completion"], rel
+        else:
+            assert hashlib.sha256((root / (rel + SIDE)).read_bytes()).hexdigest() == rec["sidecar_sha256"], rel
+    sc = c3.SimulationContract(cfg, cfg._code_identity)
+    assert sc.is_complete(root / "2_players" / "simulation.done.json") and sc.is_complete(root / "4_players" / "simulation.done.json")
+
+
+def _v3_rank_main(rank: int, world: int, port: int, cfg_path: str) -> None:
+    import os
+    import sys
+
+    root = Path(__file__).resolve().parent.parent
+    for p in (root, root / "oracle", root / "tests"):
+        sys.path.insert(0, str(p))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    import oracle_engine_stub
+    from farkle_ii_amd import contract_v3 as c3
+    from farkle_ii_amd import engine as eng_mod
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.config import load_app_config
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng_mod.set_engine(oracle_engine_stub.Engine(0))
+    runner.MAX_GAMES_PER_LAUNCH = 40  # several launch groups, each cut over the two ranks
+    cfg = load_app_config(Path(cfg_path), seed_list_len=1)
+    cfg._code_identity = c3.make_code_identity(COMMIT, DIRTY)
+    cfg.sim.sidecars = True
+    for k in (2, 4):
+        runner.run_single_n(cfg, k)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_write_the_same_v3_documents(tmp_path):
+    """Two gloo ranks: each writes the row shards (and their sidecars) of its own batches from the same template, rank 0 seals the
+    manifests and publishes the completion — the documents of the single-process run."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from farkle_ii_amd import contract_v3 as c3
+    from farkle_ii_amd.config import load_app_config
+
+    cfg_path = _config(tmp_path)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_v3_rank_main, args=(2, port, str(cfg_path)), nprocs=2, join=True)
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    root = cfg.results_root
+    for rel, rec in GOLD["standalone_documents"].items():
+        if "completion" in rec:
+            assert (root / rel).read_text() == rec["completion"], rel
+        else:
+            assert hashlib.sha256((root / (rel + SIDE)).read_bytes()).hexdigest() == rec["sidecar_sha256"], rel
