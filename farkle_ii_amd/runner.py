@@ -47,7 +47,7 @@ from .workload_planner import TournamentWorkloadPlan, WorkloadCapExceeded, plan_
 
 LOGGER = logging.getLogger(__name__)
 MAX_GAMES_PER_LAUNCH = 200_000_000  # checkpoint cadence on the GPU: a launch group is at most this many games
-ROWS_GROUP_BYTES = 256 << 20  # rows mode: a launch group's column images (one of two page-locked buffers; group i is written while i + 1 plays)
+ROWS_GROUP_BYTES = int(os.environ.get("FK_ROWS_GROUP_MB", "256")) << 20  # rows mode: a launch group's column images (one of two page-locked buffers; group i is written while i + 1 plays)
 ROW_WRITER_THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))  # row-shard writer PROCESSES (rows mode)
 
 
