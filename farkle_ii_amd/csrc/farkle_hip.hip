@@ -1379,6 +1379,11 @@ int fk_write_row_shards(const fk_shard_job *job, int64_t *byte_length, uint8_t *
 
 int fk_debug_sha256(const void *data, size_t n, uint8_t *out32, int32_t portable) {
     if ((!data && n) || !out32) return FK_ERR_ARG;
+    if (portable == 2) { // the two-message form the shard writer uses: data = [first half | second half], out32 = 64 bytes
+        const uint8_t *p = static_cast<const uint8_t *>(data);
+        fksw::sha256_pair(p, n / 2, out32, p + n / 2, n - n / 2, out32 + 32);
+        return FK_OK;
+    }
     fksw::sha256(static_cast<const uint8_t *>(data), n, out32, portable != 0);
     return FK_OK;
 }

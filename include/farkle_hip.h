@@ -222,7 +222,8 @@ typedef struct {
     const char *side_directory;     /* results-root-relative directory of the shards, with a trailing '/' */
 } fk_shard_job;
 int fk_write_row_shards(const fk_shard_job *job, int64_t *byte_length, uint8_t *sha256, uint8_t *sidecar_sha256, char *error, size_t error_len);
-/* SHA-256 as the shard writer computes it (SHA-NI when the CPU has it; portable != 0 forces the scalar rounds): parity probe. */
+/* SHA-256 as the shard writer computes it (SHA-NI when the CPU has it; portable = 1 forces the scalar rounds; portable = 2: the two-message
+ * lockstep form — digests of data[0 .. n/2) and data[n/2 .. n) into out32[0 .. 32) and out32[32 .. 64)): parity probe. */
 int fk_debug_sha256(const void *data, size_t n, uint8_t *out32, int32_t portable);
 
 /* fk_tournament_run plus the integer sufficient statistics of ALL seats (not winners only), per batch and strategy:

@@ -54,12 +54,17 @@ def test_sha256_of_the_shard_writer_matches_hashlib():
 
     lib = load_library()
     rng = np.random.default_rng(7)
-    for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 1000, 65536 + 17):
+    for n in (0, 1, 55, 56, 63, 64, 65, 119, 120, 127, 128, 129, 257, 1000, 65536 + 17, 400_001):
         data = rng.integers(0, 256, n, dtype=np.uint8)
         for portable in (0, 1):  # SHA-NI (when the CPU has it) and the scalar rounds
             out = np.zeros(32, dtype=np.uint8)
             assert lib.fk_debug_sha256(data.ctypes.data_as(C.c_void_p), C.c_size_t(n), out.ctypes.data_as(C.c_void_p), C.c_int32(portable)) == 0
             assert out.tobytes() == hashlib.sha256(data.tobytes()).digest(), (n, portable)
+        # the two-message lockstep form (what a writer thread runs over the two files it has just built): unequal halves, short tails
+        pair = np.zeros(64, dtype=np.uint8)
+        assert lib.fk_debug_sha256(data.ctypes.data_as(C.c_void_p), C.c_size_t(n), pair.ctypes.data_as(C.c_void_p), C.c_int32(2)) == 0
+        blob = data.tobytes()
+        assert pair[:32].tobytes() == hashlib.sha256(blob[:n // 2]).digest() and pair[32:].tobytes() == hashlib.sha256(blob[n // 2:]).digest(), n
 
 
 @pytest.mark.parametrize("k,gps,n_sh,null_rate", [(2, 32, 6, 0.2), (5, 7, 3, 0.5), (12, 430, 3, 0.02), (3, 1, 4, 0.5), (2, 2580, 2, 0.0),
