@@ -140,6 +140,19 @@ struct fk_ctx {
     DevBuf ids;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
+    // option "rows_async": a rows call returns when its last copy to the host is QUEUED, not done; fk_rows_wait(slot) waits for it.  The caller
+    // (farkle run: two page-locked buffers) then starts the next launch group at once, whose game kernel runs beside that copy.
+    int32_t rows_async = 0;
+    hipEvent_t ev_call_copy[2] = {nullptr, nullptr};
+    uint32_t rows_calls = 0;      // rows calls made in async mode: call n records ev_call_copy[n & 1]
+    // The mailbox: page-locked host memory the device STORES small results into (tallies, error records, game seeds) while a rows DMA
+    // is in flight — a copy-engine transfer would queue behind those 256 MB and the call would wait for them after all (measured: an
+    // async call took exactly as long as a waiting one until its tally left this way).
+    uint8_t *mail = nullptr;
+    size_t mail_cap = 0, mail_used = 0;
+    struct Letter { void *dst; size_t off, bytes; };
+    std::vector<Letter> letters;
+    int32_t last_rows_event = -1; // ... and this is the slot of the last one (option "rows_event")
     int64_t rows_chunk_games = 4000000; // rows mode plays in chunks of about this many games (overlap granularity)
     int32_t resident = 0;
     size_t last_tally_bytes = 0; // bytes of the last successful tournament call's tally in `tally`
@@ -651,10 +664,54 @@ int report_device_error(fk_ctx *c, const int32_t *h, int64_t game_base, const ch
     return FK_OK;
 }
 
+// Device -> mailbox by stores (no copy engine), 4-byte words.
+__global__ void fk_mail_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t n_words) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// Is a rows DMA (option "rows_async") in flight or about to be queued?  Then small results leave through the mailbox.
+bool rows_dma_pending(fk_ctx *c) { return c->rows_async || (c->rows_calls && hipStreamQuery(c->copy_stream) == hipErrorNotReady); }
+
+// `bytes` (a multiple of 4) of device memory -> `dst` on the host, behind what is queued on the main stream; complete after the
+// stream has been synchronised AND deliver_mail() has run.  Through the mailbox while a rows DMA is pending, else one async copy.
+int post_d2h(fk_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return FK_OK;
+    if ((bytes & 3u) == 0 && bytes < ((size_t)1 << 31) && rows_dma_pending(c)) {
+        const size_t off = (c->mail_used + 63u) & ~(size_t)63u;
+        if (off + bytes > c->mail_cap && c->letters.empty()) { // grow (nothing of the old one is awaited)
+            if (c->mail) (void)hipHostFree(c->mail);
+            c->mail = nullptr;
+            c->mail_cap = 0;
+            const size_t cap = std::max<size_t>((size_t)4 << 20, (bytes + 4095u) & ~(size_t)4095u);
+            if (hipHostMalloc(reinterpret_cast<void **>(&c->mail), cap, hipHostMallocDefault) == hipSuccess) c->mail_cap = cap;
+            else (void)hipGetLastError();
+        }
+        if (off + bytes <= c->mail_cap) {
+            const uint32_t n_words = (uint32_t)(bytes / 4);
+            hipLaunchKernelGGL(fk_mail_kernel, dim3(std::min<uint32_t>((n_words + 255u) / 256u, 1024u)), dim3(256), 0, c->stream,
+                               static_cast<const uint32_t *>(src), reinterpret_cast<uint32_t *>(c->mail + off), n_words);
+            HIPCHK(c, hipGetLastError());
+            c->letters.push_back({dst, off, bytes});
+            c->mail_used = off + bytes;
+            return FK_OK;
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return FK_OK;
+}
+
+void deliver_mail(fk_ctx *c) { // the main stream has been synchronised
+    for (const auto &l : c->letters) std::memcpy(l.dst, c->mail + l.off, l.bytes);
+    c->letters.clear();
+    c->mail_used = 0;
+}
+
 int check_device_error(fk_ctx *c, const int32_t *d_err, int64_t game_base, const char *what) {
     int32_t h[2] = {0, 0};
-    HIPCHK(c, hipMemcpyAsync(h, d_err, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    const int rc = post_d2h(c, h, d_err, sizeof(h));
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    deliver_mail(c);
     return report_device_error(c, h, game_base, what);
 }
 
@@ -1136,6 +1193,7 @@ int fk_init(int device_ordinal, fk_ctx **out) {
         for (int i = 0; i < 2; ++i) {
             ok = ok && hipEventCreateWithFlags(&c->ev_rows[i], hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&c->ev_call_copy[i], hipEventDisableTiming) == hipSuccess;
         }
         ok = ok && hipEventCreateWithFlags(&c->main_idle, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&c->err_host), 2 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
@@ -1204,9 +1262,11 @@ void fk_destroy(fk_ctx *c) {
     for (int i = 0; i < 2; ++i) {
         if (c->ev_rows[i]) (void)hipEventDestroy(c->ev_rows[i]);
         if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
+        if (c->ev_call_copy[i]) (void)hipEventDestroy(c->ev_call_copy[i]);
     }
     if (c->main_idle) (void)hipEventDestroy(c->main_idle);
     if (c->err_host) (void)hipHostFree(c->err_host);
+    if (c->mail) (void)hipHostFree(c->mail);
     if (c->prep_stream) (void)hipStreamDestroy(c->prep_stream);
     for (auto &b : c->dbg) release(b);
     for (auto &e : c->ev)
@@ -1287,6 +1347,8 @@ int fk_get_option(fk_ctx *c, const char *name, int64_t *value) {
     else if (n == "oom_replays") *value = c->oom_replays;
     else if (n == "comm_timeout_ms") *value = effective_comm_timeout_ms(c);
     else if (n == "rows_chunk_games") *value = c->rows_chunk_games;
+    else if (n == "rows_async") *value = c->rows_async;
+    else if (n == "rows_event") *value = c->last_rows_event;
     else return fail(c, FK_ERR_ARG, "fk_get_option: unknown option %s", name);
     return FK_OK;
 }
@@ -1308,6 +1370,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "lean") c->lean = (int32_t)value;
     else if (n == "state_store") c->gs = (int32_t)value;
     else if (n == "rows_chunk_games") c->rows_chunk_games = std::max<int64_t>(value, 1);
+    else if (n == "rows_async") c->rows_async = value != 0;
     else if (n == "resident_tally") {
         c->resident = value != 0;
         c->acc_n = 0; // the next tournament call starts a fresh accumulator
@@ -1344,6 +1407,13 @@ int fk_tournament_run_columns(fk_ctx *c, const fk_strategy *strategies, int32_t 
                                            max_rounds, ov, n_ov, tally, columns, nullptr, nullptr);
     c->columns_ids = nullptr;
     return rc;
+}
+
+int fk_rows_wait(fk_ctx *c, int32_t slot) {
+    if (!c || slot < 0 || slot > 1) return FK_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev_call_copy[slot]));
+    return FK_OK;
 }
 
 size_t fk_row_columns_bytes(int32_t k, int32_t games_per_shuffle) {
@@ -1506,6 +1576,8 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
     HIPCHK(c, hipSetDevice(c->device));
     c->timing = fk_timing{};
     c->pending.clear();
+    c->letters.clear(); // (a failed call may have left some)
+    c->mail_used = 0;
 
     const uint64_t n_sh_total = shuffle_end - shuffle_begin;
     const uint32_t gps = (uint32_t)(S / k);
@@ -1663,7 +1735,8 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
         }
         rc = upload_overrides(c, dov);
         if (rc) return rc;
-        const int rb = (int)((done / chunk_sh) & 1u);
+        // the device row buffers alternate over chunks — and, in async mode, over calls: a one-chunk call's row kernel then has not to wait for the previous call's copy
+        const int rb = (int)((done / chunk_sh + (c->rows_async ? c->rows_calls : 0u)) & 1u);
         DevBuf &row_buf = rb ? c->rows_alt : c->rows;
         if (rows) {
             if ((size_t)n_sh * rows_per_shuffle > row_buf.cap) HIPCHK(c, hipStreamSynchronize(c->copy_stream)); // growing: no copy may be reading it
@@ -1843,14 +1916,21 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
             HIPCHK(c, hipEventRecord(c->ev_copy[rb], c->copy_stream));
         }
     }
-    if (rows) HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    if (rows && c->rows_async) { // the caller waits (fk_rows_wait): the next call's game kernel may run beside this call's last copy
+        c->last_rows_event = (int32_t)(c->rows_calls & 1u);
+        HIPCHK(c, hipEventRecord(c->ev_call_copy[c->last_rows_event], c->copy_stream));
+        ++c->rows_calls;
+    } else if (rows) {
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    }
     const uint32_t n_rows = (uint32_t)(n_batches * (uint64_t)S);
     hipLaunchKernelGGL(fk_finalize_tally, dim3((n_rows + 255u) / 256u), dim3(256), 0, c->stream,
                        static_cast<unsigned long long *>(c->tally.p), n_rows, (uint32_t)S, shuffles_per_batch, n_sh_total, 1u);
     HIPCHK(c, hipGetLastError());
     c->last_tally_bytes = tally_bytes; // (fk_tournament_run_stats adds it to the resident accumulator once the call has succeeded)
     HIPCHK(c, hipEventRecord(t1, c->stream));
-    HIPCHK(c, hipMemcpyAsync(tally, c->tally.p, tally_bytes, hipMemcpyDeviceToHost, c->stream));
+    rc = post_d2h(c, tally, c->tally.p, tally_bytes);
+    if (rc) return rc;
     if (seat_stats) HIPCHK(c, hipMemcpyAsync(seat_stats, c->stats.p, stats_bytes, hipMemcpyDeviceToHost, c->stream));
     if (seat_ratios) HIPCHK(c, hipMemcpyAsync(seat_ratios, c->ratios.p, ratio_bytes, hipMemcpyDeviceToHost, c->stream));
     if (lag) {
@@ -1860,6 +1940,7 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
         HIPCHK(c, hipMemcpyAsync(lag->tail, static_cast<uint8_t *>(c->lag_edge.p) + edge_bytes, edge_bytes, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    deliver_mail(c);
     if (deferred) {
         rc = report_device_error(c, c->err_host, deferred_base, "tournament");
         const int rc_t = finish_timers(c);
@@ -1886,6 +1967,8 @@ int fk_play_games(fk_ctx *c, const fk_coord *coords, int64_t n_games, const fk_s
     HIPCHK(c, hipSetDevice(c->device));
     c->timing = fk_timing{};
     c->pending.clear();
+    c->letters.clear(); // (a failed call may have left some)
+    c->mail_used = 0;
     if (n_games == 0) return FK_OK;
     int rc = upload_strategies(c, table, S);
     if (rc) return rc;
@@ -1974,6 +2057,8 @@ static int h2h_run_blocks_impl(fk_ctx *c, fk_h2h_block *blocks, int64_t n_blocks
     HIPCHK(c, hipSetDevice(c->device));
     c->timing = fk_timing{};
     c->pending.clear();
+    c->letters.clear(); // (a failed call may have left some)
+    c->mail_used = 0;
     if (n_blocks == 0) return FK_OK;
     std::vector<fk_strategy> table((size_t)n_blocks * 2);
     std::vector<uint64_t> stop((size_t)n_blocks);
@@ -2557,14 +2642,18 @@ int fk_game_seeds(fk_ctx *c, uint32_t purpose, uint64_t root_seed, uint64_t k, u
         return fail(c, FK_ERR_ARG, "bad arguments");
     if (n_shuffles == 0) return FK_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    c->letters.clear();
+    c->mail_used = 0;
     const size_t n = (size_t)n_shuffles * games_per_shuffle;
     int rc = ensure(c, c->dbg[5], n * 4);
     if (rc) return rc;
     hipLaunchKernelGGL(fk_game_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, seed_prefix(purpose, root_seed, k),
                        shuffle_begin, (uint32_t)n_shuffles, games_per_shuffle, static_cast<uint32_t *>(c->dbg[5].p));
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(seed32, c->dbg[5].p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    rc = post_d2h(c, seed32, c->dbg[5].p, n * 4);
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    deliver_mail(c);
     return FK_OK;
 }
 

@@ -47,6 +47,7 @@ from .workload_planner import TournamentWorkloadPlan, WorkloadCapExceeded, plan_
 
 LOGGER = logging.getLogger(__name__)
 MAX_GAMES_PER_LAUNCH = 200_000_000  # checkpoint cadence on the GPU: a launch group is at most this many games
+ROWS_ASYNC = os.environ.get("FK_ROWS_ASYNC", "1") != "0"  # (A/B switch: the images' last copy awaited by the shard job / by the engine call)
 ROWS_GROUP_BYTES = int(os.environ.get("FK_ROWS_GROUP_MB", "256")) << 20  # rows mode: a launch group's column images (one of two page-locked buffers; group i is written while i + 1 plays)
 ROW_WRITER_THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))  # row-shard writer PROCESSES (rows mode)
 
@@ -101,6 +102,16 @@ def _helper_thread():
 
 
 _SHARD_THREAD = None
+
+
+def _write_group_shards(eng, rows_event, row_dir, tasks, columns, game_seeds, game_profile_sha256, **kwargs):
+    """One launch group's shard job (on the shard thread): wait for the group's column images to be on the host — ``rows_event`` names the
+    engine's completion event of an ``async_rows`` call — then frame and publish the files."""
+    from . import tournament as rt
+
+    if rows_event is not None:
+        eng.rows_wait(rows_event)
+    return rt.write_row_shards_from_columns(row_dir, tasks, columns, game_seeds, game_profile_sha256, **kwargs)
 
 
 def _shard_thread():
@@ -809,9 +820,12 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                       pinned_rows = None
                       pinned_rows = eng.pinned_empty(need, row_dtype(k))
                   extra["rows_out"] = pinned_rows
+              # the images' last copy to the host is awaited by the shard job, not here: the next launch group's games run beside it
+              async_rows = use_columns and pinned_rows is not None and hasattr(eng, "rows_wait") and ROWS_ASYNC
               if use_columns:
                   res = eng.tournament_columns(table, k, cfg.sim.seed, lo, hi, ids, shuffles_per_batch=spb if per_batch else hi - lo,
-                                               target_score=target, max_rounds=max_rounds, overrides=ov, columns_out=pinned_rows)
+                                               target_score=target, max_rounds=max_rounds, overrides=ov, columns_out=pinned_rows,
+                                               **({"async_rows": True} if async_rows else {}))
               elif rng_lags:
                   res = eng.tournament_lags(table, k, cfg.sim.seed, lo, hi, rng_lags, shuffles_per_batch=spb if per_batch else hi - lo,
                                             target_score=target, max_rounds=max_rounds, overrides=ov)
@@ -838,8 +852,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                           seeds102 = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=cfg.sim.seed, k=k,
                                                               shuffle_index=np.repeat(np.arange(lo, hi, dtype=np.uint64), gps),
                                                               game_index=np.tile(np.arange(gps, dtype=np.uint64), hi - lo), dtype=np.uint32)
-                      shard_job = _shard_thread().submit(rt.write_row_shards_from_columns, row_dir, tasks, res["columns"], seeds102, sha,
-                                                         threads=ROW_WRITER_THREADS, sidecar=shard_sidecar)
+                      shard_job = _shard_thread().submit(_write_group_shards, eng, res.get("rows_event") if async_rows else None, row_dir, tasks,
+                                                         res["columns"], seeds102, sha, threads=ROW_WRITER_THREADS, sidecar=shard_sidecar)
                       if getattr(eng, "_pinned_columns", None) is not None and pinned_rows is not None:
                           eng._pinned_columns["jobs"][slot] = shard_job
                   else:

@@ -213,3 +213,49 @@ def test_column_images_of_the_kernel_equal_the_rows_of_the_same_launch(tmp_path,
         got = pq.read_table(tmp_path / f"rows_42_{k}p_{sh[i]:012d}.parquet")
         assert got.equals(want.slice(i * gps, gps)), (k, i)
     assert int(res["byte_length"].min()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [2, 5, 12])
+def test_async_rows_calls_deliver_the_same_images(k):
+    """Option ``rows_async`` (`farkle run`, rows mode): four launch groups back to back into two page-locked buffers, each awaited with
+    ``fk_rows_wait`` only after the NEXT call has been made — images and tallies equal those of the waiting form, also with several chunks
+    per call and with the calls' chunk count odd (the device row buffers alternate over chunks and calls)."""
+    from farkle_ii_amd.backend import row_columns_bytes
+    from farkle_ii_amd.engine import get_engine, set_engine
+    from farkle_ii_amd.strategies import generate_strategy_grid, pack_strategies, prepare_public_helper_strategies
+
+    set_engine(None)
+    eng = get_engine()
+    table = pack_strategies(prepare_public_helper_strategies(generate_strategy_grid()[0]))
+    ids = np.arange(len(table), dtype=np.int32)
+    gps = len(table) // k
+    stride = row_columns_bytes(k, gps)
+    groups = [(0, 9), (9, 18), (18, 21), (21, 30)]
+    want = [eng.tournament_columns(table, k, 7, lo, hi, ids) for lo, hi in groups]
+    defined = ((4 + 13 * k) * 4 + 2 + k) * gps
+    for chunk_games in (4_000_000, 3 * gps):  # one chunk per call / three (the 3-shuffle group: one)
+        eng.set_option("rows_chunk_games", chunk_games)
+        try:
+            pins = [eng.pinned_empty(9 * stride, np.uint8) for _ in range(2)]
+            waiting: list = []
+            got = []
+            for g, (lo, hi) in enumerate(groups):
+                res = eng.tournament_columns(table, k, 7, lo, hi, ids, columns_out=pins[g & 1], async_rows=True)
+                assert res["rows_event"] in (0, 1)
+                if waiting:  # the previous group: awaited after this call was made, copied out before its buffer is used again
+                    prev, ev = waiting.pop()
+                    eng.rows_wait(ev)
+                    got.append((prev["tally"].copy(), prev["columns"].copy()))
+                waiting.append((res, res["rows_event"]))
+            prev, ev = waiting.pop()
+            eng.rows_wait(ev)
+            got.append((prev["tally"].copy(), prev["columns"].copy()))
+        finally:
+            eng.set_option("rows_chunk_games", 4_000_000)
+        assert eng.get_option("rows_async") == 0  # the option is the call's, not the engine's
+        for (tally, columns), w in zip(got, want):
+            assert np.array_equal(tally, w["tally"])
+            assert np.array_equal(columns[:, :defined], w["columns"][:, :defined])
+    with pytest.raises(RuntimeError):
+        eng.rows_wait(2)
