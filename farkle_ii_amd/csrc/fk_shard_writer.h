@@ -231,7 +231,7 @@ struct Sink {
     void binary(const void *p, size_t n) { varint(n); raw(p, n); }
 };
 enum { T_I32 = 5, T_I64 = 6, T_BINARY = 8, T_LIST = 9, T_STRUCT = 12 };
-enum { ENC_PLAIN = 0, ENC_RLE = 3, ENC_RLE_DICTIONARY = 8 };
+enum { ENC_PLAIN = 0, ENC_RLE = 3, ENC_DELTA_BINARY_PACKED = 5, ENC_RLE_DICTIONARY = 8 };
 enum { PT_BOOLEAN = 0, PT_INT32 = 1, PT_INT64 = 2, PT_BYTE_ARRAY = 6 };
 
 static void page_header(Sink &s, bool dictionary, uint32_t payload, uint32_t num_values, int encoding) {
@@ -272,8 +272,61 @@ struct BitPacker {
 
 struct ColumnMeta { // what the footer records of a column chunk
     int64_t num_values, total_size, data_page_offset, dictionary_page_offset; // dictionary_page_offset < 0: none
-    bool dictionary;
+    bool dictionary, delta;
 };
+
+// ---- DELTA_BINARY_PACKED (Parquet encoding 5) of int32 values ----
+// Header: block size (128 values), miniblocks per block (4), value count, first value; then per block of 128 deltas: the smallest delta,
+// four miniblock bit widths, and each miniblock's 32 (delta - smallest) values bit-packed LSB-first.  The widths used here are 0, 8, 16
+// and 32 — whole bytes, so "bit-packing" is a narrowing store — which already brings the counters of a row shard (farkles, rolls, turns,
+// ranks: < 256) to one byte each and points and strategy ids to two: about a third of PLAIN's bytes to hash and to write.
+// Arithmetic wraps modulo 2^32 on both sides (the reader adds the same way), so every int32 sequence round-trips.
+static inline uint32_t zigzag32(int32_t v) { return ((uint32_t)v << 1) ^ (uint32_t)(v >> 31); }
+
+#define FK_DELTA_BODY                                                                                                                   \
+    uint8_t head[24];                                                                                                                   \
+    size_t h = 0;                                                                                                                       \
+    auto varint = [&](uint64_t x) { while (x >= 0x80) { head[h++] = (uint8_t)(x | 0x80); x >>= 7; } head[h++] = (uint8_t)x; };          \
+    varint(128); varint(4); varint(n); varint(zigzag32(n ? v[0] : 0));                                                                  \
+    out.insert(out.end(), head, head + h);                                                                                              \
+    const uint32_t n_deltas = n ? n - 1 : 0;                                                                                            \
+    for (uint32_t first = 0; first < n_deltas; first += 128) {                                                                          \
+        const uint32_t cnt = n_deltas - first < 128 ? n_deltas - first : 128;                                                           \
+        const int32_t *src = v + first;                                                                                                 \
+        int32_t d[128];                                                                                                                 \
+        uint32_t a[128];                                                                                                                \
+        for (uint32_t j = 0; j < cnt; ++j) d[j] = (int32_t)((uint32_t)src[j + 1] - (uint32_t)src[j]);                                   \
+        int32_t mn = d[0];                                                                                                              \
+        for (uint32_t j = 1; j < cnt; ++j) mn = d[j] < mn ? d[j] : mn;                                                                  \
+        for (uint32_t j = 0; j < cnt; ++j) a[j] = (uint32_t)d[j] - (uint32_t)mn;                                                        \
+        for (uint32_t j = cnt; j < 128; ++j) a[j] = 0;                                                                                  \
+        uint8_t block[5 + 4 + 512];                                                                                                     \
+        size_t b = 0;                                                                                                                   \
+        for (uint32_t x = zigzag32(mn);; x >>= 7) { if (x >= 0x80) block[b++] = (uint8_t)(x | 0x80); else { block[b++] = (uint8_t)x; break; } } \
+        uint8_t *widths = block + b;                                                                                                    \
+        b += 4;                                                                                                                         \
+        for (uint32_t m = 0; m < 4; ++m) {                                                                                              \
+            const uint32_t *am = a + 32 * m;                                                                                            \
+            if (32 * m >= cnt) { widths[m] = 0; continue; }                                                                             \
+            uint32_t any = 0;                                                                                                           \
+            for (int j = 0; j < 32; ++j) any |= am[j];                                                                                  \
+            if (any == 0) widths[m] = 0;                                                                                                \
+            else if (any < 0x100u) { widths[m] = 8; for (int j = 0; j < 32; ++j) block[b + j] = (uint8_t)am[j]; b += 32; }              \
+            else if (any < 0x10000u) { widths[m] = 16; uint16_t t[32]; for (int j = 0; j < 32; ++j) t[j] = (uint16_t)am[j]; std::memcpy(block + b, t, 64); b += 64; } \
+            else { widths[m] = 32; std::memcpy(block + b, am, 128); b += 128; }                                                         \
+        }                                                                                                                               \
+        out.insert(out.end(), block, block + b);                                                                                        \
+    }
+
+__attribute__((target("avx2"))) static void delta_pack_int32_avx2(std::vector<uint8_t> &out, const int32_t *v, uint32_t n) { FK_DELTA_BODY }
+static void delta_pack_int32_base(std::vector<uint8_t> &out, const int32_t *v, uint32_t n) { FK_DELTA_BODY }
+#undef FK_DELTA_BODY
+
+// appends the encoding of v[0 .. n) to `out`
+static void delta_pack_int32(std::vector<uint8_t> &out, const int32_t *v, uint32_t n) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    (avx2 ? delta_pack_int32_avx2 : delta_pack_int32_base)(out, v, n);
+}
 
 struct Job {
     int32_t k, gps, n_shuffles, threads, atomic;
@@ -306,7 +359,8 @@ static inline int index_width(int k) { int w = 1; while ((1 << w) < k) ++w; retu
 struct ShardBuilder {
     const Job &job;
     Sink file;
-    std::vector<uint8_t> tmp, hit_bits, def_bits, rep_lv, def_lv2, idx;
+    std::vector<uint8_t> tmp, hit_bits, def_bits, rep_lv, def_lv2, idx, enc;
+    std::vector<int32_t> packed;
     std::vector<ColumnMeta> meta;
     std::vector<std::vector<std::string>> paths;
     std::vector<uint8_t> iota_plain;      // game_index: the same PLAIN payload in every shard
@@ -340,6 +394,7 @@ struct ShardBuilder {
     void begin_column(bool dictionary) {
         ColumnMeta m{};
         m.dictionary = dictionary;
+        m.delta = false;
         m.dictionary_page_offset = dictionary ? (int64_t)file.size() : -1;
         m.data_page_offset = (int64_t)file.size();
         m.total_size = (int64_t)file.size(); // start; turned into a size by end_column
@@ -390,20 +445,23 @@ struct ShardBuilder {
     void boolean_plain(const std::vector<uint8_t> &bits, uint32_t n_values) {
         plain_required(bits.data(), (n_values + 7) / 8, n_values);
     }
-    void nullable_int32(const int32_t *dense, const uint8_t *status, uint32_t n, uint32_t n_valid) {
-        begin_column(false);
-        const size_t payload = hybrid_bitpacked_size(n, 1, true) + (size_t)n_valid * 4;
-        page_header(file, false, (uint32_t)payload, n, ENC_PLAIN);
-        hybrid_bitpacked(file, def_bits.data(), def_bits.size(), n, 1, true);
-        if (n_valid == n) file.raw(dense, (size_t)n * 4);
+    // int32 columns of a row shard: DELTA_BINARY_PACKED (see delta_pack_int32).  `status` != null: rows with status[g] != 0 are null.
+    void delta_int32(const int32_t *dense, const uint8_t *status, uint32_t n, uint32_t n_valid) {
+        enc.clear();
+        if (!status || n_valid == n) delta_pack_int32(enc, dense, n);
         else {
-            uint32_t run = 0; // copy the runs between null rows
-            for (uint32_t g = 0; g <= n; ++g) {
-                if (g < n && !status[g]) { ++run; continue; }
-                if (run) file.raw(dense + (g - run), (size_t)run * 4);
-                run = 0;
-            }
+            packed.resize(n_valid);
+            uint32_t at = 0;
+            for (uint32_t g = 0; g < n; ++g)
+                if (!status[g]) packed[at++] = dense[g];
+            delta_pack_int32(enc, packed.data(), n_valid);
         }
+        begin_column(false);
+        meta.back().delta = true;
+        const size_t payload = (status ? hybrid_bitpacked_size(n, 1, true) : 0) + enc.size();
+        page_header(file, false, (uint32_t)payload, n, ENC_DELTA_BINARY_PACKED);
+        if (status) hybrid_bitpacked(file, def_bits.data(), def_bits.size(), n, 1, true);
+        file.raw(enc.data(), enc.size());
         end_column(n);
     }
     void status_column(uint32_t n) { // termination_status: dictionary {completed, safety_limit}, index = the hit bit
@@ -484,28 +542,27 @@ struct ShardBuilder {
         constant(&root, 8, n);                 // root_seed
         constant(&kk, 4, n);                   // k
         constant(&sh, 8, n);                   // shuffle_index
-        plain_required(iota_plain.data(), iota_plain.size(), n); // game_index
+        delta_int32(reinterpret_cast<const int32_t *>(iota_plain.data()), nullptr, n, n); // game_index
         constant(&batch, 4, n);                // deterministic_batch_id
         constant(&seed, 8, n);                 // shuffle_seed
         status_column(n);                      // termination_status
         boolean_plain(hit_bits, n);            // hit_safety_limit
         constant(&two, 4, n);                  // outcome_schema_version
         winner_seat_column(winner, status, n, n_valid);
-        nullable_int32(plane(0), status, n, n_valid); // winner_strategy
+        delta_int32(plane(0), status, n, n_valid); // winner_strategy
         tmp.resize((size_t)n * 8);             // game_seed: uint32 fingerprints as int64
         for (uint32_t g = 0; g < n; ++g) { const int64_t v = job.game_seed[(size_t)i * n + g]; std::memcpy(&tmp[(size_t)g * 8], &v, 8); }
         plain_required(tmp.data(), tmp.size(), n);
         constant(&two, 4, n);                  // rng_scheme_version
         constant(&ns, 4, n);                   // rng_purpose_namespace
         seat_ranks_column(order, status, n, n_valid);
-        nullable_int32(plane(1), status, n, n_valid); // winning_score
-        nullable_int32(plane(2), status, n, n_valid); // victory_margin
-        plain_required(plane(3), (size_t)n * 4, n);   // n_rounds
+        delta_int32(plane(1), status, n, n_valid); // winning_score
+        delta_int32(plane(2), status, n, n_valid); // victory_margin
+        delta_int32(plane(3), nullptr, n, n);      // n_rounds
         for (int s = 0; s < k; ++s) {
             const size_t base = 4 + 13 * (size_t)s;
             for (int f = 0; f < 13; ++f) { // score farkles rolls highest_turn strategy rank loss_margin sf_uses sf_dice so_uses so_dice hot_dice n_turns
-                if (f == 5 || f == 6) nullable_int32(plane(base + f), status, n, n_valid);
-                else plain_required(plane(base + f), (size_t)n * 4, n);
+                delta_int32(plane(base + f), f == 5 || f == 6 ? status : nullptr, n, n_valid);
             }
             boolean_plain(hit_bits, n);        // P#_hit_max_rounds: every seat of a safety-limit game is flagged (engine.py:485-489)
         }
@@ -529,6 +586,7 @@ struct ShardBuilder {
             file.i32f(1, job.leaf_type[c]);             //       1: type
             file.field(1, T_LIST);                      //       2: encodings
             if (m.dictionary) { file.list(3, T_I32); file.zz(ENC_PLAIN); file.zz(ENC_RLE); file.zz(ENC_RLE_DICTIONARY); }
+            else if (m.delta) { file.list(2, T_I32); file.zz(ENC_RLE); file.zz(ENC_DELTA_BINARY_PACKED); }
             else { file.list(2, T_I32); file.zz(ENC_PLAIN); file.zz(ENC_RLE); }
             file.field(1, T_LIST);                      //       3: path_in_schema
             file.list((int)paths[c].size(), T_BINARY);
@@ -546,7 +604,7 @@ struct ShardBuilder {
         file.i64f(1, n_rows);                           //   3: num_rows
         file.put(0);
         file.raw(job.footer_kv, job.footer_kv_len);     // 5: key_value_metadata (ARROW:schema)
-        static const char created_by[] = "farkle_ii_amd shard writer version 6 (build 0)";
+        static const char created_by[] = "farkle_ii_amd shard writer version 7 (build 0)";
         file.field(1, T_BINARY);                        // 6: created_by
         file.binary(created_by, sizeof(created_by) - 1);
         file.raw(job.footer_orders, job.footer_orders_len); // 7: column_orders
@@ -641,13 +699,14 @@ static int write_shards(const Job &job, int64_t *byte_length, uint8_t *sha, uint
             }
         }
     };
+    const long long wall0 = timing ? now() : 0;
     std::vector<std::thread> pool;
     for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
     work();
     for (auto &t : pool) t.join();
     if (timing)
-        std::fprintf(stderr, "[fk shards] %d shards, %d threads: build %.1f ms, sha256 %.1f ms, write %.1f ms (thread time, summed)\n", job.n_shuffles, n_threads,
-                     ns_build.load() / 1e6, ns_sha.load() / 1e6, ns_write.load() / 1e6);
+        std::fprintf(stderr, "[fk shards] %d shards, %d threads: build %.1f ms, sha256 %.1f ms, write %.1f ms (thread time, summed); wall %.1f ms, began at %.1f ms\n",
+                     job.n_shuffles, n_threads, ns_build.load() / 1e6, ns_sha.load() / 1e6, ns_write.load() / 1e6, (now() - wall0) / 1e6, (wall0 % 100000000000ll) / 1e6);
     if (failed.load()) { error = first_error; return -1; }
     return 0;
 }

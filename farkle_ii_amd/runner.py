@@ -52,6 +52,16 @@ ROWS_GROUP_BYTES = int(os.environ.get("FK_ROWS_GROUP_MB", "256")) << 20  # rows 
 ROW_WRITER_THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))  # row-shard writer PROCESSES (rows mode)
 
 
+_TRACE: list | None = [] if os.environ.get("FK_RUN_TRACE") else None  # diagnostics: (time, thread, label) of a run's phases, dumped to stderr
+
+
+def _trace(label: str) -> None:
+    if _TRACE is not None:
+        import threading
+
+        _TRACE.append((time.perf_counter(), threading.current_thread().name, label))
+
+
 def _rank_world() -> tuple[int, int]:
     try:
         import torch.distributed as dist
@@ -109,9 +119,14 @@ def _write_group_shards(eng, rows_event, row_dir, tasks, columns, game_seeds, ga
     engine's completion event of an ``async_rows`` call — then frame and publish the files."""
     from . import tournament as rt
 
+    _trace("shard job begins")
     if rows_event is not None:
         eng.rows_wait(rows_event)
-    return rt.write_row_shards_from_columns(row_dir, tasks, columns, game_seeds, game_profile_sha256, **kwargs)
+    _trace("shard job: images here")
+    try:
+        return rt.write_row_shards_from_columns(row_dir, tasks, columns, game_seeds, game_profile_sha256, deferred_lines=True, **kwargs)
+    finally:
+        _trace("shard job ends")
 
 
 def _shard_thread():
@@ -123,6 +138,20 @@ def _shard_thread():
 
         _SHARD_THREAD = ThreadPoolExecutor(max_workers=1, thread_name_prefix="fk-shards")
     return _SHARD_THREAD
+
+
+_PIN_THREADS = None
+
+
+def _pin_threads():
+    """Two threads that page-lock the two column-image buffers of an engine (77 ms per 256 MB) while the run's first launches are prepared
+    and played, instead of in front of them."""
+    global _PIN_THREADS
+    if _PIN_THREADS is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _PIN_THREADS = ThreadPoolExecutor(max_workers=2, thread_name_prefix="fk-pin")
+    return _PIN_THREADS
 
 
 _PUBLISHER = None
@@ -623,6 +652,11 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
 
         image_bytes = row_columns_bytes(k, gps)
         group_batches = max(1, min(group_batches, ROWS_GROUP_BYTES // max(spb * image_bytes, 1)))
+        if pending and hasattr(eng, "pinned_empty") and getattr(eng, "_pinned_columns", None) is None:
+            # the engine's two page-locked image buffers, allocated beside what follows (the second one beside the first group's launch)
+            size = max(group_batches * spb * image_bytes, min(ROWS_GROUP_BYTES, plan.required_shuffles * image_bytes))
+            eng._pinned_columns = {"slots": [None, None], "jobs": [None, None], "turn": 0,
+                                   "allocating": [_pin_threads().submit(eng.pinned_empty, size, np.uint8) for _ in range(2)]}
     pinned_rows = None
     t_start = time.perf_counter()
     games_done = 0
@@ -667,6 +701,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         nonlocal total, games_done, lag_total, batches_since_save, last_save
         if shard_job is not None:
             row_records = shard_job.result()
+            if callable(row_records):  # the per-shard manifest lines: built here, not on the shard thread (its host threads would idle)
+                row_records = row_records()
         if rng_lags:  # this group's ranges in rank order (contiguous whole batches per rank), appended to the run's summary
             from .rng_lags import LagSummary
 
@@ -806,6 +842,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                               pass
                           pin["jobs"][slot] = None
                       slots = pin["slots"]
+                      if slots[slot] is None and pin.get("allocating") and pin["allocating"][slot] is not None:
+                          slots[slot], pin["allocating"][slot] = pin["allocating"][slot].result(), None
                       if slots[slot] is None or len(slots[slot]) < need:
                           slots[slot] = None
                           slots[slot] = eng.pinned_empty(max(need, min(ROWS_GROUP_BYTES, plan.required_shuffles * image_bytes)), np.uint8)
@@ -822,6 +860,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                   extra["rows_out"] = pinned_rows
               # the images' last copy to the host is awaited by the shard job, not here: the next launch group's games run beside it
               async_rows = use_columns and pinned_rows is not None and hasattr(eng, "rows_wait") and ROWS_ASYNC
+              _trace(f"{k}p group {n_groups}: engine call")
               if use_columns:
                   res = eng.tournament_columns(table, k, cfg.sim.seed, lo, hi, ids, shuffles_per_batch=spb if per_batch else hi - lo,
                                                target_score=target, max_rounds=max_rounds, overrides=ov, columns_out=pinned_rows,
@@ -832,6 +871,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
               else:
                   res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=spb if per_batch else hi - lo,
                                        target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows, **extra)
+              _trace(f"{k}p group {n_groups}: engine returned")
               first = lo // spb - b0 if per_batch else 0
               local[first:first + len(res["tally"])] = res["tally"]
               if local_stats is not None:
@@ -913,6 +953,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
     import pyarrow as pa
 
     rank, _ = _rank_world()
+    _trace(f"{n}p run_single_n")
     if _shared is not None:
         strategies, grid_size = _shared.strategies, len(_shared.strategies)
     else:
@@ -961,6 +1002,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
                 shared.verified.add(str(manifest_path))
         else:
             write_manifest = True
+    _trace(f"{n}p checked")
     sidecars = _Sidecars(cfg, n, [cfg.strategy_manifest_root_path(), plan_path], bool(cfg.sim.sidecars))
 
     def publish_inputs() -> None:
@@ -984,6 +1026,7 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         if d is not None:
             d.mkdir(parents=True, exist_ok=True)
     barrier()  # rank 0's --force cleanup and manifest write are complete before any rank plays or writes a shard
+    _trace(f"{n}p inputs published")
     run_tail: list = []  # rows mode under run_multi: the last launch group's shard writing + final checkpoint, deferred with the publishing tail
     try:
         result = run_tournament(cfg=cfg, n_players=n, strategies=strategies, plan=plan, checkpoint_path=ckpt_path,
@@ -999,9 +1042,12 @@ def run_single_n(cfg: AppConfig, n: int, strategies: list[ThresholdStrategy] | N
         return plan.required_games
 
     def publish() -> None:
+        _trace(f"{n}p tail begins")
         for tail in run_tail:
             tail()  # (fills `result`)
+        _trace(f"{n}p tail: run complete")
         _publish_results(cfg, n, strategies, plan, result, grid_size, ckpt_path, n_dir, sidecars, oracle_game_profile)
+        _trace(f"{n}p tail ends")
 
     if _defer_publish is not None:
         _defer_publish.append(publish)
@@ -1128,6 +1174,12 @@ def run_multi(cfg: AppConfig, player_counts: Sequence[int] | None = None, *, for
     overlap = _rank_world()[1] == 1
     shared = _SweepShared(strategies, background=overlap)  # manifest, packed table, ... once for the sweep (every count plays the same grid)
     in_flight = None
+    # The launching thread shares the interpreter with the publishing tail and the shard thread: with the default 5-ms switch interval
+    # every return from an engine call or a file operation could wait that long for the lock while a tail ran Python (measured on the
+    # production sweep with contract-v3 sidecars: 118 ms between two launches, the shard writer's threads idle for 0.3 of its 1.1 s).
+    switch_interval = sys.getswitchinterval()
+    if overlap:
+        sys.setswitchinterval(min(switch_interval, 2e-4))
     try:
         for n in valid:
             tail: list = []
@@ -1139,8 +1191,14 @@ def run_multi(cfg: AppConfig, player_counts: Sequence[int] | None = None, *, for
             if tail:
                 in_flight = _publisher_thread().submit(tail[0])
     finally:
+        sys.setswitchinterval(switch_interval)
         if in_flight is not None:
             in_flight.result()
+        if _TRACE:
+            t0 = _TRACE[0][0]
+            for t, thread, label in _TRACE:
+                print(f"[fk trace] {(t - t0) * 1e3:9.2f} ms  {thread:24s} {label}", file=sys.stderr)
+            _TRACE.clear()
     return results
 
 

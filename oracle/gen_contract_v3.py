@@ -77,6 +77,9 @@ def write_config(tmp: Path, name: str) -> Path:
 def reference_config(cfg_path: Path):
     cfg = ref_load_app_config(cfg_path, seed_list_len=1)
     cfg._code_identity = CodeIdentity(commit=COMMIT, policy="development_dirty", state="development_dirty", dirty_fingerprint_sha256=DIRTY)
+    # an execution-only budget (config.py:406-411; no identity reads it): this generator's own process — both packages, Arrow, pandas — sits
+    # at the default 768-MiB process-tree warning level, where the reference's scheduler stops admitting work
+    cfg.resources.process_tree_warning_threshold_mb = 1536
     return cfg
 
 
@@ -222,6 +225,8 @@ def reproduce_reference_documents(cfg_path: Path, root: Path) -> int:
 def main() -> None:
     tmp = Path(tempfile.mkdtemp(prefix="fk_contract_v3_"))
     try:
+        # (the reference's own run goes first: its memory guard counts this process's RSS — 768 MiB — and (a) + (b) leave Arrow pools behind)
+        ref_cfg_path, ref_root = reference_writes(tmp)
         cfg_path, root = standalone_run(tmp)
         standalone_docs = documents(root, digests_only=True)  # (what the reference accepts below; the texts that travel whole are its own)
         verdict = reference_judges(cfg_path, root)
@@ -229,7 +234,6 @@ def main() -> None:
               f"{len(verdict['load_immutable_manifest_sidecar'])} sealed manifests, simulation_is_complete {verdict['simulation_is_complete']}, "
               f"ingest snapshot {({k: v['shards'] for k, v in verdict['ingest_source_snapshot'].items()})} shards, "
               f"analyze ingest wrote {verdict['analyze_ingest']['rows']}")
-        ref_cfg_path, ref_root = reference_writes(tmp)
         reference_docs = documents(ref_root)
         checked = reproduce_reference_documents(ref_cfg_path, ref_root)
         print(f"(c) contract_v3 reproduces {checked} of the reference's own documents byte for byte")

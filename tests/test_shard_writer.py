@@ -115,6 +115,71 @@ def test_native_shards_read_back_as_the_reference_tables(tmp_path, k, gps, n_sh,
     assert md.num_rows == gps and md.num_row_groups == 1 and md.num_columns == 18 + 14 * k
 
 
+@pytest.mark.parametrize("k,gps", [(2, 1), (2, 2), (3, 33), (2, 129), (1, 130), (5, 257), (2, 2580)])
+def test_delta_packed_columns_round_trip_any_int32(tmp_path, k, gps):
+    """The int32 planes are written DELTA_BINARY_PACKED (blocks of 128 deltas, miniblock widths 0 / 8 / 16 / 32): every column reads back
+    as the plane — full-range values whose deltas wrap modulo 2^32, constant runs (width 0), lengths around the block and miniblock
+    edges, nullable columns with none, some or all rows null — in its logical type's range for the int8 / int16 columns."""
+    import pyarrow.parquet as pq
+
+    from farkle_ii_amd.backend import row_columns_bytes, write_row_shards_native
+    from farkle_ii_amd.rows import raw_simulation_schema_for
+
+    rng = np.random.default_rng(gps * 31 + k)
+    n_sh = 4
+    stride = row_columns_bytes(k, gps)
+    n_planes = 4 + 13 * k
+    names = ["winner_strategy", "winning_score", "victory_margin", "n_rounds"]
+    for s in range(1, k + 1):
+        names += [f"P{s}_{f}" for f in ("score", "farkles", "rolls", "highest_turn", "strategy", "rank", "loss_margin", "smart_five_uses",
+                                        "n_smart_five_dice", "smart_one_uses", "n_smart_one_dice", "hot_dice", "n_turns")]
+    schema = raw_simulation_schema_for(k)
+    limits = {"int8": 2**7, "int16": 2**15, "int32": 2**31}
+    images = np.zeros((n_sh, stride), dtype=np.uint8)
+    planes = np.zeros((n_sh, n_planes, gps), dtype=np.int32)
+    status = np.zeros((n_sh, gps), dtype=np.uint8)
+    for i in range(n_sh):
+        status[i] = (rng.random(gps) < (0.0, 0.3, 1.0, 0.05)[i])
+        for c, name in enumerate(names):
+            lim = limits[str(schema.field(name).type)]
+            kind = (c + i) % 5
+            if kind == 0:
+                v = rng.integers(-lim, lim, gps)                      # the whole range: deltas wrap
+            elif kind == 1:
+                v = np.full(gps, rng.integers(-lim, lim))              # constant: every width 0
+            elif kind == 2:
+                v = rng.integers(0, min(lim, 200), gps)                # a counter: 8-bit miniblocks
+            elif kind == 3:
+                v = np.where(rng.random(gps) < 0.5, lim - 1, -lim)     # the extremes, alternating at random
+            else:
+                v = np.cumsum(rng.integers(0, 3, gps)) % lim           # slowly rising; one jump in some miniblock
+                if gps > 40:
+                    v[37] = lim - 1
+            planes[i, c] = v
+        ni = n_planes * 4 * gps
+        images[i, :ni] = planes[i].view(np.uint8).reshape(-1)
+        images[i, ni:ni + gps] = status[i]
+        images[i, ni + gps:ni + 2 * gps] = 0                                            # winner seat
+        images[i, ni + 2 * gps:ni + 2 * gps + gps * k] = np.tile(np.arange(k, dtype=np.uint8), gps)  # rank order
+    sh = np.arange(n_sh, dtype=np.int64)
+    write_row_shards_native(tmp_path, k, 9, images, sh, sh + 1, sh.astype(np.int32), rng.integers(0, 2**32, gps * n_sh, dtype=np.uint64).astype(np.uint32),
+                            102, threads=2)
+    nullable = {"winner_strategy", "winning_score", "victory_margin"} | {f"P{s}_{f}" for s in range(1, k + 1) for f in ("rank", "loss_margin")}
+    for i in range(n_sh):
+        got = pq.read_table(tmp_path / f"rows_9_{k}p_{i:012d}.parquet")
+        assert got.schema.equals(schema, check_metadata=False)
+        assert got.column("game_index").to_pylist() == list(range(gps))
+        for c, name in enumerate(names):
+            col = got.column(name)
+            want = planes[i, c].tolist()
+            if name in nullable:
+                want = [None if st else v for v, st in zip(want, status[i].tolist())]
+            assert col.to_pylist() == want, (k, gps, i, name)
+        meta = pq.ParquetFile(tmp_path / f"rows_9_{k}p_{i:012d}.parquet").metadata.row_group(0)
+        encodings = {meta.column(j).path_in_schema: meta.column(j).encodings for j in range(meta.num_columns)}
+        assert "DELTA_BINARY_PACKED" in encodings["P1_score"] and "DELTA_BINARY_PACKED" in encodings["game_index"]
+
+
 def test_native_writer_publishes_the_contract_v3_sidecar(tmp_path):
     """The sidecar the library writes per shard = contract_v3.fill_shard_template(template, name, size, sha256): same text, same digest."""
     import yaml
