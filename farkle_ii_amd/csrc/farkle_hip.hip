@@ -27,6 +27,8 @@ using namespace fk;
 // ========================================================================================
 // host side
 // ========================================================================================
+constexpr int FK_ROWS_EVENTS = 4; // completion events of async rows calls: a ring (a caller may have this many calls' images not yet awaited)
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -143,8 +145,8 @@ struct fk_ctx {
     // option "rows_async": a rows call returns when its last copy to the host is QUEUED, not done; fk_rows_wait(slot) waits for it.  The caller
     // (farkle run: two page-locked buffers) then starts the next launch group at once, whose game kernel runs beside that copy.
     int32_t rows_async = 0;
-    hipEvent_t ev_call_copy[2] = {nullptr, nullptr};
-    uint32_t rows_calls = 0;      // rows calls made in async mode: call n records ev_call_copy[n & 1]
+    hipEvent_t ev_call_copy[FK_ROWS_EVENTS] = {};
+    uint32_t rows_calls = 0;      // rows calls made in async mode: call n records ev_call_copy[n % FK_ROWS_EVENTS]
     // The mailbox: page-locked host memory the device STORES small results into (tallies, error records, game seeds) while a rows DMA
     // is in flight — a copy-engine transfer would queue behind those 256 MB and the call would wait for them after all (measured: an
     // async call took exactly as long as a waiting one until its tally left this way).
@@ -1193,6 +1195,8 @@ int fk_init(int device_ordinal, fk_ctx **out) {
         for (int i = 0; i < 2; ++i) {
             ok = ok && hipEventCreateWithFlags(&c->ev_rows[i], hipEventDisableTiming) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming) == hipSuccess;
+        }
+        for (int i = 0; i < FK_ROWS_EVENTS; ++i) {
             ok = ok && hipEventCreateWithFlags(&c->ev_call_copy[i], hipEventDisableTiming) == hipSuccess;
         }
         ok = ok && hipEventCreateWithFlags(&c->main_idle, hipEventDisableTiming) == hipSuccess;
@@ -1262,8 +1266,9 @@ void fk_destroy(fk_ctx *c) {
     for (int i = 0; i < 2; ++i) {
         if (c->ev_rows[i]) (void)hipEventDestroy(c->ev_rows[i]);
         if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
-        if (c->ev_call_copy[i]) (void)hipEventDestroy(c->ev_call_copy[i]);
     }
+    for (auto &e : c->ev_call_copy)
+        if (e) (void)hipEventDestroy(e);
     if (c->main_idle) (void)hipEventDestroy(c->main_idle);
     if (c->err_host) (void)hipHostFree(c->err_host);
     if (c->mail) (void)hipHostFree(c->mail);
@@ -1410,7 +1415,7 @@ int fk_tournament_run_columns(fk_ctx *c, const fk_strategy *strategies, int32_t 
 }
 
 int fk_rows_wait(fk_ctx *c, int32_t slot) {
-    if (!c || slot < 0 || slot > 1) return FK_ERR_ARG;
+    if (!c || slot < 0 || slot >= FK_ROWS_EVENTS) return FK_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventSynchronize(c->ev_call_copy[slot]));
     return FK_OK;
@@ -1917,7 +1922,7 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
         }
     }
     if (rows && c->rows_async) { // the caller waits (fk_rows_wait): the next call's game kernel may run beside this call's last copy
-        c->last_rows_event = (int32_t)(c->rows_calls & 1u);
+        c->last_rows_event = (int32_t)(c->rows_calls % FK_ROWS_EVENTS);
         HIPCHK(c, hipEventRecord(c->ev_call_copy[c->last_rows_event], c->copy_stream));
         ++c->rows_calls;
     } else if (rows) {

@@ -48,6 +48,7 @@ from .workload_planner import TournamentWorkloadPlan, WorkloadCapExceeded, plan_
 LOGGER = logging.getLogger(__name__)
 MAX_GAMES_PER_LAUNCH = 200_000_000  # checkpoint cadence on the GPU: a launch group is at most this many games
 ROWS_ASYNC = os.environ.get("FK_ROWS_ASYNC", "1") != "0"  # (A/B switch: the images' last copy awaited by the shard job / by the engine call)
+ROWS_SLOTS = max(2, int(os.environ.get("FK_ROWS_SLOTS", "3")))  # rows mode: page-locked image buffers per engine = launch groups played ahead of the shard writer + 1
 ROWS_GROUP_BYTES = int(os.environ.get("FK_ROWS_GROUP_MB", "256")) << 20  # rows mode: a launch group's column images (one of two page-locked buffers; group i is written while i + 1 plays)
 ROW_WRITER_THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))  # row-shard writer PROCESSES (rows mode)
 
@@ -655,8 +656,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         if pending and hasattr(eng, "pinned_empty") and getattr(eng, "_pinned_columns", None) is None:
             # the engine's two page-locked image buffers, allocated beside what follows (the second one beside the first group's launch)
             size = max(group_batches * spb * image_bytes, min(ROWS_GROUP_BYTES, plan.required_shuffles * image_bytes))
-            eng._pinned_columns = {"slots": [None, None], "jobs": [None, None], "turn": 0,
-                                   "allocating": [_pin_threads().submit(eng.pinned_empty, size, np.uint8) for _ in range(2)]}
+            eng._pinned_columns = {"slots": [None] * ROWS_SLOTS, "jobs": [None] * ROWS_SLOTS, "turn": 0,
+                                   "allocating": [_pin_threads().submit(eng.pinned_empty, size, np.uint8) for _ in range(ROWS_SLOTS)]}
     pinned_rows = None
     t_start = time.perf_counter()
     games_done = 0
@@ -693,7 +694,13 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             _atomic_write_bytes(checkpoint_path, content)
 
     n_groups = 0
-    in_flight: dict | None = None  # the launch group whose shards are being written while the next one plays
+    from collections import deque
+
+    # the launch groups whose shards are being written while the next ones play, oldest first: one fewer than the engine has image buffers
+    # (three buffers: the engine may be two groups ahead of the writer — a group's engine and writer times differ by player count and by
+    # group, and with a single group in flight each waited for the other in turn: 0.15 s of a 0.74-s production sweep)
+    in_flight: deque = deque()
+    max_in_flight = 1
     batches_since_save, last_save = 0, time.perf_counter()
 
     def finish(b0, b1, lo, hi, j, local, local_stats, local_ratios, row_records, fragments, res, shard_job, per_batch) -> None:
@@ -832,9 +839,10 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                       # written — its tail deferred to the publisher thread, run_multi — while the next count's first group plays
                       pin = getattr(eng, "_pinned_columns", None)
                       if pin is None:
-                          pin = eng._pinned_columns = {"slots": [None, None], "jobs": [None, None], "turn": 0}
-                      slot = pin["turn"] & 1
+                          pin = eng._pinned_columns = {"slots": [None] * ROWS_SLOTS, "jobs": [None] * ROWS_SLOTS, "turn": 0}
+                      slot = pin["turn"] % len(pin["slots"])
                       pin["turn"] += 1
+                      max_in_flight = len(pin["slots"]) - 1
                       if pin["jobs"][slot] is not None:  # the shard job that read this buffer last
                           try:
                               pin["jobs"][slot].result()
@@ -902,31 +910,32 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
           group_args = dict(b0=b0, b1=b1, lo=lo, hi=hi, j=j, local=local, local_stats=local_stats, local_ratios=local_ratios,
                             row_records=row_records, fragments=fragments, res=res, shard_job=shard_job, per_batch=per_batch)
           n_groups += 1
-          if in_flight is not None:  # the previous group: its shards were written while this one played
-              previous, in_flight = in_flight, None
-              finish(**previous)
           if shard_job is not None:
-              in_flight = group_args
-          else:
+              in_flight.append(group_args)
+          while len(in_flight) > (max_in_flight if shard_job is not None else 0):  # earlier groups: their shards were written while later ones played
+              finish(**in_flight.popleft())
+          if shard_job is None:
               finish(**group_args)
           i = j + 1
-      if in_flight is not None and not (defer_tail is not None and world == 1):
-          previous, in_flight = in_flight, None
-          finish(**previous)
+      if not (defer_tail is not None and world == 1):
+          while in_flight:
+              finish(**in_flight.popleft())
     finally:
-        if in_flight is not None and in_flight["shard_job"] is not None and sys.exc_info()[0] is not None:
-            try:  # an error above: no writer thread may outlive the call
-                in_flight["shard_job"].result()
-            except Exception:  # noqa: BLE001 - the first error is the one that propagates
-                pass
+        if sys.exc_info()[0] is not None:
+            for group in in_flight:  # an error above: no writer thread may outlive the call
+                try:
+                    if group["shard_job"] is not None:
+                        group["shard_job"].result()
+                except Exception:  # noqa: BLE001 - the first error is the one that propagates
+                    pass
     result = {"shard_identities": shard_identities, "checkpoint_written": checkpoint_written}
-    last_group, in_flight = in_flight, None
+    last_groups, in_flight = list(in_flight), deque()
 
     def complete() -> dict:
-        """The run's tail: the last launch group's shards (still being written when the tail is deferred), the final checkpoint, the
+        """The run's tail: the last launch groups' shards (still being written when the tail is deferred), the final checkpoint, the
         manifests' sidecars."""
-        if last_group is not None:
-            finish(**last_group)
+        for group in last_groups:
+            finish(**group)
         if rank == 0:
             save(final=True)
             sidecars.write("checkpoint", checkpoint_path)
@@ -940,7 +949,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         result.update(tally=total, games=games_done, seconds=time.perf_counter() - t_start, lag_summary=lag_total)
         return result
 
-    if last_group is not None:  # (only with defer_tail, one process): the caller runs it — run_multi on its publisher thread, under the next count
+    if last_groups:  # (only with defer_tail, one process): the caller runs it — run_multi on its publisher thread, under the next count
         defer_tail.append(complete)
         return result
     return complete()

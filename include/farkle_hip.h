@@ -192,7 +192,8 @@ int fk_tournament_run_columns(fk_ctx *ctx, const fk_strategy *strategies, int32_
                               int64_t *tally, const int32_t *strategy_ids, void *columns);
 size_t fk_row_columns_bytes(int32_t k, int32_t games_per_shuffle);
 /* Option "rows_async" = 1: a call that delivers rows (AoS or column images) returns when its last device-to-host copy is QUEUED; the
- * buffer may be read after fk_rows_wait(ctx, slot) with slot = fk_get_option("rows_event") read right after that call (0 / 1, alternating).
+ * buffer may be read after fk_rows_wait(ctx, slot) with slot = fk_get_option("rows_event") read right after that call (a ring of 4:
+ * at most four calls' images may be outstanding).
  * The next call's game kernel then runs beside the copy (a caller with two destination buffers: `farkle run`, rows mode). */
 int fk_rows_wait(fk_ctx *ctx, int32_t slot);
 

@@ -163,7 +163,15 @@ class Engine:
         """fk_tournament_run_columns from the oracle's ROWS: the per-shuffle column images, restated with NumPy."""
         res = self.tournament(table, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=shuffles_per_batch,
                               target_score=target_score, max_rounds=max_rounds, overrides=overrides, want_rows=True)
-        return {"tally": res["tally"], "columns": column_images(res["rows"], k, np.asarray(strategy_ids, dtype=np.int32), len(table) // k)}
+        images = column_images(res["rows"], k, np.asarray(strategy_ids, dtype=np.int32), len(table) // k)
+        if columns_out is not None:  # the caller's buffer (farkle run: a ring of image buffers, reused while earlier groups are still written)
+            out = columns_out.reshape(-1)[:images.size].reshape(images.shape)
+            out[...] = images
+            images = out
+        return {"tally": res["tally"], "columns": images}
+
+    def pinned_empty(self, n: int, dtype) -> np.ndarray:
+        return np.full(int(n), 0xA5, dtype=dtype)  # (stale bytes of an earlier group, never zeros)
 
     def tournament_lags(self, table, k, root_seed, shuffle_begin, shuffle_end, lags, shuffles_per_batch=None, target_score=10_000,
                         max_rounds=200, overrides=None) -> dict:

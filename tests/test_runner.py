@@ -938,3 +938,39 @@ def test_a_sweep_over_player_counts_writes_what_the_single_count_runs_write(engi
     for k in (2, 4, 8):
         a, b = tmp_path / "sweep_seed_7" / f"{k}_players", tmp_path / f"single{k}_seed_7" / f"{k}_players"
         assert pickle.loads((a / f"{k}p_checkpoint.pkl").read_bytes()) == pickle.loads((b / f"{k}p_checkpoint.pkl").read_bytes())
+
+
+def test_rows_sweep_with_groups_in_flight_writes_the_same_files(engine, tmp_path, monkeypatch):
+    """Rows mode keeps up to ROWS_SLOTS - 1 launch groups' shards in flight (a ring of image buffers per engine, reused across player
+    counts; the last groups of a count are finished by the publishing tail under the next count): cut into one-batch launch groups,
+    the sweep writes byte for byte the shards, manifests and checkpoints of the run that plays each count in a single group."""
+    import hashlib
+    import pickle
+
+    from farkle_ii_amd import runner
+    from farkle_ii_amd.cli import main
+
+    def cfg(name: str) -> Path:
+        path = _tiny_config(tmp_path, '  row_dir: "rows"\n')
+        text = path.read_text().replace("n_players_list: [2]", "n_players_list: [2, 4, 8]").replace(str(tmp_path / "out"), str(tmp_path / name))
+        out = tmp_path / f"{name}.yaml"
+        out.write_text(text)
+        return out
+
+    main(["--config", str(cfg("whole")), "--log-level", "WARNING", "run", "--metrics"])
+    monkeypatch.setattr(runner, "ROWS_GROUP_BYTES", 1)  # a launch group = one deterministic batch: several per count, three buffers in turn
+    calls: list[int] = []
+    real = engine.tournament_columns
+    monkeypatch.setattr(engine, "tournament_columns", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1], raising=False)
+    main(["--config", str(cfg("cut")), "--log-level", "WARNING", "run", "--metrics"])
+    assert len(calls) >= 3 * 3  # (at least three groups per player count: the ring went round)
+    a, b = tmp_path / "whole_seed_7", tmp_path / "cut_seed_7"
+    shards = sorted(p.relative_to(a) for p in a.rglob("rows_*.parquet"))
+    assert len(shards) > 9 and shards == sorted(p.relative_to(b) for p in b.rglob("rows_*.parquet"))
+    for rel in shards:
+        assert hashlib.sha256((a / rel).read_bytes()).digest() == hashlib.sha256((b / rel).read_bytes()).digest(), rel
+    for k in (2, 4, 8):
+        la, lb = ((root / f"{k}_players" / f"{k}p_rows" / "manifest.jsonl").read_text().splitlines() for root in (a, b))
+        strip = lambda lines: [{key: v for key, v in __import__("json").loads(line).items() if key != "pid"} for line in lines]  # noqa: E731
+        assert strip(la) == strip(lb) and len(la) == len(set(la))
+        assert pickle.loads((a / f"{k}_players" / f"{k}p_checkpoint.pkl").read_bytes()) == pickle.loads((b / f"{k}_players" / f"{k}p_checkpoint.pkl").read_bytes())

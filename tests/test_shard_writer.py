@@ -307,7 +307,7 @@ def test_async_rows_calls_deliver_the_same_images(k):
             got = []
             for g, (lo, hi) in enumerate(groups):
                 res = eng.tournament_columns(table, k, 7, lo, hi, ids, columns_out=pins[g & 1], async_rows=True)
-                assert res["rows_event"] in (0, 1)
+                assert res["rows_event"] == g % 4 or res["rows_event"] in range(4)
                 if waiting:  # the previous group: awaited after this call was made, copied out before its buffer is used again
                     prev, ev = waiting.pop()
                     eng.rows_wait(ev)
@@ -323,4 +323,4 @@ def test_async_rows_calls_deliver_the_same_images(k):
             assert np.array_equal(tally, w["tally"])
             assert np.array_equal(columns[:, :defined], w["columns"][:, :defined])
     with pytest.raises(RuntimeError):
-        eng.rows_wait(2)
+        eng.rows_wait(4)
