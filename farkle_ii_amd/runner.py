@@ -654,10 +654,13 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         image_bytes = row_columns_bytes(k, gps)
         group_batches = max(1, min(group_batches, ROWS_GROUP_BYTES // max(spb * image_bytes, 1)))
         if pending and hasattr(eng, "pinned_empty") and getattr(eng, "_pinned_columns", None) is None:
-            # the engine's two page-locked image buffers, allocated beside what follows (the second one beside the first group's launch)
+            # the engine's page-locked image buffers, allocated beside what follows: two at once (the second one is ready when the first
+            # group's launch returns), the others after the engine's first call — page-locking beside that call, which creates the
+            # device workspace, made it take 120 ms instead of 55
             size = max(group_batches * spb * image_bytes, min(ROWS_GROUP_BYTES, plan.required_shuffles * image_bytes))
-            eng._pinned_columns = {"slots": [None] * ROWS_SLOTS, "jobs": [None] * ROWS_SLOTS, "turn": 0,
-                                   "allocating": [_pin_threads().submit(eng.pinned_empty, size, np.uint8) for _ in range(ROWS_SLOTS)]}
+            eng._pinned_columns = {"slots": [None] * ROWS_SLOTS, "jobs": [None] * ROWS_SLOTS, "turn": 0, "late": size,
+                                   "allocating": [_pin_threads().submit(eng.pinned_empty, size, np.uint8) if i < 2 else None
+                                                  for i in range(ROWS_SLOTS)]}
     pinned_rows = None
     t_start = time.perf_counter()
     games_done = 0
@@ -840,8 +843,14 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                       pin = getattr(eng, "_pinned_columns", None)
                       if pin is None:
                           pin = eng._pinned_columns = {"slots": [None] * ROWS_SLOTS, "jobs": [None] * ROWS_SLOTS, "turn": 0}
-                      slot = pin["turn"] % len(pin["slots"])
-                      pin["turn"] += 1
+                      for _ in pin["slots"]:  # the next buffer of the ring that exists (one still being page-locked is passed over)
+                          slot = pin["turn"] % len(pin["slots"])
+                          pin["turn"] += 1
+                          waiting = pin.get("allocating", [None] * len(pin["slots"]))[slot]
+                          if pin["slots"][slot] is not None or (waiting is not None and (waiting.done() or pin["turn"] <= 2)):
+                              break
+                          if waiting is None and not pin.get("late"):
+                              break  # (no allocation was started ahead: made below)
                       max_in_flight = len(pin["slots"]) - 1
                       if pin["jobs"][slot] is not None:  # the shard job that read this buffer last
                           try:
@@ -880,6 +889,11 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                   res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=spb if per_batch else hi - lo,
                                        target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows, **extra)
               _trace(f"{k}p group {n_groups}: engine returned")
+              if use_columns and getattr(eng, "_pinned_columns", None) and eng._pinned_columns.get("late"):
+                  late, eng._pinned_columns["late"] = eng._pinned_columns["late"], None
+                  for i, started in enumerate(eng._pinned_columns["allocating"]):
+                      if started is None and eng._pinned_columns["slots"][i] is None:
+                          eng._pinned_columns["allocating"][i] = _pin_threads().submit(eng.pinned_empty, late, np.uint8)
               first = lo // spb - b0 if per_batch else 0
               local[first:first + len(res["tally"])] = res["tally"]
               if local_stats is not None:
