@@ -158,6 +158,15 @@ def write_row_shards_native(row_dir, k: int, root_seed: int, columns: np.ndarray
     """``fk_write_row_shards``: the row-shard files of ``columns`` (``[n_shuffles][stride]`` column images) in ``row_dir``, written by
     ``threads`` host threads of the library.  Returns ``byte_length`` int64 ``[n]``, ``sha256`` uint8 ``[n][32]`` and — with a contract-v3
     ``sidecar`` template (``contract_v3.SimulationContract.shard_template``) — ``sidecar_sha256``."""
+    return prepare_row_shards_native(row_dir, k, root_seed, columns, shuffle_index, shuffle_seed, batch_id, game_seeds, rng_purpose_namespace,
+                                     threads=threads, atomic=atomic, sidecar=sidecar)()
+
+
+def prepare_row_shards_native(row_dir, k: int, root_seed: int, columns: np.ndarray, shuffle_index, shuffle_seed, batch_id, game_seeds,
+                              rng_purpose_namespace: int, *, threads: int = 1, atomic: bool = True, sidecar: dict | None = None):
+    """``write_row_shards_native`` in two steps: the job is checked and laid out here; the returned callable makes the one library call
+    (``columns`` may be filled in between: `farkle run` hands the callable to its shard thread, which then holds the interpreter lock
+    for a few bytecodes per launch group)."""
     from .parquet_template import shard_footer_template
 
     lib = load_library()
@@ -191,10 +200,16 @@ def write_row_shards_native(row_dir, k: int, root_seed: int, columns: np.ndarray
     sha = np.zeros((n, 32), dtype=np.uint8)
     err = C.create_string_buffer(512)
     lib.fk_write_row_shards.restype = C.c_int
-    rc = lib.fk_write_row_shards(C.byref(job), _p(sizes), _p(sha), _p(side_sha), err, C.c_size_t(len(err)))
-    if rc != 0:
-        raise OSError(f"fk_write_row_shards failed ({rc}): {err.value.decode('utf-8', 'replace')}")
-    return {"byte_length": sizes, "sha256": sha, "sidecar_sha256": side_sha}
+    keep = (columns, sh, seeds, batch, gs, leaf_type, leaf_paths, tpl, sidecar)  # what the job points into
+
+    def run() -> dict:
+        rc = lib.fk_write_row_shards(C.byref(job), _p(sizes), _p(sha), _p(side_sha), err, C.c_size_t(len(err)))
+        if rc != 0:
+            raise OSError(f"fk_write_row_shards failed ({rc}): {err.value.decode('utf-8', 'replace')}")
+        return {"byte_length": sizes, "sha256": sha, "sidecar_sha256": side_sha}
+
+    run.keep = keep  # (alive as long as the callable is)
+    return run
 
 
 def make_overrides(items) -> np.ndarray:

@@ -115,17 +115,15 @@ def _helper_thread():
 _SHARD_THREAD = None
 
 
-def _write_group_shards(eng, rows_event, row_dir, tasks, columns, game_seeds, game_profile_sha256, **kwargs):
+def _write_group_shards(eng, rows_event, write):
     """One launch group's shard job (on the shard thread): wait for the group's column images to be on the host — ``rows_event`` names the
-    engine's completion event of an ``async_rows`` call — then frame and publish the files."""
-    from . import tournament as rt
-
+    engine's completion event of an ``async_rows`` call — then frame and publish the files (``write``: the prepared library call)."""
     _trace("shard job begins")
     if rows_event is not None:
         eng.rows_wait(rows_event)
     _trace("shard job: images here")
     try:
-        return rt.write_row_shards_from_columns(row_dir, tasks, columns, game_seeds, game_profile_sha256, deferred_lines=True, **kwargs)
+        return write()
     finally:
         _trace("shard job ends")
 
@@ -914,8 +912,9 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                           seeds102 = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=cfg.sim.seed, k=k,
                                                               shuffle_index=np.repeat(np.arange(lo, hi, dtype=np.uint64), gps),
                                                               game_index=np.tile(np.arange(gps, dtype=np.uint64), hi - lo), dtype=np.uint32)
-                      shard_job = _shard_thread().submit(_write_group_shards, eng, res.get("rows_event") if async_rows else None, row_dir, tasks,
-                                                         res["columns"], seeds102, sha, threads=ROW_WRITER_THREADS, sidecar=shard_sidecar)
+                      write = rt.write_row_shards_from_columns(row_dir, tasks, res["columns"], seeds102, sha, threads=ROW_WRITER_THREADS,
+                                                               sidecar=shard_sidecar, deferred_lines=True, deferred_write=True)
+                      shard_job = _shard_thread().submit(_write_group_shards, eng, res.get("rows_event") if async_rows else None, write)
                       if getattr(eng, "_pinned_columns", None) is not None and pinned_rows is not None:
                           eng._pinned_columns["jobs"][slot] = shard_job
                   else:
@@ -1191,12 +1190,17 @@ def run_multi(cfg: AppConfig, player_counts: Sequence[int] | None = None, *, for
     strategies, grid_size = _resolve_strategies(cfg, None)
     valid, _ = _filter_player_counts(counts, grid_size)
     results: dict[int, int] = {}
-    # A player count's publishing tail (summary tables, completion stamp: 10 - 20 ms of Python on the 5 160-strategy grid) runs on its own
-    # thread under the NEXT player count's engine call (ctypes drops the GIL for its duration): one tail in flight, joined — and any error
-    # of it raised — before the next one starts and before the sweep returns.  Ranked runs publish in line (their barriers order the ranks).
+    # A player count's publishing tail (summary tables, completion stamp: 10 - 20 ms of Python on the 5 160-strategy grid; in rows mode
+    # also the count's last launch groups, whose shards are still being written) runs on its own thread under the NEXT player counts'
+    # engine calls (ctypes drops the GIL for their duration).  The tails run in order on that one thread; the launching thread joins a
+    # tail — and raises its error — once it is done or two later ones are queued behind it, and all of them before the sweep returns
+    # (it used to join the previous tail before queueing the next: 15 - 20 ms without a launch at every change of player count, the
+    # shard writer idle meanwhile).  Ranked runs publish in line (their barriers order the ranks).
     overlap = _rank_world()[1] == 1
     shared = _SweepShared(strategies, background=overlap)  # manifest, packed table, ... once for the sweep (every count plays the same grid)
-    in_flight = None
+    from collections import deque
+
+    tails: deque = deque()
     # The launching thread shares the interpreter with the publishing tail and the shard thread: with the default 5-ms switch interval
     # every return from an engine call or a file operation could wait that long for the lock while a tail ran Python (measured on the
     # production sweep with contract-v3 sidecars: 118 ms between two launches, the shard writer's threads idle for 0.3 of its 1.1 s).
@@ -1208,15 +1212,20 @@ def run_multi(cfg: AppConfig, player_counts: Sequence[int] | None = None, *, for
             tail: list = []
             results[n] = run_single_n(cfg, n, strategies=strategies, force=force, oracle_game_profile=oracle_game_profile, _shared=shared,
                                       _defer_publish=tail if overlap else None)
-            if in_flight is not None:
-                in_flight.result()
-                in_flight = None
+            while tails and (tails[0].done() or len(tails) > 2):
+                tails.popleft().result()
             if tail:
-                in_flight = _publisher_thread().submit(tail[0])
+                tails.append(_publisher_thread().submit(tail[0]))
     finally:
         sys.setswitchinterval(switch_interval)
-        if in_flight is not None:
-            in_flight.result()
+        first_error = None
+        while tails:  # every tail has run (or failed) before the sweep returns; the first error is the one raised
+            try:
+                tails.popleft().result()
+            except BaseException as exc:  # noqa: BLE001
+                first_error = first_error or exc
+        if first_error is not None and sys.exc_info()[0] is None:
+            raise first_error
         if _TRACE:
             t0 = _TRACE[0][0]
             for t, thread, label in _TRACE:

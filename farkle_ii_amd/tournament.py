@@ -513,31 +513,40 @@ def write_row_shards(row_dir: Path, tasks: "Sequence[ShuffleTask] | ShuffleRange
 
 def write_row_shards_from_columns(row_dir: Path, tasks: ShuffleRange, columns: np.ndarray, game_seeds: np.ndarray,
                                   game_profile_sha256: str | None = None, *, threads: int = 1, sidecar: Mapping[str, Any] | None = None,
-                                  atomic: bool = True, deferred_lines: bool = False):
+                                  atomic: bool = True, deferred_lines: bool = False, deferred_write: bool = False):
     """The row shards of ``tasks`` from per-shuffle COLUMN IMAGES (``Engine.tournament_columns``): the files are framed by the library's
     own Parquet writer on ``threads`` host threads (``fk_write_row_shards``, csrc/fk_shard_writer.h) — the same tables and Arrow schema as
     ``write_row_shards`` writes through Arrow (run_tournament.py:530-558), without the AoS -> Arrow conversion and Arrow's per-column
     encoder set-up.  ``sidecar``: a contract-v3 shard template (the library writes each shard's sidecar too).  Returns
     ``(shuffle_index, manifest line, shard bytes, shard sha256)`` tuples in task order, as ``write_row_shards(as_lines=True)`` does —
     ``deferred_lines``: a zero-argument callable that builds them (the files are written on return; a caller that runs this on a writer
-    thread keeps the per-shard Python off it: ~4 ms per 1 000 shards during which its host threads would idle)."""
+    thread keeps the per-shard Python off it: ~4 ms per 1 000 shards during which its host threads would idle); ``deferred_write``: a
+    zero-argument callable that WRITES (and returns what this function would have) — the job is checked and laid out here, ``columns``
+    may be filled in between."""
     import os
 
-    from .backend import write_row_shards_native
+    from .backend import prepare_row_shards_native
 
     n = len(tasks)
     if n == 0:
-        return []
+        empty = (lambda: []) if deferred_lines else []
+        return (lambda: empty) if deferred_write else empty
     row_dir.mkdir(parents=True, exist_ok=True)
     k, root = tasks.k, tasks.root_seed
     gps = np.asarray(game_seeds).size // n
     v3 = sidecar is not None and "body" in sidecar
-    res = write_row_shards_native(row_dir, k, root, columns, tasks.shuffle_index, tasks.shuffle_seed, tasks.deterministic_batch_id, game_seeds,
-                                  int(urandom.RandomPurpose.TOURNAMENT_GAME), threads=threads, atomic=atomic, sidecar=sidecar if v3 else None)
-    def lines() -> list:
-        return _shard_manifest_lines(res, tasks, n, gps, root, k, game_profile_sha256, sidecar, v3, row_dir)
+    job = prepare_row_shards_native(row_dir, k, root, columns, tasks.shuffle_index, tasks.shuffle_seed, tasks.deterministic_batch_id, game_seeds,
+                                    int(urandom.RandomPurpose.TOURNAMENT_GAME), threads=threads, atomic=atomic, sidecar=sidecar if v3 else None)
 
-    return lines if deferred_lines else lines()
+    def write():
+        res = job()
+
+        def lines() -> list:
+            return _shard_manifest_lines(res, tasks, n, gps, root, k, game_profile_sha256, sidecar, v3, row_dir)
+
+        return lines if deferred_lines else lines()
+
+    return write if deferred_write else write()
 
 
 def _shard_manifest_lines(res, tasks: ShuffleRange, n: int, gps: int, root: int, k: int, game_profile_sha256: str | None,

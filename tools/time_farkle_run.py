@@ -52,9 +52,20 @@ def timed_tournament_columns(*a, **kw):
 def timed_shard_columns(*a, **kw):
     t0 = time.perf_counter()
     try:
-        return real_wc(*a, **kw)
+        out = real_wc(*a, **kw)
     finally:
         acc["shard_s"] += time.perf_counter() - t0
+    if not kw.get("deferred_write"):
+        return out
+
+    def timed_write():  # (the prepared library call, made on the shard thread)
+        t1 = time.perf_counter()
+        try:
+            return out()
+        finally:
+            acc["shard_s"] += time.perf_counter() - t1
+
+    return timed_write
 
 eng.tournament_columns = timed_tournament_columns
 rt.write_row_shards_from_columns = timed_shard_columns
