@@ -48,6 +48,7 @@ from .workload_planner import TournamentWorkloadPlan, WorkloadCapExceeded, plan_
 LOGGER = logging.getLogger(__name__)
 MAX_GAMES_PER_LAUNCH = 200_000_000  # checkpoint cadence on the GPU: a launch group is at most this many games
 ROWS_ASYNC = os.environ.get("FK_ROWS_ASYNC", "1") != "0"  # (A/B switch: the images' last copy awaited by the shard job / by the engine call)
+ROWS_PIPELINE = os.environ.get("FK_ROWS_PIPELINE", "1") != "0"  # (A/B switch: a launch group's engine part on the launcher thread / in line)
 ROWS_SLOTS = max(2, int(os.environ.get("FK_ROWS_SLOTS", "3")))  # rows mode: page-locked image buffers per engine = launch groups played ahead of the shard writer + 1
 ROWS_GROUP_BYTES = int(os.environ.get("FK_ROWS_GROUP_MB", "256")) << 20  # rows mode: a launch group's column images (one of two page-locked buffers; group i is written while i + 1 plays)
 ROW_WRITER_THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))  # row-shard writer PROCESSES (rows mode)
@@ -137,6 +138,19 @@ def _shard_thread():
 
         _SHARD_THREAD = ThreadPoolExecutor(max_workers=1, thread_name_prefix="fk-shards")
     return _SHARD_THREAD
+
+
+_LAUNCHER = None
+
+
+def _launcher_thread():
+    """The thread the engine part of a launch group runs on in rows mode (run_tournament: `pipelined`)."""
+    global _LAUNCHER
+    if _LAUNCHER is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _LAUNCHER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="fk-launch")
+    return _LAUNCHER
 
 
 _PIN_THREADS = None
@@ -793,7 +807,93 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 batches_since_save, last_save = 0, time.perf_counter()
             LOGGER.info("Batches %d..%d done: %.3g games/s so far", b0, b1 - 1,
                         games_done / max(time.perf_counter() - t_start, 1e-9))
+    # A launch group passes three steps: the prelude (its shuffle range, buffers, image slot), the ENGINE PART (every device call, in
+    # order: hint, the games, the shuffle and game fingerprints) and what follows (shard job, manifest lines, checkpoint: `post`).  One
+    # process in rows mode runs the engine part on its own thread, so that group g + 1 plays while this thread lays out group g's shard
+    # job and finishes earlier groups: 5 ms of interpreter work per group that used to stand between two 7-ms launches (production
+    # sweep, 41 groups).  The engine is only ever entered from one thread at a time: this one between joining a group's engine part and
+    # submitting the next, the launcher in between.
+    pipelined = columns_mode and world == 1 and hasattr(eng, "rows_wait") and ROWS_PIPELINE
+
+    def engine_part(g: dict) -> dict:
+        lo, hi = g["lo"], g["hi"]
+        if g["hint"] is not None:
+            eng.hint_next(*g["hint"], need_state=want_rows)
+        batch_arg = spb if g["per_batch"] else hi - lo
+        _trace(f"{k}p group {g['index']}: engine call")
+        if g["use_columns"]:
+            res = eng.tournament_columns(table, k, cfg.sim.seed, lo, hi, ids, shuffles_per_batch=batch_arg, target_score=target,
+                                         max_rounds=max_rounds, overrides=ov, columns_out=g["pinned_rows"],
+                                         **({"async_rows": True} if g["async_rows"] else {}))
+        elif rng_lags:
+            res = eng.tournament_lags(table, k, cfg.sim.seed, lo, hi, rng_lags, shuffles_per_batch=batch_arg, target_score=target,
+                                      max_rounds=max_rounds, overrides=ov)
+        else:
+            res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=batch_arg, target_score=target, max_rounds=max_rounds,
+                                 overrides=ov, want_rows=want_rows, **g["extra"])
+        _trace(f"{k}p group {g['index']}: engine returned")
+        played = {"res": res, "shuffle_seeds": None, "seeds102": None}
+        if want_rows:
+            played["shuffle_seeds"] = _shuffle_seeds(eng, cfg.sim.seed, k, lo, hi)
+            if hasattr(eng, "game_seeds"):  # the rows' game_seed column, hashed on the device
+                played["seeds102"] = eng.game_seeds(int(urandom.RandomPurpose.TOURNAMENT_GAME), cfg.sim.seed, k, lo, hi, gps)
+            _trace("fingerprints here")
+        return played
+
+    def post(g: dict, played: dict | None) -> None:
+        nonlocal n_groups
+        b0, b1, lo, hi, per_batch = g["b0"], g["b1"], g["lo"], g["hi"], g["per_batch"]
+        local, local_stats, local_ratios, row_records = g["local"], g["local_stats"], g["local_ratios"], g["row_records"]
+        shard_job = res = None
+        if played is not None:
+            res = played["res"]
+            pin = getattr(eng, "_pinned_columns", None)
+            if g["use_columns"] and pin and pin.get("late"):
+                late, pin["late"] = pin["late"], None
+                for slot_i, started in enumerate(pin["allocating"]):
+                    if started is None and pin["slots"][slot_i] is None:
+                        pin["allocating"][slot_i] = _pin_threads().submit(eng.pinned_empty, late, np.uint8)
+            first = lo // spb - b0 if per_batch else 0
+            local[first:first + len(res["tally"])] = res["tally"]
+            if local_stats is not None:
+                local_stats[first:first + len(res["seat_stats"])] = res["seat_stats"]
+                local_ratios[first:first + len(res["seat_ratio_sums"])] = res["seat_ratio_sums"]
+            if want_rows:  # every rank writes the shards of its own shuffles; rank 0 appends the manifest lines
+                sh_index = np.arange(lo, hi, dtype=np.int64)  # the ShuffleTask identities (run_tournament.py:97-105), as arrays
+                tasks = rt.ShuffleRange(cfg.sim.seed, k, sh_index, played["shuffle_seeds"], sh_index // spb)
+                sha = oracle_game_profile.sha256 if oracle_game_profile else None
+                # one parquet file per shuffle is the reference's format: the host side of rows mode is file framing and file
+                # creation — by the library's writer threads from column images, or (AoS rows) Arrow in writer processes
+                seeds102 = played["seeds102"]
+                shard_sidecar = sidecars.template("row_shard", row_dir / "rows_template.parquet",
+                                                  schema=lambda: _stored_schema(raw_simulation_schema_for(k), **rt.SHARD_WRITER_OPTIONS))
+                _trace("sidecar template here")
+                if g["use_columns"]:
+                    if seeds102 is None:
+                        seeds102 = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=cfg.sim.seed, k=k,
+                                                            shuffle_index=np.repeat(np.arange(lo, hi, dtype=np.uint64), gps),
+                                                            game_index=np.tile(np.arange(gps, dtype=np.uint64), hi - lo), dtype=np.uint32)
+                    write = rt.write_row_shards_from_columns(row_dir, tasks, res["columns"], seeds102, sha, threads=ROW_WRITER_THREADS,
+                                                             sidecar=shard_sidecar, deferred_lines=True, deferred_write=True)
+                    _trace("shard job laid out")
+                    shard_job = _shard_thread().submit(_write_group_shards, eng, res.get("rows_event") if g["async_rows"] else None, write)
+                    if pin is not None and g["pinned_rows"] is not None:
+                        pin["jobs"][g["slot"]] = shard_job
+                else:
+                    row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
+                                                           game_seeds=seeds102, as_lines=True, sidecar=shard_sidecar))
+        group_args = dict(b0=b0, b1=b1, lo=lo, hi=hi, j=g["j"], local=local, local_stats=local_stats, local_ratios=local_ratios,
+                          row_records=row_records, fragments=g["fragments"], res=res, shard_job=shard_job, per_batch=per_batch)
+        n_groups += 1
+        if shard_job is not None:
+            in_flight.append(group_args)
+        while len(in_flight) > (max_in_flight if shard_job is not None else 0):  # earlier groups: their shards were written while later ones played
+            finish(**in_flight.popleft())
+        if shard_job is None:
+            finish(**group_args)
+
     i = 0
+    awaiting_post: tuple | None = None  # (pipelined) the group whose engine part has returned and whose `post` runs beside the next one's
     try:
       while i < len(pending):
           # contiguous run of pending batches, capped by the launch-group size
@@ -805,20 +905,20 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
           # Per-batch tallies are only needed for the metric chunk files; without them the group is one tally, which the
           # engine keeps in LDS when the table is small.
           per_batch = metric_chunk_dir is not None or all_player_dir is not None
-          local = np.zeros((b1 - b0 if per_batch else 1, S, 26), dtype=np.int64)
-          local_stats = np.zeros((b1 - b0, S, SEAT_STAT_COLS), dtype=np.int64) if all_player_dir is not None else None
-          local_ratios = np.zeros((b1 - b0, S, SEAT_RATIO_COLS), dtype=np.float64) if all_player_dir is not None else None
-          row_records: list[tuple] = []  # (shuffle index, manifest line, shard bytes, shard sha256)
-          shard_job = res = None
-          fragments = None
+          g: dict[str, Any] = dict(
+              index=n_groups + (1 if awaiting_post is not None else 0), b0=b0, b1=b1, lo=lo, hi=hi, j=j, per_batch=per_batch,
+              local=np.zeros((b1 - b0 if per_batch else 1, S, 26), dtype=np.int64),
+              local_stats=np.zeros((b1 - b0, S, SEAT_STAT_COLS), dtype=np.int64) if all_player_dir is not None else None,
+              local_ratios=np.zeros((b1 - b0, S, SEAT_RATIO_COLS), dtype=np.float64) if all_player_dir is not None else None,
+              row_records=[],  # (shuffle index, manifest line, shard bytes, shard sha256)
+              fragments=None, hint=None, use_columns=False, async_rows=False, pinned_rows=None, slot=None, extra={})
           if metric_chunk_dir is not None and rank == 0:
               # the shuffle fingerprints of the whole group in one vectorised pass (on the device), and their JSON text on the
               # helper thread while the group plays
               g_first, g_last = b0 * spb, min(b1 * spb, plan.required_shuffles)
               group_seeds = _shuffle_seeds(eng, cfg.sim.seed, k, g_first, g_last)
               bounds = [(b * spb, min((b + 1) * spb, plan.required_shuffles)) for b in range(b0, b1)]
-              fragments = _helper_thread().submit(_shuffle_list_fragments, group_seeds, g_first, spb, bounds)
-          use_columns = False
+              g["fragments"] = _helper_thread().submit(_shuffle_list_fragments, group_seeds, g_first, spb, bounds)
           if hi > lo:
               if j + 1 < len(pending) and hasattr(eng, "hint_next"):
                   # the launch group after this one (same table, k, root): prepared in the drain tail of this group's kernel
@@ -828,16 +928,17 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                   lo2, hi2 = shard_shuffle_range(pending[j + 1] * spb, min((pending[j2] + 1) * spb, plan.required_shuffles), rank, world,
                                                  batch_size=spb)
                   if hi2 > lo2:
-                      eng.hint_next(lo2, hi2, need_state=want_rows)
-              extra: dict[str, Any] = {"want_seat_stats": True} if all_player_dir is not None else {}
-              use_columns = columns_mode
-              if use_columns:
+                      g["hint"] = (lo2, hi2)
+              if all_player_dir is not None:
+                  g["extra"]["want_seat_stats"] = True
+              g["use_columns"] = columns_mode
+              if columns_mode:
                   need = (hi - lo) * image_bytes
                   if hasattr(eng, "pinned_empty"):
-                      # two page-locked buffers per ENGINE (kept for its life, grown when a launch group needs more: page-locking a gigabyte
-                      # takes ~0.25 s, and a sweep over eight player counts that asked for one per count spent 2.4 of its 3.5 s there)
-                      # the slots alternate over the ENGINE's launch groups (not this call's): the last group of a player count may still be
-                      # written — its tail deferred to the publisher thread, run_multi — while the next count's first group plays
+                      # page-locked image buffers per ENGINE (kept for its life, grown when a launch group needs more: page-locking a gigabyte
+                      # takes ~0.25 s, and a sweep over eight player counts that asked for one per count spent 2.4 of its 3.5 s there);
+                      # the ring turns over the ENGINE's launch groups (not this call's): the last groups of a player count may still be
+                      # written — their tail deferred to the publisher thread, run_multi — while the next count's first groups play
                       pin = getattr(eng, "_pinned_columns", None)
                       if pin is None:
                           pin = eng._pinned_columns = {"slots": [None] * ROWS_SLOTS, "jobs": [None] * ROWS_SLOTS, "turn": 0}
@@ -862,7 +963,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                       if slots[slot] is None or len(slots[slot]) < need:
                           slots[slot] = None
                           slots[slot] = eng.pinned_empty(max(need, min(ROWS_GROUP_BYTES, plan.required_shuffles * image_bytes)), np.uint8)
-                      pinned_rows = slots[slot]
+                      g["pinned_rows"], g["slot"] = slots[slot], slot
               elif want_rows and hasattr(eng, "pinned_empty"):
                   # rows land in a page-locked buffer (one per run, sized for the largest launch group): one DMA per chunk at PCIe
                   # rate, under the next chunk's game kernel
@@ -872,64 +973,30 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
 
                       pinned_rows = None
                       pinned_rows = eng.pinned_empty(need, row_dtype(k))
-                  extra["rows_out"] = pinned_rows
+                  g["extra"]["rows_out"] = pinned_rows
               # the images' last copy to the host is awaited by the shard job, not here: the next launch group's games run beside it
-              async_rows = use_columns and pinned_rows is not None and hasattr(eng, "rows_wait") and ROWS_ASYNC
-              _trace(f"{k}p group {n_groups}: engine call")
-              if use_columns:
-                  res = eng.tournament_columns(table, k, cfg.sim.seed, lo, hi, ids, shuffles_per_batch=spb if per_batch else hi - lo,
-                                               target_score=target, max_rounds=max_rounds, overrides=ov, columns_out=pinned_rows,
-                                               **({"async_rows": True} if async_rows else {}))
-              elif rng_lags:
-                  res = eng.tournament_lags(table, k, cfg.sim.seed, lo, hi, rng_lags, shuffles_per_batch=spb if per_batch else hi - lo,
-                                            target_score=target, max_rounds=max_rounds, overrides=ov)
+              g["async_rows"] = columns_mode and g["pinned_rows"] is not None and hasattr(eng, "rows_wait") and ROWS_ASYNC
+              if pipelined:
+                  engine_call = _launcher_thread().submit(engine_part, g)
+                  try:
+                      if awaiting_post is not None:
+                          previous, awaiting_post = awaiting_post, None
+                          post(*previous)
+                  except BaseException:
+                      try:
+                          engine_call.result()  # the engine is not left running; the error of `post` is the one raised
+                      except BaseException:  # noqa: BLE001
+                          pass
+                      raise
+                  awaiting_post = (g, engine_call.result())
               else:
-                  res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=spb if per_batch else hi - lo,
-                                       target_score=target, max_rounds=max_rounds, overrides=ov, want_rows=want_rows, **extra)
-              _trace(f"{k}p group {n_groups}: engine returned")
-              if use_columns and getattr(eng, "_pinned_columns", None) and eng._pinned_columns.get("late"):
-                  late, eng._pinned_columns["late"] = eng._pinned_columns["late"], None
-                  for i, started in enumerate(eng._pinned_columns["allocating"]):
-                      if started is None and eng._pinned_columns["slots"][i] is None:
-                          eng._pinned_columns["allocating"][i] = _pin_threads().submit(eng.pinned_empty, late, np.uint8)
-              first = lo // spb - b0 if per_batch else 0
-              local[first:first + len(res["tally"])] = res["tally"]
-              if local_stats is not None:
-                  local_stats[first:first + len(res["seat_stats"])] = res["seat_stats"]
-                  local_ratios[first:first + len(res["seat_ratio_sums"])] = res["seat_ratio_sums"]
-              if want_rows:  # every rank writes the shards of its own shuffles; rank 0 appends the manifest lines
-                  sh_index = np.arange(lo, hi, dtype=np.int64)  # the ShuffleTask identities (run_tournament.py:97-105), as arrays
-                  tasks = rt.ShuffleRange(cfg.sim.seed, k, sh_index, _shuffle_seeds(eng, cfg.sim.seed, k, lo, hi), sh_index // spb)
-                  sha = oracle_game_profile.sha256 if oracle_game_profile else None
-                  # one parquet file per shuffle is the reference's format: the host side of rows mode is Arrow encoding and
-                  # file creation — one vectorised conversion per 64 shuffles, shards and their manifest lines by writer processes
-                  seeds102 = (eng.game_seeds(int(urandom.RandomPurpose.TOURNAMENT_GAME), cfg.sim.seed, k, lo, hi, gps)
-                              if hasattr(eng, "game_seeds") else None)  # the rows' game_seed column, hashed on the device
-                  shard_sidecar = sidecars.template("row_shard", row_dir / "rows_template.parquet",
-                                                    schema=lambda: _stored_schema(raw_simulation_schema_for(k), **rt.SHARD_WRITER_OPTIONS))
-                  if use_columns:
-                      if seeds102 is None:
-                          seeds102 = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=cfg.sim.seed, k=k,
-                                                              shuffle_index=np.repeat(np.arange(lo, hi, dtype=np.uint64), gps),
-                                                              game_index=np.tile(np.arange(gps, dtype=np.uint64), hi - lo), dtype=np.uint32)
-                      write = rt.write_row_shards_from_columns(row_dir, tasks, res["columns"], seeds102, sha, threads=ROW_WRITER_THREADS,
-                                                               sidecar=shard_sidecar, deferred_lines=True, deferred_write=True)
-                      shard_job = _shard_thread().submit(_write_group_shards, eng, res.get("rows_event") if async_rows else None, write)
-                      if getattr(eng, "_pinned_columns", None) is not None and pinned_rows is not None:
-                          eng._pinned_columns["jobs"][slot] = shard_job
-                  else:
-                      row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
-                                                             game_seeds=seeds102, as_lines=True, sidecar=shard_sidecar))
-          group_args = dict(b0=b0, b1=b1, lo=lo, hi=hi, j=j, local=local, local_stats=local_stats, local_ratios=local_ratios,
-                            row_records=row_records, fragments=fragments, res=res, shard_job=shard_job, per_batch=per_batch)
-          n_groups += 1
-          if shard_job is not None:
-              in_flight.append(group_args)
-          while len(in_flight) > (max_in_flight if shard_job is not None else 0):  # earlier groups: their shards were written while later ones played
-              finish(**in_flight.popleft())
-          if shard_job is None:
-              finish(**group_args)
+                  post(g, engine_part(g))
+          else:
+              post(g, None)
           i = j + 1
+      if awaiting_post is not None:
+          previous, awaiting_post = awaiting_post, None
+          post(*previous)
       if not (defer_tail is not None and world == 1):
           while in_flight:
               finish(**in_flight.popleft())

@@ -159,7 +159,7 @@ class Engine:
                 "seat_ratio_sums": ratios}
 
     def tournament_columns(self, table, k, root_seed, shuffle_begin, shuffle_end, strategy_ids, shuffles_per_batch=None, target_score=10_000,
-                           max_rounds=200, overrides=None, columns_out=None) -> dict:
+                           max_rounds=200, overrides=None, columns_out=None, async_rows=False) -> dict:
         """fk_tournament_run_columns from the oracle's ROWS: the per-shuffle column images, restated with NumPy."""
         res = self.tournament(table, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=shuffles_per_batch,
                               target_score=target_score, max_rounds=max_rounds, overrides=overrides, want_rows=True)
@@ -168,7 +168,11 @@ class Engine:
             out = columns_out.reshape(-1)[:images.size].reshape(images.shape)
             out[...] = images
             images = out
-        return {"tally": res["tally"], "columns": images}
+        self._rows_calls = getattr(self, "_rows_calls", 0) + (1 if async_rows else 0)
+        return {"tally": res["tally"], "columns": images, "rows_event": (self._rows_calls - 1) % 4 if async_rows else None}
+
+    def rows_wait(self, slot: int) -> None:  # (the images are complete when tournament_columns returns; farkle run pipelines its groups
+        assert 0 <= slot < 4                 # through a launcher thread when the engine has this method)
 
     def pinned_empty(self, n: int, dtype) -> np.ndarray:
         return np.full(int(n), 0xA5, dtype=dtype)  # (stale bytes of an earlier group, never zeros)
