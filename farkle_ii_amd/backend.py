@@ -109,7 +109,7 @@ def build_library(force: bool = False, verbose: bool = False, variant: str | Non
 _EXPORTS = ["fk_init", "fk_destroy", "fk_last_error", "fk_get_device_info", "fk_get_timing", "fk_set_option",
             "fk_tournament_run", "fk_tournament_run_stats", "fk_tournament_run_all_player", "fk_tournament_run_lags", "fk_tournament_hint_next", "fk_play_games", "fk_h2h_run", "fk_h2h_run_blocks", "fk_coordinate_seeds", "fk_debug_score", "fk_debug_should_continue",
             "fk_debug_dice", "fk_debug_dice_state", "fk_debug_dice_keys", "fk_comm_unique_id", "fk_comm_init", "fk_reduce_tally", "fk_comm_destroy", "fk_tally_resident_reduce", "fk_comm_ranks", "fk_host_alloc", "fk_host_free", "fk_game_seeds",
-            "fk_tournament_run_columns", "fk_row_columns_bytes", "fk_write_row_shards", "fk_debug_sha256", "fk_get_option", "fk_debug_deadline_handshake", "fk_debug_hold_memory", "fk_rows_wait"]
+            "fk_tournament_run_columns", "fk_row_columns_bytes", "fk_write_row_shards", "fk_debug_sha256", "fk_get_option", "fk_debug_deadline_handshake", "fk_debug_hold_memory", "fk_rows_wait", "fk_tournament_run_columns_seeds"]
 _libs: dict = {}
 
 
@@ -332,10 +332,13 @@ class Engine:
 
     def tournament_columns(self, table: np.ndarray, k: int, root_seed: int, shuffle_begin: int, shuffle_end: int, strategy_ids,
                            shuffles_per_batch: int | None = None, target_score: int = 10_000, max_rounds: int = 200,
-                           overrides: np.ndarray | None = None, columns_out: np.ndarray | None = None, async_rows: bool = False) -> dict:
+                           overrides: np.ndarray | None = None, columns_out: np.ndarray | None = None, async_rows: bool = False,
+                           shuffle_seeds_out: np.ndarray | None = None, game_seeds_out: np.ndarray | None = None) -> dict:
         """``tournament`` with the rows as per-shuffle COLUMN IMAGES (``fk_tournament_run_columns``): ``columns`` uint8
         ``[n_shuffles][fk_row_columns_bytes(k, S / k)]`` — what ``write_row_shards_native`` frames as the row-shard Parquet files.
-        ``async_rows``: return when the last copy to the host is queued; read ``columns`` after ``rows_wait(result["rows_event"])``."""
+        ``async_rows``: return when the last copy to the host is queued; read ``columns`` after ``rows_wait(result["rows_event"])``.
+        ``shuffle_seeds_out`` uint32 ``[n_shuffles]`` / ``game_seeds_out`` uint32 ``[n_shuffles * S / k]``: also filled, complete on return
+        (``fk_tournament_run_columns_seeds``: the fingerprints a shard's manifest record and its game_seed column carry)."""
         table = np.ascontiguousarray(table, dtype=STRATEGY_DTYPE)
         S = len(table)
         ids = np.ascontiguousarray(strategy_ids, dtype=np.int32)
@@ -358,7 +361,11 @@ class Engine:
             if async_rows:
                 self.set_option("rows_async", 1)
             try:
-                self._run_columns(table, S, k, root_seed, shuffle_begin, shuffle_end, spb, target_score, max_rounds, ov, tally, ids, columns)
+                for name, arr, want in (("shuffle_seeds_out", shuffle_seeds_out, n_sh), ("game_seeds_out", game_seeds_out, n_sh * (S // k))):
+                    if arr is not None and (arr.dtype != np.uint32 or arr.size != want or not arr.flags["C_CONTIGUOUS"]):
+                        raise ValueError(f"{name} must be a contiguous uint32 array of {want} elements")
+                self._run_columns(table, S, k, root_seed, shuffle_begin, shuffle_end, spb, target_score, max_rounds, ov, tally, ids, columns,
+                                  shuffle_seeds_out, game_seeds_out)
                 if async_rows:
                     rows_event = self.get_option("rows_event")
             finally:
@@ -370,11 +377,16 @@ class Engine:
         """``fk_rows_wait``: the column images of the ``async_rows`` call that reported ``rows_event == slot`` are in the host buffer."""
         self._check(self._lib.fk_rows_wait(self._ctx, C.c_int32(slot)))
 
-    def _run_columns(self, table, S, k, root_seed, shuffle_begin, shuffle_end, spb, target_score, max_rounds, ov, tally, ids, columns) -> None:
-        if True:
-            self._check(self._lib.fk_tournament_run_columns(
-                self._ctx, _p(table), C.c_int32(S), C.c_int32(k), C.c_uint64(root_seed), C.c_uint64(shuffle_begin), C.c_uint64(shuffle_end),
-                C.c_uint32(spb), C.c_int32(target_score), C.c_int32(max_rounds), _p(ov), C.c_int32(len(ov)), _p(tally), _p(ids), _p(columns)))
+    columns_with_seeds = True  # (tournament_columns takes shuffle_seeds_out / game_seeds_out)
+
+    def _run_columns(self, table, S, k, root_seed, shuffle_begin, shuffle_end, spb, target_score, max_rounds, ov, tally, ids, columns,
+                     shuffle_seeds=None, game_seeds=None) -> None:
+        args = (self._ctx, _p(table), C.c_int32(S), C.c_int32(k), C.c_uint64(root_seed), C.c_uint64(shuffle_begin), C.c_uint64(shuffle_end),
+                C.c_uint32(spb), C.c_int32(target_score), C.c_int32(max_rounds), _p(ov), C.c_int32(len(ov)), _p(tally), _p(ids), _p(columns))
+        if shuffle_seeds is None and game_seeds is None:
+            self._check(self._lib.fk_tournament_run_columns(*args))
+        else:
+            self._check(self._lib.fk_tournament_run_columns_seeds(*args, _p(shuffle_seeds), _p(game_seeds)))
 
     def tournament_lags(self, table: np.ndarray, k: int, root_seed: int, shuffle_begin: int, shuffle_end: int, lags,
                         shuffles_per_batch: int | None = None, target_score: int = 10_000, max_rounds: int = 200,

@@ -139,6 +139,7 @@ struct fk_ctx {
     DevBuf rows_alt;
     // fk_tournament_run_columns: the rows buffer receives per-shuffle column images (fk_row_columns_kernel); the strategy ids they name
     const int32_t *columns_ids = nullptr;
+    uint32_t *want_shuffle_seeds = nullptr, *want_game_seeds = nullptr; // fk_tournament_run_columns_seeds: host destinations of this call
     DevBuf ids;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
@@ -700,6 +701,17 @@ int post_d2h(fk_ctx *c, void *dst, const void *src, size_t bytes) {
     }
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     return FK_OK;
+}
+
+// Room for `bytes` of letters before the first one is posted (a letter that does not fit goes by the copy engine — behind a rows DMA).
+void reserve_mail(fk_ctx *c, size_t bytes) {
+    if (!c->letters.empty() || bytes <= c->mail_cap || !rows_dma_pending(c)) return;
+    if (c->mail) (void)hipHostFree(c->mail);
+    c->mail = nullptr;
+    c->mail_cap = 0;
+    const size_t cap = std::max<size_t>((size_t)4 << 20, (bytes + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1));
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->mail), cap, hipHostMallocDefault) == hipSuccess) c->mail_cap = cap;
+    else (void)hipGetLastError();
 }
 
 void deliver_mail(fk_ctx *c) { // the main stream has been synchronised
@@ -1414,6 +1426,19 @@ int fk_tournament_run_columns(fk_ctx *c, const fk_strategy *strategies, int32_t 
     return rc;
 }
 
+int fk_tournament_run_columns_seeds(fk_ctx *c, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed, uint64_t shuffle_begin,
+                                    uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score, int32_t max_rounds,
+                                    const fk_override *ov, int32_t n_ov, int64_t *tally, const int32_t *strategy_ids, void *columns,
+                                    uint32_t *shuffle_seeds, uint32_t *game_seeds) {
+    if (!c) return FK_ERR_ARG;
+    c->want_shuffle_seeds = shuffle_seeds;
+    c->want_game_seeds = game_seeds;
+    const int rc = fk_tournament_run_columns(c, strategies, S, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch, target_score, max_rounds,
+                                             ov, n_ov, tally, strategy_ids, columns);
+    c->want_shuffle_seeds = c->want_game_seeds = nullptr;
+    return rc;
+}
+
 int fk_rows_wait(fk_ctx *c, int32_t slot) {
     if (!c || slot < 0 || slot >= FK_ROWS_EVENTS) return FK_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1934,8 +1959,33 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
     HIPCHK(c, hipGetLastError());
     c->last_tally_bytes = tally_bytes; // (fk_tournament_run_stats adds it to the resident accumulator once the call has succeeded)
     HIPCHK(c, hipEventRecord(t1, c->stream));
+    const size_t game_seed_bytes = c->want_game_seeds ? (size_t)n_sh_total * gps * 4 : 0, shuffle_seed_bytes = c->want_shuffle_seeds ? (size_t)n_sh_total * 4 : 0;
+    reserve_mail(c, tally_bytes + game_seed_bytes + shuffle_seed_bytes + 256);
     rc = post_d2h(c, tally, c->tally.p, tally_bytes);
     if (rc) return rc;
+    if (game_seed_bytes + shuffle_seed_bytes) {
+        // the fingerprints the row shards carry (game_seed column: ns 102, run_tournament.py:340-350) and their manifest names
+        // (shuffle_seed: ns 100 = the same coordinate with game_index 0): with the tally, one host round trip for the launch group
+        const size_t shuffle_at = (game_seed_bytes + 255u) & ~(size_t)255u;
+        rc = ensure(c, c->dbg[5], shuffle_at + shuffle_seed_bytes);
+        if (rc) return rc;
+        uint8_t *d_seeds = static_cast<uint8_t *>(c->dbg[5].p);
+        if (game_seed_bytes) {
+            const size_t n = (size_t)n_sh_total * gps;
+            hipLaunchKernelGGL(fk_game_seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, seed_prefix(102u /* TOURNAMENT_GAME */, root_seed, (uint64_t)k),
+                               shuffle_begin, (uint32_t)n_sh_total, gps, reinterpret_cast<uint32_t *>(d_seeds));
+            HIPCHK(c, hipGetLastError());
+            rc = post_d2h(c, c->want_game_seeds, d_seeds, game_seed_bytes);
+            if (rc) return rc;
+        }
+        if (shuffle_seed_bytes) {
+            hipLaunchKernelGGL(fk_game_seed_kernel, dim3((unsigned)((n_sh_total + 255) / 256)), dim3(256), 0, c->stream, seed_prefix(100u /* TOURNAMENT_SHUFFLE */, root_seed, (uint64_t)k),
+                               shuffle_begin, (uint32_t)n_sh_total, 1u, reinterpret_cast<uint32_t *>(d_seeds + shuffle_at));
+            HIPCHK(c, hipGetLastError());
+            rc = post_d2h(c, c->want_shuffle_seeds, d_seeds + shuffle_at, shuffle_seed_bytes);
+            if (rc) return rc;
+        }
+    }
     if (seat_stats) HIPCHK(c, hipMemcpyAsync(seat_stats, c->stats.p, stats_bytes, hipMemcpyDeviceToHost, c->stream));
     if (seat_ratios) HIPCHK(c, hipMemcpyAsync(seat_ratios, c->ratios.p, ratio_bytes, hipMemcpyDeviceToHost, c->stream));
     if (lag) {

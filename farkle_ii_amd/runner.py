@@ -822,9 +822,18 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         batch_arg = spb if g["per_batch"] else hi - lo
         _trace(f"{k}p group {g['index']}: engine call")
         if g["use_columns"]:
+            early = g["write"] is not None  # the shard job was laid out in the prelude, around buffers this call fills
             res = eng.tournament_columns(table, k, cfg.sim.seed, lo, hi, ids, shuffles_per_batch=batch_arg, target_score=target,
                                          max_rounds=max_rounds, overrides=ov, columns_out=g["pinned_rows"],
-                                         **({"async_rows": True} if g["async_rows"] else {}))
+                                         **({"async_rows": True} if g["async_rows"] else {}),
+                                         **({"shuffle_seeds_out": g["shuffle_seeds32"], "game_seeds_out": g["game_seeds"]} if early else {}))
+            if early:
+                _trace(f"{k}p group {g['index']}: engine returned")
+                g["tasks"].shuffle_seed[...] = g["shuffle_seeds32"]  # (int64 in the shard records)
+                shard_job = _shard_thread().submit(_write_group_shards, eng, res.get("rows_event") if g["async_rows"] else None, g["write"])
+                if g["slot"] is not None:
+                    eng._pinned_columns["jobs"][g["slot"]] = shard_job
+                return {"res": res, "shard_job": shard_job}
         elif rng_lags:
             res = eng.tournament_lags(table, k, cfg.sim.seed, lo, hi, rng_lags, shuffles_per_batch=batch_arg, target_score=target,
                                       max_rounds=max_rounds, overrides=ov)
@@ -832,7 +841,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             res = eng.tournament(table, k, cfg.sim.seed, lo, hi, shuffles_per_batch=batch_arg, target_score=target, max_rounds=max_rounds,
                                  overrides=ov, want_rows=want_rows, **g["extra"])
         _trace(f"{k}p group {g['index']}: engine returned")
-        played = {"res": res, "shuffle_seeds": None, "seeds102": None}
+        played = {"res": res, "shuffle_seeds": None, "seeds102": None, "shard_job": None}
         if want_rows:
             played["shuffle_seeds"] = _shuffle_seeds(eng, cfg.sim.seed, k, lo, hi)
             if hasattr(eng, "game_seeds"):  # the rows' game_seed column, hashed on the device
@@ -858,7 +867,9 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             if local_stats is not None:
                 local_stats[first:first + len(res["seat_stats"])] = res["seat_stats"]
                 local_ratios[first:first + len(res["seat_ratio_sums"])] = res["seat_ratio_sums"]
-            if want_rows:  # every rank writes the shards of its own shuffles; rank 0 appends the manifest lines
+            if played["shard_job"] is not None:  # (laid out in the prelude, submitted by the engine part)
+                shard_job = played["shard_job"]
+            elif want_rows:  # every rank writes the shards of its own shuffles; rank 0 appends the manifest lines
                 sh_index = np.arange(lo, hi, dtype=np.int64)  # the ShuffleTask identities (run_tournament.py:97-105), as arrays
                 tasks = rt.ShuffleRange(cfg.sim.seed, k, sh_index, played["shuffle_seeds"], sh_index // spb)
                 sha = oracle_game_profile.sha256 if oracle_game_profile else None
@@ -911,7 +922,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
               local_stats=np.zeros((b1 - b0, S, SEAT_STAT_COLS), dtype=np.int64) if all_player_dir is not None else None,
               local_ratios=np.zeros((b1 - b0, S, SEAT_RATIO_COLS), dtype=np.float64) if all_player_dir is not None else None,
               row_records=[],  # (shuffle index, manifest line, shard bytes, shard sha256)
-              fragments=None, hint=None, use_columns=False, async_rows=False, pinned_rows=None, slot=None, extra={})
+              fragments=None, hint=None, use_columns=False, async_rows=False, pinned_rows=None, slot=None, extra={}, write=None, tasks=None,
+              shuffle_seeds32=None, game_seeds=None)
           if metric_chunk_dir is not None and rank == 0:
               # the shuffle fingerprints of the whole group in one vectorised pass (on the device), and their JSON text on the
               # helper thread while the group plays
@@ -976,6 +988,24 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                   g["extra"]["rows_out"] = pinned_rows
               # the images' last copy to the host is awaited by the shard job, not here: the next launch group's games run beside it
               g["async_rows"] = columns_mode and g["pinned_rows"] is not None and hasattr(eng, "rows_wait") and ROWS_ASYNC
+              if columns_mode and getattr(eng, "columns_with_seeds", False):
+                  # The shard job of the group, laid out BEFORE it plays: around the image buffer and two fingerprint arrays the engine
+                  # call fills (fk_tournament_run_columns_seeds), so that the engine part hands it to the shard thread the moment the call
+                  # returns — between a launch and its shards' first byte there is then no interpreter work that a publishing tail
+                  # holding the lock could delay (measured at every change of player count: 10 + 3 ms, the writer's threads idle).
+                  n_sh = hi - lo
+                  sh_index = np.arange(lo, hi, dtype=np.int64)  # the ShuffleTask identities (run_tournament.py:97-105), as arrays
+                  g["shuffle_seeds32"], g["game_seeds"] = np.empty(n_sh, dtype=np.uint32), np.empty(n_sh * gps, dtype=np.uint32)
+                  g["tasks"] = rt.ShuffleRange(cfg.sim.seed, k, sh_index, np.zeros(n_sh, dtype=np.int64), sh_index // spb)
+                  if g["pinned_rows"] is None:  # (an engine without page-locked buffers: a plain one per group)
+                      g["pinned_rows"] = np.empty(n_sh * image_bytes, dtype=np.uint8)
+                  images = g["pinned_rows"].reshape(-1)[:n_sh * image_bytes].reshape(n_sh, image_bytes)
+                  shard_sidecar = sidecars.template("row_shard", row_dir / "rows_template.parquet",
+                                                    schema=lambda: _stored_schema(raw_simulation_schema_for(k), **rt.SHARD_WRITER_OPTIONS))
+                  g["write"] = rt.write_row_shards_from_columns(row_dir, g["tasks"], images, g["game_seeds"],
+                                                                oracle_game_profile.sha256 if oracle_game_profile else None,
+                                                                threads=ROW_WRITER_THREADS, sidecar=shard_sidecar, deferred_lines=True, deferred_write=True)
+                  _trace("shard job laid out")
               if pipelined:
                   engine_call = _launcher_thread().submit(engine_part, g)
                   try:

@@ -190,6 +190,14 @@ int fk_tournament_run_columns(fk_ctx *ctx, const fk_strategy *strategies, int32_
                               uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch,
                               int32_t target_score, int32_t max_rounds, const fk_override *ov, int32_t n_ov,
                               int64_t *tally, const int32_t *strategy_ids, void *columns);
+/* fk_tournament_run_columns that also delivers what a row shard carries besides the images: shuffle_seeds[n_shuffles] = the ns-100
+ * fingerprint of each shuffle (the shards' manifest records, run_tournament.py:97-105) and game_seeds[n_shuffles][S / k] = the ns-102
+ * fingerprint of each game (the game_seed column, run_tournament.py:340-350), as fk_game_seeds computes them; either may be null.
+ * Complete on return (not subject to "rows_async"). */
+int fk_tournament_run_columns_seeds(fk_ctx *ctx, const fk_strategy *strategies, int32_t S, int32_t k, uint64_t root_seed,
+                                    uint64_t shuffle_begin, uint64_t shuffle_end, uint32_t shuffles_per_batch, int32_t target_score,
+                                    int32_t max_rounds, const fk_override *overrides, int32_t n_overrides, int64_t *tally,
+                                    const int32_t *strategy_ids, void *columns, uint32_t *shuffle_seeds, uint32_t *game_seeds);
 size_t fk_row_columns_bytes(int32_t k, int32_t games_per_shuffle);
 /* Option "rows_async" = 1: a call that delivers rows (AoS or column images) returns when its last device-to-host copy is QUEUED; the
  * buffer may be read after fk_rows_wait(ctx, slot) with slot = fk_get_option("rows_event") read right after that call (a ring of 4:

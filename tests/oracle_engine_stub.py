@@ -159,7 +159,8 @@ class Engine:
                 "seat_ratio_sums": ratios}
 
     def tournament_columns(self, table, k, root_seed, shuffle_begin, shuffle_end, strategy_ids, shuffles_per_batch=None, target_score=10_000,
-                           max_rounds=200, overrides=None, columns_out=None, async_rows=False) -> dict:
+                           max_rounds=200, overrides=None, columns_out=None, async_rows=False, shuffle_seeds_out=None,
+                           game_seeds_out=None) -> dict:
         """fk_tournament_run_columns from the oracle's ROWS: the per-shuffle column images, restated with NumPy."""
         res = self.tournament(table, k, root_seed, shuffle_begin, shuffle_end, shuffles_per_batch=shuffles_per_batch,
                               target_score=target_score, max_rounds=max_rounds, overrides=overrides, want_rows=True)
@@ -168,8 +169,21 @@ class Engine:
             out = columns_out.reshape(-1)[:images.size].reshape(images.shape)
             out[...] = images
             images = out
+        from farkle_ii_amd import random as urandom
+
+        sh = np.arange(shuffle_begin, shuffle_end, dtype=np.uint64)
+        gps = len(table) // k
+        if shuffle_seeds_out is not None:  # the ns-100 / ns-102 fingerprints, with NumPy (farkle_ii_amd.random restates utils/random.py)
+            shuffle_seeds_out[...] = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_SHUFFLE, root_seed=root_seed, k=k, shuffle_index=sh,
+                                                              dtype=np.uint32)
+        if game_seeds_out is not None and len(sh):
+            game_seeds_out[...] = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=root_seed, k=k,
+                                                           shuffle_index=np.repeat(sh, gps), game_index=np.tile(np.arange(gps, dtype=np.uint64), len(sh)),
+                                                           dtype=np.uint32)
         self._rows_calls = getattr(self, "_rows_calls", 0) + (1 if async_rows else 0)
         return {"tally": res["tally"], "columns": images, "rows_event": (self._rows_calls - 1) % 4 if async_rows else None}
+
+    columns_with_seeds = True
 
     def rows_wait(self, slot: int) -> None:  # (the images are complete when tournament_columns returns; farkle run pipelines its groups
         assert 0 <= slot < 4                 # through a launcher thread when the engine has this method)

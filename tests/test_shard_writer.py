@@ -324,3 +324,27 @@ def test_async_rows_calls_deliver_the_same_images(k):
             assert np.array_equal(columns[:, :defined], w["columns"][:, :defined])
     with pytest.raises(RuntimeError):
         eng.rows_wait(4)
+    # fk_tournament_run_columns_seeds: the shards' fingerprints with the images, in the waiting and the async form, one and several chunks
+    from farkle_ii_amd import random as urandom
+    from farkle_ii_amd.backend import make_coords
+
+    lo, hi = 40, 49
+    want_sh = eng.coordinate_seeds(make_coords(int(urandom.RandomPurpose.TOURNAMENT_SHUFFLE), 7, k, np.arange(lo, hi, dtype=np.uint64)), want32=True)[0]
+    assert np.array_equal(want_sh, urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_SHUFFLE, root_seed=7, k=k,
+                                                            shuffle_index=np.arange(lo, hi, dtype=np.uint64), dtype=np.uint32))
+    want_games = eng.game_seeds(int(urandom.RandomPurpose.TOURNAMENT_GAME), 7, k, lo, hi, gps)
+    plain = eng.tournament_columns(table, k, 7, lo, hi, ids)
+    for async_rows, chunk_games in ((False, 4_000_000), (True, 4_000_000), (True, 2 * gps)):
+        eng.set_option("rows_chunk_games", chunk_games)
+        try:
+            sh_out, g_out = np.zeros(hi - lo, dtype=np.uint32), np.zeros((hi - lo) * gps, dtype=np.uint32)
+            res = eng.tournament_columns(table, k, 7, lo, hi, ids, columns_out=pins[0], async_rows=async_rows, shuffle_seeds_out=sh_out,
+                                         game_seeds_out=g_out)
+            assert np.array_equal(sh_out, want_sh) and np.array_equal(g_out.reshape(hi - lo, gps), want_games)  # complete on return
+            if async_rows:
+                eng.rows_wait(res["rows_event"])
+            assert np.array_equal(res["tally"], plain["tally"]) and np.array_equal(res["columns"][:, :defined], plain["columns"][:, :defined])
+        finally:
+            eng.set_option("rows_chunk_games", 4_000_000)
+    with pytest.raises(ValueError):
+        eng.tournament_columns(table, k, 7, lo, hi, ids, shuffle_seeds_out=np.zeros(3, dtype=np.uint32))
