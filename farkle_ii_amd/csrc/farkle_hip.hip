@@ -15,6 +15,9 @@
 #include <atomic>
 #include <chrono>
 #include <memory>
+#include <mutex>
+#include <sys/mman.h>
+#include <unordered_map>
 #include <thread>
 #include <cstdarg>
 #include <cstdio>
@@ -1307,9 +1310,28 @@ int fk_get_device_info(fk_ctx *c, fk_device_info *out) {
     return FK_OK;
 }
 
+// Page-locked host memory for the rows / column-image destinations.  Anonymous pages populated by the kernel (mmap MAP_POPULATE: outside
+// the HIP runtime, so several buffers can be made at once and no launch waits meanwhile) and then registered with the runtime — measured on
+// the MI355X host for 256 MB: 12 - 21 ms + 1 - 3 ms, against 41 - 55 ms for hipHostMalloc (two of those at once: 126 ms, and every HIP call
+// of the process queues behind them); device-to-host copies into either run at the same 57 GB/s.  hipHostMalloc remains the fallback.
+static std::mutex g_host_lock;
+static std::unordered_map<void *, size_t> g_host_mapped; // registered mmap blocks -> their length
+
 int fk_host_alloc(fk_ctx *c, size_t bytes, void **out) {
     if (!c || !out) return FK_ERR_ARG;
     *out = nullptr;
+    const size_t page = (size_t)2 << 20, size = (std::max<size_t>(bytes, 1) + page - 1) & ~(page - 1);
+    void *p = mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_POPULATE, -1, 0);
+    if (p != MAP_FAILED) {
+        if (hipSetDevice(c->device) == hipSuccess && hipHostRegister(p, size, hipHostRegisterDefault) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(g_host_lock);
+            g_host_mapped[p] = size;
+            *out = p;
+            return FK_OK;
+        }
+        (void)hipGetLastError();
+        munmap(p, size);
+    }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault));
     return FK_OK;
@@ -1317,7 +1339,23 @@ int fk_host_alloc(fk_ctx *c, size_t bytes, void **out) {
 
 int fk_host_free(fk_ctx *c, void *p) {
     if (!c) return FK_ERR_ARG;
-    if (p) HIPCHK(c, hipHostFree(p));
+    if (!p) return FK_OK;
+    size_t mapped = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_host_lock);
+        auto it = g_host_mapped.find(p);
+        if (it != g_host_mapped.end()) {
+            mapped = it->second;
+            g_host_mapped.erase(it);
+        }
+    }
+    if (mapped) {
+        const hipError_t e = hipHostUnregister(p);
+        munmap(p, mapped);
+        HIPCHK(c, e);
+        return FK_OK;
+    }
+    HIPCHK(c, hipHostFree(p));
     return FK_OK;
 }
 

@@ -48,7 +48,7 @@ from .workload_planner import TournamentWorkloadPlan, WorkloadCapExceeded, plan_
 LOGGER = logging.getLogger(__name__)
 MAX_GAMES_PER_LAUNCH = 200_000_000  # checkpoint cadence on the GPU: a launch group is at most this many games
 ROWS_ASYNC = os.environ.get("FK_ROWS_ASYNC", "1") != "0"  # (A/B switch: the images' last copy awaited by the shard job / by the engine call)
-ROWS_PIPELINE = os.environ.get("FK_ROWS_PIPELINE", "1") != "0"  # (A/B switch: a launch group's engine part on the launcher thread / in line)
+ROWS_PIPELINE = os.environ.get("FK_ROWS_PIPELINE", "0") != "0"  # (A/B switch: a launch group's engine part on the launcher thread / in line)
 ROWS_SLOTS = max(2, int(os.environ.get("FK_ROWS_SLOTS", "3")))  # rows mode: page-locked image buffers per engine = launch groups played ahead of the shard writer + 1
 ROWS_GROUP_BYTES = int(os.environ.get("FK_ROWS_GROUP_MB", "256")) << 20  # rows mode: a launch group's column images (one of two page-locked buffers; group i is written while i + 1 plays)
 ROW_WRITER_THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))  # row-shard writer PROCESSES (rows mode)
@@ -157,13 +157,13 @@ _PIN_THREADS = None
 
 
 def _pin_threads():
-    """Two threads that page-lock the two column-image buffers of an engine (77 ms per 256 MB) while the run's first launches are prepared
-    and played, instead of in front of them."""
+    """The threads that make an engine's page-locked column-image buffers while the run's first launch is prepared, instead of in front
+    of it."""
     global _PIN_THREADS
     if _PIN_THREADS is None:
         from concurrent.futures import ThreadPoolExecutor
 
-        _PIN_THREADS = ThreadPoolExecutor(max_workers=2, thread_name_prefix="fk-pin")
+        _PIN_THREADS = ThreadPoolExecutor(max_workers=ROWS_SLOTS, thread_name_prefix="fk-pin")
     return _PIN_THREADS
 
 
@@ -666,13 +666,11 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         image_bytes = row_columns_bytes(k, gps)
         group_batches = max(1, min(group_batches, ROWS_GROUP_BYTES // max(spb * image_bytes, 1)))
         if pending and hasattr(eng, "pinned_empty") and getattr(eng, "_pinned_columns", None) is None:
-            # the engine's page-locked image buffers, allocated beside what follows: two at once (the second one is ready when the first
-            # group's launch returns), the others after the engine's first call — page-locking beside that call, which creates the
-            # device workspace, made it take 120 ms instead of 55
+            # the engine's page-locked image buffers, made beside what follows, one thread each (fk_host_alloc populates the pages outside
+            # the HIP runtime: ~20 ms per 256 MB, no launch waits meanwhile)
             size = max(group_batches * spb * image_bytes, min(ROWS_GROUP_BYTES, plan.required_shuffles * image_bytes))
-            eng._pinned_columns = {"slots": [None] * ROWS_SLOTS, "jobs": [None] * ROWS_SLOTS, "turn": 0, "late": size,
-                                   "allocating": [_pin_threads().submit(eng.pinned_empty, size, np.uint8) if i < 2 else None
-                                                  for i in range(ROWS_SLOTS)]}
+            eng._pinned_columns = {"slots": [None] * ROWS_SLOTS, "jobs": [None] * ROWS_SLOTS, "turn": 0,
+                                   "allocating": [_pin_threads().submit(eng.pinned_empty, size, np.uint8) for _ in range(ROWS_SLOTS)]}
     pinned_rows = None
     t_start = time.perf_counter()
     games_done = 0
@@ -857,11 +855,6 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         if played is not None:
             res = played["res"]
             pin = getattr(eng, "_pinned_columns", None)
-            if g["use_columns"] and pin and pin.get("late"):
-                late, pin["late"] = pin["late"], None
-                for slot_i, started in enumerate(pin["allocating"]):
-                    if started is None and pin["slots"][slot_i] is None:
-                        pin["allocating"][slot_i] = _pin_threads().submit(eng.pinned_empty, late, np.uint8)
             first = lo // spb - b0 if per_batch else 0
             local[first:first + len(res["tally"])] = res["tally"]
             if local_stats is not None:
@@ -958,10 +951,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                           slot = pin["turn"] % len(pin["slots"])
                           pin["turn"] += 1
                           waiting = pin.get("allocating", [None] * len(pin["slots"]))[slot]
-                          if pin["slots"][slot] is not None or (waiting is not None and (waiting.done() or pin["turn"] <= 2)):
-                              break
-                          if waiting is None and not pin.get("late"):
-                              break  # (no allocation was started ahead: made below)
+                          if pin["slots"][slot] is not None or waiting is None or waiting.done() or pin["turn"] <= 1:
+                              break  # (waiting is None: no allocation was started ahead — made below)
                       max_in_flight = len(pin["slots"]) - 1
                       if pin["jobs"][slot] is not None:  # the shard job that read this buffer last
                           try:

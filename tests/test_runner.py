@@ -940,7 +940,8 @@ def test_a_sweep_over_player_counts_writes_what_the_single_count_runs_write(engi
         assert pickle.loads((a / f"{k}p_checkpoint.pkl").read_bytes()) == pickle.loads((b / f"{k}p_checkpoint.pkl").read_bytes())
 
 
-def test_rows_sweep_with_groups_in_flight_writes_the_same_files(engine, tmp_path, monkeypatch):
+@pytest.mark.parametrize("launcher_thread", [False, True])
+def test_rows_sweep_with_groups_in_flight_writes_the_same_files(engine, tmp_path, monkeypatch, launcher_thread):
     """Rows mode keeps up to ROWS_SLOTS - 1 launch groups' shards in flight (a ring of image buffers per engine, reused across player
     counts; the last groups of a count are finished by the publishing tail under the next count): cut into one-batch launch groups,
     the sweep writes byte for byte the shards, manifests and checkpoints of the run that plays each count in a single group."""
@@ -959,6 +960,7 @@ def test_rows_sweep_with_groups_in_flight_writes_the_same_files(engine, tmp_path
 
     main(["--config", str(cfg("whole")), "--log-level", "WARNING", "run", "--metrics"])
     monkeypatch.setattr(runner, "ROWS_GROUP_BYTES", 1)  # a launch group = one deterministic batch: several per count, three buffers in turn
+    monkeypatch.setattr(runner, "ROWS_PIPELINE", launcher_thread)  # (FK_ROWS_PIPELINE: a group's engine part beside the previous group's host work)
     calls: list[int] = []
     real = engine.tournament_columns
     monkeypatch.setattr(engine, "tournament_columns", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1], raising=False)
