@@ -157,13 +157,15 @@ _PIN_THREADS = None
 
 
 def _pin_threads():
-    """The threads that make an engine's page-locked column-image buffers while the run's first launch is prepared, instead of in front
-    of it."""
+    """The thread that makes an engine's page-locked column-image buffers while the run's first launches are prepared and played, instead
+    of in front of them."""
     global _PIN_THREADS
     if _PIN_THREADS is None:
         from concurrent.futures import ThreadPoolExecutor
 
-        _PIN_THREADS = ThreadPoolExecutor(max_workers=ROWS_SLOTS, thread_name_prefix="fk-pin")
+        # (one thread: three buffers populated at once took 89 ms each — the kernel serialises a process's page faults — against ~20 ms
+        # one after the other, and the first launch only needs the first)
+        _PIN_THREADS = ThreadPoolExecutor(max_workers=1, thread_name_prefix="fk-pin")
     return _PIN_THREADS
 
 
@@ -666,8 +668,8 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         image_bytes = row_columns_bytes(k, gps)
         group_batches = max(1, min(group_batches, ROWS_GROUP_BYTES // max(spb * image_bytes, 1)))
         if pending and hasattr(eng, "pinned_empty") and getattr(eng, "_pinned_columns", None) is None:
-            # the engine's page-locked image buffers, made beside what follows, one thread each (fk_host_alloc populates the pages outside
-            # the HIP runtime: ~20 ms per 256 MB, no launch waits meanwhile)
+            # the engine's page-locked image buffers, made beside what follows, one after the other on their own thread (fk_host_alloc
+            # populates the pages outside the HIP runtime: ~20 ms per 256 MB, no launch waits meanwhile)
             size = max(group_batches * spb * image_bytes, min(ROWS_GROUP_BYTES, plan.required_shuffles * image_bytes))
             eng._pinned_columns = {"slots": [None] * ROWS_SLOTS, "jobs": [None] * ROWS_SLOTS, "turn": 0,
                                    "allocating": [_pin_threads().submit(eng.pinned_empty, size, np.uint8) for _ in range(ROWS_SLOTS)]}
