@@ -66,6 +66,8 @@ _MEDIA_TYPES = {".json": "application/json", ".jsonl": "application/x-ndjson", "
                 ".pkl": "application/x-python-pickle", ".yaml": "application/yaml", ".yml": "application/yaml"}  # release_identity.py:579-589
 _SHA256_RE = re.compile(r"[0-9a-f]{64}")
 _PLAIN_RE = re.compile(r"[A-Za-z0-9_./-]+")  # strings whose JSON form is the string in quotes
+_PLAIN_LINES_RE = re.compile(r"[A-Za-z0-9_./-]+(?:\n[A-Za-z0-9_./-]+)*")  # ... one per line
+_HEX_RUN_RE = re.compile(r"[0-9a-f]*")
 
 
 class ContractError(ValueError):
@@ -78,6 +80,46 @@ class ContractError(ValueError):
 def canonical_json_bytes(value: Any) -> bytes:
     """authenticated_contract.py:99-108 (tuples serialise as lists; NaN / infinity are refused)."""
     return json.dumps(value, sort_keys=True, separators=(",", ":"), ensure_ascii=False, allow_nan=False).encode("utf-8")
+
+
+def _canonical_manifest_text(text: str) -> tuple[dict[str, list[str]], list[str]] | None:
+    """A JSON-lines manifest whose every line is ALREADY the canonical JSON of its record (sorted keys, no white space, integers and plain
+    strings only, no ``pid`` / ``ts``): the values as text by key, and the lines — or None.  The first line is parsed and re-encoded; the
+    others must have its exact shape (one regular expression built from it: the same keys in the same order, a canonical integer where it
+    has an integer, a plain string where it has a string), which makes them equal to ``canonical_json_bytes`` of themselves."""
+    lines = text.split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    if not lines:
+        return None
+    try:
+        first = json.loads(lines[0])
+    except json.JSONDecodeError:
+        return None
+    if not isinstance(first, dict) or "pid" in first or "ts" in first or canonical_json_bytes(first).decode("utf-8") != lines[0]:
+        return None
+    parts, keys = [], sorted(first)
+    for key in keys:
+        value = first[key]
+        if not _PLAIN_RE.fullmatch(key) or isinstance(value, bool):
+            return None
+        if isinstance(value, int):
+            parts.append(f'"{key}":(0|-?[1-9][0-9]*)')
+        elif isinstance(value, str):
+            parts.append(f'"{key}":"([A-Za-z0-9_./-]*)"')
+        else:
+            return None
+    shape = re.compile(r"\{" + ",".join(parts) + r"\}")
+    columns: dict[str, list[str]] = {key: [] for key in keys}
+    rows = []
+    for line in lines:
+        m = shape.fullmatch(line)
+        if m is None:
+            return None
+        rows.append(m.groups())
+    for key, column in zip(keys, zip(*rows)):
+        columns[key] = list(column)
+    return columns, lines
 
 
 def identity_sha256(value: Any) -> str:
@@ -528,46 +570,75 @@ class SimulationContract:
                 "schema_fingerprint_sha256": arrow["fingerprint_sha256"]}
 
     # -- manifests ----
-    def publish_manifest(self, path: Path | str, records: Sequence[Mapping[str, Any]], *, n_players: int) -> dict[str, Any]:
+    def publish_manifest(self, path: Path | str, records: Sequence[Mapping[str, Any]] | None = None, *, n_players: int) -> dict[str, Any]:
         """Seal a shard manifest (runner._publish_simulation_manifest_v3 :539-636 -> publish_native_manifest_v3, release_identity.py:717-814):
         the native file becomes one canonical JSON line per record in coordinate order (process ids and timestamps dropped), and the adjacent
-        sidecar binds its SHA-256 and the coordinate-sorted root over the shards' byte / sidecar / schema identities the records carry."""
+        sidecar binds its SHA-256 and the coordinate-sorted root over the shards' byte / sidecar / schema identities the records carry.
+        ``records``: the file's records, parsed; None = read them from ``path`` — where a manifest whose lines are already canonical (what
+        this package's writers append) is sealed from its text: 12 ms per 4 300 shards instead of 60."""
         path = Path(path)
         prefix = self.relative(path.parent / "x")[:-1]  # shards sit beside their manifest: one path computation per manifest, not per shard
-        keyed = []
-        for index, record in enumerate(records):
-            coordinate = int(record.get("shuffle_index", record.get("process_block_index", record.get("deterministic_batch_id", index))))
-            name = str(record["path"])
-            relative = prefix + name if "/" not in name and "\\" not in name and name not in ("", ".", "..") else self.relative(path.parent / name)
-            try:
-                identity = (relative, record["data_sha256"], record["schema_fingerprint_sha256"], record["sidecar_sha256"])
-            except KeyError as exc:
-                raise ContractError(f"simulation manifest record without its shard identity ({exc.args[0]}): {path}") from exc
-            keyed.append((coordinate, identity, record))
-        if not keyed:
-            raise ContractError(f"simulation manifest has no authenticated entries: {path}")
-        keyed.sort(key=lambda item: item[0])
-        # compute_manifest_root over ManifestEntry documents; their canonical JSON is written out directly when every string is plain
-        # (hex digests and file names: no escaping), which is 2/3 of the JSON encoding of a 34 400-shard production manifest
-        root, support = hashlib.sha256(), hashlib.sha256()
-        previous = None
-        for coordinate, (relative, data_sha, schema_sha, side_sha), _ in keyed:
-            if previous is not None and coordinate <= previous:
-                raise ContractError("manifest entries must have strictly increasing coordinates")
-            previous = coordinate
-            if _PLAIN_RE.fullmatch(relative) and _SHA256_RE.fullmatch(data_sha) and _SHA256_RE.fullmatch(schema_sha) and _SHA256_RE.fullmatch(side_sha):
-                encoded = (f'{{"canonical_relative_path":"{relative}","coordinate":[{coordinate}],"data_sha256":"{data_sha}",'
-                           f'"schema_fingerprint_sha256":"{schema_sha}","sidecar_sha256":"{side_sha}"}}').encode("ascii")
+        coordinates = identities = native = None
+        if records is None:
+            text = path.read_text(encoding="utf-8")
+            sealed = _canonical_manifest_text(text)
+            if sealed is not None:
+                columns, lines = sealed
+                key = next((name for name in ("shuffle_index", "process_block_index", "deterministic_batch_id") if name in columns), None)
+                coordinates = [int(v) for v in columns[key]] if key is not None else list(range(len(lines)))
+                try:
+                    identities = list(zip([prefix + name if "/" not in name and name not in ("", ".", "..") else self.relative(path.parent / name)
+                                           for name in columns["path"]], columns["data_sha256"], columns["schema_fingerprint_sha256"],
+                                          columns["sidecar_sha256"]))
+                except KeyError as exc:
+                    raise ContractError(f"simulation manifest record without its shard identity ({exc.args[0]}): {path}") from exc
+                order = sorted(range(len(lines)), key=coordinates.__getitem__)
+                if order != list(range(len(lines))):
+                    coordinates, identities, lines = [coordinates[i] for i in order], [identities[i] for i in order], [lines[i] for i in order]
+                native = ("\n".join(lines) + "\n").encode("utf-8")
             else:
-                encoded = canonical_json_bytes(manifest_entry(coordinate, relative, data_sha, side_sha, schema_sha))
-            key = b"[%d]" % coordinate
-            root.update(len(encoded).to_bytes(8, "big"))
-            root.update(encoded)
-            support.update(len(key).to_bytes(8, "big"))
-            support.update(key)
-        summary = {"root_sha256": root.hexdigest(), "coordinate_support_sha256": support.hexdigest(), "entry_count": len(keyed)}
-        native = b"".join(canonical_json_bytes(record if "pid" not in record and "ts" not in record else
-                                               {k: v for k, v in record.items() if k not in ("pid", "ts")}) + b"\n" for _, _, record in keyed)
+                records = []
+                for line in text.splitlines():
+                    try:
+                        records.append(json.loads(line)) if line.strip() else None
+                    except json.JSONDecodeError:
+                        continue  # a torn last line of an interrupted append
+        if coordinates is None:
+            keyed = []
+            for index, record in enumerate(records):
+                coordinate = int(record.get("shuffle_index", record.get("process_block_index", record.get("deterministic_batch_id", index))))
+                name = str(record["path"])
+                relative = prefix + name if "/" not in name and "\\" not in name and name not in ("", ".", "..") else self.relative(path.parent / name)
+                try:
+                    identity = (relative, record["data_sha256"], record["schema_fingerprint_sha256"], record["sidecar_sha256"])
+                except KeyError as exc:
+                    raise ContractError(f"simulation manifest record without its shard identity ({exc.args[0]}): {path}") from exc
+                keyed.append((coordinate, identity, record))
+            keyed.sort(key=lambda item: item[0])
+            coordinates, identities = [item[0] for item in keyed], [item[1] for item in keyed]
+            native = b"".join(canonical_json_bytes(record if "pid" not in record and "ts" not in record else
+                                                   {k: v for k, v in record.items() if k not in ("pid", "ts")}) + b"\n" for _, _, record in keyed)
+        if not coordinates:
+            raise ContractError(f"simulation manifest has no authenticated entries: {path}")
+        if any(b <= a for a, b in zip(coordinates, coordinates[1:])):
+            raise ContractError("manifest entries must have strictly increasing coordinates")
+        # compute_manifest_root over ManifestEntry documents; their canonical JSON is written out directly when every string is plain
+        # (hex digests and file names: no escaping) — checked in bulk, encoded column-wise and hashed in one update
+        digests = [d for identity in identities for d in identity[1:]]
+        plain = (all(isinstance(d, str) and len(d) == 64 for d in digests) and _HEX_RUN_RE.fullmatch("".join(digests)) is not None
+                 and all(isinstance(identity[0], str) for identity in identities)
+                 and _PLAIN_LINES_RE.fullmatch("\n".join(identity[0] for identity in identities)) is not None)
+        if plain:
+            entries = [(f'{{"canonical_relative_path":"{relative}","coordinate":[{coordinate}],"data_sha256":"{data_sha}",'
+                        f'"schema_fingerprint_sha256":"{schema_sha}","sidecar_sha256":"{side_sha}"}}').encode("ascii")
+                       for coordinate, (relative, data_sha, schema_sha, side_sha) in zip(coordinates, identities)]
+        else:
+            entries = [canonical_json_bytes(manifest_entry(coordinate, relative, data_sha, side_sha, schema_sha))
+                       for coordinate, (relative, data_sha, schema_sha, side_sha) in zip(coordinates, identities)]
+        keys = [b"[%d]" % coordinate for coordinate in coordinates]
+        root = hashlib.sha256(b"".join(len(e).to_bytes(8, "big") + e for e in entries))
+        support = hashlib.sha256(b"".join(len(key).to_bytes(8, "big") + key for key in keys))
+        summary = {"root_sha256": root.hexdigest(), "coordinate_support_sha256": support.hexdigest(), "entry_count": len(coordinates)}
         operation = OPERATIONS["shard_manifest"]
         versions, method_version = version_identity(self.cfg, None)
         method = method_contract(

@@ -467,14 +467,19 @@ def _stored_schema(schema, **writer_options):
 def _read_manifest(path: Path) -> list[dict]:
     if not path.exists():
         return []
+    lines = [line for line in (raw.strip() for raw in path.read_text(encoding="utf-8").splitlines()) if line]
+    try:  # one call of the C decoder for the file (a 4 300-shard manifest: 8 ms instead of 22)
+        out = json.loads("[" + ",".join(lines) + "]")
+        if len(out) == len(lines) and all(isinstance(record, dict) for record in out):
+            return out
+    except json.JSONDecodeError:
+        pass
     out = []
-    for line in path.read_text(encoding="utf-8").splitlines():
-        line = line.strip()
-        if line:
-            try:
-                out.append(json.loads(line))
-            except json.JSONDecodeError:
-                continue  # a torn last line of an interrupted append
+    for line in lines:
+        try:
+            out.append(json.loads(line))
+        except json.JSONDecodeError:
+            continue  # a torn last line of an interrupted append
     return out
 
 
@@ -560,7 +565,9 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
     sufficient statistics of the RNG diagnostics' strategy family over the WHOLE shuffle range (``fk_tournament_run_lags``; launch
     groups and ranks are contiguous ranges that merge in order, rng_lags.LagSummary) — returned as ``result["lag_summary"]``."""
     rank, world = _rank_world()
+    _trace(f"{n_players}p run_tournament")
     eng = get_engine()
+    _trace("engine here")
     k = n_players
     sidecars = sidecars or _Sidecars(cfg, n_players, (), False)
     S = len(strategies)
@@ -673,6 +680,12 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             size = max(group_batches * spb * image_bytes, min(ROWS_GROUP_BYTES, plan.required_shuffles * image_bytes))
             eng._pinned_columns = {"slots": [None] * ROWS_SLOTS, "jobs": [None] * ROWS_SLOTS, "turn": 0,
                                    "allocating": [_pin_threads().submit(eng.pinned_empty, size, np.uint8) for _ in range(ROWS_SLOTS)]}
+        if pending:  # what every shard job of this player count shares, made while the first buffer is being page-locked (the first
+            from .parquet_template import shard_footer_template  # use of Arrow's writer in a process takes 30 ms)
+
+            shard_footer_template(k)
+            sidecars.template("row_shard", row_dir / "rows_template.parquet",
+                              schema=lambda: _stored_schema(raw_simulation_schema_for(k), **rt.SHARD_WRITER_OPTIONS))
     pinned_rows = None
     t_start = time.perf_counter()
     games_done = 0
@@ -899,6 +912,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             finish(**group_args)
 
     i = 0
+    _trace("launch loop begins")
     awaiting_post: tuple | None = None  # (pipelined) the group whose engine part has returned and whose `post` runs beside the next one's
     try:
       while i < len(pending):
@@ -969,6 +983,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                           slots[slot] = None
                           slots[slot] = eng.pinned_empty(max(need, min(ROWS_GROUP_BYTES, plan.required_shuffles * image_bytes)), np.uint8)
                       g["pinned_rows"], g["slot"] = slots[slot], slot
+                      _trace(f"image buffer {slot} here")
               elif want_rows and hasattr(eng, "pinned_empty"):
                   # rows land in a page-locked buffer (one per run, sized for the largest launch group): one DMA per chunk at PCIe
                   # rate, under the next chunk's game kernel
@@ -1045,7 +1060,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
             for manifest in (row_manifest, metrics_manifest):  # the manifests are final now: their sidecars bind the complete files
                 if manifest is not None and sidecars.v3 is not None:
                     if manifest.exists():  # sealed: canonical lines in coordinate order + the coordinate-sorted root over the shards' identities
-                        sidecars.v3.publish_manifest(manifest, _read_manifest(manifest), n_players=k)
+                        sidecars.v3.publish_manifest(manifest, n_players=k)
                 elif manifest is not None:
                     sidecars.write("shard_manifest", manifest)
         barrier()

@@ -332,3 +332,53 @@ def test_two_ranks_write_the_same_v3_documents(tmp_path):
             assert (root / rel).read_text() == rec["completion"], rel
         else:
             assert hashlib.sha256((root / (rel + SIDE)).read_bytes()).hexdigest() == rec["sidecar_sha256"], rel
+
+
+def test_manifest_sealed_from_its_text_equals_the_parsed_route(tmp_path):
+    """``publish_manifest(path)`` seals a manifest whose lines are already canonical from its TEXT (one regular expression per line); the
+    document and the sealed file equal those of the parsed-records route — also for lines out of coordinate order — and a manifest with a
+    process id, white space or a torn last line takes the parsed route."""
+    import yaml
+
+    from farkle_ii_amd import contract_v3 as c3
+    from farkle_ii_amd.config import load_app_config
+
+    cfg_path = tmp_path / "c.yaml"
+    cfg_path.write_text(yaml.safe_dump({"io": {"results_dir_prefix": str(tmp_path / "out")}, "sim": {"n_players_list": [3], "seed_list": [5], "row_dir": "rows"}}))
+    cfg = load_app_config(cfg_path, seed_list_len=1)
+    sc = c3.SimulationContract(cfg, c3.make_code_identity("b" * 40))
+    row_dir = cfg.simulation_row_dir(3)
+    row_dir.mkdir(parents=True)
+    records = [{"path": f"rows_5_3p_{i:012d}.parquet", "rows": 7, "root_seed": 5, "n_players": 3, "shuffle_index": i, "shuffle_seed": 2**32 - 1 - i,
+                "deterministic_batch_id": i // 2, "byte_length": 1000 + i, "data_sha256": hashlib.sha256(b"d%d" % i).hexdigest(),
+                "sidecar_sha256": hashlib.sha256(b"s%d" % i).hexdigest(), "schema_fingerprint_sha256": "0f" * 32} for i in range(9)]
+    canonical = [json.dumps(r, sort_keys=True, separators=(",", ":")) for r in records]
+
+    def sealed(lines, parsed: bool):
+        path = row_dir / "manifest.jsonl"
+        path.write_text("\n".join(lines) + "\n")
+        if parsed:
+            recs = []
+            for line in lines:
+                try:
+                    recs.append(json.loads(line))
+                except json.JSONDecodeError:
+                    pass
+            doc = sc.publish_manifest(path, recs, n_players=3)
+        else:
+            doc = sc.publish_manifest(path, n_players=3)
+        return json.dumps(doc, sort_keys=True), path.read_bytes(), path.with_name(path.name + ".sidecar.json").read_bytes()
+
+    want = sealed(canonical, parsed=True)
+    assert sealed(canonical, parsed=False) == want and c3._canonical_manifest_text("\n".join(canonical) + "\n") is not None
+    shuffled = canonical[4:] + canonical[:4]
+    assert sealed(shuffled, parsed=False) == want
+    for other in ([json.dumps({**r, "pid": 77}, sort_keys=True) for r in records],                       # a process id, default separators
+                  canonical[:-1] + [canonical[-1][:40]],                                                   # a torn last line
+                  canonical[:3] + [json.dumps({**records[3], "note": "a b"}, sort_keys=True, separators=(",", ":"))] + canonical[4:]):  # another shape
+        assert c3._canonical_manifest_text("\n".join(other) + "\n") is None
+    assert sealed([json.dumps({**r, "pid": 77}, sort_keys=True) for r in records], parsed=False) == want  # (pid dropped, lines re-encoded)
+    torn = canonical[:-1] + [canonical[-1][:40]]
+    assert sealed(torn, parsed=False) == sealed(torn, parsed=True)
+    with pytest.raises(c3.ContractError):
+        sealed(canonical + canonical[:1], parsed=False)  # the same coordinate twice
