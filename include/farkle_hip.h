@@ -134,7 +134,9 @@ int fk_get_device_info(fk_ctx *ctx, fk_device_info *out);
 int fk_get_timing(fk_ctx *ctx, fk_timing *out);
 /* Page-locked host memory for the caller-owned output buffers (rows above all: 60 bytes per k=2 game).  A buffer from here is
  * copied to by one DMA per chunk at PCIe rate, while the next chunk plays; any other host pointer works too (staged by the HIP
- * runtime, about a third of the rate, the host thread waits).  Free with fk_host_free before fk_destroy. */
+ * runtime, about a third of the rate, the host thread waits).  Free with fk_host_free before fk_destroy.  The pages are anonymous
+ * memory populated by the kernel and then registered with the HIP runtime (256 MB: ~15 + ~2 ms, and only the registration takes the
+ * runtime's lock — hipHostMalloc, the fallback, holds it for ~45 ms); may be called from any thread. */
 int fk_host_alloc(fk_ctx *ctx, size_t bytes, void **out);
 int fk_host_free(fk_ctx *ctx, void *p);
 /* Tunables: "chunk_bytes" (device workspace budget per chunk), "batch_threshold" (lanes that must be waiting
