@@ -976,3 +976,54 @@ def test_rows_sweep_with_groups_in_flight_writes_the_same_files(engine, tmp_path
         strip = lambda lines: [{key: v for key, v in __import__("json").loads(line).items() if key != "pid"} for line in lines]  # noqa: E731
         assert strip(la) == strip(lb) and len(la) == len(set(la))
         assert pickle.loads((a / f"{k}_players" / f"{k}p_checkpoint.pkl").read_bytes()) == pickle.loads((b / f"{k}_players" / f"{k}p_checkpoint.pkl").read_bytes())
+
+
+@pytest.mark.parametrize("launcher_thread", [False, True])
+def test_a_failing_shard_job_ends_the_run_and_leaves_the_threads_usable(engine, tmp_path, monkeypatch, launcher_thread):
+    """A shard job that fails (a full disk: here the second launch group's library call raises) is raised from `farkle run` once the group
+    is finished — no writer outlives the call, the engine is not left inside a launch — and the next run in the same process, resumed over
+    what the failed one published, completes with the files of an undisturbed run."""
+    import hashlib
+
+    from farkle_ii_amd import backend, runner
+    from farkle_ii_amd import tournament as rt
+    from farkle_ii_amd.cli import main
+
+    def cfg(name: str) -> Path:
+        path = _tiny_config(tmp_path, '  row_dir: "rows"\n')
+        out = tmp_path / f"{name}.yaml"
+        out.write_text(path.read_text().replace("n_players_list: [2]", "n_players_list: [2, 4]").replace(str(tmp_path / "out"), str(tmp_path / name)))
+        return out
+
+    main(["--config", str(cfg("clean")), "--log-level", "WARNING", "run", "--metrics"])
+    monkeypatch.setattr(runner, "ROWS_GROUP_BYTES", 1)
+    monkeypatch.setattr(runner, "ROWS_PIPELINE", launcher_thread)
+    real = backend.prepare_row_shards_native
+    calls: list[int] = []
+
+    def failing(*a, **kw):
+        job = real(*a, **kw)
+        calls.append(1)
+        if len(calls) != 2:
+            return job
+
+        def full_disk():
+            raise OSError("fk_write_row_shards failed (-7): write rows_7_2p_000000000002.parquet: No space left on device")
+
+        return full_disk
+
+    monkeypatch.setattr(backend, "prepare_row_shards_native", failing)
+    with pytest.raises(OSError, match="No space left"):
+        main(["--config", str(cfg("hurt")), "--log-level", "WARNING", "run", "--metrics"])
+    assert not (tmp_path / "hurt_seed_7" / "2_players" / "simulation.done.json").exists()
+    monkeypatch.setattr(backend, "prepare_row_shards_native", real)
+    main(["--config", str(tmp_path / "hurt.yaml"), "--log-level", "WARNING", "run", "--metrics"])  # resumes: owned batches stay, the rest is replayed
+    a, b = tmp_path / "clean_seed_7", tmp_path / "hurt_seed_7"
+    shards = sorted(p.relative_to(a) for p in a.rglob("rows_*.parquet"))
+    assert shards == sorted(p.relative_to(b) for p in b.rglob("rows_*.parquet")) and len(shards) > 6
+    for rel in shards:
+        assert hashlib.sha256((a / rel).read_bytes()).digest() == hashlib.sha256((b / rel).read_bytes()).digest(), rel
+    for k in (2, 4):
+        assert (b / f"{k}_players" / "simulation.done.json").exists()
+        assert len((b / f"{k}_players" / f"{k}p_rows" / "manifest.jsonl").read_text().splitlines()) == len([s for s in shards if f"{k}p_rows" in str(s)])
+    del rt
