@@ -667,7 +667,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
     # rows as per-shuffle column images (fk_tournament_run_columns) whenever the engine offers them: the shards are framed by the library's
     # own Parquet writer on host threads instead of Arrow in writer processes (tournament.write_row_shards_from_columns).  Launch groups
     # are then cut by image bytes, and group i's shards are written while group i + 1 plays (two page-locked buffers per engine).
-    columns_mode = want_rows and hasattr(eng, "tournament_columns") and k <= 64 and not rng_lags and all_player_dir is None
+    columns_mode = want_rows and getattr(eng, "columns_with_seeds", False) and k <= 64 and not rng_lags and all_player_dir is None
     checkpoint_batches = group_batches  # an intermediate checkpoint at least every this many batches (or sim.ckpt_every_sec)
     if columns_mode:
         from .backend import row_columns_bytes
@@ -835,18 +835,16 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         batch_arg = spb if g["per_batch"] else hi - lo
         _trace(f"{k}p group {g['index']}: engine call")
         if g["use_columns"]:
-            early = g["write"] is not None  # the shard job was laid out in the prelude, around buffers this call fills
+            # (the shard job was laid out in the prelude, around the buffers this call fills)
             res = eng.tournament_columns(table, k, cfg.sim.seed, lo, hi, ids, shuffles_per_batch=batch_arg, target_score=target,
-                                         max_rounds=max_rounds, overrides=ov, columns_out=g["pinned_rows"],
-                                         **({"async_rows": True} if g["async_rows"] else {}),
-                                         **({"shuffle_seeds_out": g["shuffle_seeds32"], "game_seeds_out": g["game_seeds"]} if early else {}))
-            if early:
-                _trace(f"{k}p group {g['index']}: engine returned")
-                g["tasks"].shuffle_seed[...] = g["shuffle_seeds32"]  # (int64 in the shard records)
-                shard_job = _shard_thread().submit(_write_group_shards, eng, res.get("rows_event") if g["async_rows"] else None, g["write"])
-                if g["slot"] is not None:
-                    eng._pinned_columns["jobs"][g["slot"]] = shard_job
-                return {"res": res, "shard_job": shard_job}
+                                         max_rounds=max_rounds, overrides=ov, columns_out=g["pinned_rows"], shuffle_seeds_out=g["shuffle_seeds32"],
+                                         game_seeds_out=g["game_seeds"], **({"async_rows": True} if g["async_rows"] else {}))
+            _trace(f"{k}p group {g['index']}: engine returned")
+            g["tasks"].shuffle_seed[...] = g["shuffle_seeds32"]  # (int64 in the shard records)
+            shard_job = _shard_thread().submit(_write_group_shards, eng, res.get("rows_event") if g["async_rows"] else None, g["write"])
+            if g["slot"] is not None:
+                eng._pinned_columns["jobs"][g["slot"]] = shard_job
+            return {"res": res, "shard_job": shard_job}
         elif rng_lags:
             res = eng.tournament_lags(table, k, cfg.sim.seed, lo, hi, rng_lags, shuffles_per_batch=batch_arg, target_score=target,
                                       max_rounds=max_rounds, overrides=ov)
@@ -869,7 +867,6 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
         shard_job = res = None
         if played is not None:
             res = played["res"]
-            pin = getattr(eng, "_pinned_columns", None)
             first = lo // spb - b0 if per_batch else 0
             local[first:first + len(res["tally"])] = res["tally"]
             if local_stats is not None:
@@ -877,30 +874,15 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                 local_ratios[first:first + len(res["seat_ratio_sums"])] = res["seat_ratio_sums"]
             if played["shard_job"] is not None:  # (laid out in the prelude, submitted by the engine part)
                 shard_job = played["shard_job"]
-            elif want_rows:  # every rank writes the shards of its own shuffles; rank 0 appends the manifest lines
+            elif want_rows:  # AoS rows (more than 64 seats, lag or all-player runs, an engine without column images): Arrow in writer processes
                 sh_index = np.arange(lo, hi, dtype=np.int64)  # the ShuffleTask identities (run_tournament.py:97-105), as arrays
                 tasks = rt.ShuffleRange(cfg.sim.seed, k, sh_index, played["shuffle_seeds"], sh_index // spb)
                 sha = oracle_game_profile.sha256 if oracle_game_profile else None
-                # one parquet file per shuffle is the reference's format: the host side of rows mode is file framing and file
-                # creation — by the library's writer threads from column images, or (AoS rows) Arrow in writer processes
                 seeds102 = played["seeds102"]
                 shard_sidecar = sidecars.template("row_shard", row_dir / "rows_template.parquet",
                                                   schema=lambda: _stored_schema(raw_simulation_schema_for(k), **rt.SHARD_WRITER_OPTIONS))
-                _trace("sidecar template here")
-                if g["use_columns"]:
-                    if seeds102 is None:
-                        seeds102 = urandom.coordinate_seeds(urandom.RandomPurpose.TOURNAMENT_GAME, root_seed=cfg.sim.seed, k=k,
-                                                            shuffle_index=np.repeat(np.arange(lo, hi, dtype=np.uint64), gps),
-                                                            game_index=np.tile(np.arange(gps, dtype=np.uint64), hi - lo), dtype=np.uint32)
-                    write = rt.write_row_shards_from_columns(row_dir, tasks, res["columns"], seeds102, sha, threads=ROW_WRITER_THREADS,
-                                                             sidecar=shard_sidecar, deferred_lines=True, deferred_write=True)
-                    _trace("shard job laid out")
-                    shard_job = _shard_thread().submit(_write_group_shards, eng, res.get("rows_event") if g["async_rows"] else None, write)
-                    if pin is not None and g["pinned_rows"] is not None:
-                        pin["jobs"][g["slot"]] = shard_job
-                else:
-                    row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
-                                                           game_seeds=seeds102, as_lines=True, sidecar=shard_sidecar))
+                row_records.extend(rt.write_row_shards(row_dir, tasks, res["rows"], ids, sha, threads=ROW_WRITER_THREADS,
+                                                       game_seeds=seeds102, as_lines=True, sidecar=shard_sidecar))
         group_args = dict(b0=b0, b1=b1, lo=lo, hi=hi, j=g["j"], local=local, local_stats=local_stats, local_ratios=local_ratios,
                           row_records=row_records, fragments=g["fragments"], res=res, shard_job=shard_job, per_batch=per_batch)
         n_groups += 1
@@ -996,7 +978,7 @@ def run_tournament(*, cfg: AppConfig, n_players: int, strategies: list[Threshold
                   g["extra"]["rows_out"] = pinned_rows
               # the images' last copy to the host is awaited by the shard job, not here: the next launch group's games run beside it
               g["async_rows"] = columns_mode and g["pinned_rows"] is not None and hasattr(eng, "rows_wait") and ROWS_ASYNC
-              if columns_mode and getattr(eng, "columns_with_seeds", False):
+              if columns_mode:
                   # The shard job of the group, laid out BEFORE it plays: around the image buffer and two fingerprint arrays the engine
                   # call fills (fk_tournament_run_columns_seeds), so that the engine part hands it to the shard thread the moment the call
                   # returns — between a launch and its shards' first byte there is then no interpreter work that a publishing tail

@@ -32,11 +32,14 @@ class NullEngine:
         return {"tally": t, "rows": None, "perms": None, "seat_stats": None, "seat_ratio_sums": None}
     def game_seeds(self, purpose, root, k, lo, hi, gps):
         return np.arange((hi - lo) * gps, dtype=np.uint32)
-    def tournament_columns(self, table, k, root, lo, hi, ids, shuffles_per_batch=None, columns_out=None, **kw):
+    columns_with_seeds = True
+    def tournament_columns(self, table, k, root, lo, hi, ids, shuffles_per_batch=None, columns_out=None, shuffle_seeds_out=None, game_seeds_out=None, **kw):
         from farkle_ii_amd.backend import row_columns_bytes
         S, n = len(table), hi - lo
         gps = S // k
         stride = row_columns_bytes(k, gps)
+        if shuffle_seeds_out is not None: shuffle_seeds_out[...] = np.arange(lo, hi, dtype=np.uint32)
+        if game_seeds_out is not None: game_seeds_out[...] = np.arange(n * gps, dtype=np.uint32)
         if getattr(self, "_img", None) is None or self._img.shape != (n, stride):
             rng = np.random.default_rng(k)
             one = rng.integers(0, 200, stride, dtype=np.uint8)  # one random shard, repeated: the writer's cost does not depend on the values
@@ -44,6 +47,8 @@ class NullEngine:
             one[ni:ni + gps] = rng.random(gps) < 0.01
             one[ni + gps:] %= k
             self._img = np.broadcast_to(one, (n, stride)).copy()
+        if columns_out is not None:  # (the runner lays the shard job out around ITS buffer)
+            columns_out.reshape(-1)[:n * stride].reshape(n, stride)[...] = self._img
         return {"tally": self.tournament(table, k, root, lo, hi, shuffles_per_batch)["tally"], "columns": self._img}
 
 
