@@ -104,9 +104,9 @@ def _canonical_manifest_text(text: str) -> tuple[dict[str, list[str]], list[str]
         if not _PLAIN_RE.fullmatch(key) or isinstance(value, bool):
             return None
         if isinstance(value, int):
-            parts.append(f'"{key}":(0|-?[1-9][0-9]*)')
+            parts.append(f'"{re.escape(key)}":(0|-?[1-9][0-9]*)')
         elif isinstance(value, str):
-            parts.append(f'"{key}":"([A-Za-z0-9_./-]*)"')
+            parts.append(f'"{re.escape(key)}":"([A-Za-z0-9_./-]*)"')
         else:
             return None
     shape = re.compile(r"\{" + ",".join(parts) + r"\}")
