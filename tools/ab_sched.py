@@ -15,6 +15,15 @@ from farkle_ii_amd.strategies import generate_strategy_grid, pack_strategies, pr
 STRATEGIES = {"max-ilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "max-memory-clause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
               # ("iterative-ilp" crashes clang 22 / ROCm 7.2 in the register allocator on fk_seat_ratio_kernel: not built)
               "iterative-minreg": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"]}
+# second set (usage: python tools/ab_sched.py OUT.json codegen): other code-generation knobs of the same compiler over the same sources — what
+# decides the copies (50 v_mov_b32 in the k = 8 roll loop), the branches (lane utilisation 0.64 - 0.80) and the order within a block
+CODEGEN = {"early-ifcvt": ["-mllvm", "-amdgpu-early-ifcvt=1"], "no-vgpr-liverange-opt": ["-mllvm", "-amdgpu-opt-vgpr-liverange=0"],
+           "no-unclustered-high-rp-reschedule": ["-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule=1"],
+           "no-clustered-low-occupancy-reschedule": ["-mllvm", "-amdgpu-disable-clustered-low-occupancy-reschedule=1"],
+           "schedule-metric-bias-0": ["-mllvm", "-amdgpu-schedule-metric-bias=0"], "schedule-metric-bias-100": ["-mllvm", "-amdgpu-schedule-metric-bias=100"],
+           "no-loop-alignment": ["-mllvm", "-amdgpu-disable-loop-alignment=1"], "O2": ["-O2"]}
+if len(sys.argv) > 2 and sys.argv[2] == "codegen":
+    STRATEGIES = CODEGEN
 for name, flags in STRATEGIES.items():
     backend.VARIANTS["sched_" + name.replace("-", "_")] = flags
 g64, _ = generate_strategy_grid(score_thresholds=[250, 300, 350, 400], dice_thresholds=[0, 1, 2, 3], smart_five_opts=[True], smart_one_opts=[True],
