@@ -6,6 +6,7 @@
 // No MFMA (integer/table work), no CPU fallback.
 #include "fk_kernels.h" // device side: every kernel of the engine (pulls in farkle_hip.h, fk_device.h, hip_runtime.h)
 #include "fk_shard_writer.h" // host side: column images -> row-shard Parquet files
+#include "fk_perm_wave.h"    // device side: a shuffle's Fisher-Yates draws by a whole wave (small launches)
 
 #include <dlfcn.h>
 #include <rccl/rccl.h> // TYPES ONLY (ncclConfig_t, result codes): the library itself is bound with dlopen on first use
@@ -127,6 +128,7 @@ struct fk_ctx {
     DevBuf lag_v, lag_out, lag_lags, lag_edge, lag_tmp; // fk_tournament_run_lags: value matrix, sums, lag list, head / tail rows
     bool ran_hc = false;       // the current tournament call launched the hot / cold kernel
     int32_t perm_split = -1;   // -1 auto, 0 one-kernel Fisher-Yates, 1 draws + serial swap chains, 2 draws + chain-free kernel
+    int32_t perm_draw_wave = -1; // the draws of a shuffle by -1: a wave up to WAVE_DRAW_MAX_SH shuffles per chunk, a thread beyond; 0: a thread; 1: a wave
     void *comm = nullptr;      // RCCL communicator (fk_comm_init), one per context / GPU
     int comm_rank = 0, comm_world = 1;
     bool comm_async = false;   // (non-blocking communicators: every RCCL call settled by polling; not used — see fk_comm_init)
@@ -967,12 +969,19 @@ int prep_tournament_chunk(fk_ctx *c, int si, hipStream_t st_seed, const ChunkDes
         const bool split = c->perm_split >= 1 || (c->perm_split < 0 && S >= 1024 && n_sh >= 256);
         const size_t pp_lds = (size_t)S * 14;
         const bool parallel = split && c->perm_split != 1 && pp_lds <= LDS_LIMIT - 1024;
+        // the draws: a wave per shuffle while the launch is small (fk_perm_wave.h: ~20 us instead of the thread-per-shuffle kernel's
+        // 1 ms latency), a thread per shuffle when there are enough shuffles to fill the chip with them
+        const bool wave_draw = c->perm_draw_wave == 1 || (c->perm_draw_wave < 0 && n_sh <= WAVE_DRAW_MAX_SH);
         if (parallel) {
             const uint32_t groups = ((uint32_t)S - 1u + 7u) / 8u, row_u4 = groups + 1u; // a row also holds the S results
             rc = ensure(c, cs.draws, (size_t)n_sh * row_u4 * 16);
             if (rc) return rc;
-            hipLaunchKernelGGL(fk_perm_draw_kernel, dim3((n_sh + DRAW_BLOCK - 1u) / DRAW_BLOCK), dim3(DRAW_BLOCK), 0, st,
-                               perm_prefix, d.sh0, n_sh, (uint32_t)S, 1u, row_u4, static_cast<uint4 *>(cs.draws.p));
+            if (wave_draw)
+                hipLaunchKernelGGL(fk_perm_draw_wave_kernel, dim3((n_sh + WAVE_DRAW_BLOCK / 64 - 1u) / (WAVE_DRAW_BLOCK / 64)), dim3(WAVE_DRAW_BLOCK), 0, st,
+                                   perm_prefix, d.sh0, n_sh, (uint32_t)S, 1u, row_u4, static_cast<uint4 *>(cs.draws.p));
+            else
+                hipLaunchKernelGGL(fk_perm_draw_kernel, dim3((n_sh + DRAW_BLOCK - 1u) / DRAW_BLOCK), dim3(DRAW_BLOCK), 0, st,
+                                   perm_prefix, d.sh0, n_sh, (uint32_t)S, 1u, row_u4, static_cast<uint4 *>(cs.draws.p));
             hipLaunchKernelGGL(fk_perm_parallel_kernel, dim3(n_sh), dim3(PP_BLOCK), pp_lds, st,
                                static_cast<uint4 *>(cs.draws.p), row_u4, n_sh, (uint32_t)S);
             hipLaunchKernelGGL(fk_perm_block_kernel, dim3(((uint32_t)S + 255u) / 256u, perm_blocks), dim3(256), 0, st,
@@ -982,8 +991,12 @@ int prep_tournament_chunk(fk_ctx *c, int si, hipStream_t st_seed, const ChunkDes
             const uint32_t n_sh_pad = (n_sh + 63u) & ~63u, groups = ((uint32_t)S - 1u + 7u) / 8u;
             rc = ensure(c, cs.draws, (size_t)groups * n_sh_pad * 16);
             if (rc) return rc;
-            hipLaunchKernelGGL(fk_perm_draw_kernel, dim3((n_sh + DRAW_BLOCK - 1u) / DRAW_BLOCK), dim3(DRAW_BLOCK), 0, st,
-                               perm_prefix, d.sh0, n_sh, (uint32_t)S, n_sh_pad, 1u, static_cast<uint4 *>(cs.draws.p));
+            if (wave_draw)
+                hipLaunchKernelGGL(fk_perm_draw_wave_kernel, dim3((n_sh + WAVE_DRAW_BLOCK / 64 - 1u) / (WAVE_DRAW_BLOCK / 64)), dim3(WAVE_DRAW_BLOCK), 0, st,
+                                   perm_prefix, d.sh0, n_sh, (uint32_t)S, n_sh_pad, 1u, static_cast<uint4 *>(cs.draws.p));
+            else
+                hipLaunchKernelGGL(fk_perm_draw_kernel, dim3((n_sh + DRAW_BLOCK - 1u) / DRAW_BLOCK), dim3(DRAW_BLOCK), 0, st,
+                                   perm_prefix, d.sh0, n_sh, (uint32_t)S, n_sh_pad, 1u, static_cast<uint4 *>(cs.draws.p));
             hipLaunchKernelGGL(fk_perm_apply_kernel, dim3(perm_blocks), dim3(PERM_BLOCK), perm_lds, st,
                                static_cast<const uint4 *>(cs.draws.p), n_sh_pad, n_sh, (uint32_t)S, slots,
                                static_cast<uint16_t *>(cs.perm.p));
@@ -1435,6 +1448,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     }
     else if (n == "clock_stamps") c->clock_stamps = value != 0;
     else if (n == "perm_split") c->perm_split = (int32_t)value;
+    else if (n == "perm_draw_wave") c->perm_draw_wave = (int32_t)value;
     else if (n == "pipeline") c->pipeline = (int32_t)value;
     else if (n == "uniform_flags") c->uniform_flags_opt = (int32_t)value;
     else if (n == "block") {

@@ -356,22 +356,27 @@ def test_resident_tally_accumulates_on_the_device_and_reduces_through_rccl(eng):
 @pytest.mark.parametrize("S,k", [(8, 2), (64, 2), (96, 3), (1290, 2), (5160, 4), (7140, 5)])
 def test_permutation_kernels_agree_with_numpy_semantics(eng, po, S, k):
     """Generator.permutation through the three device paths — one-kernel Fisher-Yates, draws + serial swap chains, draws +
-    the chain-free kernel (bucket sort + pointer jumping) — against the oracle's restatement of NumPy's loop, permutations
-    and tallies; shuffle counts that leave partial blocks and partial 8-draw groups."""
+    the chain-free kernel (bucket sort + pointer jumping), the draws by a thread or by a wave per shuffle — against the oracle's
+    restatement of NumPy's loop, permutations and tallies; shuffle counts that leave partial blocks and partial 8-draw groups."""
     table = _random_valid_table(S, S) if (S <= 96 or S > 5160) else _default_table()[:S]  # 7 140: the reference's largest documented grid
     n_sh = {8: 300, 64: 521, 96: 77, 1290: 70, 5160: 37, 7140: 260}[S]
     ref = po.tournament(table.view(po.STRATEGY_DTYPE), k, 21, 1000, 1000 + n_sh, want_perms=True, max_rounds=3, n_threads=16)
     try:
         for mode in (0, 1, 2, -1):
             eng.set_option("perm_split", mode)
-            try:
-                got = eng.tournament(table, k, 21, 1000, 1000 + n_sh, want_perms=True, max_rounds=3)
-            except Exception as exc:
-                raise AssertionError(f"perm_split={mode} S={S}: {exc}") from exc
-            assert np.array_equal(got["perms"], ref["perms"]), (S, mode, np.argwhere(got["perms"] != ref["perms"])[:4])
-            assert np.array_equal(got["tally"], ref["tally"]), (S, mode)
+            # the draws of the two split paths: by one thread per shuffle (0) or by a whole wave (1: jump-ahead by 64 + the rejection
+            # scan iterated to its fixed point, csrc/fk_perm_wave.h) — the same 16-bit draws in the same groups
+            for draw_by_wave in ((0, 1) if mode in (1, 2) else (-1,)):
+                eng.set_option("perm_draw_wave", draw_by_wave)
+                try:
+                    got = eng.tournament(table, k, 21, 1000, 1000 + n_sh, want_perms=True, max_rounds=3)
+                except Exception as exc:
+                    raise AssertionError(f"perm_split={mode} S={S}: {exc}") from exc
+                assert np.array_equal(got["perms"], ref["perms"]), (S, mode, draw_by_wave, np.argwhere(got["perms"] != ref["perms"])[:4])
+                assert np.array_equal(got["tally"], ref["tally"]), (S, mode, draw_by_wave)
     finally:
         eng.set_option("perm_split", -1)
+        eng.set_option("perm_draw_wave", -1)
 
 
 def test_pipelined_preparation_never_changes_results(eng, po):
