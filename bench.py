@@ -488,6 +488,12 @@ def main() -> None:
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
+    # stdout carries ONE line, the JSON: whatever a library writes to file descriptor 1 meanwhile (gloo announces "[Gloo] Rank 0 is connected
+    # to 7 peer ranks" there from C++, once per rank) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -844,7 +850,7 @@ def main() -> None:
             e2e = sorted((ROOT / "profiles").glob("r*_farkle_run_end_to_end.json"))
             if e2e:  # the latest committed measurement of `farkle run` end to end (rows off / on), not of this run
                 line["farkle_run_end_to_end_fixture"] = {"file": f"profiles/{e2e[-1].name}", **json.loads(e2e[-1].read_text())}
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode("utf-8"))
     eng.close()
     if distributed:
         dist.barrier()
