@@ -92,7 +92,7 @@ def build_library(force: bool = False, verbose: bool = False, variant: str | Non
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU).  ``variant``: a test build with extra
     definitions (``VARIANTS``), never loaded by the product."""
     out = library_path(variant)
-    deps = hip_sources() + [SRC_DIR / "fk_device.h", SRC_DIR / "fk_kernels.h", SRC_DIR / "fk_play_hc.h", SRC_DIR / "fk_shard_writer.h", SRC_DIR / "fk_perm_wave.h", PKG_DIR.parent / "include" / "farkle_hip.h"]
+    deps = hip_sources() + [SRC_DIR / "fk_device.h", SRC_DIR / "fk_kernels.h", SRC_DIR / "fk_play_hc.h", SRC_DIR / "fk_shard_writer.h", SRC_DIR / "fk_perm_wave.h", SRC_DIR / "fk_row_columns_seats.h", PKG_DIR.parent / "include" / "farkle_hip.h"]
     if out.exists() and not force and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return out
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *(VARIANTS[variant] if variant else []), "-o", str(out),

@@ -7,6 +7,7 @@
 #include "fk_kernels.h" // device side: every kernel of the engine (pulls in farkle_hip.h, fk_device.h, hip_runtime.h)
 #include "fk_shard_writer.h" // host side: column images -> row-shard Parquet files
 #include "fk_perm_wave.h"    // device side: a shuffle's Fisher-Yates draws by a whole wave (small launches)
+#include "fk_row_columns_seats.h" // device side: column images with one thread per (game, seat)
 
 #include <dlfcn.h>
 #include <rccl/rccl.h> // TYPES ONLY (ncclConfig_t, result codes): the library itself is bound with dlopen on first use
@@ -128,6 +129,7 @@ struct fk_ctx {
     DevBuf lag_v, lag_out, lag_lags, lag_edge, lag_tmp; // fk_tournament_run_lags: value matrix, sums, lag list, head / tail rows
     bool ran_hc = false;       // the current tournament call launched the hot / cold kernel
     int32_t perm_split = -1;   // -1 auto, 0 one-kernel Fisher-Yates, 1 draws + serial swap chains, 2 draws + chain-free kernel
+    int32_t columns_by_seat = -1; // column images: -1 one thread per (game, seat) up to sixteen seats, per game beyond; 0 per game; 1 per (game, seat)
     int32_t perm_draw_wave = -1; // the draws of a shuffle by -1: a wave up to WAVE_DRAW_MAX_SH shuffles per chunk, a thread beyond; 0: a thread; 1: a wave
     void *comm = nullptr;      // RCCL communicator (fk_comm_init), one per context / GPU
     int comm_rank = 0, comm_world = 1;
@@ -1449,6 +1451,7 @@ int fk_set_option(fk_ctx *c, const char *name, int64_t value) {
     else if (n == "clock_stamps") c->clock_stamps = value != 0;
     else if (n == "perm_split") c->perm_split = (int32_t)value;
     else if (n == "perm_draw_wave") c->perm_draw_wave = (int32_t)value;
+    else if (n == "columns_by_seat") c->columns_by_seat = (int32_t)value;
     else if (n == "pipeline") c->pipeline = (int32_t)value;
     else if (n == "uniform_flags") c->uniform_flags_opt = (int32_t)value;
     else if (n == "block") {
@@ -1981,7 +1984,13 @@ static int tournament_run_impl(fk_ctx *c, const fk_strategy *strategies, int32_t
             // rows kernel on the main stream (behind this buffer's previous copy), the copy to the host on the copy stream: it
             // runs beside the next chunk's game kernel.  With a pinned destination (fk_host_alloc) it is one DMA at PCIe rate.
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_copy[rb], 0));
-            if (columns) {
+            if (columns && k <= 16 && c->columns_by_seat != 0) {
+                hipLaunchKernelGGL(fk_row_columns_seats_kernel, dim3((n_games + 63u) / 64u), dim3(64u * (uint32_t)k), 0, c->stream,
+                                   static_cast<const uint32_t *>(CSET(c).state.p), static_cast<const uint32_t *>(c->recs.p),
+                                   scheduled ? static_cast<const uint32_t *>(c->inv.p) : nullptr, n_games, gps, n_sh, (uint32_t)k, 1u,
+                                   static_cast<const int32_t *>(c->ids.p), static_cast<uint8_t *>(row_buf.p), rows_per_shuffle);
+                HIPCHK(c, hipGetLastError());
+            } else if (columns) {
                 hipLaunchKernelGGL(fk_row_columns_kernel, dim3((n_games + 255u) / 256u), dim3(256), 0, c->stream,
                                    static_cast<const uint32_t *>(CSET(c).state.p), static_cast<const uint32_t *>(c->recs.p),
                                    scheduled ? static_cast<const uint32_t *>(c->inv.p) : nullptr, n_games, gps, n_sh, (uint32_t)k, 1u,

@@ -145,7 +145,7 @@ int fk_host_free(fk_ctx *ctx, void *p);
  * k of them do not fit LDS (k > 64); 0 the same; 1 always), "blocks_per_cu", "max_waves" (resident waves per SIMD the launch plan counts
  * on, default 6), "longest_first" (1 = deal
  * never-banking pairings first), "uniform_flags" (-1 auto: tables whose strategies share all flag bits run the scalar-flag
- * kernel instance, 0 never), "perm_split" (-1 auto), "perm_draw_wave" (-1 auto: a shuffle's Fisher-Yates draws by a whole wave in chunks of up to 32 768 shuffles, by one thread beyond; 0 / 1 force), "pipeline" (1, default: the next chunk / hinted call is prepared around the
+ * kernel instance, 0 never), "perm_split" (-1 auto), "columns_by_seat" (-1 auto: the column images of fk_tournament_run_columns by one thread per (game, seat) up to sixteen seats, per game beyond; 0 / 1 force), "perm_draw_wave" (-1 auto: a shuffle's Fisher-Yates draws by a whole wave in chunks of up to 32 768 shuffles, by one thread beyond; 0 / 1 force), "pipeline" (1, default: the next chunk / hinted call is prepared around the
  * current game kernel — permutations in front of it, schedule and seat seeding on a low-priority stream in its drain tail;
  * 0: every chunk is prepared on the main stream in front of its own game kernel), "hot_cold" (tournament launches of 4..12 seats on
  * the hot / cold game kernel, csrc/fk_play_hc.h: -1 auto, 0 never — the LDS-record kernel plays them), "comm_timeout_ms" (deadline of

@@ -247,9 +247,12 @@ def test_column_images_of_the_kernel_equal_the_rows_of_the_same_launch(tmp_path,
     eng.set_option("rows_chunk_games", 3 * gps)  # several chunks: images of chunk i cross PCIe while chunk i + 1 plays
     try:
         rows = eng.tournament(table, k, 42, lo, hi, max_rounds=max_rounds, want_rows=True)
-        cols = eng.tournament_columns(table, k, 42, lo, hi, ids, max_rounds=max_rounds)
+        cols = eng.tournament_columns(table, k, 42, lo, hi, ids, max_rounds=max_rounds)  # (one thread per (game, seat): the default to 16 seats)
+        eng.set_option("columns_by_seat", 0)
+        per_game = eng.tournament_columns(table, k, 42, lo, hi, ids, max_rounds=max_rounds)  # fk_row_columns_kernel: one thread per game
     finally:
         eng.set_option("rows_chunk_games", 4_000_000)
+        eng.set_option("columns_by_seat", -1)
     assert np.array_equal(rows["tally"], cols["tally"])
     status = rows["rows"]["status"]
     if max_rounds <= 3:
@@ -258,6 +261,7 @@ def test_column_images_of_the_kernel_equal_the_rows_of_the_same_launch(tmp_path,
     assert cols["columns"].shape == want_images.shape
     defined = ((4 + 13 * k) * 4 + 2 + k) * gps  # (an image is padded to a multiple of 64 bytes; nothing reads the padding)
     cols["columns"][:, defined:] = 0
+    assert np.array_equal(per_game["columns"][:, :defined], cols["columns"][:, :defined]) and np.array_equal(per_game["tally"], cols["tally"])
     if not np.array_equal(cols["columns"], want_images):  # name the first differing values: plane / byte array, game, both values
         sh_i, off = (int(v[0]) for v in np.nonzero(cols["columns"] != want_images))
         ni = (4 + 13 * k) * 4 * gps
